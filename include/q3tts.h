@@ -1,0 +1,207 @@
+/*
+ * q3tts.h — C ABI of the MI355X-native Qwen3-TTS inference path (libq3tts.so).
+ *
+ * This is the drop-in boundary for the hot path of cgisky1980/Qwen3-TTS-Rust
+ * (TtsEngine::generate_with_voice -> run_inference_stream). It REPLACES the two
+ * foreign runtimes the reference crate binds by hand:
+ *   - the 29 dlsym'd llama.cpp symbols          (reference: src/models/llama/mod.rs:81-144,240-294)
+ *   - the onnxruntime vocoder session           (reference: src/models/onnx.rs:324-459)
+ * and keeps the host-visible semantics of
+ *   - TtsEngine::{new,set_max_steps,set_sampler_config,generate_with_voice}
+ *                                               (reference: src/tts/engine.rs:84,172,177,390)
+ *   - SamplerConfig{temperature,top_k,top_p,seed}  (reference: src/tts/engine.rs:14-45)
+ *   - PromptBuilder::{build_core,build_clone_prompt} (reference: src/tts/prompt.rs:141,28)
+ *
+ * Conventions: plain pointers and sizes, no C++ / torch types. Every function
+ * returns an int status (0 = ok, <0 = error class) and leaves a message readable
+ * through q3tts_last_error(). The library never aborts and never silently
+ * truncates (the reference swallows vocoder-thread errors:
+ * src/tts/engine.rs:496-502,520). Result buffers are allocated by the callee and
+ * released with q3tts_result_free(); inputs are borrowed for the call only.
+ * An engine handle is NOT re-entrant (same contract as `&mut self`,
+ * src/tts/engine.rs:390); use one engine per GPU / host thread.
+ */
+#ifndef Q3TTS_H
+#define Q3TTS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define Q3TTS_OK 0
+#define Q3TTS_ERR_INVALID (-1)     /* bad argument / shape / config */
+#define Q3TTS_ERR_DEVICE (-2)      /* HIP runtime error */
+#define Q3TTS_ERR_OOM (-3)
+#define Q3TTS_ERR_IO (-4)          /* weight / asset file problem */
+#define Q3TTS_ERR_STATE (-5)       /* call order / handle state */
+#define Q3TTS_ERR_UNSUPPORTED (-6)
+
+#define Q3TTS_MAX_UPSAMPLE 4
+#define Q3TTS_MAX_DEC_BLOCKS 8
+
+/* ---- model configuration (every dimension is data, never a literal) -------------------------- */
+
+/* Autoregressive codec-token decoder: Talker + Predictor (reference: llama.cpp GGUF models loaded at
+ * src/tts/engine.rs:123-137; dims read at src/models/llama/mod.rs:348-353). */
+typedef struct q3tts_model_config {
+    /* Talker (Qwen3 decoder: RMSNorm, QK-RMSNorm, M-RoPE, GQA, SwiGLU) */
+    int32_t t_n_layer, t_d_model, t_n_head, t_n_kv_head, t_head_dim, t_d_ffn, t_vocab;
+    float t_rope_theta;
+    int32_t t_mrope_sections[4]; /* rotary pairs per (t,h,w,extra) section; sum == head_dim/2 */
+    /* Predictor (same block, plain RoPE, 15 heads of codebook_size logits) */
+    int32_t p_n_layer, p_d_model, p_n_head, p_n_kv_head, p_head_dim, p_d_ffn;
+    float p_rope_theta;
+    int32_t n_codebooks;   /* 16  (reference: src/tts/engine.rs:587) */
+    int32_t codebook_size; /* 2048 (reference: src/tts/engine.rs:588-589) */
+    float rms_eps;
+    /* embedding tables (reference: src/assets_manager.rs:212-249) */
+    int32_t d_embed;     /* 2048 */
+    int32_t text_vocab;  /* rows of text_embd */
+    int32_t codec0_rows; /* rows of codec_embd.0 (holds specials + speaker ids) */
+    int32_t codecq_rows; /* rows of codec_embd.1..15 */
+    /* protocol (reference: src/tts/prompt.rs:5-16, src/tts/engine.rs:555-558) */
+    int32_t sample_limit; /* 2160: Talker samples over logits[0, sample_limit) */
+    int32_t eos_code;     /* 2150 */
+    int32_t tts_pad_id;   /* 151671: text row used as marker and tts_pad */
+} q3tts_model_config;
+
+/* Streaming neural-codec vocoder (reference: ONNX graph behind src/models/onnx.rs:342-459; state shapes
+ * src/models/onnx.rs:474-495 pin latent 1024 / pre-conv 512 / 8 layers x 16 heads x 64). */
+typedef struct q3tts_vocoder_config {
+    int32_t n_codebooks, codebook_size, codebook_dim; /* 16, 2048, 512 */
+    int32_t latent_dim;                               /* 1024 */
+    int32_t pre_conv_kernel;                          /* 3 */
+    int32_t n_layer, n_head, head_dim, d_ffn, sliding_window;
+    float rope_theta, rms_eps, layer_scale_init;
+    int32_t n_upsample;
+    int32_t upsample_ratios[Q3TTS_MAX_UPSAMPLE]; /* ConvTranspose1d(k=r,s=r) + ConvNeXt each */
+    int32_t decoder_dim;                         /* 1536 */
+    int32_t n_dec_blocks;
+    int32_t dec_rates[Q3TTS_MAX_DEC_BLOCKS]; /* 8,5,4,3 -> 1920 samples per frame with 2x2 above */
+    int32_t lookahead_frames;                /* frames withheld until more input or is_last (V4) */
+    int32_t sample_rate;                     /* 24000 */
+} q3tts_vocoder_config;
+
+typedef struct q3tts_engine_config {
+    q3tts_model_config model;
+    q3tts_vocoder_config vocoder;
+    int32_t device;        /* HIP device ordinal */
+    int32_t max_batch;     /* concurrent utterance slots, 1..64 */
+    int32_t n_ctx;         /* Talker context per slot (reference 4096: src/tts/engine.rs:133) */
+    int32_t max_steps_cap; /* upper bound accepted by q3tts_set_max_steps (reference default 512) */
+    int32_t with_vocoder;  /* 0: codes only (no vocoder weights allocated) */
+    uint64_t synth_seed;   /* seeded synthetic weights when weights_path == NULL */
+    const char* weights_path; /* NULL -> synthetic; else a Q3TW container written by q3tts_write_weights */
+} q3tts_engine_config;
+
+typedef struct q3tts_engine q3tts_engine;
+typedef struct q3tts_stream q3tts_stream;
+
+/* Fill cfg with the Qwen3-TTS-12Hz-1.7B shape assumed by SURVEY.md §8 (28x2048 Talker, 5x1024 Predictor). */
+void q3tts_default_config(q3tts_engine_config* cfg);
+
+/* TtsEngine::new (reference: src/tts/engine.rs:84-169): allocates weights, KV slabs, vocoder state on the
+ * device and builds the replayable frame-step graphs. */
+int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine** out);
+void q3tts_engine_destroy(q3tts_engine* e);
+
+/* Message for the last failing call on this engine (or on this thread when e == NULL). */
+const char* q3tts_last_error(const q3tts_engine* e);
+
+/* set_sampler_config / set_max_steps (reference: src/tts/engine.rs:172-184). has_seed == 0 reproduces
+ * `seed: None` (wall-clock nanoseconds, src/tts/engine.rs:473-478). */
+int q3tts_set_sampler(q3tts_engine* e, float temperature, int32_t top_k, float top_p, int32_t has_seed, uint64_t seed);
+int q3tts_set_max_steps(q3tts_engine* e, int32_t max_steps);
+
+/* ---- prompt (H1: src/tts/prompt.rs:141-277 build_core, :28-118 build_clone_prompt) ------------- */
+typedef struct q3tts_prompt_desc {
+    const uint32_t* text_ids;     int32_t n_text;     /* tokenizer.encode(text) */
+    const uint32_t* instruct_ids; int32_t n_instruct; /* NULL -> instruct == None */
+    int32_t lang_id;                                  /* <0 -> None (NOTHINK control block) */
+    int32_t spk_id;                                   /* <0 -> None */
+    const float* spk_emb;                             /* [d_embed] or NULL */
+    const int32_t* ref_codes;     int32_t n_ref_frames; /* clone path: [n_ref_frames*16] or NULL */
+    const uint32_t* ref_text_ids; int32_t n_ref_text;
+} q3tts_prompt_desc;
+
+/* Builds the prompt embeddings on the device and copies them back: *out_embd = malloc'd [n_tok][d_embed] f32
+ * (free with q3tts_free). */
+int q3tts_build_prompt(q3tts_engine* e, const q3tts_prompt_desc* p, float** out_embd, int32_t* out_n_tok);
+void q3tts_free(void* p);
+
+/* ---- generation (run_inference_stream: src/tts/engine.rs:445-656) ------------------------------ */
+typedef struct q3tts_request {
+    const float* prompt_embd; int32_t n_tok; /* [n_tok][d_embed] f32 host rows (PromptData.embd), or NULL ... */
+    const q3tts_prompt_desc* prompt;         /* ... to build from ids on the device */
+    int32_t use_engine_sampler;              /* 1: ignore the five fields below, use q3tts_set_sampler state */
+    float temperature; int32_t top_k; float top_p; int32_t has_seed; uint64_t seed;
+    int32_t max_steps;    /* 0 -> engine value */
+    int32_t min_frames;   /* bench control: EOS logit masked while n_frames < min_frames (0 = reference) */
+    int32_t force_eos_at; /* bench control: EOS forced at this step (<0 = off) */
+    int32_t want_pcm;     /* 0: codec ids only */
+} q3tts_request;
+
+typedef struct q3tts_result {
+    int32_t status;
+    int32_t n_frames;      /* frames kept (EOS frame excluded, as src/tts/engine.rs:558-562) */
+    int32_t hit_eos;
+    int32_t* codes;        /* [n_frames][n_codebooks] raw ids (unclamped) */
+    float* pcm;            /* [n_samples] mono f32, or NULL */
+    int32_t n_samples;
+    int32_t sample_rate;
+    float first_chunk_ms;  /* entry -> first 4-frame PCM chunk resident on host (0 if none) */
+    float total_ms;
+} q3tts_result;
+
+int q3tts_generate(q3tts_engine* e, const q3tts_request* req, q3tts_result* out);
+/* Continuous batching over max_batch slots; results are independent of n, of slot assignment and of the
+ * number of GPUs the caller shards over (per-utterance RNG stream is a function of req->seed only). */
+int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, int32_t n, q3tts_result* outs);
+void q3tts_result_free(q3tts_result* r);
+
+/* Streaming: 4-frame (64-code) chunks as in the reference's vocoder thread (src/tts/engine.rs:507-541). */
+int q3tts_stream_begin(q3tts_engine* e, const q3tts_request* req, q3tts_stream** out);
+/* Blocks until the next chunk; *chunk is owned by the stream and valid until the next poll/end. */
+int q3tts_stream_poll(q3tts_stream* s, const float** chunk, int32_t* n_samples, int32_t* is_final);
+int q3tts_stream_end(q3tts_stream* s, q3tts_result* out_codes_optional);
+
+/* Synthetic weight container: lets tests exercise the file path with the same tensors. */
+int q3tts_write_weights(q3tts_engine* e, const char* path);
+
+/* Per-stage device timings of the last generate call (hipEvent), ms. */
+typedef struct q3tts_timings {
+    float prefill_ms, decode_ms, vocoder_ms, total_ms;
+    float frame_step_ms;      /* mean device time of one frame-step graph replay */
+    float talker_gemm_ms;     /* mean device time of the dominant kernel family per frame step */
+    int64_t frame_steps;      /* graph replays timed */
+    int64_t algo_bytes_per_step; /* SURVEY.md §8(d) algorithmic bytes of one frame step at the batch run */
+} q3tts_timings;
+int q3tts_get_timings(const q3tts_engine* e, q3tts_timings* out);
+
+/* ---- kernel-level test hooks (host buffers in/out; used only by tests/ and bench.py) ----------- */
+/* y[B][N] = exact_gemm(norm?(x)[B][K], W[N][K] bf16 bits) (+bias) — canonical order of DESIGN.md §4.1 */
+int q3tts_k_gemm_exact(int32_t device, const float* x, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N,
+                       const float* norm_w /*NULL: no RMSNorm*/, float eps, const float* bias /*NULL*/,
+                       int32_t epilogue /*0 store,1 residual(y+=),2 swiglu,3 argmax*/, float* y, uint64_t* argmax_keys,
+                       int32_t iters, float* mean_kernel_ms);
+/* fused q/k RMSNorm + RoPE + KV append + decode attention for rows of ONE sequence processed in order */
+int q3tts_k_attention(int32_t device, const float* qkv /*[n][(Hq+2Hkv)*hd]*/, int32_t n_rows, int32_t pos0,
+                      int32_t n_head, int32_t n_kv_head, int32_t head_dim, const float* q_norm_w, const float* k_norm_w,
+                      float eps, float rope_theta, const int32_t* mrope_sections, float* out /*[n][Hq*hd]*/);
+/* sampler (H4: src/models/llama/mod.rs:666-772) on n rows of logits; r_uniform[n] are the f32 draws */
+int q3tts_k_sample(int32_t device, const float* logits, int32_t n, int32_t ld, int32_t limit, float temperature,
+                   int32_t top_k, float top_p, const float* r_uniform, int32_t* out_ids);
+/* Talker forward over a prompt: hidden[d] (post final norm) and logits[t_vocab] of the LAST row */
+int q3tts_k_talker_prefill(q3tts_engine* e, const float* embd, int32_t n_tok, float* hidden_out, float* logits_out);
+/* Vocoder: codes [n_frames][n_codebooks] -> pcm; chunk_frames frames per streaming call (0 = one call) */
+int q3tts_k_vocoder(q3tts_engine* e, const int32_t* codes, int32_t n_frames, int32_t chunk_frames, float* pcm_out,
+                    int32_t* n_samples_out);
+/* rand 0.8 StdRng (ChaCha12) stream: seed_from_u64(seed) then n x gen::<f32>() */
+int q3tts_k_rng_f32(uint64_t seed, int32_t n, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* Q3TTS_H */

@@ -1,0 +1,129 @@
+/*
+ * q3_oracle.h — CPU restatement (plain C) of the Qwen3-TTS inference hot path of
+ * cgisky1980/Qwen3-TTS-Rust. TEST INFRASTRUCTURE ONLY: nothing in the product path
+ * (qwen3-tts-rust_amd/, include/) may include, link or call this; only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg load libq3oracle.so.
+ *
+ * PARITY UNPINNED: the reference has no tests, golden vectors or fixtures for this
+ * path and its arithmetic lives in llama.cpp b7885 / onnxruntime
+ * 1.23.2 binaries that are not in the repository and cannot be fetched. What IS
+ * followed line by line is the host logic the crate owns (citations at each
+ * function). The transformer math is the standard Qwen3 decoder definition with a
+ * canonical fp32 summation order that the HIP kernels reproduce
+ * bit for bit.
+ *
+ * The structs below restate include/q3tts.h field for field (same layout) so the
+ * tests can fill one ctypes structure for both libraries; the oracle does not
+ * include the product header.
+ */
+#ifndef Q3_ORACLE_H
+#define Q3_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct q3o_model_config {
+    int32_t t_n_layer, t_d_model, t_n_head, t_n_kv_head, t_head_dim, t_d_ffn, t_vocab;
+    float t_rope_theta;
+    int32_t t_mrope_sections[4];
+    int32_t p_n_layer, p_d_model, p_n_head, p_n_kv_head, p_head_dim, p_d_ffn;
+    float p_rope_theta;
+    int32_t n_codebooks;
+    int32_t codebook_size;
+    float rms_eps;
+    int32_t d_embed;
+    int32_t text_vocab;
+    int32_t codec0_rows;
+    int32_t codecq_rows;
+    int32_t sample_limit;
+    int32_t eos_code;
+    int32_t tts_pad_id;
+} q3o_model_config;
+
+typedef struct q3o_vocoder_config {
+    int32_t n_codebooks, codebook_size, codebook_dim;
+    int32_t latent_dim;
+    int32_t pre_conv_kernel;
+    int32_t n_layer, n_head, head_dim, d_ffn, sliding_window;
+    float rope_theta, rms_eps, layer_scale_init;
+    int32_t n_upsample;
+    int32_t upsample_ratios[4];
+    int32_t decoder_dim;
+    int32_t n_dec_blocks;
+    int32_t dec_rates[8];
+    int32_t lookahead_frames;
+    int32_t sample_rate;
+} q3o_vocoder_config;
+
+typedef struct q3o_prompt_desc {
+    const uint32_t* text_ids;     int32_t n_text;
+    const uint32_t* instruct_ids; int32_t n_instruct;
+    int32_t lang_id;
+    int32_t spk_id;
+    const float* spk_emb;
+    const int32_t* ref_codes;     int32_t n_ref_frames;
+    const uint32_t* ref_text_ids; int32_t n_ref_text;
+} q3o_prompt_desc;
+
+typedef struct q3o_model q3o_model;
+
+/* seeded synthetic weights (identical generator to the device one) */
+q3o_model* q3o_create(const q3o_model_config* cfg, uint64_t seed, int32_t n_ctx, int32_t n_threads);
+void q3o_destroy(q3o_model* m);
+
+/* primitives ------------------------------------------------------------------------------ */
+float q3o_expf(float x);
+float q3o_synth(uint64_t seed, uint32_t tensor, uint64_t idx, float scale);
+uint16_t q3o_bf16(float x);
+/* y = gemm_exact(norm?(x), W[N][K] bf16) ; epilogue 0 store(+bias) 1 residual 2 swiglu 3 argmax keys */
+void q3o_gemm_exact(const float* x, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, const float* norm_w,
+                    float eps, const float* bias, int32_t epilogue, float* y, uint64_t* argmax_keys);
+void q3o_rmsnorm(const float* x, int32_t d, const float* w, float eps, float* y);
+/* rows of one sequence processed in order, fresh cache */
+void q3o_attention(const float* qkv, int32_t n_rows, int32_t pos0, int32_t n_head, int32_t n_kv_head,
+                   int32_t head_dim, const float* q_norm_w, const float* k_norm_w, float eps, float rope_theta,
+                   const int32_t* mrope_sections, float* out);
+/* H4 sampler: src/models/llama/mod.rs:666-772 */
+int32_t q3o_sample(const float* logits, int32_t limit, float temperature, int32_t top_k, float top_p, float r);
+/* rand 0.8 StdRng: seed_from_u64 + gen::<f32>() */
+void q3o_rng_f32(uint64_t seed, int32_t n, float* out);
+void q3o_chacha_block(const uint32_t in[16], int32_t rounds, uint32_t out[16]);
+/* H2 positions: src/tts/engine.rs:306-318 */
+void q3o_qwen3_position(int32_t start, int32_t len, int32_t* out4n);
+
+/* H1 prompt: src/tts/prompt.rs:141-277 / :28-118 ; returns n_tok (out may be NULL to size) */
+int32_t q3o_build_prompt(const q3o_model* m, const q3o_prompt_desc* p, float* out, int32_t max_tok);
+/* table access with the reference's OOB rules (src/assets_manager.rs:419-460) */
+void q3o_text_embedding(const q3o_model* m, int64_t id, float* out);
+void q3o_codec_embedding(const q3o_model* m, int32_t q, int32_t code, float* out);
+/* H6: src/assets_manager.rs:383-399 (canonical summation order, bias added last) */
+void q3o_project(const q3o_model* m, const float* x2048, float* y1024);
+
+/* Talker prefill: hidden (post final norm) and logits of the last prompt row */
+void q3o_talker_prefill(q3o_model* m, const float* embd, int32_t n_tok, float* hidden_out, float* logits_out);
+
+/* run_inference_stream (src/tts/engine.rs:445-656) up to the codec ids. Returns n_frames. */
+int32_t q3o_generate(q3o_model* m, const float* prompt_embd, int32_t n_tok, float temperature, int32_t top_k,
+                     float top_p, uint64_t seed, int32_t max_steps, int32_t min_frames, int32_t force_eos_at,
+                     int32_t* codes_out, int32_t* hit_eos);
+
+/* H8 chunker (src/tts/engine.rs:507-541): given n_frames, writes the sequence of vocoder calls as
+ * (n_frames_in_call, is_final) pairs; returns the number of calls. */
+int32_t q3o_chunk_plan(int32_t n_frames, int32_t* calls_frames, int32_t* calls_final, int32_t max_calls);
+
+/* vocoder (q3_oracle_vocoder.c) ------------------------------------------------------------- */
+typedef struct q3o_vocoder q3o_vocoder;
+q3o_vocoder* q3o_vocoder_create(const q3o_vocoder_config* cfg, uint64_t seed, int32_t n_threads);
+void q3o_vocoder_destroy(q3o_vocoder* v);
+void q3o_vocoder_reset(q3o_vocoder* v);
+/* streaming call: codes [n_frames][n_codebooks] (clamped by the caller as src/tts/engine.rs:515-519);
+ * returns samples written */
+int32_t q3o_vocoder_decode(q3o_vocoder* v, const int32_t* codes, int32_t n_frames, int32_t is_last, float* pcm_out,
+                           int32_t max_samples);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

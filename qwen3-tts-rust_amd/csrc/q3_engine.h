@@ -1,0 +1,90 @@
+// q3_engine.h — internal engine state of libq3tts (host side, C++). The public surface is include/q3tts.h.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/q3tts.h"
+#include "q3_kernels.h"
+
+struct Q3Voc;  // vocoder (q3_vocoder.hip)
+
+struct Q3Tfm {
+    int L = 0, d = 0, Hq = 0, Hkv = 0, hd = 0, F = 0, nq = 0, nkv = 0, nqkv = 0, head_n = 0;
+    std::vector<float*> attn_norm, ffn_norm, qn, kn;
+    std::vector<uint4*> wqkv, wo, wgu, wd;
+    float* out_norm = nullptr;
+    uint4* head = nullptr;
+    uint16_t *kc = nullptr, *vc = nullptr;  // [L][slots][Hkv][n_ctx*hd]
+    size_t layer_stride = 0;
+    int n_ctx = 0, n_slots = 0;
+    float *cs = nullptr, *sn = nullptr;  // RoPE tables [n_ctx][hd/2]
+    size_t weight_bytes = 0;              // bf16 matrix bytes of all layers + head
+};
+
+struct Q3Scratch {
+    float *qkv = nullptr, *att = nullptr, *h = nullptr;
+    int rows = 0;
+};
+
+struct q3tts_engine {
+    q3tts_engine_config cfg;
+    std::string err;
+    hipStream_t stream = nullptr, vstream = nullptr;
+    Q3Tfm T, P;
+    // assets
+    float* text = nullptr;
+    std::vector<float*> codec;            // host array of device pointers
+    const float** codec_dev = nullptr;    // device array of the same pointers
+    uint4* proj_w = nullptr;
+    float* proj_b = nullptr;
+    float* tts_pad = nullptr;             // = text[tts_pad_id]
+    // decode state (B = max_batch rows)
+    int B = 0;
+    Q3Slot* slots = nullptr;              // device
+    Q3Slot* slots_host = nullptr;         // pinned mirror
+    float *xT = nullptr, *logits = nullptr, *X = nullptr, *fb = nullptr, *px = nullptr;
+    unsigned long long* keys = nullptr;
+    int* codes = nullptr;                 // [B][max_steps_cap][ncb]
+    float* rng = nullptr;                 // [B][max_steps_cap]
+    int *row_pos_t = nullptr, *slot_id = nullptr, *posA = nullptr, *slotA = nullptr, *pos_q = nullptr;
+    Q3Scratch sc_dec, sc_pre;
+    // prefill
+    float* xp = nullptr;                  // [n_ctx][d]
+    int *pf_pos = nullptr, *pf_slot = nullptr;
+    Q3PromptRow* prow_dev = nullptr; int prow_cap = 0;
+    float* spk_dev = nullptr; int* refcodes_dev = nullptr;
+    // graph of one frame step
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    // sampler defaults (SamplerConfig::default: src/tts/engine.rs:25-34)
+    float temperature = 0.7f; int top_k = 40; float top_p = 0.9f; int has_seed = 0; uint64_t seed = 0;
+    int max_steps = 512;
+    // timing
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    q3tts_timings tm{};
+    Q3Voc* voc = nullptr;
+};
+
+// helpers shared with q3_vocoder.hip
+int q3_set_err(q3tts_engine* e, int code, const std::string& msg);
+#define Q3_HIP(e, call)                                                                                         \
+    do {                                                                                                        \
+        hipError_t err__ = (call);                                                                              \
+        if (err__ != hipSuccess)                                                                                \
+            return q3_set_err((e), Q3TTS_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(err__));     \
+    } while (0)
+
+// host ChaCha12 StdRng (q3_rng.cpp)
+void q3_stdrng_f32(uint64_t seed, int n, float* out);
+
+// vocoder interface (q3_vocoder.hip)
+int q3_voc_create(q3tts_engine* e);
+void q3_voc_destroy(q3tts_engine* e);
+// reset the streaming state of a slot
+int q3_voc_reset(q3tts_engine* e, int slot);
+// decode frames [f0, f0+nf) of slot (codes already on device in e->codes) into the slot's PCM buffer on stream
+int q3_voc_decode(q3tts_engine* e, int slot, int f0, int nf, int is_last, hipStream_t s);
+// PCM buffer of a slot (device) and samples produced so far
+float* q3_voc_pcm(q3tts_engine* e, int slot);
+int q3_voc_samples(q3tts_engine* e, int slot);
+int q3_voc_samples_per_frame(const q3tts_engine* e);

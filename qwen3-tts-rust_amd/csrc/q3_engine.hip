@@ -1,0 +1,793 @@
+// q3_engine.hip — host side of libq3tts: weights, KV slabs, the replayable frame-step graph, the continuous
+// batching loop and the C ABI of include/q3tts.h. The loop restates run_inference_stream
+// (/root/reference/src/tts/engine.rs:445-656) with every per-frame decision on the device: one graph replay =
+// sample -> 15 predictor passes -> feedback -> Talker step, no host round trip (the reference crosses the
+// host<->backend boundary >= 33 times per frame).
+#include "q3_engine.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+static thread_local std::string g_err;
+
+int q3_set_err(q3tts_engine* e, int code, const std::string& msg) {
+    if (e) e->err = msg;
+    g_err = msg;
+    return code;
+}
+extern "C" const char* q3tts_last_error(const q3tts_engine* e) { return e ? e->err.c_str() : g_err.c_str(); }
+
+// ------------------------------------------------------------------------------------------------
+// configuration
+// ------------------------------------------------------------------------------------------------
+extern "C" void q3tts_default_config(q3tts_engine_config* c) {
+    memset(c, 0, sizeof(*c));
+    q3tts_model_config& m = c->model;
+    m.t_n_layer = 28; m.t_d_model = 2048; m.t_n_head = 16; m.t_n_kv_head = 8; m.t_head_dim = 128; m.t_d_ffn = 6144;
+    m.t_vocab = 3072; m.t_rope_theta = 1000000.0f;
+    m.t_mrope_sections[0] = 24; m.t_mrope_sections[1] = 20; m.t_mrope_sections[2] = 20; m.t_mrope_sections[3] = 0;
+    m.p_n_layer = 5; m.p_d_model = 1024; m.p_n_head = 16; m.p_n_kv_head = 8; m.p_head_dim = 128; m.p_d_ffn = 3072;
+    m.p_rope_theta = 1000000.0f;
+    m.n_codebooks = 16; m.codebook_size = 2048; m.rms_eps = 1e-6f;
+    m.d_embed = 2048; m.text_vocab = 151936; m.codec0_rows = 3072; m.codecq_rows = 2048;
+    m.sample_limit = 2160; m.eos_code = 2150; m.tts_pad_id = 151671;
+    q3tts_vocoder_config& v = c->vocoder;
+    v.n_codebooks = 16; v.codebook_size = 2048; v.codebook_dim = 512; v.latent_dim = 1024; v.pre_conv_kernel = 3;
+    v.n_layer = 8; v.n_head = 16; v.head_dim = 64; v.d_ffn = 3072; v.sliding_window = 72;
+    v.rope_theta = 10000.0f; v.rms_eps = 1e-5f; v.layer_scale_init = 0.01f;
+    v.n_upsample = 2; v.upsample_ratios[0] = 2; v.upsample_ratios[1] = 2;
+    v.decoder_dim = 1536; v.n_dec_blocks = 4;
+    v.dec_rates[0] = 8; v.dec_rates[1] = 5; v.dec_rates[2] = 4; v.dec_rates[3] = 3;
+    v.lookahead_frames = 0; v.sample_rate = 24000;
+    c->device = 0; c->max_batch = 1; c->n_ctx = 4096; c->max_steps_cap = 512; c->with_vocoder = 1;
+    c->synth_seed = 0; c->weights_path = nullptr;
+}
+
+static int validate(const q3tts_engine_config& c, std::string& why) {
+    const q3tts_model_config& m = c.model;
+#define REQ(cond) do { if (!(cond)) { why = "config check failed: " #cond; return Q3TTS_ERR_INVALID; } } while (0)
+    REQ(m.t_n_layer > 0 && m.p_n_layer > 0);
+    REQ(m.t_head_dim == 128 && m.p_head_dim == 128);  // exact attention kernel: 16 lanes x 8 dims per key
+    REQ(m.t_d_model % 256 == 0 && m.p_d_model % 256 == 0 && m.t_d_ffn % 256 == 0 && m.p_d_ffn % 256 == 0);
+    REQ((m.t_n_head * m.t_head_dim) % 256 == 0 && (m.p_n_head * m.p_head_dim) % 256 == 0);
+    REQ(m.t_n_head % m.t_n_kv_head == 0 && m.p_n_head % m.p_n_kv_head == 0);
+    { int r = m.t_n_head / m.t_n_kv_head; REQ(r == 1 || r == 2 || r == 4); r = m.p_n_head / m.p_n_kv_head; REQ(r == 1 || r == 2 || r == 4); }
+    REQ(m.t_vocab % 16 == 0 && m.codebook_size % 16 == 0 && m.t_d_ffn % 8 == 0);
+    REQ(m.d_embed == m.t_d_model);  // feedback row feeds the Talker directly (src/tts/engine.rs:631)
+    REQ(m.d_embed % 256 == 0);
+    REQ(m.n_codebooks >= 2 && m.n_codebooks <= 16);
+    REQ(m.sample_limit > 0 && m.sample_limit <= m.t_vocab && m.sample_limit <= 4096);
+    REQ(m.t_mrope_sections[0] + m.t_mrope_sections[1] + m.t_mrope_sections[2] + m.t_mrope_sections[3] == m.t_head_dim / 2);
+    REQ(m.tts_pad_id >= 0 && m.tts_pad_id < m.text_vocab);
+    REQ(c.max_batch >= 1 && c.max_batch <= 64);
+    REQ(c.n_ctx >= 64 && c.n_ctx % 64 == 0 && c.n_ctx <= 8192);
+    REQ(c.max_steps_cap >= 1 && c.max_steps_cap < c.n_ctx);
+    REQ(m.n_codebooks + 1 <= 64);
+#undef REQ
+    return Q3TTS_OK;
+}
+
+template <class T>
+static int dalloc(q3tts_engine* e, T** p, size_t n) {
+    void* q = nullptr;
+    hipError_t err = hipMalloc(&q, n * sizeof(T) + 64);
+    if (err != hipSuccess) return q3_set_err(e, Q3TTS_ERR_OOM, std::string("hipMalloc: ") + hipGetErrorString(err));
+    err = hipMemsetAsync(q, 0, n * sizeof(T) + 64, e->stream);
+    if (err != hipSuccess) return q3_set_err(e, Q3TTS_ERR_DEVICE, std::string("hipMemset: ") + hipGetErrorString(err));
+    *p = (T*)q;
+    return Q3TTS_OK;
+}
+#define TRY(x) do { int rc__ = (x); if (rc__ != Q3TTS_OK) return rc__; } while (0)
+
+// RoPE tables in double on the host (same formula the oracle restates)
+static void rope_tables(int n_pos, int hd, float theta, const int* sections, std::vector<float>& cs, std::vector<float>& sn) {
+    const int half = hd / 2;
+    int s3 = half;
+    if (sections) s3 = sections[0] + sections[1] + sections[2];
+    cs.resize((size_t)n_pos * half); sn.resize((size_t)n_pos * half);
+    for (int p = 0; p < n_pos; ++p)
+        for (int i = 0; i < half; ++i) {
+            const double inv = pow((double)theta, -2.0 * (double)i / (double)hd);
+            const double ang = (i < s3) ? (double)p * inv : 0.0;
+            cs[(size_t)p * half + i] = (float)cos(ang);
+            sn[(size_t)p * half + i] = (float)sin(ang);
+        }
+}
+
+static int init_tfm(q3tts_engine* e, Q3Tfm& t, int grp, int L, int d, int Hq, int Hkv, int hd, int F, int head_n, float theta,
+                    const int* sections, int n_ctx, int n_slots) {
+    t.L = L; t.d = d; t.Hq = Hq; t.Hkv = Hkv; t.hd = hd; t.F = F; t.nq = Hq * hd; t.nkv = Hkv * hd; t.nqkv = t.nq + 2 * t.nkv;
+    t.head_n = head_n; t.n_ctx = n_ctx; t.n_slots = n_slots;
+    const uint64_t seed = e->cfg.synth_seed;
+    const float ms = 0.02f / Q3_IH4_STD, ns = 0.05f / Q3_IH4_STD;
+    hipStream_t s = e->stream;
+    t.attn_norm.resize(L); t.ffn_norm.resize(L); t.qn.resize(L); t.kn.resize(L);
+    t.wqkv.resize(L); t.wo.resize(L); t.wgu.resize(L); t.wd.resize(L);
+    for (int l = 0; l < L; ++l) {
+        TRY(dalloc(e, &t.attn_norm[l], (size_t)d)); TRY(dalloc(e, &t.ffn_norm[l], (size_t)d));
+        TRY(dalloc(e, &t.qn[l], (size_t)hd)); TRY(dalloc(e, &t.kn[l], (size_t)hd));
+        q3_launch_fill_f32(t.attn_norm[l], d, seed, Q3_TID(grp, l, Q3W_ATTN_NORM), 1.0f, ns, 0, s);
+        q3_launch_fill_f32(t.ffn_norm[l], d, seed, Q3_TID(grp, l, Q3W_FFN_NORM), 1.0f, ns, 0, s);
+        q3_launch_fill_f32(t.qn[l], hd, seed, Q3_TID(grp, l, Q3W_QNORM), 1.0f, ns, 0, s);
+        q3_launch_fill_f32(t.kn[l], hd, seed, Q3_TID(grp, l, Q3W_KNORM), 1.0f, ns, 0, s);
+        TRY(dalloc(e, &t.wqkv[l], (size_t)t.nqkv * d / 8)); TRY(dalloc(e, &t.wo[l], (size_t)d * t.nq / 8));
+        TRY(dalloc(e, &t.wgu[l], (size_t)2 * F * d / 8)); TRY(dalloc(e, &t.wd[l], (size_t)d * F / 8));
+        Q3Fill f{}; f.seed = seed; f.scale = ms;
+        f.dst = t.wqkv[l]; f.N = t.nqkv; f.K = d; f.mode = 0;
+        f.row0 = 0; f.rows = t.nq; f.tid_a = Q3_TID(grp, l, Q3W_Q); q3_launch_fill_tiled(f, s);
+        f.row0 = t.nq; f.rows = t.nkv; f.tid_a = Q3_TID(grp, l, Q3W_K); q3_launch_fill_tiled(f, s);
+        f.row0 = t.nq + t.nkv; f.rows = t.nkv; f.tid_a = Q3_TID(grp, l, Q3W_V); q3_launch_fill_tiled(f, s);
+        f.dst = t.wo[l]; f.N = d; f.K = t.nq; f.row0 = 0; f.rows = d; f.tid_a = Q3_TID(grp, l, Q3W_O); q3_launch_fill_tiled(f, s);
+        f.dst = t.wgu[l]; f.N = 2 * F; f.K = d; f.mode = 1; f.tid_a = Q3_TID(grp, l, Q3W_GATE); f.tid_b = Q3_TID(grp, l, Q3W_UP);
+        q3_launch_fill_tiled(f, s);
+        f.dst = t.wd[l]; f.N = d; f.K = F; f.mode = 0; f.row0 = 0; f.rows = d; f.tid_a = Q3_TID(grp, l, Q3W_DOWN); q3_launch_fill_tiled(f, s);
+        t.weight_bytes += 2ull * ((size_t)t.nqkv * d + (size_t)d * t.nq + 3ull * F * d);
+    }
+    TRY(dalloc(e, &t.out_norm, (size_t)d));
+    q3_launch_fill_f32(t.out_norm, d, seed, Q3_TID(grp, Q3_L_MODEL, Q3WM_OUT_NORM), 1.0f, ns, 0, s);
+    TRY(dalloc(e, &t.head, (size_t)head_n * d / 8));
+    { Q3Fill f{}; f.seed = seed; f.scale = ms; f.dst = t.head; f.N = head_n; f.K = d; f.mode = 0; f.row0 = 0; f.rows = head_n;
+      f.tid_a = Q3_TID(grp, Q3_L_MODEL, Q3WM_HEAD); q3_launch_fill_tiled(f, s); }
+    t.layer_stride = (size_t)n_slots * Hkv * n_ctx * hd;
+    TRY(dalloc(e, &t.kc, t.layer_stride * L)); TRY(dalloc(e, &t.vc, t.layer_stride * L));
+    std::vector<float> cs, sn;
+    rope_tables(n_ctx, hd, theta, sections, cs, sn);
+    TRY(dalloc(e, &t.cs, cs.size())); TRY(dalloc(e, &t.sn, sn.size()));
+    Q3_HIP(e, hipMemcpyAsync(t.cs, cs.data(), cs.size() * 4, hipMemcpyHostToDevice, s));
+    Q3_HIP(e, hipMemcpyAsync(t.sn, sn.data(), sn.size() * 4, hipMemcpyHostToDevice, s));
+    Q3_HIP(e, hipStreamSynchronize(s));
+    return Q3TTS_OK;
+}
+static void free_tfm(Q3Tfm& t) {
+    for (auto p : t.attn_norm) hipFree(p); for (auto p : t.ffn_norm) hipFree(p); for (auto p : t.qn) hipFree(p);
+    for (auto p : t.kn) hipFree(p); for (auto p : t.wqkv) hipFree(p); for (auto p : t.wo) hipFree(p);
+    for (auto p : t.wgu) hipFree(p); for (auto p : t.wd) hipFree(p);
+    hipFree(t.out_norm); hipFree(t.head); hipFree(t.kc); hipFree(t.vc); hipFree(t.cs); hipFree(t.sn);
+}
+
+static int alloc_scratch(q3tts_engine* e, Q3Scratch& sc, int rows, int nqkv, int nq, int F) {
+    sc.rows = rows;
+    TRY(dalloc(e, &sc.qkv, (size_t)rows * nqkv)); TRY(dalloc(e, &sc.att, (size_t)rows * nq)); TRY(dalloc(e, &sc.h, (size_t)rows * F));
+    return Q3TTS_OK;
+}
+
+// K1-K8 of SURVEY.md §8a: one decoder block per iteration, 6 launches (norm+QKV, qk-prep, attention, O+residual,
+// norm+gate/up+SwiGLU, down+residual)
+static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, int rows, const int* row_pos, const int* row_slot, Q3Scratch& sc, hipStream_t s) {
+    const float eps = e->cfg.model.rms_eps;
+    for (int l = 0; l < t.L; ++l) {
+        Q3Gemm g{};
+        g.x = x; g.ldx = t.d; g.B = rows; g.w = t.wqkv[l]; g.K = t.d; g.N = t.nqkv; g.norm_w = t.attn_norm[l]; g.eps = eps;
+        g.y = sc.qkv; g.ldy = t.nqkv; g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);
+        Q3QkPrep qp{}; qp.qkv = sc.qkv; qp.ld = t.nqkv; qp.rows = rows; qp.Hq = t.Hq; qp.Hkv = t.Hkv; qp.hd = t.hd;
+        qp.qnw = t.qn[l]; qp.knw = t.kn[l]; qp.eps = eps; qp.cs = t.cs; qp.sn = t.sn;
+        qp.kc = t.kc + l * t.layer_stride; qp.vc = t.vc + l * t.layer_stride; qp.n_ctx = t.n_ctx; qp.row_pos = row_pos; qp.row_slot = row_slot;
+        q3_launch_qk_prep(qp, s);
+        Q3Attend at{}; at.qkv = sc.qkv; at.ld = t.nqkv; at.rows = rows; at.out = sc.att; at.ldo = t.nq; at.Hq = t.Hq; at.Hkv = t.Hkv; at.hd = t.hd;
+        at.kc = qp.kc; at.vc = qp.vc; at.n_ctx = t.n_ctx; at.row_pos = row_pos; at.row_slot = row_slot;
+        q3_launch_attend(at, s);
+        g = Q3Gemm{}; g.x = sc.att; g.ldx = t.nq; g.B = rows; g.w = t.wo[l]; g.K = t.nq; g.N = t.d; g.y = x; g.ldy = t.d; g.epi = Q3_EPI_RESID;
+        q3_launch_gemm(g, s);
+        g = Q3Gemm{}; g.x = x; g.ldx = t.d; g.B = rows; g.w = t.wgu[l]; g.K = t.d; g.N = 2 * t.F; g.norm_w = t.ffn_norm[l]; g.eps = eps;
+        g.y = sc.h; g.ldy = t.F; g.epi = Q3_EPI_SWIGLU; q3_launch_gemm(g, s);
+        g = Q3Gemm{}; g.x = sc.h; g.ldx = t.F; g.B = rows; g.w = t.wd[l]; g.K = t.F; g.N = t.d; g.y = x; g.ldy = t.d; g.epi = Q3_EPI_RESID;
+        q3_launch_gemm(g, s);
+    }
+}
+
+// one frame: src/tts/engine.rs:545-642 for all B slots
+static void record_frame(q3tts_engine* e, hipStream_t s) {
+    const q3tts_model_config& m = e->cfg.model;
+    const int B = e->B, ncb = m.n_codebooks, cbs = m.codebook_size, dp = m.p_d_model, de = m.d_embed;
+    const float eps = m.rms_eps;
+    Q3Sample sa{}; sa.logits = e->logits; sa.ld = m.t_vocab; sa.limit = m.sample_limit; sa.eos = m.eos_code; sa.slots = e->slots; sa.B = B;
+    sa.rng = e->rng; sa.codes = e->codes; sa.max_steps_cap = e->cfg.max_steps_cap; sa.ncb = ncb; sa.keys = e->keys;
+    q3_launch_sample(sa, s);
+    Q3PredInput pi{}; pi.xT = e->xT; pi.out_norm = e->T.out_norm; pi.eps = eps; pi.d = de; pi.codec0 = e->codec[0]; pi.codec0_rows = m.codec0_rows;
+    pi.slots = e->slots; pi.X = e->X; pi.fb = e->fb; pi.B = B;
+    q3_launch_pred_input(pi, s);
+    const size_t head_tile_stride = (size_t)(cbs / 16) * (dp / 32) * 64;  // uint4 per predictor head
+    for (int q = 0; q < ncb - 1; ++q) {  // pass q produces code_{q+1}
+        const int rows = q == 0 ? 2 * B : B;
+        if (q > 0) {
+            Q3PredNext pn{}; pn.keys = e->keys; pn.q = q; pn.ncb = ncb; pn.codec_q = e->codec[q]; pn.rows_q = m.codecq_rows; pn.d = de;
+            pn.slots = e->slots; pn.B = B; pn.codes = e->codes; pn.max_steps_cap = e->cfg.max_steps_cap; pn.fb = e->fb; pn.X = e->X;
+            pn.tts_pad = e->tts_pad; pn.xT = e->xT; pn.row_pos_t = e->row_pos_t;
+            q3_launch_pred_next(pn, s);
+        }
+        Q3Gemm g{}; g.x = e->X; g.ldx = de; g.B = rows; g.w = e->proj_w; g.K = de; g.N = dp; g.bias = e->proj_b; g.y = e->px; g.ldy = dp;
+        g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);  // H6: src/assets_manager.rs:383-399
+        run_layers(e, e->P, e->px, rows, q == 0 ? e->posA : e->pos_q + (size_t)q * B, q == 0 ? e->slotA : e->slot_id, e->sc_dec, s);
+        g = Q3Gemm{}; g.x = q == 0 ? e->px + dp : e->px; g.ldx = q == 0 ? 2 * dp : dp; g.B = B; g.w = e->P.head + head_tile_stride * q;
+        g.K = dp; g.N = cbs; g.norm_w = e->P.out_norm; g.eps = eps; g.keys = e->keys + (q + 1); g.key_stride = ncb; g.epi = Q3_EPI_ARGMAX;
+        q3_launch_gemm(g, s);
+    }
+    { Q3PredNext pn{}; pn.keys = e->keys; pn.q = ncb - 1; pn.ncb = ncb; pn.codec_q = e->codec[ncb - 1]; pn.rows_q = m.codecq_rows; pn.d = de;
+      pn.slots = e->slots; pn.B = B; pn.codes = e->codes; pn.max_steps_cap = e->cfg.max_steps_cap; pn.fb = e->fb; pn.X = e->X;
+      pn.tts_pad = e->tts_pad; pn.xT = e->xT; pn.row_pos_t = e->row_pos_t;
+      q3_launch_pred_next(pn, s); }
+    run_layers(e, e->T, e->xT, B, e->row_pos_t, e->slot_id, e->sc_dec, s);
+    Q3Gemm g{}; g.x = e->xT; g.ldx = m.t_d_model; g.B = B; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab; g.norm_w = e->T.out_norm; g.eps = eps;
+    g.y = e->logits; g.ldy = m.t_vocab; g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);
+}
+
+extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine** out) {
+    if (!cfg || !out) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "null argument");
+    std::string why;
+    if (validate(*cfg, why) != Q3TTS_OK) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, why);
+    if (cfg->weights_path) return q3_set_err(nullptr, Q3TTS_ERR_UNSUPPORTED, "weights_path: Q3TW loader not built in this round; use synthetic weights");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return q3_set_err(nullptr, Q3TTS_ERR_DEVICE, "no HIP device: libq3tts has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "device ordinal out of range");
+    q3tts_engine* e = new q3tts_engine();
+    e->cfg = *cfg; e->cfg.weights_path = nullptr;
+    e->max_steps = cfg->max_steps_cap < 512 ? cfg->max_steps_cap : 512;
+    auto fail = [&](int rc) { std::string m = e->err; q3tts_engine_destroy(e); g_err = m; return rc; };
+#define TRYC(x) do { int rc__ = (x); if (rc__ != Q3TTS_OK) return fail(rc__); } while (0)
+#define HIPC(call) do { hipError_t er__ = (call); if (er__ != hipSuccess) { q3_set_err(e, Q3TTS_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(er__)); return fail(Q3TTS_ERR_DEVICE); } } while (0)
+    HIPC(hipSetDevice(cfg->device));
+    HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIPC(hipStreamCreateWithFlags(&e->vstream, hipStreamNonBlocking));
+    HIPC(hipEventCreate(&e->ev0)); HIPC(hipEventCreate(&e->ev1)); HIPC(hipEventCreate(&e->ev2)); HIPC(hipEventCreate(&e->ev3));
+    const q3tts_model_config& m = cfg->model;
+    const int B = cfg->max_batch;
+    e->B = B;
+    hipStream_t s = e->stream;
+    TRYC(init_tfm(e, e->T, Q3G_TALKER, m.t_n_layer, m.t_d_model, m.t_n_head, m.t_n_kv_head, m.t_head_dim, m.t_d_ffn, m.t_vocab,
+                  m.t_rope_theta, m.t_mrope_sections, cfg->n_ctx, B));
+    TRYC(init_tfm(e, e->P, Q3G_PRED, m.p_n_layer, m.p_d_model, m.p_n_head, m.p_n_kv_head, m.p_head_dim, m.p_d_ffn,
+                  (m.n_codebooks - 1) * m.codebook_size, m.p_rope_theta, nullptr, 64, B));
+    // assets (F32 tables like qwen3_assets.gguf: src/assets_manager.rs:212-241; values bf16-representable)
+    const uint64_t seed = cfg->synth_seed;
+    const float es = 0.05f / Q3_IH4_STD;
+    TRYC(dalloc(e, &e->text, (size_t)m.text_vocab * m.d_embed));
+    q3_launch_fill_f32(e->text, (size_t)m.text_vocab * m.d_embed, seed, Q3_TID(Q3G_ASSET, 0, Q3WA_TEXT), 0.0f, es, 1, s);
+    e->codec.resize(m.n_codebooks);
+    for (int q = 0; q < m.n_codebooks; ++q) {
+        const size_t rows = q == 0 ? m.codec0_rows : m.codecq_rows;
+        TRYC(dalloc(e, &e->codec[q], rows * m.d_embed));
+        q3_launch_fill_f32(e->codec[q], rows * m.d_embed, seed, Q3_TID(Q3G_ASSET, 1 + q, 0), 0.0f, es, 1, s);
+    }
+    { void* cd = nullptr; HIPC(hipMalloc(&cd, sizeof(float*) * 16)); e->codec_dev = (const float**)cd; }
+    HIPC(hipMemcpyAsync((void*)e->codec_dev, e->codec.data(), sizeof(float*) * m.n_codebooks, hipMemcpyHostToDevice, s));
+    TRYC(dalloc(e, &e->proj_w, (size_t)m.p_d_model * m.d_embed / 8));
+    { Q3Fill f{}; f.seed = seed; f.scale = 0.02f / Q3_IH4_STD; f.dst = e->proj_w; f.N = m.p_d_model; f.K = m.d_embed; f.mode = 0; f.row0 = 0;
+      f.rows = m.p_d_model; f.tid_a = Q3_TID(Q3G_ASSET, 0, Q3WA_PROJ_W); q3_launch_fill_tiled(f, s); }
+    TRYC(dalloc(e, &e->proj_b, (size_t)m.p_d_model));
+    q3_launch_fill_f32(e->proj_b, m.p_d_model, seed, Q3_TID(Q3G_ASSET, 0, Q3WA_PROJ_B), 0.0f, 0.02f / Q3_IH4_STD, 0, s);
+    e->tts_pad = e->text + (size_t)m.tts_pad_id * m.d_embed;  // src/assets_manager.rs:244-249
+    // decode state
+    TRYC(dalloc(e, &e->slots, (size_t)B));
+    HIPC(hipHostMalloc((void**)&e->slots_host, sizeof(Q3Slot) * 2 * B, hipHostMallocDefault));
+    memset(e->slots_host, 0, sizeof(Q3Slot) * 2 * B);
+    TRYC(dalloc(e, &e->xT, (size_t)B * m.t_d_model)); TRYC(dalloc(e, &e->logits, (size_t)B * m.t_vocab));
+    TRYC(dalloc(e, &e->X, (size_t)2 * B * m.d_embed)); TRYC(dalloc(e, &e->fb, (size_t)B * m.d_embed));
+    TRYC(dalloc(e, &e->px, (size_t)2 * B * m.p_d_model)); TRYC(dalloc(e, &e->keys, (size_t)B * m.n_codebooks));
+    TRYC(dalloc(e, &e->codes, (size_t)B * cfg->max_steps_cap * m.n_codebooks)); TRYC(dalloc(e, &e->rng, (size_t)B * cfg->max_steps_cap));
+    TRYC(dalloc(e, &e->row_pos_t, (size_t)B)); TRYC(dalloc(e, &e->slot_id, (size_t)B));
+    TRYC(dalloc(e, &e->posA, (size_t)2 * B)); TRYC(dalloc(e, &e->slotA, (size_t)2 * B)); TRYC(dalloc(e, &e->pos_q, (size_t)m.n_codebooks * B));
+    {
+        std::vector<int> sid(B), pa(2 * B), sla(2 * B), pq((size_t)m.n_codebooks * B), rp(B, -1);
+        for (int b = 0; b < B; ++b) { sid[b] = b; pa[2 * b] = 0; pa[2 * b + 1] = 1; sla[2 * b] = sla[2 * b + 1] = b; }
+        for (int q = 0; q < m.n_codebooks; ++q) for (int b = 0; b < B; ++b) pq[(size_t)q * B + b] = q + 1;  // src/tts/engine.rs:604
+        HIPC(hipMemcpyAsync(e->slot_id, sid.data(), B * 4, hipMemcpyHostToDevice, s));
+        HIPC(hipMemcpyAsync(e->posA, pa.data(), 2 * B * 4, hipMemcpyHostToDevice, s));
+        HIPC(hipMemcpyAsync(e->slotA, sla.data(), 2 * B * 4, hipMemcpyHostToDevice, s));
+        HIPC(hipMemcpyAsync(e->pos_q, pq.data(), pq.size() * 4, hipMemcpyHostToDevice, s));
+        HIPC(hipMemcpyAsync(e->row_pos_t, rp.data(), B * 4, hipMemcpyHostToDevice, s));
+        HIPC(hipStreamSynchronize(s));
+    }
+    const int nqkv_max = std::max(e->T.nqkv, e->P.nqkv), nq_max = std::max(e->T.nq, e->P.nq), F_max = std::max(e->T.F, e->P.F);
+    TRYC(alloc_scratch(e, e->sc_dec, 2 * B, nqkv_max, nq_max, F_max));
+    TRYC(alloc_scratch(e, e->sc_pre, cfg->n_ctx, e->T.nqkv, e->T.nq, e->T.F));
+    TRYC(dalloc(e, &e->xp, (size_t)cfg->n_ctx * m.t_d_model));
+    TRYC(dalloc(e, &e->pf_pos, (size_t)cfg->n_ctx)); TRYC(dalloc(e, &e->pf_slot, (size_t)cfg->n_ctx));
+    { std::vector<int> pp(cfg->n_ctx); for (int i = 0; i < cfg->n_ctx; ++i) pp[i] = i;
+      HIPC(hipMemcpyAsync(e->pf_pos, pp.data(), pp.size() * 4, hipMemcpyHostToDevice, s)); HIPC(hipStreamSynchronize(s)); }
+    e->prow_cap = cfg->n_ctx;
+    TRYC(dalloc(e, &e->prow_dev, (size_t)e->prow_cap)); TRYC(dalloc(e, &e->spk_dev, (size_t)m.d_embed));
+    TRYC(dalloc(e, &e->refcodes_dev, (size_t)cfg->n_ctx * 16));
+    if (cfg->with_vocoder) TRYC(q3_voc_create(e));
+    // capture the frame step once; every later frame is a replay
+    HIPC(hipStreamSynchronize(s));
+    HIPC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    record_frame(e, s);
+    HIPC(hipStreamEndCapture(s, &e->graph));
+    HIPC(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
+    HIPC(hipStreamSynchronize(s));
+    // algorithmic bytes of one frame step, context term added per run
+    e->tm.algo_bytes_per_step = 0;
+#undef TRYC
+#undef HIPC
+    *out = e;
+    return Q3TTS_OK;
+}
+
+extern "C" void q3tts_engine_destroy(q3tts_engine* e) {
+    if (!e) return;
+    hipSetDevice(e->cfg.device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->vstream) hipStreamSynchronize(e->vstream);
+    if (e->voc) q3_voc_destroy(e);
+    if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
+    if (e->graph) hipGraphDestroy(e->graph);
+    free_tfm(e->T); free_tfm(e->P);
+    hipFree(e->text); for (auto p : e->codec) hipFree(p); hipFree((void*)e->codec_dev); hipFree(e->proj_w); hipFree(e->proj_b);
+    hipFree(e->slots); if (e->slots_host) hipHostFree(e->slots_host);
+    hipFree(e->xT); hipFree(e->logits); hipFree(e->X); hipFree(e->fb); hipFree(e->px); hipFree(e->keys); hipFree(e->codes); hipFree(e->rng);
+    hipFree(e->row_pos_t); hipFree(e->slot_id); hipFree(e->posA); hipFree(e->slotA); hipFree(e->pos_q);
+    hipFree(e->sc_dec.qkv); hipFree(e->sc_dec.att); hipFree(e->sc_dec.h); hipFree(e->sc_pre.qkv); hipFree(e->sc_pre.att); hipFree(e->sc_pre.h);
+    hipFree(e->xp); hipFree(e->pf_pos); hipFree(e->pf_slot); hipFree(e->prow_dev); hipFree(e->spk_dev); hipFree(e->refcodes_dev);
+    if (e->ev0) hipEventDestroy(e->ev0); if (e->ev1) hipEventDestroy(e->ev1); if (e->ev2) hipEventDestroy(e->ev2); if (e->ev3) hipEventDestroy(e->ev3);
+    if (e->stream) hipStreamDestroy(e->stream);
+    if (e->vstream) hipStreamDestroy(e->vstream);
+    delete e;
+}
+
+extern "C" int q3tts_set_sampler(q3tts_engine* e, float temperature, int32_t top_k, float top_p, int32_t has_seed, uint64_t seed) {
+    if (!e) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "null engine");
+    e->temperature = temperature; e->top_k = top_k; e->top_p = top_p; e->has_seed = has_seed; e->seed = seed;
+    return Q3TTS_OK;
+}
+extern "C" int q3tts_set_max_steps(q3tts_engine* e, int32_t n) {
+    if (!e) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "null engine");
+    if (n < 0 || n > e->cfg.max_steps_cap) return q3_set_err(e, Q3TTS_ERR_INVALID, "max_steps exceeds max_steps_cap");
+    e->max_steps = n;
+    return Q3TTS_OK;
+}
+extern "C" void q3tts_free(void* p) { free(p); }
+
+// ------------------------------------------------------------------------------------------------
+// H1 prompt builder: row list on the host (src/tts/prompt.rs:141-277, :28-118), gathers on the device
+// ------------------------------------------------------------------------------------------------
+enum { PAD = 2148, BOS = 2149, THINK = 2154, NOTHINK = 2155, THINK_BOS = 2156, THINK_EOS = 2157, CODEC_BOS_ICL = 2160 };
+enum { BOS_TOKEN = 151672, EOS_TOKEN = 151673 };
+
+static int build_prompt_dev(q3tts_engine* e, const q3tts_prompt_desc* p, float* out, int max_rows, int* n_out) {
+    const q3tts_model_config& m = e->cfg.model;
+    if (!p || (p->n_text > 0 && !p->text_ids)) return q3_set_err(e, Q3TTS_ERR_INVALID, "prompt: text_ids missing");
+    const int marker = m.tts_pad_id;
+    std::vector<Q3PromptRow> rows;
+    int ref_row0 = -1;
+    auto T1 = [&](int id) { rows.push_back({1, id, 0, 0}); };
+    auto MC = [&](int cid) { rows.push_back({1, marker, 2, cid}); };       // marker + codec0[cid]
+    auto TP = [&](int tid) { rows.push_back({1, tid, 2, PAD}); };          // text[tid] + codec0[PAD]
+    if (p->instruct_ids) {  // :153-169
+        T1(151644); T1(872); T1(198);
+        for (int i = 0; i < p->n_instruct; ++i) T1((int)p->instruct_ids[i]);
+        T1(151645); T1(198);
+    }
+    T1(151644); T1(77091); T1(198);  // :171-175
+    if (p->lang_id >= 0) { MC(THINK); MC(THINK_BOS); MC(p->lang_id); MC(THINK_EOS); }  // :180-191
+    else { MC(NOTHINK); MC(THINK_BOS); MC(THINK_EOS); }                                // :192-204
+    if (p->spk_id >= 0) MC(p->spk_id);                                                 // :207-214
+    else if (p->spk_emb) rows.push_back({1, marker, -1, 0});                           // :215-222
+    if (p->ref_codes) {  // build_clone_prompt :38-106
+        TP(BOS_TOKEN);
+        for (int i = 0; i < p->n_ref_text; ++i) TP((int)p->ref_text_ids[i]);
+        TP(EOS_TOKEN);
+        MC(CODEC_BOS_ICL);
+        ref_row0 = (int)rows.size();
+        for (int i = 0; i < p->n_ref_frames; ++i) rows.push_back({-2, 0, 0, 0});  // filled by the frame kernel
+        MC(PAD);
+    }
+    TP(BOS_TOKEN);                                             // :229-239
+    for (int i = 0; i < p->n_text; ++i) TP((int)p->text_ids[i]);  // :241-245
+    TP(EOS_TOKEN);                                             // :247-254
+    MC(BOS);                                                   // :256-264
+    const int n = (int)rows.size();
+    if (n > max_rows || n > e->prow_cap) return q3_set_err(e, Q3TTS_ERR_INVALID, "prompt longer than n_ctx");
+    hipStream_t s = e->stream;
+    Q3_HIP(e, hipMemcpyAsync(e->prow_dev, rows.data(), sizeof(Q3PromptRow) * n, hipMemcpyHostToDevice, s));
+    if (p->spk_emb) Q3_HIP(e, hipMemcpyAsync(e->spk_dev, p->spk_emb, (size_t)m.d_embed * 4, hipMemcpyHostToDevice, s));
+    Q3_HIP(e, hipStreamSynchronize(s));  // rows is a stack vector
+    q3_launch_prompt_rows(e->prow_dev, n, e->text, m.text_vocab, e->codec_dev, m.codec0_rows, m.codecq_rows, m.n_codebooks, e->spk_dev,
+                          m.d_embed, out, s);
+    if (ref_row0 >= 0 && p->n_ref_frames > 0) {
+        Q3_HIP(e, hipMemcpyAsync(e->refcodes_dev, p->ref_codes, (size_t)p->n_ref_frames * 16 * 4, hipMemcpyHostToDevice, s));
+        Q3_HIP(e, hipStreamSynchronize(s));
+        q3_launch_prompt_ref_frames(e->refcodes_dev, p->n_ref_frames, e->text + (size_t)marker * m.d_embed, e->codec_dev, m.codec0_rows,
+                                    m.codecq_rows, m.n_codebooks, m.d_embed, out + (size_t)ref_row0 * m.d_embed, s);
+    }
+    *n_out = n;
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_build_prompt(q3tts_engine* e, const q3tts_prompt_desc* p, float** out_embd, int32_t* out_n) {
+    if (!e || !p || !out_embd || !out_n) return q3_set_err(e, Q3TTS_ERR_INVALID, "null argument");
+    Q3_HIP(e, hipSetDevice(e->cfg.device));
+    int n = 0;
+    TRY(build_prompt_dev(e, p, e->xp, e->cfg.n_ctx, &n));
+    const size_t bytes = (size_t)n * e->cfg.model.d_embed * 4;
+    float* h = (float*)malloc(bytes);
+    if (!h) return q3_set_err(e, Q3TTS_ERR_OOM, "malloc");
+    hipError_t er = hipMemcpyAsync(h, e->xp, bytes, hipMemcpyDeviceToHost, e->stream);
+    if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
+    if (er != hipSuccess) { free(h); return q3_set_err(e, Q3TTS_ERR_DEVICE, hipGetErrorString(er)); }
+    *out_embd = h; *out_n = n;
+    return Q3TTS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// generation
+// ------------------------------------------------------------------------------------------------
+static uint64_t wall_seed() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+}
+
+// Talker prefill of one request into slot b (src/tts/engine.rs:455-462) + slot state
+static int admit(q3tts_engine* e, int b, const q3tts_request* r) {
+    const q3tts_model_config& m = e->cfg.model;
+    hipStream_t s = e->stream;
+    int n = 0;
+    if (r->prompt_embd) {
+        n = r->n_tok;
+        if (n <= 0 || n > e->cfg.n_ctx) return q3_set_err(e, Q3TTS_ERR_INVALID, "n_tok out of range");
+        Q3_HIP(e, hipMemcpyAsync(e->xp, r->prompt_embd, (size_t)n * m.d_embed * 4, hipMemcpyHostToDevice, s));
+    } else if (r->prompt) {
+        TRY(build_prompt_dev(e, r->prompt, e->xp, e->cfg.n_ctx, &n));
+    } else return q3_set_err(e, Q3TTS_ERR_INVALID, "request has neither prompt_embd nor prompt");
+    int max_steps = r->max_steps > 0 ? r->max_steps : e->max_steps;
+    if (max_steps > e->cfg.max_steps_cap) return q3_set_err(e, Q3TTS_ERR_INVALID, "max_steps exceeds max_steps_cap");
+    if (n + max_steps > e->cfg.n_ctx) return q3_set_err(e, Q3TTS_ERR_INVALID, "prompt + max_steps exceeds n_ctx");
+    Q3_HIP(e, hipMemsetD32Async((hipDeviceptr_t)e->pf_slot, b, n, s));
+    run_layers(e, e->T, e->xp, n, e->pf_pos, e->pf_slot, e->sc_pre, s);
+    q3_launch_copy_rows(e->xT + (size_t)b * m.t_d_model, m.t_d_model, e->xp + (size_t)(n - 1) * m.t_d_model, m.t_d_model, 1, m.t_d_model, s);
+    Q3Gemm g{}; g.x = e->xT + (size_t)b * m.t_d_model; g.ldx = m.t_d_model; g.B = 1; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab;
+    g.norm_w = e->T.out_norm; g.eps = m.rms_eps; g.y = e->logits + (size_t)b * m.t_vocab; g.ldy = m.t_vocab; g.epi = Q3_EPI_STORE;
+    q3_launch_gemm(g, s);
+    // sampler stream (src/tts/engine.rs:473-485)
+    float temperature = e->temperature, top_p = e->top_p; int top_k = e->top_k, has_seed = e->has_seed; uint64_t seed = e->seed;
+    if (!r->use_engine_sampler) { temperature = r->temperature; top_k = r->top_k; top_p = r->top_p; has_seed = r->has_seed; seed = r->seed; }
+    if (!has_seed) seed = wall_seed();
+    if (temperature > 0.0f) {
+        std::vector<float> draws(max_steps);
+        q3_stdrng_f32(seed, max_steps, draws.data());
+        Q3_HIP(e, hipMemcpyAsync(e->rng + (size_t)b * e->cfg.max_steps_cap, draws.data(), (size_t)max_steps * 4, hipMemcpyHostToDevice, s));
+        Q3_HIP(e, hipStreamSynchronize(s));
+    }
+    Q3Slot* st = e->slots_host + e->B + b;  // pinned staging half
+    memset(st, 0, sizeof(*st));
+    st->active = 1; st->cur_pos = n; st->n_frames = 0; st->max_steps = max_steps; st->min_frames = r->min_frames;
+    st->force_eos_at = r->force_eos_at; st->top_k = top_k; st->temperature = temperature; st->top_p = top_p;
+    st->rng_base = b * e->cfg.max_steps_cap;
+    Q3_HIP(e, hipMemcpyAsync(e->slots + b, st, sizeof(Q3Slot), hipMemcpyHostToDevice, s));
+    if (e->voc) TRY(q3_voc_reset(e, b));
+    return Q3TTS_OK;
+}
+
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct SlotRun { int req = -1; int voc_frames = 0; double t_first = 0; };
+
+static int finalize(q3tts_engine* e, int b, const q3tts_request* r, q3tts_result* o, const SlotRun& sr, double t0) {
+    const int ncb = e->cfg.model.n_codebooks;
+    const Q3Slot& st = e->slots_host[b];
+    o->n_frames = st.n_frames; o->hit_eos = st.hit_eos;
+    o->codes = (int32_t*)malloc(sizeof(int32_t) * (size_t)std::max(1, st.n_frames * ncb));
+    if (!o->codes) return q3_set_err(e, Q3TTS_ERR_OOM, "malloc");
+    if (st.n_frames > 0)
+        Q3_HIP(e, hipMemcpyAsync(o->codes, e->codes + (size_t)b * e->cfg.max_steps_cap * ncb, sizeof(int32_t) * (size_t)st.n_frames * ncb,
+                                 hipMemcpyDeviceToHost, e->stream));
+    o->sample_rate = e->cfg.vocoder.sample_rate;
+    if (r->want_pcm && e->voc) {
+        const int ns = q3_voc_samples(e, b);
+        o->n_samples = ns;
+        o->pcm = (float*)malloc(sizeof(float) * (size_t)std::max(1, ns));
+        if (!o->pcm) return q3_set_err(e, Q3TTS_ERR_OOM, "malloc");
+        Q3_HIP(e, hipStreamSynchronize(e->vstream));
+        if (ns > 0) Q3_HIP(e, hipMemcpyAsync(o->pcm, q3_voc_pcm(e, b), sizeof(float) * (size_t)ns, hipMemcpyDeviceToHost, e->stream));
+    }
+    Q3_HIP(e, hipStreamSynchronize(e->stream));
+    o->first_chunk_ms = sr.t_first > 0 ? (float)(sr.t_first - t0) : 0.0f;
+    o->total_ms = (float)(now_ms() - t0);
+    o->status = Q3TTS_OK;
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, int32_t n, q3tts_result* outs) {
+    if (!e || !reqs || !outs || n <= 0) return q3_set_err(e, Q3TTS_ERR_INVALID, "null/empty argument");
+    Q3_HIP(e, hipSetDevice(e->cfg.device));
+    for (int i = 0; i < n; ++i) { memset(&outs[i], 0, sizeof(outs[i])); outs[i].status = Q3TTS_ERR_STATE; }
+    for (int i = 0; i < n; ++i)
+        if (reqs[i].want_pcm && !e->voc) return q3_set_err(e, Q3TTS_ERR_STATE, "want_pcm on an engine created with with_vocoder = 0");
+    const int B = e->B, CH = 4;  // 4-frame chunks: src/tts/engine.rs:509-512
+    const int spf = e->voc ? q3_voc_samples_per_frame(e) : 0;
+    std::vector<SlotRun> run(B);
+    int next = 0, done = 0;
+    const double t0 = now_ms();
+    double dec_ms = 0, pre_ms = 0, voc_ms = 0;
+    long long steps = 0, ctx_tokens = 0;
+    hipStream_t s = e->stream;
+    while (done < n) {
+        bool admitted = false;
+        for (int b = 0; b < B && next < n; ++b)
+            if (run[b].req < 0) {
+                if (!admitted) Q3_HIP(e, hipEventRecord(e->ev0, s));
+                admitted = true;
+                int rc = admit(e, b, &reqs[next]);
+                if (rc != Q3TTS_OK) { outs[next].status = rc; ++next; ++done; --b; continue; }
+                run[b] = SlotRun{}; run[b].req = next++;
+            }
+        if (admitted) { Q3_HIP(e, hipEventRecord(e->ev1, s)); }
+        bool any = false;
+        for (int b = 0; b < B; ++b) any |= run[b].req >= 0;
+        if (!any) break;
+        Q3_HIP(e, hipEventRecord(e->ev2, s));
+        for (int i = 0; i < CH; ++i) Q3_HIP(e, hipGraphLaunch(e->graph_exec, s));
+        Q3_HIP(e, hipEventRecord(e->ev3, s));
+        Q3_HIP(e, hipMemcpyAsync(e->slots_host, e->slots, sizeof(Q3Slot) * B, hipMemcpyDeviceToHost, s));
+        Q3_HIP(e, hipStreamSynchronize(s));
+        float ms = 0;
+        if (admitted) { hipEventElapsedTime(&ms, e->ev0, e->ev1); pre_ms += ms; }
+        hipEventElapsedTime(&ms, e->ev2, e->ev3); dec_ms += ms; steps += CH;
+        for (int b = 0; b < B; ++b) if (run[b].req >= 0) ctx_tokens += (long long)e->slots_host[b].cur_pos * CH;
+        // H8: vocoder on chunks of 4 frames, flushed with is_last on completion (src/tts/engine.rs:507-541)
+        for (int b = 0; b < B; ++b) {
+            if (run[b].req < 0) continue;
+            const q3tts_request* r = &reqs[run[b].req];
+            const Q3Slot& st = e->slots_host[b];
+            if (r->want_pcm && e->voc) {
+                const double tv0 = now_ms();
+                while (st.n_frames - run[b].voc_frames >= 4) {
+                    TRY(q3_voc_decode(e, b, run[b].voc_frames, 4, 0, s));
+                    run[b].voc_frames += 4;
+                    if (run[b].t_first == 0) {  // first-chunk latency: PCM of the first chunk resident on the host
+                        Q3_HIP(e, hipStreamSynchronize(s));
+                        run[b].t_first = now_ms();
+                    }
+                }
+                if (!st.active && st.n_frames > run[b].voc_frames) {
+                    TRY(q3_voc_decode(e, b, run[b].voc_frames, st.n_frames - run[b].voc_frames, 1, s));
+                    run[b].voc_frames = st.n_frames;
+                    if (run[b].t_first == 0) { Q3_HIP(e, hipStreamSynchronize(s)); run[b].t_first = now_ms(); }
+                }
+                voc_ms += now_ms() - tv0;
+            }
+            if (!st.active) {
+                TRY(finalize(e, b, r, &outs[run[b].req], run[b], t0));
+                run[b].req = -1; ++done;
+            }
+        }
+        (void)spf;
+    }
+    e->tm.prefill_ms = (float)pre_ms; e->tm.decode_ms = (float)dec_ms; e->tm.vocoder_ms = (float)voc_ms;
+    e->tm.total_ms = (float)(now_ms() - t0); e->tm.frame_steps = steps; e->tm.frame_step_ms = steps ? (float)(dec_ms / steps) : 0.0f;
+    // bytes = 2*W_T + 15*2*W_P(layers) + 15*2*h + 16*2*pj + KV bytes of the live context + gathers
+    {
+        const q3tts_model_config& m = e->cfg.model;
+        const long long wt = (long long)e->T.weight_bytes;  // includes lm_head
+        const long long wp_layers = (long long)e->P.weight_bytes - 2ll * e->P.head_n * m.p_d_model;
+        const long long head1 = 2ll * m.codebook_size * m.p_d_model, pj = 2ll * m.p_d_model * m.d_embed;
+        const long long kv_per_tok = 2ll * m.t_n_layer * 2 * m.t_n_kv_head * m.t_head_dim;
+        const long long fixed = wt + (m.n_codebooks - 1) * (wp_layers + head1) + m.n_codebooks * pj;
+        e->tm.algo_bytes_per_step = fixed + (steps ? kv_per_tok * (ctx_tokens / steps) : 0);
+    }
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_generate(q3tts_engine* e, const q3tts_request* req, q3tts_result* out) {
+    int rc = q3tts_generate_batch(e, req, 1, out);
+    if (rc != Q3TTS_OK) return rc;
+    return out->status;
+}
+
+extern "C" void q3tts_result_free(q3tts_result* r) {
+    if (!r) return;
+    free(r->codes); free(r->pcm);
+    r->codes = nullptr; r->pcm = nullptr;
+}
+
+extern "C" int q3tts_get_timings(const q3tts_engine* e, q3tts_timings* out) {
+    if (!e || !out) return Q3TTS_ERR_INVALID;
+    *out = e->tm;
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_write_weights(q3tts_engine* e, const char* path) {
+    (void)path;
+    return q3_set_err(e, Q3TTS_ERR_UNSUPPORTED, "Q3TW writer not built in this round");
+}
+
+// ------------------------------------------------------------------------------------------------
+// streaming (H8): 4-frame chunks
+// ------------------------------------------------------------------------------------------------
+struct q3tts_stream {
+    q3tts_engine* e; q3tts_request req; int voc_frames = 0; bool finished = false; bool final_sent = false;
+    std::vector<float> chunk; double t0 = 0, t_first = 0;
+};
+
+extern "C" int q3tts_stream_begin(q3tts_engine* e, const q3tts_request* req, q3tts_stream** out) {
+    if (!e || !req || !out) return q3_set_err(e, Q3TTS_ERR_INVALID, "null argument");
+    if (!e->voc) return q3_set_err(e, Q3TTS_ERR_STATE, "streaming needs with_vocoder = 1");
+    Q3_HIP(e, hipSetDevice(e->cfg.device));
+    q3tts_stream* st = new q3tts_stream();
+    st->e = e; st->req = *req; st->t0 = now_ms();
+    int rc = admit(e, 0, req);
+    if (rc != Q3TTS_OK) { delete st; return rc; }
+    *out = st;
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_stream_poll(q3tts_stream* st, const float** chunk, int32_t* n_samples, int32_t* is_final) {
+    if (!st || !chunk || !n_samples || !is_final) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "null argument");
+    q3tts_engine* e = st->e;
+    *chunk = nullptr; *n_samples = 0; *is_final = 0;
+    if (st->final_sent) { *is_final = 1; return Q3TTS_OK; }
+    hipStream_t s = e->stream;
+    const int spf = q3_voc_samples_per_frame(e);
+    for (;;) {
+        const Q3Slot& sl = e->slots_host[0];
+        if (!st->finished) {
+            for (int i = 0; i < 4; ++i) Q3_HIP(e, hipGraphLaunch(e->graph_exec, s));
+            Q3_HIP(e, hipMemcpyAsync(e->slots_host, e->slots, sizeof(Q3Slot), hipMemcpyDeviceToHost, s));
+            Q3_HIP(e, hipStreamSynchronize(s));
+            if (!sl.active) st->finished = true;
+        }
+        int nf = 0, last = 0;
+        if (sl.n_frames - st->voc_frames >= 4) nf = 4;
+        else if (st->finished && sl.n_frames > st->voc_frames) { nf = sl.n_frames - st->voc_frames; last = 1; }
+        if (nf > 0) {
+            const int before = q3_voc_samples(e, 0);
+            TRY(q3_voc_decode(e, 0, st->voc_frames, nf, last, s));
+            st->voc_frames += nf;
+            const int after = q3_voc_samples(e, 0);
+            st->chunk.resize((size_t)std::max(1, after - before));
+            if (after > before)
+                Q3_HIP(e, hipMemcpyAsync(st->chunk.data(), q3_voc_pcm(e, 0) + before, sizeof(float) * (size_t)(after - before), hipMemcpyDeviceToHost, s));
+            Q3_HIP(e, hipStreamSynchronize(s));
+            if (st->t_first == 0) st->t_first = now_ms();
+            *chunk = st->chunk.data(); *n_samples = after - before;
+            if (st->finished && st->voc_frames >= sl.n_frames) { *is_final = 1; st->final_sent = true; }
+            (void)spf;
+            return Q3TTS_OK;
+        }
+        if (st->finished) { *is_final = 1; st->final_sent = true; return Q3TTS_OK; }
+    }
+}
+
+extern "C" int q3tts_stream_end(q3tts_stream* st, q3tts_result* out) {
+    if (!st) return Q3TTS_ERR_INVALID;
+    q3tts_engine* e = st->e;
+    int rc = Q3TTS_OK;
+    // make sure the slot is retired even if the caller stops early
+    Q3Slot* stage = e->slots_host + e->B;
+    memset(stage, 0, sizeof(Q3Slot));
+    hipMemcpyAsync(e->slots_host, e->slots, sizeof(Q3Slot), hipMemcpyDeviceToHost, e->stream);
+    hipStreamSynchronize(e->stream);
+    if (out) {
+        memset(out, 0, sizeof(*out));
+        SlotRun sr; sr.t_first = st->t_first;
+        q3tts_request r = st->req; r.want_pcm = 1;
+        rc = finalize(e, 0, &r, out, sr, st->t0);
+    }
+    hipMemcpyAsync(e->slots, stage, sizeof(Q3Slot), hipMemcpyHostToDevice, e->stream);
+    hipStreamSynchronize(e->stream);
+    delete st;
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel-level test hooks
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes + 64) == hipSuccess && hipMemset(p, 0, bytes + 64) == hipSuccess ? 0 : -1; }
+};
+#define HK(call) do { hipError_t er__ = (call); if (er__ != hipSuccess) return q3_set_err(nullptr, Q3TTS_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(er__)); } while (0)
+
+extern "C" int q3tts_k_gemm_exact(int32_t device, const float* x, int32_t B, int32_t K, const uint16_t* w, int32_t N, const float* norm_w,
+                                  float eps, const float* bias, int32_t epi, float* y, uint64_t* keys, int32_t iters, float* mean_ms) {
+    if (!x || !w || !y || B <= 0 || K % 256 || N % 16) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "gemm hook: bad shape");
+    if (epi == Q3_EPI_SWIGLU && (N % 32)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "swiglu needs N % 32 == 0");
+    HK(hipSetDevice(device));
+    const int F = N / 2;
+    const size_t ny = epi == Q3_EPI_SWIGLU ? (size_t)B * F : (size_t)B * N;
+    DevBuf dx, dw, dwt, dn, db, dy, dk;
+    if (dx.alloc((size_t)B * K * 4) || dw.alloc((size_t)N * K * 2) || dwt.alloc((size_t)N * K * 2) || dn.alloc((size_t)K * 4) ||
+        db.alloc((size_t)N * 4) || dy.alloc(ny * 4) || dk.alloc((size_t)B * 8))
+        return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
+    HK(hipMemcpy(dx.p, x, (size_t)B * K * 4, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dw.p, w, (size_t)N * K * 2, hipMemcpyHostToDevice));
+    if (norm_w) HK(hipMemcpy(dn.p, norm_w, (size_t)K * 4, hipMemcpyHostToDevice));
+    if (bias) HK(hipMemcpy(db.p, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+    if (epi == Q3_EPI_RESID) HK(hipMemcpy(dy.p, y, ny * 4, hipMemcpyHostToDevice));
+    Q3Fill f{}; f.dst = (uint4*)dwt.p; f.N = N; f.K = K;
+    if (epi == Q3_EPI_SWIGLU) { f.mode = 1; f.src_a = (const uint16_t*)dw.p; f.src_b = (const uint16_t*)dw.p + (size_t)F * K; }
+    else { f.mode = 0; f.row0 = 0; f.rows = N; f.src_a = (const uint16_t*)dw.p; }
+    q3_launch_fill_tiled(f, nullptr);
+    Q3Gemm g{}; g.x = (const float*)dx.p; g.ldx = K; g.B = B; g.w = (const uint4*)dwt.p; g.K = K; g.N = N;
+    g.norm_w = norm_w ? (const float*)dn.p : nullptr; g.eps = eps; g.bias = bias ? (const float*)db.p : nullptr;
+    g.y = (float*)dy.p; g.ldy = epi == Q3_EPI_SWIGLU ? F : N; g.keys = (unsigned long long*)dk.p; g.key_stride = 1; g.epi = epi;
+    q3_launch_gemm(g, nullptr);
+    HK(hipDeviceSynchronize());
+    if (epi == Q3_EPI_ARGMAX) {
+        if (keys) HK(hipMemcpy(keys, dk.p, (size_t)B * 8, hipMemcpyDeviceToHost));
+    } else HK(hipMemcpy(y, dy.p, ny * 4, hipMemcpyDeviceToHost));
+    if (iters > 0 && mean_ms) {
+        g.epi = epi == Q3_EPI_RESID ? Q3_EPI_STORE : epi;
+        hipEvent_t a, b; HK(hipEventCreate(&a)); HK(hipEventCreate(&b));
+        q3_launch_gemm(g, nullptr);
+        HK(hipEventRecord(a, nullptr));
+        for (int i = 0; i < iters; ++i) q3_launch_gemm(g, nullptr);
+        HK(hipEventRecord(b, nullptr)); HK(hipEventSynchronize(b));
+        float ms = 0; hipEventElapsedTime(&ms, a, b); *mean_ms = ms / iters;
+        hipEventDestroy(a); hipEventDestroy(b);
+    }
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_k_attention(int32_t device, const float* qkv, int32_t n_rows, int32_t pos0, int32_t Hq, int32_t Hkv, int32_t hd,
+                                 const float* qnw, const float* knw, float eps, float theta, const int32_t* sections, float* out) {
+    if (!qkv || !out || hd != 128 || n_rows <= 0 || Hq % Hkv) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "attention hook: bad shape");
+    HK(hipSetDevice(device));
+    const int n_ctx = ((pos0 + n_rows + 63) / 64) * 64, ld = (Hq + 2 * Hkv) * hd;
+    std::vector<float> cs, sn;
+    rope_tables(n_ctx, hd, theta, sections, cs, sn);
+    std::vector<int> rp(n_rows), rs(n_rows, 0);
+    for (int i = 0; i < n_rows; ++i) rp[i] = pos0 + i;
+    DevBuf dq, dout, dqn, dkn, dcs, dsn, dkc, dvc, drp, drs;
+    if (dq.alloc((size_t)n_rows * ld * 4) || dout.alloc((size_t)n_rows * Hq * hd * 4) || dqn.alloc(hd * 4) || dkn.alloc(hd * 4) ||
+        dcs.alloc(cs.size() * 4) || dsn.alloc(sn.size() * 4) || dkc.alloc((size_t)Hkv * n_ctx * hd * 2) || dvc.alloc((size_t)Hkv * n_ctx * hd * 2) ||
+        drp.alloc(n_rows * 4) || drs.alloc(n_rows * 4))
+        return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
+    HK(hipMemcpy(dq.p, qkv, (size_t)n_rows * ld * 4, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dqn.p, qnw, hd * 4, hipMemcpyHostToDevice)); HK(hipMemcpy(dkn.p, knw, hd * 4, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dcs.p, cs.data(), cs.size() * 4, hipMemcpyHostToDevice)); HK(hipMemcpy(dsn.p, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+    HK(hipMemcpy(drp.p, rp.data(), n_rows * 4, hipMemcpyHostToDevice)); HK(hipMemcpy(drs.p, rs.data(), n_rows * 4, hipMemcpyHostToDevice));
+    Q3QkPrep qp{}; qp.qkv = (float*)dq.p; qp.ld = ld; qp.rows = n_rows; qp.Hq = Hq; qp.Hkv = Hkv; qp.hd = hd; qp.qnw = (const float*)dqn.p;
+    qp.knw = (const float*)dkn.p; qp.eps = eps; qp.cs = (const float*)dcs.p; qp.sn = (const float*)dsn.p; qp.kc = (uint16_t*)dkc.p;
+    qp.vc = (uint16_t*)dvc.p; qp.n_ctx = n_ctx; qp.row_pos = (const int*)drp.p; qp.row_slot = (const int*)drs.p;
+    q3_launch_qk_prep(qp, nullptr);
+    Q3Attend at{}; at.qkv = (const float*)dq.p; at.ld = ld; at.rows = n_rows; at.out = (float*)dout.p; at.ldo = Hq * hd; at.Hq = Hq; at.Hkv = Hkv;
+    at.hd = hd; at.kc = (const uint16_t*)dkc.p; at.vc = (const uint16_t*)dvc.p; at.n_ctx = n_ctx; at.row_pos = qp.row_pos; at.row_slot = qp.row_slot;
+    q3_launch_attend(at, nullptr);
+    HK(hipDeviceSynchronize());
+    HK(hipMemcpy(out, dout.p, (size_t)n_rows * Hq * hd * 4, hipMemcpyDeviceToHost));
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_k_sample(int32_t device, const float* logits, int32_t n, int32_t ld, int32_t limit, float temperature, int32_t top_k,
+                              float top_p, const float* r, int32_t* out) {
+    if (!logits || !out || n <= 0 || limit <= 0 || limit > 4096 || limit > ld) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "sample hook: bad shape");
+    HK(hipSetDevice(device));
+    DevBuf dl, dr, dout;
+    if (dl.alloc((size_t)n * ld * 4) || dr.alloc((size_t)n * 4) || dout.alloc((size_t)n * 4)) return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
+    HK(hipMemcpy(dl.p, logits, (size_t)n * ld * 4, hipMemcpyHostToDevice));
+    if (r) HK(hipMemcpy(dr.p, r, (size_t)n * 4, hipMemcpyHostToDevice));
+    q3_launch_sample_rows((const float*)dl.p, n, ld, limit, temperature, top_k, top_p, r ? (const float*)dr.p : nullptr, (int*)dout.p, nullptr);
+    HK(hipDeviceSynchronize());
+    HK(hipMemcpy(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_k_talker_prefill(q3tts_engine* e, const float* embd, int32_t n_tok, float* hidden_out, float* logits_out) {
+    if (!e || !embd || n_tok <= 0) return q3_set_err(e, Q3TTS_ERR_INVALID, "null argument");
+    Q3_HIP(e, hipSetDevice(e->cfg.device));
+    q3tts_request r{}; r.prompt_embd = embd; r.n_tok = n_tok; r.use_engine_sampler = 0; r.temperature = 0; r.max_steps = 1;
+    TRY(admit(e, 0, &r));
+    const q3tts_model_config& m = e->cfg.model;
+    hipStream_t s = e->stream;
+    if (hidden_out) {
+        q3_launch_rmsnorm_rows(e->xT, m.t_d_model, e->T.out_norm, m.rms_eps, m.t_d_model, 1, e->X, m.t_d_model, s);
+        Q3_HIP(e, hipMemcpyAsync(hidden_out, e->X, (size_t)m.t_d_model * 4, hipMemcpyDeviceToHost, s));
+    }
+    if (logits_out) Q3_HIP(e, hipMemcpyAsync(logits_out, e->logits, (size_t)m.t_vocab * 4, hipMemcpyDeviceToHost, s));
+    Q3Slot* stage = e->slots_host + e->B; memset(stage, 0, sizeof(Q3Slot));
+    Q3_HIP(e, hipMemcpyAsync(e->slots, stage, sizeof(Q3Slot), hipMemcpyHostToDevice, s));  // retire the slot again
+    Q3_HIP(e, hipStreamSynchronize(s));
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_k_rng_f32(uint64_t seed, int32_t n, float* out) {
+    if (!out || n < 0) return Q3TTS_ERR_INVALID;
+    q3_stdrng_f32(seed, n, out);
+    return Q3TTS_OK;
+}

@@ -1,0 +1,590 @@
+// q3_kernels.hip — hand-written gfx950 (CDNA4) kernels of the Qwen3-TTS codec-token decoder.
+//
+// Numerics contract: every reduction has ONE canonical order that the CPU oracle restates.
+//  * GEMM: v_mfma_f32_16x16x4_f32 (f32 in / f32 accumulate) is bit-for-bit a k-ordered fmaf chain
+//    (measured: tools/probe_mfma.hip, 0/256 mismatches at K=2048), so the 8-slice / (t, kq) order below is exact.
+//  * norms / softmax: 64-lane butterflies (xor 32,16,8,4,2,1) over per-lane sequential partials.
+// Built with -ffp-contract=off: every fused multiply-add is an explicit fmaf.
+#include "q3_kernels.h"
+
+#define WAVE 64
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = v + __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Exact GEMM. Workgroup = 8 waves = the 8 canonical K-slices of one 16-column tile; RT row tiles of 16.
+// Weights stream HBM -> VGPR as 1 KiB contiguous wave-loads (read exactly once per launch per row chunk);
+// activations (f32, L2 resident) are loaded as A fragments; partials meet in LDS and are summed in order.
+// ---------------------------------------------------------------------------------------------------
+template <int RT, bool NORM>
+__global__ __launch_bounds__(512) void k_gemm(Q3Gemm g) {
+    __shared__ float red[8 * RT * 16 * 17];
+    __shared__ float sums[RT * 16 * 16];
+    __shared__ float rinv_s[RT * 16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nb = blockIdx.x, row0 = blockIdx.y * (RT * 16);
+    const int nrows = min(RT * 16, g.B - row0);
+    const int K = g.K;
+    if (NORM) {
+        for (int r = wave; r < nrows; r += 8) {
+            const float4* xr = (const float4*)(g.x + (size_t)(row0 + r) * g.ldx);
+            float acc = 0.0f;
+            for (int c = lane; c < (K >> 2); c += 64) {
+                float4 v = xr[c];
+                acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) rinv_s[r] = 1.0f / sqrtf(acc / (float)K + g.eps);
+        }
+        __syncthreads();
+    }
+    const int bps = K >> 8;  // 32-wide k-blocks per slice
+    const int kq = lane >> 4, li = lane & 15;
+    const uint4* wp = g.w + ((size_t)nb * (K >> 5) + (size_t)wave * bps) * 64 + lane;
+    const int koff = wave * (K >> 3) + kq * 8;
+    f32x4 acc[RT];
+    const float* xr[RT];
+    float ri[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        acc[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        int lr = r * 16 + li;
+        if (lr >= nrows) lr = nrows - 1;  // padding rows replicate the last row; their results are dropped
+        xr[r] = g.x + (size_t)(row0 + lr) * g.ldx + koff;
+        ri[r] = NORM ? rinv_s[lr] : 1.0f;
+    }
+    const float* nwp = NORM ? g.norm_w + koff : nullptr;
+#pragma unroll 4
+    for (int kb = 0; kb < bps; ++kb) {
+        const uint4 wv = wp[(size_t)kb * 64];
+        float b[8];
+        b[0] = q3_u2f(wv.x << 16); b[1] = q3_u2f(wv.x & 0xffff0000u);
+        b[2] = q3_u2f(wv.y << 16); b[3] = q3_u2f(wv.y & 0xffff0000u);
+        b[4] = q3_u2f(wv.z << 16); b[5] = q3_u2f(wv.z & 0xffff0000u);
+        b[6] = q3_u2f(wv.w << 16); b[7] = q3_u2f(wv.w & 0xffff0000u);
+        float nw[8];
+        if (NORM) {
+            const float4 n0 = *(const float4*)(nwp + kb * 32), n1 = *(const float4*)(nwp + kb * 32 + 4);
+            nw[0] = n0.x; nw[1] = n0.y; nw[2] = n0.z; nw[3] = n0.w; nw[4] = n1.x; nw[5] = n1.y; nw[6] = n1.z; nw[7] = n1.w;
+        }
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const float4 x0 = *(const float4*)(xr[r] + kb * 32), x1 = *(const float4*)(xr[r] + kb * 32 + 4);
+            float a[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            if (NORM) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) a[t] = (a[t] * ri[r]) * nw[t];
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], acc[r], 0, 0, 0);
+        }
+    }
+    // D layout: lane holds rows 4*(lane>>4)+j, column lane&15
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[((wave * RT + r) * 16 + 4 * kq + j) * 17 + li] = acc[r][j];
+    __syncthreads();
+    const int epi = g.epi;
+    for (int o = tid; o < RT * 256; o += 512) {
+        const int row = o >> 4, col = o & 15;
+        if (row >= nrows) continue;
+        float s = red[row * 17 + col];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) s = s + red[(w * RT * 16 + row) * 17 + col];
+        const size_t grow = (size_t)(row0 + row);
+        if (epi == Q3_EPI_STORE) {
+            if (g.bias) s = s + g.bias[nb * 16 + col];
+            g.y[grow * g.ldy + nb * 16 + col] = s;
+        } else if (epi == Q3_EPI_RESID) {
+            float* yp = g.y + grow * g.ldy + nb * 16 + col;
+            *yp = *yp + s;
+        } else {
+            sums[row * 16 + col] = s;
+        }
+    }
+    if (epi == Q3_EPI_SWIGLU) {  // tile = 8 gate columns then the 8 matching up columns
+        __syncthreads();
+        for (int o = tid; o < RT * 128; o += 512) {
+            const int row = o >> 3, col = o & 7;
+            if (row >= nrows) continue;
+            g.y[(size_t)(row0 + row) * g.ldy + nb * 8 + col] = q3_swiglu(sums[row * 16 + col], sums[row * 16 + 8 + col]);
+        }
+    } else if (epi == Q3_EPI_ARGMAX) {
+        __syncthreads();
+        if (tid < nrows) {
+            unsigned long long best = 0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const unsigned long long kk = q3_argmax_key(sums[tid * 16 + c], (uint32_t)(nb * 16 + c));
+                best = kk > best ? kk : best;
+            }
+            atomicMax(g.keys + (size_t)(row0 + tid) * g.key_stride, best);
+        }
+    }
+}
+
+void q3_launch_gemm(const Q3Gemm& g, hipStream_t s) {
+    const int rt = g.B <= 16 ? 1 : (g.B <= 32 ? 2 : 4);
+    dim3 grid(g.N / 16, (g.B + rt * 16 - 1) / (rt * 16));
+    const bool norm = g.norm_w != nullptr;
+#define L(RT_, NORM_) hipLaunchKernelGGL((k_gemm<RT_, NORM_>), grid, dim3(512), 0, s, g)
+    if (rt == 1) { if (norm) L(1, true); else L(1, false); }
+    else if (rt == 2) { if (norm) L(2, true); else L(2, false); }
+    else { if (norm) L(4, true); else L(4, false); }
+#undef L
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weight / table initialisation
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_fill_tiled(Q3Fill f, int nb0, int nb_count) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int kblocks = f.K >> 5;
+    const size_t total = (size_t)nb_count * kblocks * 64;
+    if (gid >= total) return;
+    const int lane = (int)(gid & 63);
+    const size_t t = gid >> 6;
+    const int kb = (int)(t % kblocks), nb = nb0 + (int)(t / kblocks);
+    const int n = nb * 16 + (lane & 15), k0 = kb * 32 + (lane >> 4) * 8;
+    uint32_t tid; int lr; const uint16_t* src;
+    if (f.mode == 0) { tid = f.tid_a; lr = n - f.row0; src = f.src_a; }
+    else {
+        const int tile = n >> 4, c = n & 15;
+        if (c < 8) { tid = f.tid_a; lr = tile * 8 + c; src = f.src_a; }
+        else { tid = f.tid_b; lr = tile * 8 + c - 8; src = f.src_b; }
+    }
+    uint16_t h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const size_t idx = (size_t)lr * f.K + k0 + e;
+        h[e] = src ? src[idx] : q3_bf16(q3_synth(f.seed, tid, idx, f.scale));
+    }
+    uint4 v;
+    v.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16); v.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+    v.z = (uint32_t)h[4] | ((uint32_t)h[5] << 16); v.w = (uint32_t)h[6] | ((uint32_t)h[7] << 16);
+    f.dst[((size_t)nb * kblocks + kb) * 64 + lane] = v;
+}
+void q3_launch_fill_tiled(const Q3Fill& f, hipStream_t s) {
+    int nb0, nbc;
+    if (f.mode == 0) { nb0 = f.row0 / 16; nbc = f.rows / 16; } else { nb0 = 0; nbc = f.N / 16; }
+    const size_t total = (size_t)nbc * (f.K >> 5) * 64;
+    hipLaunchKernelGGL(k_fill_tiled, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, f, nb0, nbc);
+}
+__global__ void k_fill_f32(float* dst, size_t n, uint64_t seed, uint32_t tid, float base, float scale, int rb) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float v = base + q3_synth(seed, tid, i, scale);
+        dst[i] = rb ? q3_round_bf16(v) : v;
+    }
+}
+void q3_launch_fill_f32(float* dst, size_t n, uint64_t seed, uint32_t tid, float base, float scale, int rb, hipStream_t s) {
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)blocks), dim3(256), 0, s, dst, n, seed, tid, base, scale, rb);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// q/k RMSNorm + RoPE + KV append. One wave per (row, head); hd == 128 (lanes 0..31 own 4 elements each).
+// K cache layout: per (slot, kv head) blocks of 64 keys, [block][hd/8 chunks][64 keys][8] bf16,
+// so that the score kernel reads 1 KiB contiguous per wave-load with one key per lane. V is row-major [t][hd].
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_qk_prep(Q3QkPrep a) {
+    const int row = blockIdx.x, hx = blockIdx.y, lane = threadIdx.x;
+    const int pos = a.row_pos[row];
+    if (pos < 0) return;
+    const int slot = a.row_slot[row];
+    const int hd = a.hd, half = hd >> 1, nl = hd >> 2;  // nl lanes hold data
+    const bool isq = hx < a.Hq;
+    const int g = hx - a.Hq;
+    float* src = a.qkv + (size_t)row * a.ld + (size_t)(isq ? hx : a.Hq + g) * hd;
+    const float* nw = isq ? a.qnw : a.knw;
+    float4 v = (float4){0.f, 0.f, 0.f, 0.f};
+    if (lane < nl) v = ((const float4*)src)[lane];
+    float acc = 0.0f;
+    acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+    acc = wave_sum(acc);
+    const float rinv = 1.0f / sqrtf(acc / (float)hd + a.eps);
+    float4 w4 = (float4){0.f, 0.f, 0.f, 0.f};
+    if (lane < nl) w4 = ((const float4*)nw)[lane];
+    float y[4] = {(v.x * rinv) * w4.x, (v.y * rinv) * w4.y, (v.z * rinv) * w4.z, (v.w * rinv) * w4.w};
+    // RoPE (NeoX pairing i <-> i + hd/2): lanes [0, nl/2) hold the first halves, partner lane = lane ^ (nl/2)
+    const int hl = nl >> 1;
+    float o[4];
+    {
+        const int i0 = 4 * (lane & (hl - 1));
+        float4 c4 = (float4){1.f, 1.f, 1.f, 1.f}, s4 = (float4){0.f, 0.f, 0.f, 0.f};
+        if (lane < nl) { c4 = *(const float4*)(a.cs + (size_t)pos * half + i0); s4 = *(const float4*)(a.sn + (size_t)pos * half + i0); }
+        const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float other = __shfl_xor(y[e], hl);
+            if (lane < hl) o[e] = fmaf(-other, ss[e], y[e] * cc[e]);   // x_i*c - x_{i+half}*s
+            else o[e] = fmaf(other, ss[e], y[e] * cc[e]);              // x_{i+half}*c + x_i*s
+        }
+    }
+    if (lane >= nl) return;
+    if (isq) {
+        ((float4*)src)[lane] = (float4){o[0], o[1], o[2], o[3]};
+    } else {
+        const size_t hb = ((size_t)slot * a.Hkv + g) * a.n_ctx;
+        const int blk = pos >> 6, kl = pos & 63, c = lane >> 1, e0 = 4 * (lane & 1);
+        uint2 kk;
+        kk.x = (uint32_t)q3_bf16(o[0]) | ((uint32_t)q3_bf16(o[1]) << 16);
+        kk.y = (uint32_t)q3_bf16(o[2]) | ((uint32_t)q3_bf16(o[3]) << 16);
+        *(uint2*)(a.kc + hb * hd + ((size_t)(blk * (hd >> 3) + c) * 64 + kl) * 8 + e0) = kk;
+        const float4 vv = ((const float4*)(a.qkv + (size_t)row * a.ld + (size_t)(a.Hq + a.Hkv + g) * hd))[lane];
+        uint2 vk;
+        vk.x = (uint32_t)q3_bf16(vv.x) | ((uint32_t)q3_bf16(vv.y) << 16);
+        vk.y = (uint32_t)q3_bf16(vv.z) | ((uint32_t)q3_bf16(vv.w) << 16);
+        *(uint2*)(a.vc + (hb + pos) * hd + 4 * lane) = vk;
+    }
+}
+void q3_launch_qk_prep(const Q3QkPrep& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_qk_prep, dim3(a.rows, a.Hq + a.Hkv), dim3(64), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Attention over the cache, canonical order of DESIGN.md §4.4. Workgroup (kv head g, row): 4 waves per query
+// head of the GQA group. Scores: one key per lane (256 virtual lanes = 4 waves), dot over d ascending.
+// PV: 16 key-partials (u = t mod 16: wave u/4, lane group u%4), 16 lanes x 8 dims per key.
+// ---------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int g = blockIdx.x, row = blockIdx.y;
+    const int pos = a.row_pos[row];
+    if (pos < 0) return;
+    const int slot = a.row_slot[row];
+    const int T = pos + 1, Tcap = a.n_ctx, hd = a.hd, nch = hd >> 3;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hh = wave >> 2, sw = wave & 3;
+    float* p_all = smem;                      // [R][Tcap]
+    float* qh = p_all + (size_t)R * Tcap;     // [R][hd]
+    float* ow = qh + R * hd;                  // [R][4][hd]
+    float* lw = ow + R * 4 * hd;              // [R][4]
+    float* mw = lw + R * 4;                   // [R][4]
+    for (int i = tid; i < R * hd; i += R * 256) qh[i] = a.qkv[(size_t)row * a.ld + (size_t)g * R * hd + i];
+    __syncthreads();
+    const size_t hb = ((size_t)slot * a.Hkv + g) * a.n_ctx;
+    const uint16_t* kb = a.kc + hb * hd;
+    const uint16_t* vb = a.vc + hb * hd;
+    const float scale = 1.0f / sqrtf((float)hd);
+    float* p = p_all + (size_t)hh * Tcap;
+    const float* q = qh + hh * hd;
+    float mloc = -INFINITY;
+    for (int blk = sw; blk * 64 < T; blk += 4) {
+        const int t = blk * 64 + lane;
+        const uint4* kp = (const uint4*)(kb + (size_t)blk * 64 * hd) + lane;
+        float s = 0.0f;
+        for (int c = 0; c < nch; ++c) {
+            const uint4 kv = kp[c * 64];
+            const float* qc = q + c * 8;
+            s = fmaf(qc[0], q3_u2f(kv.x << 16), s); s = fmaf(qc[1], q3_u2f(kv.x & 0xffff0000u), s);
+            s = fmaf(qc[2], q3_u2f(kv.y << 16), s); s = fmaf(qc[3], q3_u2f(kv.y & 0xffff0000u), s);
+            s = fmaf(qc[4], q3_u2f(kv.z << 16), s); s = fmaf(qc[5], q3_u2f(kv.z & 0xffff0000u), s);
+            s = fmaf(qc[6], q3_u2f(kv.w << 16), s); s = fmaf(qc[7], q3_u2f(kv.w & 0xffff0000u), s);
+        }
+        s = s * scale;
+        if (t < T) { p[t] = s; mloc = fmaxf(mloc, s); }
+    }
+    mloc = wave_max(mloc);
+    if (lane == 0) mw[hh * 4 + sw] = mloc;
+    __syncthreads();
+    const float m = fmaxf(fmaxf(mw[hh * 4], mw[hh * 4 + 1]), fmaxf(mw[hh * 4 + 2], mw[hh * 4 + 3]));
+    float lsum = 0.0f;
+    for (int blk = sw; blk * 64 < T; blk += 4) {
+        const int t = blk * 64 + lane;
+        if (t < T) { const float e = q3_expf(p[t] - m); p[t] = e; lsum += e; }
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) lw[hh * 4 + sw] = lsum;
+    __syncthreads();
+    const int kg = lane >> 4, dl = lane & 15;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.0f;
+    for (int t = 4 * sw + kg; t < T; t += 16) {
+        const uint4 vv = *(const uint4*)(vb + (size_t)t * hd + dl * 8);
+        const float pt = p[t];
+        o[0] = fmaf(pt, q3_u2f(vv.x << 16), o[0]); o[1] = fmaf(pt, q3_u2f(vv.x & 0xffff0000u), o[1]);
+        o[2] = fmaf(pt, q3_u2f(vv.y << 16), o[2]); o[3] = fmaf(pt, q3_u2f(vv.y & 0xffff0000u), o[3]);
+        o[4] = fmaf(pt, q3_u2f(vv.z << 16), o[4]); o[5] = fmaf(pt, q3_u2f(vv.z & 0xffff0000u), o[5]);
+        o[6] = fmaf(pt, q3_u2f(vv.w << 16), o[6]); o[7] = fmaf(pt, q3_u2f(vv.w & 0xffff0000u), o[7]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        o[e] = o[e] + __shfl_xor(o[e], 16);
+        o[e] = o[e] + __shfl_xor(o[e], 32);
+    }
+    if (kg == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ow[(hh * 4 + sw) * hd + dl * 8 + e] = o[e];
+    }
+    __syncthreads();
+    for (int i = tid; i < R * hd; i += R * 256) {
+        const int h2 = i / hd, d = i - h2 * hd;
+        const float r0 = ow[(h2 * 4 + 0) * hd + d], r1 = ow[(h2 * 4 + 1) * hd + d], r2 = ow[(h2 * 4 + 2) * hd + d],
+                    r3 = ow[(h2 * 4 + 3) * hd + d];
+        const float ov = ((r0 + r1) + r2) + r3;
+        const float l = ((lw[h2 * 4] + lw[h2 * 4 + 1]) + lw[h2 * 4 + 2]) + lw[h2 * 4 + 3];
+        a.out[(size_t)row * a.ldo + (size_t)(g * R + h2) * hd + d] = ov / l;
+    }
+}
+void q3_launch_attend(const Q3Attend& a, hipStream_t s) {
+    const int R = a.Hq / a.Hkv;
+    const size_t lds = ((size_t)R * a.n_ctx + R * a.hd + R * 4 * a.hd + R * 8) * sizeof(float);
+    dim3 grid(a.Hkv, a.rows);
+    if (R == 1) hipLaunchKernelGGL((k_attend<1>), grid, dim3(256), lds, s, a);
+    else if (R == 2) hipLaunchKernelGGL((k_attend<2>), grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((k_attend<4>), grid, dim3(1024), lds, s, a);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Sampler (H4: src/models/llama/mod.rs:666-772). 256 threads; keys sorted by (logit desc, index asc) which is
+// what the reference's stable descending sort of an index-ordered list produces.
+// ---------------------------------------------------------------------------------------------------
+#define SAMP_MAX 4096
+__device__ int sample_row(const float* logits, int limit, float temperature, int top_k_i, float top_p, float r,
+                          unsigned long long* keys, float* probs) {
+    const int tid = threadIdx.x;
+    __shared__ unsigned long long wbest[4];
+    if (temperature <= 0.0f) {  // :690-701
+        unsigned long long best = 0;
+        for (int i = tid; i < limit; i += 256) { const unsigned long long k = q3_argmax_key(logits[i], (uint32_t)i); best = k > best ? k : best; }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(best, m); best = o > best ? o : best; }
+        if ((tid & 63) == 0) wbest[tid >> 6] = best;
+        __syncthreads();
+        unsigned long long b = wbest[0];
+        for (int w = 1; w < 4; ++w) b = wbest[w] > b ? wbest[w] : b;
+        __syncthreads();
+        return q3_argmax_idx(b);
+    }
+    int NP = 64;
+    while (NP < limit) NP <<= 1;
+    for (int i = tid; i < NP; i += 256) keys[i] = i < limit ? q3_argmax_key(logits[i], (uint32_t)i) : 0ull;
+    __syncthreads();
+    for (int k = 2; k <= NP; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < NP; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long x = keys[i], y = keys[ixj];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (x < y) : (x > y)) { keys[i] = y; keys[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    __shared__ int result;
+    if (tid == 0) {
+        int n = limit;
+        const size_t top_k = (size_t)(long long)top_k_i;                 // `top_k as usize` :646
+        if (top_k > 0 && top_k < (size_t)n) n = (int)top_k;              // :711-713
+        const float max_logit = n > 0 ? q3_key_value(keys[0]) : 0.0f;    // :716
+        float sum = 0.0f;
+        for (int i = 0; i < n; ++i) { const float e = q3_expf((q3_key_value(keys[i]) - max_logit) / temperature); probs[i] = e; sum += e; }
+        if (sum > 0.0f) for (int i = 0; i < n; ++i) probs[i] /= sum;     // :726-731
+        if (top_p < 1.0f) {                                              // :734-753
+            float cum = 0.0f; int cutoff = n;
+            for (int i = 0; i < n; ++i) { cum += probs[i]; if (cum >= top_p) { cutoff = i + 1; break; } }
+            n = cutoff;
+            float ns = 0.0f;
+            for (int i = 0; i < n; ++i) ns += probs[i];
+            if (ns > 0.0f) for (int i = 0; i < n; ++i) probs[i] /= ns;
+        }
+        float cum = 0.0f; int res = -1;                                  // :756-764
+        for (int i = 0; i < n; ++i) { cum += probs[i]; if (r < cum) { res = q3_argmax_idx(keys[i]); break; } }
+        if (res < 0) res = n > 0 ? q3_argmax_idx(keys[0]) : 0;           // :767-770
+        result = res;
+    }
+    __syncthreads();
+    const int res = result;
+    __syncthreads();
+    return res;
+}
+
+__global__ __launch_bounds__(256) void k_sample(Q3Sample a) {
+    __shared__ unsigned long long keys[SAMP_MAX];
+    __shared__ float probs[SAMP_MAX];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    Q3Slot* sl = a.slots + b;
+    if (!sl->active) return;
+    if (tid < a.ncb) a.keys[(size_t)b * a.ncb + tid] = 0ull;
+    const int step = sl->n_frames;
+    if (step >= sl->max_steps) {  // loop bound: src/tts/engine.rs:545
+        __syncthreads();
+        if (tid == 0) sl->active = 0;
+        return;
+    }
+    float* lg = a.logits + (size_t)b * a.ld;
+    int code0;
+    if (sl->force_eos_at >= 0 && step == sl->force_eos_at) code0 = a.eos;
+    else {
+        if (step < sl->min_frames && a.eos < a.limit) { if (tid == 0) lg[a.eos] = -INFINITY; }
+        __syncthreads();
+        const float temperature = sl->temperature;
+        const float r = temperature > 0.0f ? a.rng[sl->rng_base + step] : 0.0f;
+        code0 = sample_row(lg, a.limit, temperature, sl->top_k, sl->top_p, r, keys, probs);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (code0 == a.eos) { sl->hit_eos = 1; sl->active = 0; }  // :558-561
+        else { a.codes[((size_t)b * a.max_steps_cap + step) * a.ncb] = code0; sl->code0 = code0; }
+    }
+}
+void q3_launch_sample(const Q3Sample& a, hipStream_t s) { hipLaunchKernelGGL(k_sample, dim3(a.B), dim3(256), 0, s, a); }
+
+__global__ __launch_bounds__(256) void k_sample_rows(const float* logits, int ld, int limit, float temperature, int top_k,
+                                                     float top_p, const float* r, int* out) {
+    __shared__ unsigned long long keys[SAMP_MAX];
+    __shared__ float probs[SAMP_MAX];
+    const int b = blockIdx.x;
+    const int id = sample_row(logits + (size_t)b * ld, limit, temperature, top_k, top_p, r ? r[b] : 0.0f, keys, probs);
+    if (threadIdx.x == 0) out[b] = id;
+}
+void q3_launch_sample_rows(const float* logits, int n, int ld, int limit, float temperature, int top_k, float top_p,
+                           const float* r, int* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_sample_rows, dim3(n), dim3(256), 0, s, logits, ld, limit, temperature, top_k, top_p, r, out);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Predictor glue (H6/H7: src/tts/engine.rs:565-631)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pred_input(Q3PredInput a) {
+    __shared__ float rinv_s;
+    const int b = blockIdx.x, tid = threadIdx.x, d = a.d;
+    const Q3Slot* sl = a.slots + b;
+    if (!sl->active) return;
+    const float* x = a.xT + (size_t)b * d;
+    if (tid < 64) {
+        float acc = 0.0f;
+        for (int c = tid; c < (d >> 2); c += 64) {
+            const float4 v = ((const float4*)x)[c];
+            acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+        }
+        acc = wave_sum(acc);
+        if (tid == 0) rinv_s = 1.0f / sqrtf(acc / (float)d + a.eps);
+    }
+    __syncthreads();
+    const float rinv = rinv_s;
+    const int code0 = sl->code0;
+    const bool ok = code0 >= 0 && code0 < a.codec0_rows;  // OOB rows embed as zeros: src/assets_manager.rs:419-437
+    const float* e = a.codec0 + (size_t)(ok ? code0 : 0) * d;
+    for (int i = tid; i < d; i += 256) {
+        a.X[(size_t)(2 * b) * d + i] = (x[i] * rinv) * a.out_norm[i];
+        const float ev = ok ? e[i] : 0.0f;
+        a.X[(size_t)(2 * b + 1) * d + i] = ev;
+        a.fb[(size_t)b * d + i] = 0.0f + ev;
+    }
+}
+void q3_launch_pred_input(const Q3PredInput& a, hipStream_t s) { hipLaunchKernelGGL(k_pred_input, dim3(a.B), dim3(256), 0, s, a); }
+
+__global__ __launch_bounds__(256) void k_pred_next(Q3PredNext a) {
+    const int b = blockIdx.x, tid = threadIdx.x, d = a.d;
+    Q3Slot* sl = a.slots + b;
+    const bool last = a.q == a.ncb - 1;
+    if (!sl->active) {
+        if (last && tid == 0) a.row_pos_t[b] = -1;
+        return;
+    }
+    const int code = q3_argmax_idx(a.keys[(size_t)b * a.ncb + a.q]);
+    const bool ok = code >= 0 && code < a.rows_q;
+    const float* e = a.codec_q + (size_t)(ok ? code : 0) * d;
+    const int frame = sl->n_frames;
+    if (tid == 0) a.codes[((size_t)b * a.max_steps_cap + frame) * a.ncb + a.q] = code;
+    for (int i = tid; i < d; i += 256) {
+        const float ev = ok ? e[i] : 0.0f;
+        float f = a.fb[(size_t)b * d + i] + ev;
+        if (!last) { a.X[(size_t)b * d + i] = ev; a.fb[(size_t)b * d + i] = f; }
+        else { f = f + a.tts_pad[i]; a.xT[(size_t)b * d + i] = f; }
+    }
+    if (last) {
+        __syncthreads();
+        if (tid == 0) { a.row_pos_t[b] = sl->cur_pos; sl->cur_pos = sl->cur_pos + 1; sl->n_frames = frame + 1; }
+    }
+}
+void q3_launch_pred_next(const Q3PredNext& a, hipStream_t s) { hipLaunchKernelGGL(k_pred_next, dim3(a.B), dim3(256), 0, s, a); }
+
+// ---------------------------------------------------------------------------------------------------
+// Prompt builder (H1: src/tts/prompt.rs:141-277)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float prompt_elem(int kind, int id, int i, const float* text, int text_vocab,
+                                             const float* const* codec, int codec0_rows, int codecq_rows, int ncb,
+                                             const float* spk, int d) {
+    if (kind == 1) {  // src/assets_manager.rs:444-460
+        if (id >= 0 && id < text_vocab) return text[(size_t)id * d + i];
+        return fmodf((float)((unsigned long long)id * 17ull + (unsigned long long)i), 2.0f) - 1.0f;
+    }
+    if (kind >= 2) {  // src/assets_manager.rs:419-437
+        const int q = kind - 2;
+        const int rows = q == 0 ? codec0_rows : codecq_rows;
+        if (id < 0) id = 0;
+        if (q < ncb && id < rows) return codec[q][(size_t)id * d + i];
+        return 0.0f;
+    }
+    if (kind == -1) return spk[i];
+    return 0.0f;
+}
+__global__ void k_prompt_rows(const Q3PromptRow* rows, const float* text, int text_vocab, const float* const* codec,
+                              int codec0_rows, int codecq_rows, int ncb, const float* spk, int d, float* out) {
+    const Q3PromptRow r = rows[blockIdx.x];
+    for (int i = threadIdx.x; i < d; i += blockDim.x) {
+        const float a = prompt_elem(r.kindA, r.idA, i, text, text_vocab, codec, codec0_rows, codecq_rows, ncb, spk, d);
+        float v = a;
+        if (r.kindB != 0) v = a + prompt_elem(r.kindB, r.idB, i, text, text_vocab, codec, codec0_rows, codecq_rows, ncb, spk, d);
+        out[(size_t)blockIdx.x * d + i] = v;
+    }
+}
+void q3_launch_prompt_rows(const Q3PromptRow* rows, int n, const float* text, int text_vocab, const float* const* codec,
+                           int codec0_rows, int codecq_rows, int ncb, const float* spk, int d, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_prompt_rows, dim3(n), dim3(256), 0, s, rows, text, text_vocab, codec, codec0_rows, codecq_rows, ncb, spk, d, out);
+}
+__global__ void k_prompt_ref_frames(const int* codes, const float* marker, const float* const* codec, int codec0_rows,
+                                    int codecq_rows, int ncb, int d, float* out) {
+    const int f = blockIdx.x;
+    for (int i = threadIdx.x; i < d; i += blockDim.x) {
+        float sum = 0.0f;
+        for (int q = 0; q < 16; ++q)
+            sum += prompt_elem(2 + q, codes[f * 16 + q], i, nullptr, 0, codec, codec0_rows, codecq_rows, ncb, nullptr, d);
+        out[(size_t)f * d + i] = marker[i] + sum;
+    }
+}
+void q3_launch_prompt_ref_frames(const int* codes, int n_frames, const float* marker, const float* const* codec,
+                                 int codec0_rows, int codecq_rows, int ncb, int d, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_prompt_ref_frames, dim3(n_frames), dim3(256), 0, s, codes, marker, codec, codec0_rows, codecq_rows, ncb, d, out);
+}
+
+__global__ void k_copy_rows(float* dst, int ldd, const float* src, int lds, int cols) {
+    const int r = blockIdx.x;
+    for (int i = threadIdx.x; i < cols; i += blockDim.x) dst[(size_t)r * ldd + i] = src[(size_t)r * lds + i];
+}
+void q3_launch_copy_rows(float* dst, int ldd, const float* src, int lds, int rows, int cols, hipStream_t s) {
+    hipLaunchKernelGGL(k_copy_rows, dim3(rows), dim3(256), 0, s, dst, ldd, src, lds, cols);
+}
+
+__global__ __launch_bounds__(64) void k_rmsnorm_rows(const float* x, int ldx, const float* w, float eps, int d, float* out, int ldo) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const float* xr = x + (size_t)r * ldx;
+    float acc = 0.0f;
+    for (int c = lane; c < (d >> 2); c += 64) {
+        const float4 v = ((const float4*)xr)[c];
+        acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+    }
+    acc = wave_sum(acc);
+    const float rinv = 1.0f / sqrtf(acc / (float)d + eps);
+    for (int i = lane; i < d; i += 64) out[(size_t)r * ldo + i] = (xr[i] * rinv) * w[i];
+}
+void q3_launch_rmsnorm_rows(const float* x, int ldx, const float* w, float eps, int d, int rows, float* out, int ldo, hipStream_t s) {
+    hipLaunchKernelGGL(k_rmsnorm_rows, dim3(rows), dim3(64), 0, s, x, ldx, w, eps, d, out, ldo);
+}

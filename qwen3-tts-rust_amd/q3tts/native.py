@@ -1,0 +1,194 @@
+"""Thin object wrapper over the C ABI (include/q3tts.h). No arithmetic happens in Python."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+f32p, i32p, u32p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
+
+
+def _ptr(a, typ):
+    return a.ctypes.data_as(typ)
+
+
+class GenResult:
+    def __init__(self, status, codes, pcm, hit_eos, first_chunk_ms, total_ms, sample_rate):
+        self.status, self.codes, self.pcm, self.hit_eos = status, codes, pcm, hit_eos
+        self.first_chunk_ms, self.total_ms, self.sample_rate = first_chunk_ms, total_ms, sample_rate
+
+    @property
+    def n_frames(self):
+        return self.codes.shape[0]
+
+
+class NativeEngine:
+    """q3tts_engine handle. One engine per GPU; not re-entrant (same contract as `&mut self`)."""
+
+    def __init__(self, cfg):
+        self.lib = _abi.load_library()
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        rc = self.lib.q3tts_engine_create(C.byref(cfg), C.byref(self.h))
+        if rc != 0:
+            raise _abi.Q3Error(f"q3tts_engine_create failed ({rc}): {self.lib.q3tts_last_error(None).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.q3tts_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise _abi.Q3Error(f"{what} failed ({rc}): {self.lib.q3tts_last_error(self.h).decode()}")
+
+    def set_sampler(self, temperature, top_k, top_p, seed=None):
+        self._check(self.lib.q3tts_set_sampler(self.h, temperature, top_k, top_p, 0 if seed is None else 1, seed or 0),
+                    "q3tts_set_sampler")
+
+    def set_max_steps(self, n):
+        self._check(self.lib.q3tts_set_max_steps(self.h, n), "q3tts_set_max_steps")
+
+    def build_prompt(self, desc):
+        out, n = f32p(), C.c_int32()
+        self._check(self.lib.q3tts_build_prompt(self.h, C.byref(desc), C.byref(out), C.byref(n)), "q3tts_build_prompt")
+        d = self.cfg.model.d_embed
+        arr = np.ctypeslib.as_array(out, shape=(n.value, d)).copy()
+        self.lib.q3tts_free(out)
+        return arr
+
+    @staticmethod
+    def make_request(embd=None, desc=None, temperature=0.0, top_k=40, top_p=0.9, seed=None, max_steps=0, min_frames=0,
+                     force_eos_at=-1, want_pcm=0, use_engine_sampler=0):
+        r = _abi.Request()
+        keep = []
+        if embd is not None:
+            e = np.ascontiguousarray(embd, dtype=np.float32)
+            keep.append(e)
+            r.prompt_embd, r.n_tok = _ptr(e, f32p), e.shape[0]
+        if desc is not None:
+            keep.append(desc)
+            r.prompt = C.pointer(desc)
+        r.use_engine_sampler = use_engine_sampler
+        r.temperature, r.top_k, r.top_p = temperature, top_k, top_p
+        r.has_seed, r.seed = (0, 0) if seed is None else (1, seed)
+        r.max_steps, r.min_frames, r.force_eos_at, r.want_pcm = max_steps, min_frames, force_eos_at, want_pcm
+        return r, keep
+
+    def _unpack(self, res):
+        ncb = self.cfg.model.n_codebooks
+        codes = np.ctypeslib.as_array(res.codes, shape=(res.n_frames, ncb)).copy() if res.n_frames > 0 else \
+            np.zeros((0, ncb), dtype=np.int32)
+        pcm = None
+        if res.pcm:
+            pcm = np.ctypeslib.as_array(res.pcm, shape=(res.n_samples,)).copy() if res.n_samples > 0 else \
+                np.zeros(0, dtype=np.float32)
+        out = GenResult(res.status, codes, pcm, bool(res.hit_eos), res.first_chunk_ms, res.total_ms, res.sample_rate)
+        self.lib.q3tts_result_free(C.byref(res))
+        return out
+
+    def generate(self, **kw):
+        r, keep = self.make_request(**kw)
+        res = _abi.Result()
+        self._check(self.lib.q3tts_generate(self.h, C.byref(r), C.byref(res)), "q3tts_generate")
+        return self._unpack(res)
+
+    def generate_batch(self, requests):
+        """requests: list of kwargs dicts for make_request."""
+        n = len(requests)
+        arr = (_abi.Request * n)()
+        keep = []
+        for i, kw in enumerate(requests):
+            r, k = self.make_request(**kw)
+            arr[i] = r
+            keep.append(k)
+        res = (_abi.Result * n)()
+        self._check(self.lib.q3tts_generate_batch(self.h, arr, n, res), "q3tts_generate_batch")
+        return [self._unpack(res[i]) for i in range(n)]
+
+    def timings(self):
+        t = _abi.Timings()
+        self._check(self.lib.q3tts_get_timings(self.h, C.byref(t)), "q3tts_get_timings")
+        return t
+
+    def talker_prefill(self, embd):
+        e = np.ascontiguousarray(embd, dtype=np.float32)
+        hid = np.zeros(self.cfg.model.t_d_model, dtype=np.float32)
+        lg = np.zeros(self.cfg.model.t_vocab, dtype=np.float32)
+        self._check(self.lib.q3tts_k_talker_prefill(self.h, _ptr(e, f32p), e.shape[0], _ptr(hid, f32p), _ptr(lg, f32p)),
+                    "q3tts_k_talker_prefill")
+        return hid, lg
+
+    def vocoder(self, codes, chunk_frames=0):
+        c = np.ascontiguousarray(codes, dtype=np.int32)
+        spf = 1
+        v = self.cfg.vocoder
+        for i in range(v.n_upsample):
+            spf *= v.upsample_ratios[i]
+        for i in range(v.n_dec_blocks):
+            spf *= v.dec_rates[i]
+        pcm = np.zeros(c.shape[0] * spf + 16, dtype=np.float32)
+        ns = C.c_int32()
+        self._check(self.lib.q3tts_k_vocoder(self.h, _ptr(c, i32p), c.shape[0], chunk_frames, _ptr(pcm, f32p), C.byref(ns)),
+                    "q3tts_k_vocoder")
+        return pcm[:ns.value].copy()
+
+
+# ---- kernel-level hooks (host arrays in / out) -------------------------------------------------
+
+def k_gemm_exact(x, w_bf16, norm_w=None, eps=1e-6, bias=None, epilogue=0, y_in=None, device=0, iters=0):
+    lib = _abi.load_library()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(w_bf16, dtype=np.uint16)
+    B, K = x.shape
+    N = w.shape[0]
+    ny = N // 2 if epilogue == 2 else N
+    y = np.zeros((B, ny), dtype=np.float32) if y_in is None else np.ascontiguousarray(y_in, dtype=np.float32).copy()
+    keys = np.zeros(B, dtype=np.uint64)
+    ms = C.c_float(0)
+    nw = None if norm_w is None else np.ascontiguousarray(norm_w, dtype=np.float32)
+    bs = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+    rc = lib.q3tts_k_gemm_exact(device, _ptr(x, f32p), B, K, w.ctypes.data_as(C.POINTER(C.c_uint16)), N,
+                                None if nw is None else _ptr(nw, f32p), eps, None if bs is None else _ptr(bs, f32p),
+                                epilogue, _ptr(y, f32p), keys.ctypes.data_as(C.POINTER(C.c_uint64)), iters, C.byref(ms))
+    if rc != 0:
+        raise _abi.Q3Error(f"q3tts_k_gemm_exact failed ({rc}): {lib.q3tts_last_error(None).decode()}")
+    return y, keys, ms.value
+
+
+def k_attention(qkv, pos0, n_head, n_kv_head, head_dim, q_norm_w, k_norm_w, eps, rope_theta, sections, device=0):
+    lib = _abi.load_library()
+    qkv = np.ascontiguousarray(qkv, dtype=np.float32)
+    n = qkv.shape[0]
+    out = np.zeros((n, n_head * head_dim), dtype=np.float32)
+    qn = np.ascontiguousarray(q_norm_w, dtype=np.float32)
+    kn = np.ascontiguousarray(k_norm_w, dtype=np.float32)
+    sec = None if sections is None else np.ascontiguousarray(sections, dtype=np.int32)
+    rc = lib.q3tts_k_attention(device, _ptr(qkv, f32p), n, pos0, n_head, n_kv_head, head_dim, _ptr(qn, f32p), _ptr(kn, f32p), eps,
+                               rope_theta, None if sec is None else _ptr(sec, i32p), _ptr(out, f32p))
+    if rc != 0:
+        raise _abi.Q3Error(f"q3tts_k_attention failed ({rc}): {lib.q3tts_last_error(None).decode()}")
+    return out
+
+
+def k_sample(logits, limit, temperature, top_k, top_p, r=None, device=0):
+    lib = _abi.load_library()
+    lg = np.ascontiguousarray(logits, dtype=np.float32)
+    n, ld = lg.shape
+    out = np.zeros(n, dtype=np.int32)
+    rr = None if r is None else np.ascontiguousarray(r, dtype=np.float32)
+    rc = lib.q3tts_k_sample(device, _ptr(lg, f32p), n, ld, limit, temperature, top_k, top_p, None if rr is None else _ptr(rr, f32p),
+                            _ptr(out, i32p))
+    if rc != 0:
+        raise _abi.Q3Error(f"q3tts_k_sample failed ({rc}): {lib.q3tts_last_error(None).decode()}")
+    return out
+
+
+def k_rng_f32(seed, n):
+    lib = _abi.load_library()
+    out = np.zeros(n, dtype=np.float32)
+    lib.q3tts_k_rng_f32(seed, n, _ptr(out, f32p))
+    return out
