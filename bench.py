@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X-native Qwen3-TTS hot path.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU; RCCL only gathers the output PCM)
+
+A "step" is one pass of the hot path over one batch of synthetic utterances: BASELINE.json configs[2]
+(batch = 64 mixed-length prompts per GPU, temperature 0.7 / top-k 40 / top-p 0.9, prompt -> codec ids -> 24 kHz PCM).
+Weights are seeded synthetic bf16 tensors of the Qwen3-TTS-12Hz-1.7B shape (no checkpoints offline).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "qwen3-tts-rust_amd"))
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+FRAME_SEC = 0.08  # 1 frame = 16 codes = 1920 samples @ 24 kHz (reference: src/tts/engine.rs:509-512,653)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def vivian():
+    with open(os.path.join(REPO, "tests", "golden", "speakers", "vivian.json")) as f:
+        return np.asarray(json.load(f)["spk_emb"], dtype=np.float32)
+
+
+def make_workload(n, rank, spk, keepalive):
+    """n_text ~ U{8..64} (seed 1), n_frames ~ U{25..250} (seed 2, EOS forced at the target),
+    per-utterance sampler seed = 1000 + global index."""
+    from q3tts.native import make_prompt_desc
+    r1, r2 = np.random.default_rng(1 + 7919 * rank), np.random.default_rng(2 + 7919 * rank)
+    reqs, frames = [], []
+    for i in range(n):
+        n_text = int(r1.integers(8, 65))
+        ids = r1.integers(0, 151643, size=n_text)
+        target = int(r2.integers(25, 251))
+        desc, keep = make_prompt_desc(ids, spk_emb=spk)
+        keepalive.append((desc, keep))
+        reqs.append(dict(desc=desc, temperature=0.7, top_k=40, top_p=0.9, seed=1000 + rank * n + i, max_steps=256,
+                         min_frames=target, force_eos_at=target, want_pcm=1))
+        frames.append(target)
+    return reqs, frames
+
+
+def cpu_baseline(cfg, spk, with_voc, threads):
+    """The oracle (CPU restatement, kind "port") on a bounded sample of config 1: one utterance, n_text = 20, greedy."""
+    import ctypes as C
+    import _oracle as O
+    n_frames = 6
+    t0 = time.time()
+    om = O.OracleModel(cfg.model, seed=cfg.synth_seed, n_ctx=256, n_threads=threads)
+    t_load = time.time() - t0
+    ids = np.random.default_rng(1234).integers(0, 151643, size=20)
+    desc, keep = O.make_prompt_desc(ids, spk_emb=spk)
+    t0 = time.time()
+    pe = om.build_prompt(desc)
+    codes, _ = om.generate(pe, temperature=0.0, max_steps=n_frames, min_frames=n_frames)
+    t_ar = time.time() - t0
+    t_voc = 0.0
+    L = O.lib()
+    if with_voc and hasattr(L, "q3o_vocoder_create"):
+        v = L.q3o_vocoder_create(C.byref(cfg.vocoder), cfg.synth_seed, threads)
+        cc = np.clip(codes, 0, cfg.vocoder.codebook_size - 1).astype(np.int32)
+        pcm = np.zeros(cc.shape[0] * 1920 + 64, dtype=np.float32)
+        t0 = time.time()
+        L.q3o_vocoder_decode(v, O.ptr(cc, O.i32p), cc.shape[0], 1, O.ptr(pcm, O.f32p), pcm.size)
+        t_voc = time.time() - t0
+        L.q3o_vocoder_destroy(v)
+    om.close()
+    wall = t_ar + t_voc
+    return {"value": round(codes.shape[0] * FRAME_SEC / wall, 4), "unit": "audio-sec/s", "cores": threads, "kind": "port",
+            "sample": f"config 1: 1 utterance, n_text=20 (31 prompt rows), greedy, {codes.shape[0]} frames, AR {t_ar:.1f}s + vocoder "
+                      f"{t_voc:.1f}s (synthetic weight generation {t_load:.1f}s excluded); CPU restatement, not llama.cpp/ORT",
+            "rtf": round(wall / (codes.shape[0] * FRAME_SEC), 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vocoder", action="store_true", help="codes only (diagnostic; the JSON line is then marked invalid)")
+    ap.add_argument("--no-single", action="store_true", help="skip the batch=1 RTF / first-chunk leg")
+    ap.add_argument("--n-ctx", type=int, default=4096)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from q3tts import _abi, native
+    cfg = _abi.full_config_py()
+    cfg.device, cfg.max_batch, cfg.n_ctx, cfg.max_steps_cap = local_rank, min(64, args.batch), args.n_ctx, 512
+    cfg.with_vocoder = 0 if args.no_vocoder else 1
+    eng = native.NativeEngine(cfg)
+    spk = vivian()
+    keepalive = []
+    reqs, frames = make_workload(args.batch, rank, spk, keepalive)
+    if args.no_vocoder:
+        for r in reqs:
+            r["want_pcm"] = 0
+
+    def sync_all():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    def gather_pcm(outs):
+        """RCCL over xGMI: lengths all-gather, then padded PCM gather to rank 0 (the only collective on the path)."""
+        if dist is None:
+            return
+        import torch
+        lens = torch.tensor([0 if o.pcm is None else o.pcm.size for o in outs], dtype=torch.int32, device="cuda")
+        all_lens = [torch.empty_like(lens) for _ in range(world)]
+        dist.all_gather(all_lens, lens)
+        mx = int(torch.stack(all_lens).max().item())
+        buf = torch.zeros((len(outs), max(mx, 1)), dtype=torch.float16, device="cuda")
+        for i, o in enumerate(outs):
+            if o.pcm is not None and o.pcm.size:
+                buf[i, :o.pcm.size] = torch.from_numpy(o.pcm).to("cuda", non_blocking=True).half()
+        gl = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+        dist.gather(buf, gl, dst=0)
+
+    for _ in range(args.warmup):
+        outs = eng.generate_batch(reqs)
+        gather_pcm(outs)
+    sync_all()
+    t0 = time.perf_counter()
+    step_frames = 0
+    dec_ms = steps_dev = bytes_step = 0
+    for _ in range(args.steps):
+        outs = eng.generate_batch(reqs)
+        gather_pcm(outs)
+        step_frames += sum(o.n_frames for o in outs)
+        tm = eng.timings()
+        dec_ms += tm.decode_ms
+        steps_dev += tm.frame_steps
+        bytes_step = tm.algo_bytes_per_step
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    assert all(o.status == 0 for o in outs)
+    assert [o.n_frames for o in outs] == frames, "forced lengths not honoured"
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed, float(step_frames)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, total_frames = float(tmax[0].item()), float(t[1].item())
+    else:
+        total_frames = float(step_frames)
+
+    line = None
+    if rank == 0:
+        audio_sec = total_frames * FRAME_SEC
+        value = audio_sec / elapsed
+        frame_step_ms = dec_ms / max(1, steps_dev)
+        achieved = bytes_step / (frame_step_ms * 1e-3) / 1e9 if frame_step_ms > 0 else 0.0
+        tm = eng.timings()
+        line = {
+            "metric": "audio_sec_per_s", "value": round(value, 2), "unit": "audio-sec/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: batch=%d mixed-length prompts per GPU (n_text~U{8..64}, n_frames~U{25..250} "
+                                   "EOS-forced), temperature=0.7 top-k=40 top-p=0.9, prompt ids -> codec ids -> 24 kHz PCM%s" %
+                                   (args.batch, " + RCCL PCM gather" if world > 1 else ""),
+                       "shape": "Qwen3-TTS-12Hz-1.7B (28x2048 Talker, 5x1024 Predictor, 8-layer codec vocoder), seeded synthetic bf16 weights",
+                       "utterances_per_gpu": args.batch, "n_ctx": args.n_ctx, "with_vocoder": not args.no_vocoder},
+            "rtf_per_utterance": round(frame_step_ms / 80.0, 5),
+            "frame_step_ms": round(frame_step_ms, 4),
+            "stage_ms_last_step": {"prefill": round(tm.prefill_ms, 2), "decode": round(tm.decode_ms, 2), "vocoder_host_wait": round(tm.vocoder_ms, 2)},
+            "roofline": {"bound": "hbm", "kernel": "frame-step graph replay (sample + 15 Predictor passes + Talker step; k_gemm dominant)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "algorithmic_bytes_per_launch": int(bytes_step), "launch_ms": round(frame_step_ms, 4), "traffic": None},
+        }
+        if args.no_vocoder:
+            line["invalid"] = "diagnostic run without the vocoder"
+
+    # batch = 1 leg (BASELINE configs[1] / configs[4]): RTF and p50 first-chunk latency, outside the timed region
+    if rank == 0 and not args.no_single:
+        eng.close()
+        cfg1 = _abi.full_config_py()
+        cfg1.device, cfg1.max_batch, cfg1.n_ctx, cfg1.max_steps_cap = local_rank, 1, args.n_ctx, 512
+        cfg1.with_vocoder = cfg.with_vocoder
+        e1 = native.NativeEngine(cfg1)
+        ids = np.random.default_rng(1234).integers(0, 151643, size=20)
+        desc, keep = native.make_prompt_desc(ids, spk_emb=spk)
+        firsts, rtfs = [], []
+        for it in range(12):
+            t1 = time.perf_counter()
+            o = e1.generate(desc=desc, temperature=0.0, max_steps=64, min_frames=64, want_pcm=cfg.with_vocoder)
+            dt = time.perf_counter() - t1
+            if it >= 2:
+                firsts.append(o.first_chunk_ms)
+                rtfs.append(dt / (o.n_frames * FRAME_SEC))
+        t1m = e1.timings()
+        line["single_utterance"] = {"workload": "BASELINE.json configs[1]: 1 utterance, n_text=20, greedy, 64 frames",
+                                    "rtf_p50": round(float(np.median(rtfs)), 5), "first_chunk_ms_p50": round(float(np.median(firsts)), 2),
+                                    "frame_step_ms": round(t1m.frame_step_ms, 4),
+                                    "hbm_GBs": round(t1m.algo_bytes_per_step / (t1m.frame_step_ms * 1e-3) / 1e9, 1) if t1m.frame_step_ms else 0}
+        e1.close()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = min(16, os.cpu_count() or 1)
+        line["cpu_baseline"] = cpu_baseline(cfg, spk, cfg.with_vocoder, threads)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -101,18 +101,20 @@ void q3o_rmsnorm(const float* x, int32_t d, const float* w, float eps, float* y)
 
 /* ------------------------------------------------------------------------------------------ */
 /* exact GEMM, canonical order                                                */
-/*   8 contiguous K-slices; inside a slice: for 32-wide block kb, for t in 0..7, for kq in 0..3 */
-/*   k = kb*32 + kq*8 + t, acc = fmaf(x[k], w[k], acc) from +0; y = ((((((p0+p1)+p2)+...)+p7).    */
-/*   (This is the order v_mfma_f32_16x16x4_f32 produces with 16-byte bf16 weight fragments.)   */
+/*   16 contiguous K-slices (K % 512 == 0). Inside a slice: for 32-wide block kb, for t in 0..7, for kq in 0..3:  */
+/*   k = kb*32 + (t/4)*16 + kq*4 + (t%4), acc = fmaf(x[k], w[k], acc) from +0.                                     */
+/*   Slice partials p0..p15 combine as q_w = p_{2w} + p_{2w+1}, y = ((((((q0+q1)+q2)+q3)+q4)+q5)+q6)+q7.           */
+/*   (This is the order v_mfma_f32_16x16x4_f32 produces when lane group kq holds two runs of four consecutive k.)  */
 /* ------------------------------------------------------------------------------------------ */
 #define NB 32
 #define RB 8
+#define NSLICE 16
 static int g_threads = 0;
 
 /* Wt: transposed weights [K][ldw] bf16; computes raw sums for columns [col0, col0+ncols) */
 static void gemm_t(const float* xh, int B, int ldx, int K, const uint16_t* Wt, int ldw, int col0, int ncols, float* y,
                    int ldy) {
-    const int bps = K / 256; /* 32-blocks per slice */
+    const int bps = K / (32 * NSLICE); /* 32-blocks per slice */
     const int nblk = (ncols + NB - 1) / NB;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads > 0 ? g_threads : 1)
     for (int blk = 0; blk < nblk; ++blk) {
@@ -120,15 +122,15 @@ static void gemm_t(const float* xh, int B, int ldx, int K, const uint16_t* Wt, i
         const int nn = (ncols - n0 < NB) ? ncols - n0 : NB;
         for (int r0 = 0; r0 < B; r0 += RB) {
             const int rr = (B - r0 < RB) ? B - r0 : RB;
-            float tot[RB][NB];
-            for (int s = 0; s < 8; ++s) {
+            float tot[RB][NB], pair[RB][NB];
+            for (int s = 0; s < NSLICE; ++s) {
                 float acc[RB][NB];
                 for (int r = 0; r < RB; ++r)
                     for (int n = 0; n < NB; ++n) acc[r][n] = 0.0f;
                 for (int kb = s * bps; kb < (s + 1) * bps; ++kb)
                     for (int t = 0; t < 8; ++t)
                         for (int kq = 0; kq < 4; ++kq) {
-                            const int k = kb * 32 + kq * 8 + t;
+                            const int k = kb * 32 + (t >> 2) * 16 + kq * 4 + (t & 3);
                             const uint16_t* wr = Wt + (size_t)k * ldw + col0 + n0;
                             float wf[NB];
                             for (int n = 0; n < NB; ++n) wf[n] = (n < nn) ? bf16f(wr[n]) : 0.0f;
@@ -138,7 +140,13 @@ static void gemm_t(const float* xh, int B, int ldx, int K, const uint16_t* Wt, i
                             }
                         }
                 for (int r = 0; r < rr; ++r)
-                    for (int n = 0; n < NB; ++n) tot[r][n] = (s == 0) ? acc[r][n] : tot[r][n] + acc[r][n];
+                    for (int n = 0; n < NB; ++n) {
+                        if ((s & 1) == 0) pair[r][n] = acc[r][n];
+                        else {
+                            const float q = pair[r][n] + acc[r][n];
+                            tot[r][n] = (s == 1) ? q : tot[r][n] + q;
+                        }
+                    }
             }
             for (int r = 0; r < rr; ++r)
                 for (int n = 0; n < nn; ++n) y[(size_t)(r0 + r) * ldy + n0 + n] = tot[r][n];

@@ -22,7 +22,7 @@ struct Q3Tfm {
 };
 
 struct Q3Scratch {
-    float *qkv = nullptr, *att = nullptr, *h = nullptr;
+    float *qkv = nullptr, *att = nullptr, *h = nullptr, *xn = nullptr;  // xn: RMSNorm pre-kernel output [rows][d]
     int rows = 0;
 };
 

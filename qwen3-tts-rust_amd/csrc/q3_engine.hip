@@ -51,13 +51,13 @@ static int validate(const q3tts_engine_config& c, std::string& why) {
 #define REQ(cond) do { if (!(cond)) { why = "config check failed: " #cond; return Q3TTS_ERR_INVALID; } } while (0)
     REQ(m.t_n_layer > 0 && m.p_n_layer > 0);
     REQ(m.t_head_dim == 128 && m.p_head_dim == 128);  // exact attention kernel: 16 lanes x 8 dims per key
-    REQ(m.t_d_model % 256 == 0 && m.p_d_model % 256 == 0 && m.t_d_ffn % 256 == 0 && m.p_d_ffn % 256 == 0);
-    REQ((m.t_n_head * m.t_head_dim) % 256 == 0 && (m.p_n_head * m.p_head_dim) % 256 == 0);
+    REQ(m.t_d_model % 512 == 0 && m.p_d_model % 512 == 0 && m.t_d_ffn % 512 == 0 && m.p_d_ffn % 512 == 0);
+    REQ((m.t_n_head * m.t_head_dim) % 512 == 0 && (m.p_n_head * m.p_head_dim) % 512 == 0);
     REQ(m.t_n_head % m.t_n_kv_head == 0 && m.p_n_head % m.p_n_kv_head == 0);
     { int r = m.t_n_head / m.t_n_kv_head; REQ(r == 1 || r == 2 || r == 4); r = m.p_n_head / m.p_n_kv_head; REQ(r == 1 || r == 2 || r == 4); }
     REQ(m.t_vocab % 16 == 0 && m.codebook_size % 16 == 0 && m.t_d_ffn % 8 == 0);
     REQ(m.d_embed == m.t_d_model);  // feedback row feeds the Talker directly (src/tts/engine.rs:631)
-    REQ(m.d_embed % 256 == 0);
+    REQ(m.d_embed % 512 == 0);
     REQ(m.n_codebooks >= 2 && m.n_codebooks <= 16);
     REQ(m.sample_limit > 0 && m.sample_limit <= m.t_vocab && m.sample_limit <= 4096);
     REQ(m.t_mrope_sections[0] + m.t_mrope_sections[1] + m.t_mrope_sections[2] + m.t_mrope_sections[3] == m.t_head_dim / 2);
@@ -148,9 +148,10 @@ static void free_tfm(Q3Tfm& t) {
     hipFree(t.out_norm); hipFree(t.head); hipFree(t.kc); hipFree(t.vc); hipFree(t.cs); hipFree(t.sn);
 }
 
-static int alloc_scratch(q3tts_engine* e, Q3Scratch& sc, int rows, int nqkv, int nq, int F) {
+static int alloc_scratch(q3tts_engine* e, Q3Scratch& sc, int rows, int nqkv, int nq, int F, int dmax) {
     sc.rows = rows;
     TRY(dalloc(e, &sc.qkv, (size_t)rows * nqkv)); TRY(dalloc(e, &sc.att, (size_t)rows * nq)); TRY(dalloc(e, &sc.h, (size_t)rows * F));
+    TRY(dalloc(e, &sc.xn, (size_t)rows * dmax));
     return Q3TTS_OK;
 }
 
@@ -160,7 +161,7 @@ static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, int rows, const int*
     const float eps = e->cfg.model.rms_eps;
     for (int l = 0; l < t.L; ++l) {
         Q3Gemm g{};
-        g.x = x; g.ldx = t.d; g.B = rows; g.w = t.wqkv[l]; g.K = t.d; g.N = t.nqkv; g.norm_w = t.attn_norm[l]; g.eps = eps;
+        g.x = x; g.ldx = t.d; g.B = rows; g.w = t.wqkv[l]; g.K = t.d; g.N = t.nqkv; g.norm_w = t.attn_norm[l]; g.eps = eps; g.xhat = sc.xn;
         g.y = sc.qkv; g.ldy = t.nqkv; g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);
         Q3QkPrep qp{}; qp.qkv = sc.qkv; qp.ld = t.nqkv; qp.rows = rows; qp.Hq = t.Hq; qp.Hkv = t.Hkv; qp.hd = t.hd;
         qp.qnw = t.qn[l]; qp.knw = t.kn[l]; qp.eps = eps; qp.cs = t.cs; qp.sn = t.sn;
@@ -171,7 +172,7 @@ static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, int rows, const int*
         q3_launch_attend(at, s);
         g = Q3Gemm{}; g.x = sc.att; g.ldx = t.nq; g.B = rows; g.w = t.wo[l]; g.K = t.nq; g.N = t.d; g.y = x; g.ldy = t.d; g.epi = Q3_EPI_RESID;
         q3_launch_gemm(g, s);
-        g = Q3Gemm{}; g.x = x; g.ldx = t.d; g.B = rows; g.w = t.wgu[l]; g.K = t.d; g.N = 2 * t.F; g.norm_w = t.ffn_norm[l]; g.eps = eps;
+        g = Q3Gemm{}; g.x = x; g.ldx = t.d; g.B = rows; g.w = t.wgu[l]; g.K = t.d; g.N = 2 * t.F; g.norm_w = t.ffn_norm[l]; g.eps = eps; g.xhat = sc.xn;
         g.y = sc.h; g.ldy = t.F; g.epi = Q3_EPI_SWIGLU; q3_launch_gemm(g, s);
         g = Q3Gemm{}; g.x = sc.h; g.ldx = t.F; g.B = rows; g.w = t.wd[l]; g.K = t.F; g.N = t.d; g.y = x; g.ldy = t.d; g.epi = Q3_EPI_RESID;
         q3_launch_gemm(g, s);
@@ -202,7 +203,7 @@ static void record_frame(q3tts_engine* e, hipStream_t s) {
         g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);  // H6: src/assets_manager.rs:383-399
         run_layers(e, e->P, e->px, rows, q == 0 ? e->posA : e->pos_q + (size_t)q * B, q == 0 ? e->slotA : e->slot_id, e->sc_dec, s);
         g = Q3Gemm{}; g.x = q == 0 ? e->px + dp : e->px; g.ldx = q == 0 ? 2 * dp : dp; g.B = B; g.w = e->P.head + head_tile_stride * q;
-        g.K = dp; g.N = cbs; g.norm_w = e->P.out_norm; g.eps = eps; g.keys = e->keys + (q + 1); g.key_stride = ncb; g.epi = Q3_EPI_ARGMAX;
+        g.K = dp; g.N = cbs; g.norm_w = e->P.out_norm; g.eps = eps; g.xhat = e->sc_dec.xn; g.keys = e->keys + (q + 1); g.key_stride = ncb; g.epi = Q3_EPI_ARGMAX;
         q3_launch_gemm(g, s);
     }
     { Q3PredNext pn{}; pn.keys = e->keys; pn.q = ncb - 1; pn.ncb = ncb; pn.codec_q = e->codec[ncb - 1]; pn.rows_q = m.codecq_rows; pn.d = de;
@@ -210,7 +211,7 @@ static void record_frame(q3tts_engine* e, hipStream_t s) {
       pn.tts_pad = e->tts_pad; pn.xT = e->xT; pn.row_pos_t = e->row_pos_t;
       q3_launch_pred_next(pn, s); }
     run_layers(e, e->T, e->xT, B, e->row_pos_t, e->slot_id, e->sc_dec, s);
-    Q3Gemm g{}; g.x = e->xT; g.ldx = m.t_d_model; g.B = B; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab; g.norm_w = e->T.out_norm; g.eps = eps;
+    Q3Gemm g{}; g.x = e->xT; g.ldx = m.t_d_model; g.B = B; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab; g.norm_w = e->T.out_norm; g.eps = eps; g.xhat = e->sc_dec.xn;
     g.y = e->logits; g.ldy = m.t_vocab; g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);
 }
 
@@ -282,8 +283,8 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
         HIPC(hipStreamSynchronize(s));
     }
     const int nqkv_max = std::max(e->T.nqkv, e->P.nqkv), nq_max = std::max(e->T.nq, e->P.nq), F_max = std::max(e->T.F, e->P.F);
-    TRYC(alloc_scratch(e, e->sc_dec, 2 * B, nqkv_max, nq_max, F_max));
-    TRYC(alloc_scratch(e, e->sc_pre, cfg->n_ctx, e->T.nqkv, e->T.nq, e->T.F));
+    TRYC(alloc_scratch(e, e->sc_dec, 2 * B, nqkv_max, nq_max, F_max, std::max(m.t_d_model, m.p_d_model)));
+    TRYC(alloc_scratch(e, e->sc_pre, cfg->n_ctx, e->T.nqkv, e->T.nq, e->T.F, m.t_d_model));
     TRYC(dalloc(e, &e->xp, (size_t)cfg->n_ctx * m.t_d_model));
     TRYC(dalloc(e, &e->pf_pos, (size_t)cfg->n_ctx)); TRYC(dalloc(e, &e->pf_slot, (size_t)cfg->n_ctx));
     { std::vector<int> pp(cfg->n_ctx); for (int i = 0; i < cfg->n_ctx; ++i) pp[i] = i;
@@ -292,13 +293,15 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
     TRYC(dalloc(e, &e->prow_dev, (size_t)e->prow_cap)); TRYC(dalloc(e, &e->spk_dev, (size_t)m.d_embed));
     TRYC(dalloc(e, &e->refcodes_dev, (size_t)cfg->n_ctx * 16));
     if (cfg->with_vocoder) TRYC(q3_voc_create(e));
-    // capture the frame step once; every later frame is a replay
+    // capture the frame step once; every later frame is a replay (Q3TTS_NO_GRAPH=1: eager launches, for profilers)
     HIPC(hipStreamSynchronize(s));
-    HIPC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    record_frame(e, s);
-    HIPC(hipStreamEndCapture(s, &e->graph));
-    HIPC(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
-    HIPC(hipStreamSynchronize(s));
+    if (!(getenv("Q3TTS_NO_GRAPH") && atoi(getenv("Q3TTS_NO_GRAPH")))) {
+        HIPC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        record_frame(e, s);
+        HIPC(hipStreamEndCapture(s, &e->graph));
+        HIPC(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
+        HIPC(hipStreamSynchronize(s));
+    }
     // algorithmic bytes of one frame step, context term added per run
     e->tm.algo_bytes_per_step = 0;
 #undef TRYC
@@ -320,7 +323,7 @@ extern "C" void q3tts_engine_destroy(q3tts_engine* e) {
     hipFree(e->slots); if (e->slots_host) hipHostFree(e->slots_host);
     hipFree(e->xT); hipFree(e->logits); hipFree(e->X); hipFree(e->fb); hipFree(e->px); hipFree(e->keys); hipFree(e->codes); hipFree(e->rng);
     hipFree(e->row_pos_t); hipFree(e->slot_id); hipFree(e->posA); hipFree(e->slotA); hipFree(e->pos_q);
-    hipFree(e->sc_dec.qkv); hipFree(e->sc_dec.att); hipFree(e->sc_dec.h); hipFree(e->sc_pre.qkv); hipFree(e->sc_pre.att); hipFree(e->sc_pre.h);
+    hipFree(e->sc_dec.qkv); hipFree(e->sc_dec.att); hipFree(e->sc_dec.h); hipFree(e->sc_dec.xn); hipFree(e->sc_pre.xn); hipFree(e->sc_pre.qkv); hipFree(e->sc_pre.att); hipFree(e->sc_pre.h);
     hipFree(e->xp); hipFree(e->pf_pos); hipFree(e->pf_slot); hipFree(e->prow_dev); hipFree(e->spk_dev); hipFree(e->refcodes_dev);
     if (e->ev0) hipEventDestroy(e->ev0); if (e->ev1) hipEventDestroy(e->ev1); if (e->ev2) hipEventDestroy(e->ev2); if (e->ev3) hipEventDestroy(e->ev3);
     if (e->stream) hipStreamDestroy(e->stream);
@@ -415,6 +418,12 @@ extern "C" int q3tts_build_prompt(q3tts_engine* e, const q3tts_prompt_desc* p, f
 // ------------------------------------------------------------------------------------------------
 // generation
 // ------------------------------------------------------------------------------------------------
+static int launch_frame(q3tts_engine* e, hipStream_t s) {
+    if (e->graph_exec) { Q3_HIP(e, hipGraphLaunch(e->graph_exec, s)); }
+    else { record_frame(e, s); Q3_HIP(e, hipGetLastError()); }
+    return Q3TTS_OK;
+}
+
 static uint64_t wall_seed() {
     return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
 }
@@ -438,7 +447,7 @@ static int admit(q3tts_engine* e, int b, const q3tts_request* r) {
     run_layers(e, e->T, e->xp, n, e->pf_pos, e->pf_slot, e->sc_pre, s);
     q3_launch_copy_rows(e->xT + (size_t)b * m.t_d_model, m.t_d_model, e->xp + (size_t)(n - 1) * m.t_d_model, m.t_d_model, 1, m.t_d_model, s);
     Q3Gemm g{}; g.x = e->xT + (size_t)b * m.t_d_model; g.ldx = m.t_d_model; g.B = 1; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab;
-    g.norm_w = e->T.out_norm; g.eps = m.rms_eps; g.y = e->logits + (size_t)b * m.t_vocab; g.ldy = m.t_vocab; g.epi = Q3_EPI_STORE;
+    g.norm_w = e->T.out_norm; g.eps = m.rms_eps; g.xhat = e->sc_dec.xn; g.y = e->logits + (size_t)b * m.t_vocab; g.ldy = m.t_vocab; g.epi = Q3_EPI_STORE;
     q3_launch_gemm(g, s);
     // sampler stream (src/tts/engine.rs:473-485)
     float temperature = e->temperature, top_p = e->top_p; int top_k = e->top_k, has_seed = e->has_seed; uint64_t seed = e->seed;
@@ -520,7 +529,7 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
         for (int b = 0; b < B; ++b) any |= run[b].req >= 0;
         if (!any) break;
         Q3_HIP(e, hipEventRecord(e->ev2, s));
-        for (int i = 0; i < CH; ++i) Q3_HIP(e, hipGraphLaunch(e->graph_exec, s));
+        for (int i = 0; i < CH; ++i) TRY(launch_frame(e, s));
         Q3_HIP(e, hipEventRecord(e->ev3, s));
         Q3_HIP(e, hipMemcpyAsync(e->slots_host, e->slots, sizeof(Q3Slot) * B, hipMemcpyDeviceToHost, s));
         Q3_HIP(e, hipStreamSynchronize(s));
@@ -625,7 +634,7 @@ extern "C" int q3tts_stream_poll(q3tts_stream* st, const float** chunk, int32_t*
     for (;;) {
         const Q3Slot& sl = e->slots_host[0];
         if (!st->finished) {
-            for (int i = 0; i < 4; ++i) Q3_HIP(e, hipGraphLaunch(e->graph_exec, s));
+            for (int i = 0; i < 4; ++i) TRY(launch_frame(e, s));
             Q3_HIP(e, hipMemcpyAsync(e->slots_host, e->slots, sizeof(Q3Slot), hipMemcpyDeviceToHost, s));
             Q3_HIP(e, hipStreamSynchronize(s));
             if (!sl.active) st->finished = true;
@@ -685,12 +694,13 @@ struct DevBuf {
 
 extern "C" int q3tts_k_gemm_exact(int32_t device, const float* x, int32_t B, int32_t K, const uint16_t* w, int32_t N, const float* norm_w,
                                   float eps, const float* bias, int32_t epi, float* y, uint64_t* keys, int32_t iters, float* mean_ms) {
-    if (!x || !w || !y || B <= 0 || K % 256 || N % 16) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "gemm hook: bad shape");
+    if (!x || !w || !y || B <= 0 || K % 512 || N % 16) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "gemm hook: bad shape");
     if (epi == Q3_EPI_SWIGLU && (N % 32)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "swiglu needs N % 32 == 0");
     HK(hipSetDevice(device));
     const int F = N / 2;
     const size_t ny = epi == Q3_EPI_SWIGLU ? (size_t)B * F : (size_t)B * N;
-    DevBuf dx, dw, dwt, dn, db, dy, dk;
+    DevBuf dx, dw, dwt, dn, db, dy, dk, dxh;
+    if (dxh.alloc((size_t)B * K * 4)) return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
     if (dx.alloc((size_t)B * K * 4) || dw.alloc((size_t)N * K * 2) || dwt.alloc((size_t)N * K * 2) || dn.alloc((size_t)K * 4) ||
         db.alloc((size_t)N * 4) || dy.alloc(ny * 4) || dk.alloc((size_t)B * 8))
         return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
@@ -704,7 +714,7 @@ extern "C" int q3tts_k_gemm_exact(int32_t device, const float* x, int32_t B, int
     else { f.mode = 0; f.row0 = 0; f.rows = N; f.src_a = (const uint16_t*)dw.p; }
     q3_launch_fill_tiled(f, nullptr);
     Q3Gemm g{}; g.x = (const float*)dx.p; g.ldx = K; g.B = B; g.w = (const uint4*)dwt.p; g.K = K; g.N = N;
-    g.norm_w = norm_w ? (const float*)dn.p : nullptr; g.eps = eps; g.bias = bias ? (const float*)db.p : nullptr;
+    g.norm_w = norm_w ? (const float*)dn.p : nullptr; g.eps = eps; g.bias = bias ? (const float*)db.p : nullptr; g.xhat = (float*)dxh.p;
     g.y = (float*)dy.p; g.ldy = epi == Q3_EPI_SWIGLU ? F : N; g.keys = (unsigned long long*)dk.p; g.key_stride = 1; g.epi = epi;
     q3_launch_gemm(g, nullptr);
     HK(hipDeviceSynchronize());

@@ -1,0 +1,347 @@
+// q3_gemm.hip — the exact skinny GEMM of the codec-token decoder (K1/K2/K6/K8/K9, P1-P4, H6 of SURVEY.md §8a).
+//
+//   y[B][N] = x[B][K] . W[N][K]^T, bf16 weights, f32 accumulate on v_mfma_f32_16x16x4_f32, whose result is
+//   bit-for-bit a k-ordered fmaf chain (tools/probe_mfma.hip: 0/256 mismatches at K = 2048).
+//
+// Canonical order (restated by oracle/q3_oracle.c gemm_t):
+//   16 contiguous K-slices; inside a slice, for 32-wide block kb, for t in 0..7, for kq in 0..3:
+//   k = kb*32 + (t/4)*16 + kq*4 + (t%4); partials p0..p15 combine as q_w = p_2w + p_2w+1, y = q0+q1+...+q7 in order.
+//
+// HBM layout of W: tile (nb = n/16, kb = k/32) is 1 KiB; lane l = (kq = l>>4, n = l&15) owns the
+// 8 weights of its 8 MFMA steps, element e <-> k = kb*32 + (e/4)*16 + kq*4 + (e%4). A wave-load is 1 KiB contiguous
+// and every weight byte is read once per row chunk. With this k map an activation fragment load touches 64
+// contiguous bytes per row (lane group kq reads 16 B at kq*16), i.e. whole half-lines.
+//
+// vmcnt is ONE in-order queue: waiting on a young L2 load also waits for every older HBM load. Hence:
+//   k_gemm_small (rows*K <= 12288 floats; the latency-critical B = 1..6 decode case): 16 waves = 16 slices, the
+//        workgroup stages x and the norm weights in LDS once (their loads are issued BEFORE the weight stream), so
+//        the main loop's vmcnt only ever counts weights; RMSNorm is fused (stats from LDS).
+//   k_gemm_ring (larger batches, MFMA-bound): 8 waves x 2 adjacent slices; x fragments ride a register ring XPF
+//        blocks deep issued BEFORE the weight refill of the same block; each wave reuses its x fragments for NT
+//        column tiles (x traffic from L2 is the co-bottleneck at B = 64); RMSNorm runs as a pre-kernel.
+#include "q3_kernels.h"
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// once-read weight stream: non-temporal 16-byte load (MI355X_MICROARCH.md, row nt-weights)
+__device__ __forceinline__ uint4 ntload16(const uint4* p) {
+    const u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = v + __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ void unpack8(const uint4 wv, float* b) {
+    b[0] = q3_u2f(wv.x << 16); b[1] = q3_u2f(wv.x & 0xffff0000u);
+    b[2] = q3_u2f(wv.y << 16); b[3] = q3_u2f(wv.y & 0xffff0000u);
+    b[4] = q3_u2f(wv.z << 16); b[5] = q3_u2f(wv.z & 0xffff0000u);
+    b[6] = q3_u2f(wv.w << 16); b[7] = q3_u2f(wv.w & 0xffff0000u);
+}
+__device__ __forceinline__ float sq4(const float4 v, float acc) {
+    acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+    return acc;
+}
+
+#define XLDS_MAX_FLOATS 12288
+
+// shared epilogue: thread (row, col) already holds the canonical sum s of its output element
+template <int ROWS, int COLS>
+__device__ __forceinline__ void epilogue(const Q3Gemm& g, float* sums, int tid, int nthreads, int row0, int nrows, int col_base) {
+    const int epi = g.epi;
+    if (epi == Q3_EPI_SWIGLU) {  // each 16-column tile = 8 gate columns then the 8 matching up columns
+        __syncthreads();
+        for (int o = tid; o < ROWS * (COLS / 2); o += nthreads) {
+            const int row = o / (COLS / 2), hc = o - row * (COLS / 2);
+            if (row >= nrows) continue;
+            const int tile = hc >> 3, c = hc & 7;
+            g.y[(size_t)(row0 + row) * g.ldy + (col_base >> 1) + hc] =
+                q3_swiglu(sums[row * COLS + tile * 16 + c], sums[row * COLS + tile * 16 + 8 + c]);
+        }
+    } else if (epi == Q3_EPI_ARGMAX) {
+        __syncthreads();
+        if (tid < nrows) {
+            unsigned long long best = 0;
+            for (int c = 0; c < COLS; ++c) {
+                const unsigned long long kk = q3_argmax_key(sums[tid * COLS + c], (uint32_t)(col_base + c));
+                best = kk > best ? kk : best;
+            }
+            atomicMax(g.keys + (size_t)(row0 + tid) * g.key_stride, best);
+        }
+    }
+}
+__device__ __forceinline__ void store_elem(const Q3Gemm& g, float* sums, float s, size_t grow, int col, int lrow, int lcol, int COLS) {
+    if (g.epi == Q3_EPI_STORE) {
+        if (g.bias) s = s + g.bias[col];
+        g.y[grow * g.ldy + col] = s;
+    } else if (g.epi == Q3_EPI_RESID) {
+        float* yp = g.y + grow * g.ldy + col;
+        *yp = *yp + s;
+    } else {
+        sums[lrow * COLS + lcol] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// small-batch kernel: 1024 threads, wave w = slice w, one 16-column tile per workgroup. BPS = K/512 (0 = runtime).
+// ---------------------------------------------------------------------------------------------------------------
+template <bool NORM, int BPS>
+__global__ __launch_bounds__(1024) void k_gemm_small(Q3Gemm g) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];  // x[nrows][K] then norm_w[K]
+    __shared__ float red[16 * 16 * 17];
+    __shared__ float sums[16 * 16];
+    __shared__ float rinv_s[16];
+    constexpr int WPF = 8;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nb = blockIdx.x, nrows = g.B;
+    const int K = g.K, K4 = K >> 2;
+    const int bps = BPS > 0 ? BPS : (K >> 9);
+    const int kq = lane >> 4, li = lane & 15;
+    const uint4* wp = g.w + ((size_t)nb * (K >> 5) + (size_t)wave * bps) * 64 + lane;
+    const int koff = wave * (K >> 4) + kq * 4;
+    uint4 wq[WPF];
+    f32x4 acc = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    // stage raw activations (contiguous rows: ldx == K) and norm weights; these loads are the OLDEST in the queue
+    const int n4 = nrows * K4;  // <= 3072 float4
+    float* nwl = dsm + (size_t)nrows * K;
+    const float4* xsrc = (const float4*)g.x;
+    // (named scalars, not arrays: hipcc keeps a load-now/store-later float4 array in scratch)
+    const float4 xv0 = xsrc[min(tid, n4 - 1)], xv1 = xsrc[min(tid + 1024, n4 - 1)], xv2 = xsrc[min(tid + 2048, n4 - 1)];
+    const float4* nsrc = (const float4*)(NORM ? g.norm_w : g.x);
+    const float4 nv0 = nsrc[min(tid, K4 - 1)], nv1 = nsrc[min(tid + 1024, K4 - 1)];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < WPF; ++j)
+        if (j < bps) wq[j] = ntload16(wp + (size_t)j * 64);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid < n4) ((float4*)dsm)[tid] = xv0;
+    if (tid + 1024 < n4) ((float4*)dsm)[tid + 1024] = xv1;
+    if (tid + 2048 < n4) ((float4*)dsm)[tid + 2048] = xv2;
+    if (NORM) {
+        if (tid < K4) ((float4*)nwl)[tid] = nv0;
+        if (tid + 1024 < K4) ((float4*)nwl)[tid + 1024] = nv1;
+    }
+    __syncthreads();
+    if (NORM) {
+        for (int r = wave; r < nrows; r += 16) {
+            const float4* xr = (const float4*)(dsm + (size_t)r * K);
+            float a = 0.0f;
+            for (int c = lane; c < K4; c += 64) a = sq4(xr[c], a);
+            a = wsum(a);
+            if (lane == 0) rinv_s[r] = 1.0f / sqrtf(a / (float)K + g.eps);
+        }
+        __syncthreads();
+    }
+    const int lr = li < nrows ? li : nrows - 1;  // padding rows replicate the last row; their results are dropped
+    const float* xa = dsm + (size_t)lr * K + koff;
+    const float* nwa = nwl + koff;
+    const float ri0 = NORM ? rinv_s[lr] : 1.0f;
+    for (int kb0 = 0; kb0 < bps; kb0 += WPF) {
+#pragma unroll
+        for (int j = 0; j < WPF; ++j) {
+            const int kb = kb0 + j;
+            if (kb < bps) {
+                float b[8];
+                unpack8(wq[j], b);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kb + WPF < bps) wq[j] = ntload16(wp + (size_t)(kb + WPF) * 64);
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 x0 = *(const float4*)(xa + kb * 32), x1 = *(const float4*)(xa + kb * 32 + 16);
+                float a[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                if (NORM) {
+                    const float4 n0 = *(const float4*)(nwa + kb * 32), n1 = *(const float4*)(nwa + kb * 32 + 16);
+                    const float nw[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) a[t] = (a[t] * ri0) * nw[t];
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], acc, 0, 0, 0);
+            }
+        }
+    }
+    // D layout: lane holds rows 4*(lane>>4)+j, column lane&15
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[(wave * 16 + 4 * kq + j) * 17 + li] = acc[j];
+    __syncthreads();
+    if (tid < 256) {
+        const int row = tid >> 4, col = tid & 15;
+        if (row < nrows) {
+            float s = red[row * 17 + col] + red[(16 + row) * 17 + col];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) s = s + (red[(2 * w * 16 + row) * 17 + col] + red[((2 * w + 1) * 16 + row) * 17 + col]);
+            store_elem(g, sums, s, (size_t)row, nb * 16 + col, row, col, 16);
+        }
+    }
+    epilogue<16, 16>(g, sums, tid, 1024, 0, nrows, nb * 16);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ring kernel: 512 threads, wave w = slices 2w and 2w+1 (adjacent in k), RT row tiles x NT column tiles per wave.
+// BPS = K/512 blocks per slice (0 = runtime).
+// ---------------------------------------------------------------------------------------------------------------
+template <int RT, int NT, int BPS>
+__global__ __launch_bounds__(512) void k_gemm_ring(Q3Gemm g) {
+    __shared__ float red[8 * RT * 16 * (NT * 16 + 1)];
+    __shared__ float sums[RT * 16 * NT * 16];
+    constexpr int WPF = NT == 1 ? 8 : 4;
+    constexpr int XPF = RT == 4 ? 2 : (RT == 2 ? 4 : 8);
+    constexpr int CP = NT * 16 + 1;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nbt = blockIdx.x, row0 = blockIdx.y * (RT * 16);
+    const int nrows = min(RT * 16, g.B - row0);
+    const int K = g.K;
+    const int bps = BPS > 0 ? BPS : (K >> 9);
+    const int nblk = 2 * bps;  // this wave's blocks (two adjacent slices)
+    const int kq = lane >> 4, li = lane & 15;
+    const size_t tile_stride = (size_t)(K >> 5) * 64;
+    const uint4* wp = g.w + (size_t)nbt * NT * tile_stride + (size_t)wave * nblk * 64 + lane;
+    const int koff = wave * (K >> 3) + kq * 4;
+    uint4 wq[WPF][NT];
+    float4 xq[XPF][RT][2];
+    f32x4 acc[RT][NT], accA[RT][NT];
+    const float* xr[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        int lrw = r * 16 + li;
+        if (lrw >= nrows) lrw = nrows - 1;  // padding rows replicate the last row; their results are dropped
+        xr[r] = g.x + (size_t)(row0 + lrw) * g.ldx + koff;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) { acc[r][c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; accA[r][c] = acc[r][c]; }
+    }
+#pragma unroll
+    for (int j = 0; j < XPF; ++j)
+        if (j < nblk) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) { xq[j][r][0] = *(const float4*)(xr[r] + j * 32); xq[j][r][1] = *(const float4*)(xr[r] + j * 32 + 16); }
+        }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < WPF; ++j)
+        if (j < nblk) {
+#pragma unroll
+            for (int c = 0; c < NT; ++c) wq[j][c] = ntload16(wp + c * tile_stride + (size_t)j * 64);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kb0 = 0; kb0 < nblk; kb0 += WPF) {
+#pragma unroll
+        for (int j = 0; j < WPF; ++j) {
+            const int kb = kb0 + j;
+            if (kb < nblk) {
+                if (kb == bps) {  // slice 2w done: park its partial, start slice 2w+1 from +0
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+#pragma unroll
+                        for (int c = 0; c < NT; ++c) { accA[r][c] = acc[r][c]; acc[r][c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
+                }
+                float b[NT][8];
+#pragma unroll
+                for (int c = 0; c < NT; ++c) unpack8(wq[j][c], b[c]);
+                float a[RT][8];
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    const float4 x0 = xq[j % XPF][r][0], x1 = xq[j % XPF][r][1];
+                    a[r][0] = x0.x; a[r][1] = x0.y; a[r][2] = x0.z; a[r][3] = x0.w; a[r][4] = x1.x; a[r][5] = x1.y; a[r][6] = x1.z; a[r][7] = x1.w;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kb + XPF < nblk) {  // activations first: they must stay OLDER than the weight refill below
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) {
+                        xq[j % XPF][r][0] = *(const float4*)(xr[r] + (kb + XPF) * 32);
+                        xq[j % XPF][r][1] = *(const float4*)(xr[r] + (kb + XPF) * 32 + 16);
+                    }
+                }
+                if (kb + WPF < nblk) {
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) wq[j][c] = ntload16(wp + c * tile_stride + (size_t)(kb + WPF) * 64);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // independent (row tile, column tile) chains interleave; each chain still sees t = 0..7 in order
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+#pragma unroll
+                        for (int c = 0; c < NT; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], b[c][t], acc[r][c], 0, 0, 0);
+            }
+        }
+    }
+    // q_w = p_2w + p_2w+1, then the eight q meet in LDS and are summed in order
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[((wave * RT + r) * 16 + 4 * kq + j) * CP + c * 16 + li] = accA[r][c][j] + acc[r][c][j];
+    __syncthreads();
+    for (int o = tid; o < RT * 16 * NT * 16; o += 512) {
+        const int row = o / (NT * 16), col = o - row * (NT * 16);
+        if (row >= nrows) continue;
+        float s = red[row * CP + col];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) s = s + red[(w * RT * 16 + row) * CP + col];
+        store_elem(g, sums, s, (size_t)(row0 + row), nbt * NT * 16 + col, row, col, NT * 16);
+    }
+    epilogue<RT * 16, NT * 16>(g, sums, tid, 512, row0, nrows, nbt * NT * 16);
+}
+
+template <bool NORM>
+static void launch_small(const Q3Gemm& g, dim3 grid, size_t lds, hipStream_t s) {
+#define L(BPS_) hipLaunchKernelGGL((k_gemm_small<NORM, BPS_>), grid, dim3(1024), lds, s, g)
+    switch (g.K >> 9) {
+        case 1: L(1); break;
+        case 2: L(2); break;
+        case 4: L(4); break;
+        case 6: L(6); break;
+        case 12: L(12); break;
+        default: L(0); break;
+    }
+#undef L
+}
+template <int RT, int NT>
+static void launch_ring(const Q3Gemm& g, dim3 grid, hipStream_t s) {
+#define L(BPS_) hipLaunchKernelGGL((k_gemm_ring<RT, NT, BPS_>), grid, dim3(512), 0, s, g)
+    switch (g.K >> 9) {
+        case 1: L(1); break;
+        case 2: L(2); break;
+        case 4: L(4); break;
+        case 6: L(6); break;
+        case 12: L(12); break;
+        default: L(0); break;
+    }
+#undef L
+}
+
+void q3_launch_gemm(const Q3Gemm& gin, hipStream_t s) {
+    Q3Gemm g = gin;
+    const bool norm = g.norm_w != nullptr;
+    if (g.B <= 16 && g.ldx == g.K && (size_t)g.B * g.K <= XLDS_MAX_FLOATS && g.K <= 8192) {
+        const size_t lds = ((size_t)g.B * g.K + (norm ? g.K : 0)) * 4;
+        dim3 grid(g.N / 16);
+        if (norm) launch_small<true>(g, grid, lds, s); else launch_small<false>(g, grid, lds, s);
+        return;
+    }
+    if (norm) {  // RMSNorm as a pre-kernel: xhat = (x * rinv) * w, canonical order of DESIGN.md §4.2
+        q3_launch_rmsnorm_rows(g.x, g.ldx, g.norm_w, g.eps, g.K, g.B, g.xhat, g.K, s);
+        g.x = g.xhat; g.ldx = g.K; g.norm_w = nullptr;
+    }
+    const int tiles = g.N / 16;
+    int NT = 1;
+    if (g.B > 16) {
+        if (tiles >= 768 && tiles % 3 == 0) NT = 3;
+        else if (tiles >= 512 && tiles % 2 == 0) NT = 2;
+    }
+    if (NT > 1) {
+        dim3 grid(tiles / NT, (g.B + 31) / 32);
+        if (NT == 3) launch_ring<2, 3>(g, grid, s); else launch_ring<2, 2>(g, grid, s);
+        return;
+    }
+    int RT = 1;
+    if (g.B > 16) {
+        RT = g.B > 32 ? 4 : 2;
+        while (RT > 1 && (long)tiles * ((g.B + RT * 16 - 1) / (RT * 16)) < 256) RT >>= 1;
+    }
+    dim3 grid(tiles, (g.B + RT * 16 - 1) / (RT * 16));
+    if (RT == 4) launch_ring<4, 1>(g, grid, s);
+    else if (RT == 2) launch_ring<2, 1>(g, grid, s);
+    else launch_ring<1, 1>(g, grid, s);
+}

@@ -9,6 +9,13 @@
 
 #define WAVE 64
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// once-read weight stream: non-temporal 16-byte load (MI355X_MICROARCH.md, row nt-weights)
+__device__ __forceinline__ uint4 ntload16(const uint4* p) {
+    const u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = v + __shfl_xor(v, m);
@@ -20,129 +27,7 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Exact GEMM. Workgroup = 8 waves = the 8 canonical K-slices of one 16-column tile; RT row tiles of 16.
-// Weights stream HBM -> VGPR as 1 KiB contiguous wave-loads (read exactly once per launch per row chunk);
-// activations (f32, L2 resident) are loaded as A fragments; partials meet in LDS and are summed in order.
-// ---------------------------------------------------------------------------------------------------
-template <int RT, bool NORM>
-__global__ __launch_bounds__(512) void k_gemm(Q3Gemm g) {
-    __shared__ float red[8 * RT * 16 * 17];
-    __shared__ float sums[RT * 16 * 16];
-    __shared__ float rinv_s[RT * 16];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int nb = blockIdx.x, row0 = blockIdx.y * (RT * 16);
-    const int nrows = min(RT * 16, g.B - row0);
-    const int K = g.K;
-    if (NORM) {
-        for (int r = wave; r < nrows; r += 8) {
-            const float4* xr = (const float4*)(g.x + (size_t)(row0 + r) * g.ldx);
-            float acc = 0.0f;
-            for (int c = lane; c < (K >> 2); c += 64) {
-                float4 v = xr[c];
-                acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
-            }
-            acc = wave_sum(acc);
-            if (lane == 0) rinv_s[r] = 1.0f / sqrtf(acc / (float)K + g.eps);
-        }
-        __syncthreads();
-    }
-    const int bps = K >> 8;  // 32-wide k-blocks per slice
-    const int kq = lane >> 4, li = lane & 15;
-    const uint4* wp = g.w + ((size_t)nb * (K >> 5) + (size_t)wave * bps) * 64 + lane;
-    const int koff = wave * (K >> 3) + kq * 8;
-    f32x4 acc[RT];
-    const float* xr[RT];
-    float ri[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-        acc[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-        int lr = r * 16 + li;
-        if (lr >= nrows) lr = nrows - 1;  // padding rows replicate the last row; their results are dropped
-        xr[r] = g.x + (size_t)(row0 + lr) * g.ldx + koff;
-        ri[r] = NORM ? rinv_s[lr] : 1.0f;
-    }
-    const float* nwp = NORM ? g.norm_w + koff : nullptr;
-#pragma unroll 4
-    for (int kb = 0; kb < bps; ++kb) {
-        const uint4 wv = wp[(size_t)kb * 64];
-        float b[8];
-        b[0] = q3_u2f(wv.x << 16); b[1] = q3_u2f(wv.x & 0xffff0000u);
-        b[2] = q3_u2f(wv.y << 16); b[3] = q3_u2f(wv.y & 0xffff0000u);
-        b[4] = q3_u2f(wv.z << 16); b[5] = q3_u2f(wv.z & 0xffff0000u);
-        b[6] = q3_u2f(wv.w << 16); b[7] = q3_u2f(wv.w & 0xffff0000u);
-        float nw[8];
-        if (NORM) {
-            const float4 n0 = *(const float4*)(nwp + kb * 32), n1 = *(const float4*)(nwp + kb * 32 + 4);
-            nw[0] = n0.x; nw[1] = n0.y; nw[2] = n0.z; nw[3] = n0.w; nw[4] = n1.x; nw[5] = n1.y; nw[6] = n1.z; nw[7] = n1.w;
-        }
-#pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            const float4 x0 = *(const float4*)(xr[r] + kb * 32), x1 = *(const float4*)(xr[r] + kb * 32 + 4);
-            float a[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-            if (NORM) {
-#pragma unroll
-                for (int t = 0; t < 8; ++t) a[t] = (a[t] * ri[r]) * nw[t];
-            }
-#pragma unroll
-            for (int t = 0; t < 8; ++t) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], acc[r], 0, 0, 0);
-        }
-    }
-    // D layout: lane holds rows 4*(lane>>4)+j, column lane&15
-#pragma unroll
-    for (int r = 0; r < RT; ++r)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) red[((wave * RT + r) * 16 + 4 * kq + j) * 17 + li] = acc[r][j];
-    __syncthreads();
-    const int epi = g.epi;
-    for (int o = tid; o < RT * 256; o += 512) {
-        const int row = o >> 4, col = o & 15;
-        if (row >= nrows) continue;
-        float s = red[row * 17 + col];
-#pragma unroll
-        for (int w = 1; w < 8; ++w) s = s + red[(w * RT * 16 + row) * 17 + col];
-        const size_t grow = (size_t)(row0 + row);
-        if (epi == Q3_EPI_STORE) {
-            if (g.bias) s = s + g.bias[nb * 16 + col];
-            g.y[grow * g.ldy + nb * 16 + col] = s;
-        } else if (epi == Q3_EPI_RESID) {
-            float* yp = g.y + grow * g.ldy + nb * 16 + col;
-            *yp = *yp + s;
-        } else {
-            sums[row * 16 + col] = s;
-        }
-    }
-    if (epi == Q3_EPI_SWIGLU) {  // tile = 8 gate columns then the 8 matching up columns
-        __syncthreads();
-        for (int o = tid; o < RT * 128; o += 512) {
-            const int row = o >> 3, col = o & 7;
-            if (row >= nrows) continue;
-            g.y[(size_t)(row0 + row) * g.ldy + nb * 8 + col] = q3_swiglu(sums[row * 16 + col], sums[row * 16 + 8 + col]);
-        }
-    } else if (epi == Q3_EPI_ARGMAX) {
-        __syncthreads();
-        if (tid < nrows) {
-            unsigned long long best = 0;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const unsigned long long kk = q3_argmax_key(sums[tid * 16 + c], (uint32_t)(nb * 16 + c));
-                best = kk > best ? kk : best;
-            }
-            atomicMax(g.keys + (size_t)(row0 + tid) * g.key_stride, best);
-        }
-    }
-}
-
-void q3_launch_gemm(const Q3Gemm& g, hipStream_t s) {
-    const int rt = g.B <= 16 ? 1 : (g.B <= 32 ? 2 : 4);
-    dim3 grid(g.N / 16, (g.B + rt * 16 - 1) / (rt * 16));
-    const bool norm = g.norm_w != nullptr;
-#define L(RT_, NORM_) hipLaunchKernelGGL((k_gemm<RT_, NORM_>), grid, dim3(512), 0, s, g)
-    if (rt == 1) { if (norm) L(1, true); else L(1, false); }
-    else if (rt == 2) { if (norm) L(2, true); else L(2, false); }
-    else { if (norm) L(4, true); else L(4, false); }
-#undef L
-}
+// (the exact GEMM lives in q3_gemm.hip)
 
 // ---------------------------------------------------------------------------------------------------
 // weight / table initialisation
@@ -155,7 +40,7 @@ __global__ void k_fill_tiled(Q3Fill f, int nb0, int nb_count) {
     const int lane = (int)(gid & 63);
     const size_t t = gid >> 6;
     const int kb = (int)(t % kblocks), nb = nb0 + (int)(t / kblocks);
-    const int n = nb * 16 + (lane & 15), k0 = kb * 32 + (lane >> 4) * 8;
+    const int n = nb * 16 + (lane & 15), k0 = kb * 32 + (lane >> 4) * 4;  // element e <-> k = k0 + (e/4)*16 + (e%4)
     uint32_t tid; int lr; const uint16_t* src;
     if (f.mode == 0) { tid = f.tid_a; lr = n - f.row0; src = f.src_a; }
     else {
@@ -166,7 +51,7 @@ __global__ void k_fill_tiled(Q3Fill f, int nb0, int nb_count) {
     uint16_t h[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const size_t idx = (size_t)lr * f.K + k0 + e;
+        const size_t idx = (size_t)lr * f.K + k0 + (e >> 2) * 16 + (e & 3);
         h[e] = src ? src[idx] : q3_bf16(q3_synth(f.seed, tid, idx, f.scale));
     }
     uint4 v;

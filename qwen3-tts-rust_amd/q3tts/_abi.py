@@ -115,7 +115,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("Q3TTS_LIB") or LIB_PATH  # Q3TTS_LIB: experiment builds of the same HIP library
     if not os.path.exists(p):
         raise Q3Error(
             f"{p} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
@@ -168,14 +168,14 @@ def tiny_config(max_batch=4, n_ctx=256, with_vocoder=1):
     """A small shape the CPU oracle finishes in well under a second (used by parity tests)."""
     cfg = EngineConfig()
     m = cfg.model
-    m.t_n_layer, m.t_d_model, m.t_n_head, m.t_n_kv_head, m.t_head_dim, m.t_d_ffn, m.t_vocab = 2, 256, 4, 2, 128, 512, 3072
+    m.t_n_layer, m.t_d_model, m.t_n_head, m.t_n_kv_head, m.t_head_dim, m.t_d_ffn, m.t_vocab = 2, 512, 4, 2, 128, 1024, 3072
     m.t_rope_theta = 1000000.0
     m.t_mrope_sections[:] = [24, 20, 20, 0]
-    m.p_n_layer, m.p_d_model, m.p_n_head, m.p_n_kv_head, m.p_head_dim, m.p_d_ffn = 2, 256, 2, 1, 128, 256
+    m.p_n_layer, m.p_d_model, m.p_n_head, m.p_n_kv_head, m.p_head_dim, m.p_d_ffn = 2, 512, 4, 2, 128, 512
     m.p_rope_theta = 1000000.0
     m.n_codebooks, m.codebook_size = 16, 64
     m.rms_eps = 1e-6
-    m.d_embed, m.text_vocab, m.codec0_rows, m.codecq_rows = 256, 151936, 3072, 64
+    m.d_embed, m.text_vocab, m.codec0_rows, m.codecq_rows = 512, 151936, 3072, 64
     m.sample_limit, m.eos_code, m.tts_pad_id = 2160, 2150, 151671
     v = cfg.vocoder
     v.n_codebooks, v.codebook_size, v.codebook_dim = 16, 64, 32

@@ -12,6 +12,33 @@ def _ptr(a, typ):
     return a.ctypes.data_as(typ)
 
 
+def make_prompt_desc(text_ids, spk_emb=None, lang_id=2055, spk_id=-1, instruct_ids=None, ref_codes=None,
+                     ref_text_ids=None):
+    """Returns (PromptDesc, keepalive list)."""
+    keep = []
+    d = _abi.PromptDesc()
+    t = np.ascontiguousarray(text_ids, dtype=np.uint32)
+    keep.append(t)
+    d.text_ids, d.n_text = _ptr(t, u32p), len(t)
+    if instruct_ids is not None:
+        ins = np.ascontiguousarray(instruct_ids, dtype=np.uint32)
+        keep.append(ins)
+        d.instruct_ids, d.n_instruct = _ptr(ins, u32p), len(ins)
+    d.lang_id, d.spk_id = lang_id, spk_id
+    if spk_emb is not None:
+        s = np.ascontiguousarray(spk_emb, dtype=np.float32)
+        keep.append(s)
+        d.spk_emb = _ptr(s, f32p)
+    if ref_codes is not None:
+        rc = np.ascontiguousarray(ref_codes, dtype=np.int32)
+        keep.append(rc)
+        d.ref_codes, d.n_ref_frames = _ptr(rc, i32p), rc.size // 16
+        rt = np.ascontiguousarray(ref_text_ids if ref_text_ids is not None else [], dtype=np.uint32)
+        keep.append(rt)
+        d.ref_text_ids, d.n_ref_text = _ptr(rt, u32p), len(rt)
+    return d, keep
+
+
 class GenResult:
     def __init__(self, status, codes, pcm, hit_eos, first_chunk_ms, total_ms, sample_rate):
         self.status, self.codes, self.pcm, self.hit_eos = status, codes, pcm, hit_eos

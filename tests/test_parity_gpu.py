@@ -46,8 +46,8 @@ def _oracle_gemm(O, x, w, norm_w, eps, bias, epi, y_in=None):
     return y, keys
 
 
-@pytest.mark.parametrize("B,K,N", [(1, 256, 16), (1, 2048, 256), (3, 512, 48), (16, 1024, 64), (17, 2048, 32), (33, 768, 64),
-                                   (64, 2048, 128), (70, 512, 32), (2, 6144, 64)])
+@pytest.mark.parametrize("B,K,N", [(1, 512, 16), (1, 2048, 256), (3, 512, 48), (6, 2048, 64), (7, 2048, 64), (16, 1024, 64), (17, 2048, 32), (33, 1536, 64),
+                                   (64, 2048, 128), (70, 512, 32), (2, 6144, 64), (3, 6144, 32), (40, 1024, 12288), (64, 3072, 8192), (31, 2048, 96)])
 def test_gemm_exact_store_bias(oracle, native, B, K, N):
     rng = np.random.default_rng(B * 1000 + K + N)
     x = _rand(rng, (B, K))
@@ -58,7 +58,7 @@ def test_gemm_exact_store_bias(oracle, native, B, K, N):
     assert np.array_equal(_bits(y), _bits(y_ref))
 
 
-@pytest.mark.parametrize("B,K,N", [(1, 2048, 64), (5, 1024, 32), (40, 512, 64)])
+@pytest.mark.parametrize("B,K,N", [(1, 2048, 64), (5, 1024, 32), (12, 1024, 32), (13, 1024, 32), (40, 512, 64), (64, 2048, 12288)])
 def test_gemm_exact_norm_prologue(oracle, native, B, K, N):
     rng = np.random.default_rng(7 + B)
     x = _rand(rng, (B, K), 3.0)
@@ -71,7 +71,7 @@ def test_gemm_exact_norm_prologue(oracle, native, B, K, N):
 
 def test_gemm_exact_residual_swiglu_argmax(oracle, native):
     rng = np.random.default_rng(11)
-    B, K, N = 9, 1024, 96
+    B, K, N = 9, 1024, 96  # small-batch kernel
     x = _rand(rng, (B, K))
     w = _bf16_bits(_rand(rng, (N, K), 0.05))
     y0 = _rand(rng, (B, N))
