@@ -292,7 +292,10 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
     e->prow_cap = cfg->n_ctx;
     TRYC(dalloc(e, &e->prow_dev, (size_t)e->prow_cap)); TRYC(dalloc(e, &e->spk_dev, (size_t)m.d_embed));
     TRYC(dalloc(e, &e->refcodes_dev, (size_t)cfg->n_ctx * 16));
-    if (cfg->with_vocoder) TRYC(q3_voc_create(e));
+    if (cfg->with_vocoder) {
+        TRYC(q3_voc_create(e));
+        HIPC(hipHostMalloc((void**)&e->first_chunk_host, sizeof(float) * 4 * (size_t)q3_voc_samples_per_frame(e), hipHostMallocDefault));
+    }
     // capture the frame step once; every later frame is a replay (Q3TTS_NO_GRAPH=1: eager launches, for profilers)
     HIPC(hipStreamSynchronize(s));
     if (!(getenv("Q3TTS_NO_GRAPH") && atoi(getenv("Q3TTS_NO_GRAPH")))) {
@@ -316,6 +319,7 @@ extern "C" void q3tts_engine_destroy(q3tts_engine* e) {
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->vstream) hipStreamSynchronize(e->vstream);
     if (e->voc) q3_voc_destroy(e);
+    if (e->first_chunk_host) hipHostFree(e->first_chunk_host);
     if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
     if (e->graph) hipGraphDestroy(e->graph);
     free_tfm(e->T); free_tfm(e->P);
@@ -537,34 +541,50 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
         if (admitted) { hipEventElapsedTime(&ms, e->ev0, e->ev1); pre_ms += ms; }
         hipEventElapsedTime(&ms, e->ev2, e->ev3); dec_ms += ms; steps += CH;
         for (int b = 0; b < B; ++b) if (run[b].req >= 0) ctx_tokens += (long long)e->slots_host[b].cur_pos * CH;
-        // H8: vocoder on chunks of 4 frames, flushed with is_last on completion (src/tts/engine.rs:507-541)
-        for (int b = 0; b < B; ++b) {
-            if (run[b].req < 0) continue;
-            const q3tts_request* r = &reqs[run[b].req];
-            const Q3Slot& st = e->slots_host[b];
-            if (r->want_pcm && e->voc) {
-                const double tv0 = now_ms();
-                while (st.n_frames - run[b].voc_frames >= 4) {
-                    TRY(q3_voc_decode(e, b, run[b].voc_frames, 4, 0, s));
-                    run[b].voc_frames += 4;
-                    if (run[b].t_first == 0) {  // first-chunk latency: PCM of the first chunk resident on the host
-                        Q3_HIP(e, hipStreamSynchronize(s));
-                        run[b].t_first = now_ms();
+        // H8: the vocoder consumes 4-frame chunks (src/tts/engine.rs:507-541). It runs on its own stream behind an
+        // event, batched over every slot that has a chunk ready, so chunk k's PCM overlaps the decoding of chunk k+1.
+        if (e->voc) {
+            const double tv0 = now_ms();
+            hipStream_t vs = e->vstream;
+            bool waited = false, first = false;
+            auto ensure_wait = [&]() -> int { if (!waited) { Q3_HIP(e, hipStreamWaitEvent(vs, e->ev3, 0)); waited = true; } return Q3TTS_OK; };
+            int list[64];
+            for (;;) {  // full chunks
+                int ns = 0;
+                for (int b = 0; b < B; ++b)
+                    if (run[b].req >= 0 && reqs[run[b].req].want_pcm && e->slots_host[b].n_frames - run[b].voc_frames >= 4) list[ns++] = b;
+                if (!ns) break;
+                TRY(ensure_wait());
+                TRY(q3_voc_decode_batch(e, list, ns, 4, vs));
+                for (int i = 0; i < ns; ++i) { if (run[list[i]].voc_frames == 0) first = true; run[list[i]].voc_frames += 4; }
+            }
+            for (int nf = 3; nf >= 1; --nf) {  // tails of finished utterances (flushed: nothing is silently dropped)
+                int ns = 0;
+                for (int b = 0; b < B; ++b)
+                    if (run[b].req >= 0 && reqs[run[b].req].want_pcm && !e->slots_host[b].active && e->slots_host[b].n_frames - run[b].voc_frames == nf) list[ns++] = b;
+                if (!ns) continue;
+                TRY(ensure_wait());
+                TRY(q3_voc_decode_batch(e, list, ns, nf, vs));
+                for (int i = 0; i < ns; ++i) { if (run[list[i]].voc_frames == 0) first = true; run[list[i]].voc_frames += nf; }
+            }
+            if (first) {  // first-chunk latency: the first chunk's PCM resident on the host
+                for (int b = 0; b < B; ++b)
+                    if (run[b].req >= 0 && run[b].t_first == 0 && run[b].voc_frames > 0) {
+                        const int nsmp = std::min(run[b].voc_frames, 4) * spf;
+                        Q3_HIP(e, hipMemcpyAsync(e->first_chunk_host, q3_voc_pcm(e, b), sizeof(float) * (size_t)nsmp, hipMemcpyDeviceToHost, vs));
                     }
-                }
-                if (!st.active && st.n_frames > run[b].voc_frames) {
-                    TRY(q3_voc_decode(e, b, run[b].voc_frames, st.n_frames - run[b].voc_frames, 1, s));
-                    run[b].voc_frames = st.n_frames;
-                    if (run[b].t_first == 0) { Q3_HIP(e, hipStreamSynchronize(s)); run[b].t_first = now_ms(); }
-                }
-                voc_ms += now_ms() - tv0;
+                Q3_HIP(e, hipStreamSynchronize(vs));
+                const double tn = now_ms();
+                for (int b = 0; b < B; ++b) if (run[b].req >= 0 && run[b].t_first == 0 && run[b].voc_frames > 0) run[b].t_first = tn;
             }
-            if (!st.active) {
-                TRY(finalize(e, b, r, &outs[run[b].req], run[b], t0));
-                run[b].req = -1; ++done;
-            }
+            voc_ms += now_ms() - tv0;
         }
-        (void)spf;
+        for (int b = 0; b < B; ++b) {
+            if (run[b].req < 0 || e->slots_host[b].active) continue;
+            if (e->voc) q3_voc_mark_last(e, b);
+            TRY(finalize(e, b, &reqs[run[b].req], &outs[run[b].req], run[b], t0));
+            run[b].req = -1; ++done;
+        }
     }
     e->tm.prefill_ms = (float)pre_ms; e->tm.decode_ms = (float)dec_ms; e->tm.vocoder_ms = (float)voc_ms;
     e->tm.total_ms = (float)(now_ms() - t0); e->tm.frame_steps = steps; e->tm.frame_step_ms = steps ? (float)(dec_ms / steps) : 0.0f;

@@ -1,10 +1,615 @@
-// placeholder until the vocoder lands (next commit): engine runs codes-only
+// q3_vocoder.hip — streaming neural-codec vocoder (V1-V6 of SURVEY.md §8a) on gfx950.
+//
+// Replaces the onnxruntime session behind AudioDecoder::decode (/root/reference/src/models/onnx.rs:342-459): codes
+// [N][16] (+ is_last) -> 24 kHz PCM, with the streaming state (conv histories, sliding-window KV ring) resident on
+// the device per utterance slot instead of being deep-copied through the host on every call
+// (src/models/onnx.rs:369-384,410-455). Structure: restated in oracle/q3_oracle_vocoder.c (same model family as
+// transformers' qwen3_omni_moe Code2Wav); every dimension comes from q3tts_vocoder_config.
+//
+// Layout: activations are channels-last f32 [slot][hist + T][C]; every convolution (k taps, dilation d, transposed or
+// not) is a multi-tap GEMM  out[t][n] = bias[n] + sum_tap X[t - (ntap-1-tap)*d][:] . W[tap][n][:]  on
+// v_mfma_f32_16x16x32_bf16 (bf16 operands, f32 accumulate) with fused epilogues. All convolutions are causal, so
+// chunked streaming equals one-shot decoding; each conv input keeps its last (k-1)*d rows per slot.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
 #include "q3_engine.h"
-int q3_voc_create(q3tts_engine* e) { e->voc = nullptr; return Q3TTS_OK; }
-void q3_voc_destroy(q3tts_engine*) {}
-int q3_voc_reset(q3tts_engine*, int) { return Q3TTS_OK; }
-int q3_voc_decode(q3tts_engine* e, int, int, int, int, hipStream_t) { return q3_set_err(e, Q3TTS_ERR_UNSUPPORTED, "vocoder not built"); }
-float* q3_voc_pcm(q3tts_engine*, int) { return nullptr; }
-int q3_voc_samples(q3tts_engine*, int) { return 0; }
-int q3_voc_samples_per_frame(const q3tts_engine*) { return 1920; }
-extern "C" int q3tts_k_vocoder(q3tts_engine* e, const int32_t*, int32_t, int32_t, float*, int32_t*) { return q3_set_err(e, Q3TTS_ERR_UNSUPPORTED, "vocoder not built"); }
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define VOC_MAX_NS 64   // slots per batched call
+#define VOC_FCAP 4      // frames per slot per call (the reference's 4-frame chunk: src/tts/engine.rs:509-512)
+
+enum { VC_CODEBOOK = 0, VC_PRE = 32, VC_TFM = 40, VC_FINAL_NORM = 60, VC_UP = 64, VC_DEC_IN = 72, VC_BLK = 80, VC_OUT = 120 };
+enum { VW_W = 0, VW_B = 1, VW_IN_NORM = 2, VW_Q = 3, VW_K = 4, VW_V = 5, VW_O = 6, VW_LS_ATTN = 7, VW_POST_NORM = 8, VW_GATE = 9,
+       VW_UP = 10, VW_DOWN = 11, VW_LS_MLP = 12, VW_DW_W = 13, VW_DW_B = 14, VW_LN_W = 15, VW_LN_B = 16, VW_PW1 = 17, VW_PW1_B = 18,
+       VW_PW2 = 19, VW_PW2_B = 20, VW_GAMMA = 21, VW_ALPHA = 22, VW_BETA = 23, VW_W2 = 24, VW_B2 = 25, VW_ALPHA2 = 26, VW_BETA2 = 27 };
+#define VTID(l, w) Q3_TID(Q3G_VOC, l, w)
+
+struct VCall {  // passed by value to the kernels of one batched call
+    int ns, nf;
+    int slot[VOC_MAX_NS];
+    int pos[VOC_MAX_NS];      // frames already decoded for the slot
+};
+
+struct VConv { int ntap = 1, dil = 1, cin = 0, nout = 0, bias_n = 0; uint16_t* w = nullptr; float* b = nullptr; };
+// work buffer of a conv input: [VOC_MAX_NS][H + Tcap][C] (slot-major) + per-slot history [B][H][C]
+struct VBuf { float* p = nullptr; float* hist = nullptr; int H = 0, C = 0, Tcap = 0; size_t stride() const { return (size_t)(H + Tcap) * C; } };
+
+struct VLayer { float *in_norm, *post_norm, *ls_attn, *ls_mlp; VConv q, k, v, o, gate, up, down; };
+struct VUp { VConv ct, pw1, pw2; float *dw_w, *dw_b, *ln_w, *ln_b, *gamma; int r; VBuf dw_in; };
+struct VRes { float *ea, *ib, *ea2, *ib2; VConv c1, c2; VBuf c1_in; };
+struct VBlk { float *ea, *ib; VConv ct; VRes res[3]; int r, cin, cout; VBuf ct_in; };
+
+struct Q3Voc {
+    q3tts_vocoder_config c;
+    int spf = 1, B = 0, RW = 0;
+    std::vector<float*> cb; const float** cb_dev = nullptr;
+    VConv pre; VBuf pre_in;
+    std::vector<VLayer> L; float* final_norm = nullptr;
+    std::vector<VUp> U;
+    VConv dec_in; VBuf dec_in_in;
+    std::vector<VBlk> Bk;
+    float *oea = nullptr, *oib = nullptr, *out_w = nullptr, *out_b = nullptr; VBuf out_in; int out_c = 0;
+    float *kring = nullptr, *vring = nullptr;  // [n_layer][B][RW][HH]
+    float *x = nullptr, *xn = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *att = nullptr, *g = nullptr, *u = nullptr;  // transformer scratch [M][.]
+    float *t1 = nullptr, *t2 = nullptr, *t3 = nullptr;  // generic scratch (largest stage)
+    float* pcm = nullptr; size_t pcm_stride = 0;         // [B][max_steps_cap * spf]
+    std::vector<int> frames_done, last_flag;
+    std::vector<void*> allocs;
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------------------------
+struct VGemm {
+    const float* x; size_t x_stride; int x_off;   // row (s, t) tap 0 shift 0 at x + s*x_stride + x_off + t*cin
+    int T, M;                                     // rows per slot, total rows = ns*T
+    VConv c;
+    float* y; size_t y_stride; int y_off;         // out row (s,t) at y + s*y_stride + y_off + t*nout
+    const float* scale;                           // epilogue 1: y += scale[n % bias_n'] * (acc + bias)
+    int scale_n;
+    int epi;                                      // 0 store, 1 y += scale*(.), 2 y += (.), 3 gelu
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// workgroup = 4 waves, tile 128 rows x 64 cols; wave = 32 rows x 64 cols = 2 x 4 MFMA tiles. Fragments load straight
+// from global/L2 (A: 32 B of f32 per lane -> bf16x8; B: 16 B of bf16 per lane), no LDS.
+__global__ __launch_bounds__(256) void k_vgemm(VGemm g) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m0 = blockIdx.y * 128 + wave * 32, n0 = blockIdx.x * 64;
+    const int lr = lane & 15, kq = lane >> 4;
+    const int cin = g.c.cin, nout = g.c.nout;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* xrow[2]; int trow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int m = m0 + i * 16 + lr;
+        if (m >= g.M) m = g.M - 1;
+        const int s = m / g.T, t = m - s * g.T;
+        trow[i] = t;
+        xrow[i] = g.x + (size_t)s * g.x_stride + g.x_off + (size_t)t * cin + kq * 8;
+    }
+    const uint16_t* wrow[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int n = n0 + j * 16 + lr;
+        if (n >= nout) n = nout - 1;
+        wrow[j] = g.c.w + (size_t)n * cin + kq * 8;
+    }
+    for (int tap = 0; tap < g.c.ntap; ++tap) {
+        const long shift = (long)(g.c.ntap - 1 - tap) * g.c.dil * cin;
+        const size_t woff = (size_t)tap * nout * cin;
+        for (int k0 = 0; k0 < cin; k0 += 32) {
+            bf16x8 a[2], b[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float* p = xrow[i] - shift + k0;
+                const float4 v0 = *(const float4*)p, v1 = *(const float4*)(p + 4);
+                a[i][0] = (__bf16)v0.x; a[i][1] = (__bf16)v0.y; a[i][2] = (__bf16)v0.z; a[i][3] = (__bf16)v0.w;
+                a[i][4] = (__bf16)v1.x; a[i][5] = (__bf16)v1.y; a[i][6] = (__bf16)v1.z; a[i][7] = (__bf16)v1.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8*)(wrow[j] + woff + k0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    (void)trow;
+    // D layout: lane holds rows 4*(lane>>4)+e, column lane&15
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = m0 + i * 16 + 4 * kq + e;
+            if (m >= g.M) continue;
+            const int s = m / g.T, t = m - s * g.T;
+            float* yrow = g.y + (size_t)s * g.y_stride + g.y_off + (size_t)t * nout;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + j * 16 + lr;
+                if (n >= nout) continue;
+                float v = acc[i][j][e];
+                if (g.c.b) v += g.c.b[n % g.c.bias_n];
+                if (g.epi == 0) yrow[n] = v;
+                else if (g.epi == 1) yrow[n] = yrow[n] + g.scale[n % g.scale_n] * v;
+                else if (g.epi == 2) yrow[n] = yrow[n] + v;
+                else yrow[n] = gelu_erf(v);
+            }
+        }
+}
+
+__global__ void k_voc_embed(VCall cl, const int* codes, int max_steps_cap, int ncb_model, const float* const* cb, int ncb, int cbs, int cd,
+                            float* out, size_t out_stride, int out_off) {
+    const int s = blockIdx.y, t = blockIdx.x;
+    const int slot = cl.slot[s], frame = cl.pos[s] + t;
+    const int* cp = codes + ((size_t)slot * max_steps_cap + frame) * ncb_model;
+    for (int i = threadIdx.x; i < cd; i += blockDim.x) {
+        float acc = 0.0f;
+        for (int q = 0; q < ncb; ++q) {
+            int code = cp[q];
+            code = code < 0 ? 0 : (code >= cbs ? cbs - 1 : code);  // clamp [0, 2047]: src/tts/engine.rs:515-519
+            acc += cb[q][(size_t)code * cd + i];
+        }
+        out[(size_t)s * out_stride + out_off + (size_t)t * cd + i] = acc;
+    }
+}
+
+// history rows: work[s][0:H] <- hist[slot]  (load)   /   hist[slot] <- work[s][T : T+H]  (save)
+__global__ void k_voc_hist(VCall cl, float* work, size_t stride, float* hist, int H, int C, int T, int save) {
+    const int s = blockIdx.y, slot = cl.slot[s];
+    const size_t n = (size_t)H * C;
+    float* w = work + (size_t)s * stride + (save ? (size_t)T * C : 0);
+    float* h = hist + (size_t)slot * n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (save) h[i] = w[i]; else w[i] = h[i];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_voc_rmsnorm(const float* x, const float* w, float eps, int d, float* y) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const float* xr = x + (size_t)r * d;
+    float ss = 0.0f;
+    for (int i = lane; i < d; i += 64) ss += xr[i] * xr[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
+    const float rinv = 1.0f / sqrtf(ss / (float)d + eps);
+    for (int i = lane; i < d; i += 64) y[(size_t)r * d + i] = (xr[i] * rinv) * w[i];
+}
+
+// RoPE + ring append + sliding-window attention; one workgroup (64 threads) per (slot, head), tokens in order
+__global__ __launch_bounds__(64) void k_voc_attn(VCall cl, const float* q, const float* k, const float* v, float* kring, float* vring,
+                                                 int H, int hd, int RW, int W, float theta, float* att) {
+    __shared__ float sc[512];
+    __shared__ float qs[128];
+    const int s = blockIdx.y, h = blockIdx.x, lane = threadIdx.x, HH = H * hd, half = hd >> 1;
+    const int slot = cl.slot[s], T = cl.nf;
+    float* kr = kring + (size_t)slot * RW * HH + h * hd;
+    float* vr = vring + (size_t)slot * RW * HH + h * hd;
+    const float scale = 1.0f / sqrtf((float)hd);
+    for (int t = 0; t < T; ++t) {
+        const int pos = cl.pos[s] + t;
+        const size_t row = ((size_t)s * T + t) * HH + h * hd;
+        if (lane < half) {
+            const double inv = pow((double)theta, -2.0 * (double)lane / (double)hd), ang = (double)pos * inv;
+            const float cs = (float)cos(ang), sn = (float)sin(ang);
+            float a = q[row + lane], b = q[row + lane + half];
+            qs[lane] = a * cs - b * sn; qs[lane + half] = b * cs + a * sn;
+            a = k[row + lane]; b = k[row + lane + half];
+            float* kd = kr + (size_t)(pos % RW) * HH;
+            kd[lane] = a * cs - b * sn; kd[lane + half] = b * cs + a * sn;
+        }
+        for (int i = lane; i < hd; i += 64) vr[(size_t)(pos % RW) * HH + i] = v[row + i];
+        __syncthreads();
+        const int j0 = pos - W + 1 > 0 ? pos - W + 1 : 0, nk = pos - j0 + 1;
+        for (int j = lane; j < nk; j += 64) {
+            const float* kp = kr + (size_t)((j0 + j) % RW) * HH;
+            float a = 0.0f;
+            for (int i = 0; i < hd; ++i) a += qs[i] * kp[i];
+            sc[j] = a * scale;
+        }
+        __syncthreads();
+        float m = -INFINITY;
+        for (int j = 0; j < nk; ++j) m = fmaxf(m, sc[j]);
+        float l = 0.0f;
+        for (int j = 0; j < nk; ++j) l += expf(sc[j] - m);
+        for (int i = lane; i < hd; i += 64) {
+            float o = 0.0f;
+            for (int j = 0; j < nk; ++j) o += expf(sc[j] - m) * vr[(size_t)((j0 + j) % RW) * HH + i];
+            att[row + i] = o / l;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_voc_swiglu(float* g, const float* u, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        g[i] = (g[i] / (1.0f + expf(-g[i]))) * u[i];
+}
+
+// ConvNeXt front: depthwise causal conv k7 + LayerNorm(eps 1e-6) per position; one wave per (slot, t)
+__global__ __launch_bounds__(64) void k_voc_dw_ln(const float* x, size_t x_stride, int H, int T, int C, const float* dw_w, const float* dw_b,
+                                                  const float* ln_w, const float* ln_b, float* y) {
+    extern __shared__ float row[];
+    const int s = blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
+    const float* xp = x + (size_t)s * x_stride + (size_t)(H + t) * C;
+    float sum = 0.0f;
+    for (int i = lane; i < C; i += 64) {
+        float a = dw_b[i];
+#pragma unroll
+        for (int tap = 0; tap < 7; ++tap) a += xp[(long)(tap - 6) * C + i] * dw_w[(size_t)tap * C + i];
+        row[i] = a; sum += a;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+    const float mean = sum / (float)C;
+    float var = 0.0f;
+    for (int i = lane; i < C; i += 64) { const float z = row[i] - mean; var += z * z; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) var += __shfl_xor(var, m);
+    const float rinv = 1.0f / sqrtf(var / (float)C + 1e-6f);
+    float* yp = y + ((size_t)s * T + t) * C;
+    for (int i = lane; i < C; i += 64) yp[i] = ((row[i] - mean) * rinv) * ln_w[i] + ln_b[i];
+}
+
+// SnakeBeta: y = x + ib[c] * sin(x * ea[c])^2 ; x rows [s][t] contiguous (x_stride per slot), y into a work buffer
+__global__ void k_voc_snake(const float* x, size_t x_stride, int x_off, int T, int C, const float* ea, const float* ib, float* y,
+                            size_t y_stride, int y_off) {
+    const int s = blockIdx.y;
+    const size_t n = (size_t)T * C;
+    const float* xp = x + (size_t)s * x_stride + x_off;
+    float* yp = y + (size_t)s * y_stride + y_off;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const float v = xp[i], sn = sinf(v * ea[c]);
+        yp[i] = v + ib[c] * (sn * sn);
+    }
+}
+
+// V6: Conv k7 C -> 1 over the snaked input (with history) + clamp -> PCM of the slot
+__global__ void k_voc_out(VCall cl, const float* x, size_t x_stride, int H, int T, int C, const float* w, const float* b, float* pcm,
+                          size_t pcm_stride, int spf) {
+    const int s = blockIdx.y, slot = cl.slot[s];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const float* xp = x + (size_t)s * x_stride + (size_t)(H + t) * C;
+    float acc = 0.0f;
+    for (int tap = 0; tap < 7; ++tap) {
+        const float* xr = xp + (long)(tap - 6) * C;
+        float a = 0.0f;
+        for (int i = 0; i < C; ++i) a += q3_round_bf16(xr[i]) * w[tap * C + i];
+        acc += a;
+    }
+    acc += b[0];
+    acc = fminf(1.0f, fmaxf(-1.0f, acc));
+    pcm[(size_t)slot * pcm_stride + (size_t)cl.pos[s] * spf + t] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host
+// ------------------------------------------------------------------------------------------------------------------
+template <class T>
+static int valloc(q3tts_engine* e, Q3Voc* v, T** p, size_t n) {
+    void* q = nullptr;
+    if (hipMalloc(&q, n * sizeof(T) + 256) != hipSuccess) return q3_set_err(e, Q3TTS_ERR_OOM, "hipMalloc (vocoder)");
+    hipMemsetAsync(q, 0, n * sizeof(T) + 256, e->stream);
+    v->allocs.push_back(q);
+    *p = (T*)q;
+    return Q3TTS_OK;
+}
+#define VTRY(x) do { int rc__ = (x); if (rc__ != Q3TTS_OK) return rc__; } while (0)
+
+static int gen_vec(q3tts_engine* e, Q3Voc* v, float** p, uint32_t tid, size_t n, float base, float std) {
+    VTRY(valloc(e, v, p, n));
+    q3_launch_fill_f32(*p, n, e->cfg.synth_seed, tid, base, std / Q3_IH4_STD, 0, e->stream);
+    return Q3TTS_OK;
+}
+__global__ void k_fill_bf16(uint16_t* dst, size_t n, uint64_t seed, uint32_t tid, float scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = q3_bf16(q3_synth(seed, tid, i, scale));
+}
+static int gen_conv(q3tts_engine* e, Q3Voc* v, VConv* c, int comp, int ww, int wb, int ntap, int dil, int cin, int nout, int bias_n, float gain) {
+    c->ntap = ntap; c->dil = dil; c->cin = cin; c->nout = nout; c->bias_n = bias_n;
+    const size_t n = (size_t)ntap * nout * cin;
+    VTRY(valloc(e, v, &c->w, n));
+    const float scale = (gain / sqrtf((float)(ntap * cin))) / Q3_IH4_STD;
+    hipLaunchKernelGGL(k_fill_bf16, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65536)), dim3(256), 0, e->stream, c->w, n,
+                       e->cfg.synth_seed, VTID(comp, ww), scale);
+    c->b = nullptr;
+    if (bias_n) VTRY(gen_vec(e, v, &c->b, VTID(comp, wb), bias_n, 0.0f, 0.02f));
+    return Q3TTS_OK;
+}
+// SnakeBeta parameters: exp() evaluated in double on the host (same as the oracle)
+static int gen_snake(q3tts_engine* e, Q3Voc* v, uint32_t ta, uint32_t tb, int C, float** ea, float** ib) {
+    std::vector<float> a(C), b(C);
+    const float scale = 0.1f / Q3_IH4_STD;
+    for (int i = 0; i < C; ++i) {
+        const float al = 0.0f + q3_synth(e->cfg.synth_seed, ta, i, scale), be = 0.0f + q3_synth(e->cfg.synth_seed, tb, i, scale);
+        a[i] = (float)exp((double)al); b[i] = (float)(1.0 / (exp((double)be) + 1e-9));
+    }
+    VTRY(valloc(e, v, ea, (size_t)C)); VTRY(valloc(e, v, ib, (size_t)C));
+    Q3_HIP(e, hipMemcpy(*ea, a.data(), (size_t)C * 4, hipMemcpyHostToDevice));
+    Q3_HIP(e, hipMemcpy(*ib, b.data(), (size_t)C * 4, hipMemcpyHostToDevice));
+    return Q3TTS_OK;
+}
+static int mk_buf(q3tts_engine* e, Q3Voc* v, VBuf* b, int H, int C, int Tcap) {
+    b->H = H; b->C = C; b->Tcap = Tcap;
+    VTRY(valloc(e, v, &b->p, (size_t)VOC_MAX_NS * b->stride()));
+    VTRY(valloc(e, v, &b->hist, (size_t)v->B * std::max(1, H) * C));
+    return Q3TTS_OK;
+}
+
+int q3_voc_samples_per_frame(const q3tts_engine* e) { return e->voc ? e->voc->spf : 0; }
+
+int q3_voc_create(q3tts_engine* e) {
+    const q3tts_vocoder_config& c = e->cfg.vocoder;
+#define REQ(cond) do { if (!(cond)) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder config check failed: " #cond); } while (0)
+    REQ(c.n_codebooks >= 1 && c.n_codebooks <= 16 && c.n_codebooks <= e->cfg.model.n_codebooks);
+    REQ(c.codebook_dim % 32 == 0 && c.latent_dim % 32 == 0 && c.d_ffn % 32 == 0 && (c.n_head * c.head_dim) % 32 == 0);
+    REQ(c.head_dim <= 128 && c.head_dim % 2 == 0 && c.sliding_window >= 1 && c.sliding_window + VOC_FCAP <= 512);
+    REQ(c.n_upsample >= 0 && c.n_upsample <= Q3TTS_MAX_UPSAMPLE && c.n_dec_blocks >= 1 && c.n_dec_blocks <= Q3TTS_MAX_DEC_BLOCKS);
+    REQ(c.pre_conv_kernel >= 1 && c.lookahead_frames >= 0);
+    { int ch = c.decoder_dim; for (int b = 0; b < c.n_dec_blocks; ++b) { REQ(ch % 64 == 0); ch /= 2; } REQ(ch >= 1); }
+#undef REQ
+    Q3Voc* v = new Q3Voc();
+    e->voc = v;
+    v->c = c; v->B = e->B;
+    const int d = c.latent_dim, HH = c.n_head * c.head_dim;
+    v->RW = c.sliding_window + VOC_FCAP;
+    v->cb.resize(c.n_codebooks);
+    for (int q = 0; q < c.n_codebooks; ++q) {
+        VTRY(valloc(e, v, &v->cb[q], (size_t)c.codebook_size * c.codebook_dim));
+        q3_launch_fill_f32(v->cb[q], (size_t)c.codebook_size * c.codebook_dim, e->cfg.synth_seed, VTID(VC_CODEBOOK + q, VW_W), 0.0f,
+                           (1.0f / sqrtf(16.0f)) / Q3_IH4_STD, 1, e->stream);
+    }
+    { float** cd = nullptr; VTRY(valloc(e, v, &cd, (size_t)16)); v->cb_dev = (const float**)cd;
+      Q3_HIP(e, hipMemcpy((void*)cd, v->cb.data(), sizeof(float*) * c.n_codebooks, hipMemcpyHostToDevice)); }
+    VTRY(gen_conv(e, v, &v->pre, VC_PRE, VW_W, VW_B, c.pre_conv_kernel, 1, c.codebook_dim, d, d, 1.0f));
+    VTRY(mk_buf(e, v, &v->pre_in, c.pre_conv_kernel - 1, c.codebook_dim, VOC_FCAP));
+    v->L.resize(c.n_layer);
+    for (int l = 0; l < c.n_layer; ++l) {
+        VLayer& y = v->L[l]; const int comp = VC_TFM + l;
+        VTRY(gen_vec(e, v, &y.in_norm, VTID(comp, VW_IN_NORM), d, 1.0f, 0.05f));
+        VTRY(gen_vec(e, v, &y.post_norm, VTID(comp, VW_POST_NORM), d, 1.0f, 0.05f));
+        VTRY(gen_vec(e, v, &y.ls_attn, VTID(comp, VW_LS_ATTN), d, c.layer_scale_init, 0.1f * c.layer_scale_init));
+        VTRY(gen_vec(e, v, &y.ls_mlp, VTID(comp, VW_LS_MLP), d, c.layer_scale_init, 0.1f * c.layer_scale_init));
+        VTRY(gen_conv(e, v, &y.q, comp, VW_Q, 0, 1, 1, d, HH, 0, 1.0f)); VTRY(gen_conv(e, v, &y.k, comp, VW_K, 0, 1, 1, d, HH, 0, 1.0f));
+        VTRY(gen_conv(e, v, &y.v, comp, VW_V, 0, 1, 1, d, HH, 0, 1.0f)); VTRY(gen_conv(e, v, &y.o, comp, VW_O, 0, 1, 1, HH, d, 0, 1.0f));
+        VTRY(gen_conv(e, v, &y.gate, comp, VW_GATE, 0, 1, 1, d, c.d_ffn, 0, 1.0f)); VTRY(gen_conv(e, v, &y.up, comp, VW_UP, 0, 1, 1, d, c.d_ffn, 0, 1.0f));
+        VTRY(gen_conv(e, v, &y.down, comp, VW_DOWN, 0, 1, 1, c.d_ffn, d, 0, 1.0f));
+    }
+    VTRY(gen_vec(e, v, &v->final_norm, VTID(VC_FINAL_NORM, VW_W), d, 1.0f, 0.05f));
+    int rows = VOC_FCAP;  // rows per slot at the current stage
+    v->spf = 1;
+    v->U.resize(c.n_upsample);
+    for (int s = 0; s < c.n_upsample; ++s) {
+        VUp& p = v->U[s]; const int comp = VC_UP + s, r = c.upsample_ratios[s]; p.r = r; v->spf *= r;
+        VTRY(gen_conv(e, v, &p.ct, comp, VW_W, VW_B, 1, 1, d, r * d, d, 1.0f));
+        rows *= r;
+        VTRY(mk_buf(e, v, &p.dw_in, 6, d, rows));
+        VTRY(gen_vec(e, v, &p.dw_w, VTID(comp, VW_DW_W), (size_t)7 * d, 0.0f, 0.3f)); VTRY(gen_vec(e, v, &p.dw_b, VTID(comp, VW_DW_B), d, 0.0f, 0.02f));
+        VTRY(gen_vec(e, v, &p.ln_w, VTID(comp, VW_LN_W), d, 1.0f, 0.05f)); VTRY(gen_vec(e, v, &p.ln_b, VTID(comp, VW_LN_B), d, 0.0f, 0.02f));
+        VTRY(gen_conv(e, v, &p.pw1, comp, VW_PW1, VW_PW1_B, 1, 1, d, 4 * d, 4 * d, 1.0f));
+        VTRY(gen_conv(e, v, &p.pw2, comp, VW_PW2, VW_PW2_B, 1, 1, 4 * d, d, d, 1.0f));
+        VTRY(gen_vec(e, v, &p.gamma, VTID(comp, VW_GAMMA), d, 0.1f, 0.01f));
+    }
+    VTRY(gen_conv(e, v, &v->dec_in, VC_DEC_IN, VW_W, VW_B, 7, 1, d, c.decoder_dim, c.decoder_dim, 1.0f));
+    VTRY(mk_buf(e, v, &v->dec_in_in, 6, d, rows));
+    size_t scratch = (size_t)rows * std::max(4 * d, c.decoder_dim);
+    v->Bk.resize(c.n_dec_blocks);
+    int ch = c.decoder_dim;
+    for (int b = 0; b < c.n_dec_blocks; ++b) {
+        VBlk& k = v->Bk[b]; const int comp = VC_BLK + 4 * b, r = c.dec_rates[b]; k.r = r; k.cin = ch; k.cout = ch / 2; v->spf *= r;
+        VTRY(gen_snake(e, v, VTID(comp, VW_ALPHA), VTID(comp, VW_BETA), ch, &k.ea, &k.ib));
+        VTRY(gen_conv(e, v, &k.ct, comp, VW_W, VW_B, 2, 1, ch, r * k.cout, k.cout, 1.0f));
+        VTRY(mk_buf(e, v, &k.ct_in, 1, ch, rows));
+        rows *= r;
+        scratch = std::max(scratch, (size_t)rows * k.cout);
+        const int dil[3] = {1, 3, 9};
+        for (int u = 0; u < 3; ++u) {
+            VRes& s = k.res[u]; const int rc = comp + 1 + u;
+            VTRY(gen_snake(e, v, VTID(rc, VW_ALPHA), VTID(rc, VW_BETA), k.cout, &s.ea, &s.ib));
+            VTRY(gen_conv(e, v, &s.c1, rc, VW_W, VW_B, 7, dil[u], k.cout, k.cout, k.cout, 0.5f));
+            VTRY(mk_buf(e, v, &s.c1_in, 6 * dil[u], k.cout, rows));
+            VTRY(gen_snake(e, v, VTID(rc, VW_ALPHA2), VTID(rc, VW_BETA2), k.cout, &s.ea2, &s.ib2));
+            VTRY(gen_conv(e, v, &s.c2, rc, VW_W2, VW_B2, 1, 1, k.cout, k.cout, k.cout, 0.5f));
+        }
+        ch = k.cout;
+    }
+    v->out_c = ch;
+    VTRY(gen_snake(e, v, VTID(VC_OUT, VW_ALPHA), VTID(VC_OUT, VW_BETA), ch, &v->oea, &v->oib));
+    VTRY(valloc(e, v, &v->out_w, (size_t)7 * ch)); VTRY(gen_vec(e, v, &v->out_b, VTID(VC_OUT, VW_B), 1, 0.0f, 0.02f));
+    q3_launch_fill_f32(v->out_w, (size_t)7 * ch, e->cfg.synth_seed, VTID(VC_OUT, VW_W), 0.0f, (0.1f / sqrtf((float)(7 * ch))) / Q3_IH4_STD, 1, e->stream);
+    VTRY(mk_buf(e, v, &v->out_in, 6, ch, rows));
+    // transformer scratch [VOC_MAX_NS * VOC_FCAP][.]
+    const size_t M = (size_t)VOC_MAX_NS * VOC_FCAP;
+    VTRY(valloc(e, v, &v->x, M * d)); VTRY(valloc(e, v, &v->xn, M * d)); VTRY(valloc(e, v, &v->q, M * HH)); VTRY(valloc(e, v, &v->k, M * HH));
+    VTRY(valloc(e, v, &v->v, M * HH)); VTRY(valloc(e, v, &v->att, M * HH)); VTRY(valloc(e, v, &v->g, M * c.d_ffn)); VTRY(valloc(e, v, &v->u, M * c.d_ffn));
+    VTRY(valloc(e, v, &v->kring, (size_t)c.n_layer * v->B * v->RW * HH)); VTRY(valloc(e, v, &v->vring, (size_t)c.n_layer * v->B * v->RW * HH));
+    VTRY(valloc(e, v, &v->t1, (size_t)VOC_MAX_NS * scratch)); VTRY(valloc(e, v, &v->t2, (size_t)VOC_MAX_NS * scratch)); VTRY(valloc(e, v, &v->t3, (size_t)VOC_MAX_NS * scratch));
+    v->pcm_stride = (size_t)e->cfg.max_steps_cap * v->spf;
+    VTRY(valloc(e, v, &v->pcm, (size_t)v->B * v->pcm_stride));
+    v->frames_done.assign(v->B, 0); v->last_flag.assign(v->B, 0);
+    Q3_HIP(e, hipStreamSynchronize(e->stream));
+    return Q3TTS_OK;
+}
+
+void q3_voc_destroy(q3tts_engine* e) {
+    Q3Voc* v = e->voc;
+    if (!v) return;
+    for (void* p : v->allocs) hipFree(p);
+    delete v;
+    e->voc = nullptr;
+}
+
+static void zero_hist(q3tts_engine* e, VBuf& b, int slot) {
+    if (b.H > 0) hipMemsetAsync(b.hist + (size_t)slot * b.H * b.C, 0, (size_t)b.H * b.C * 4, e->stream);
+}
+int q3_voc_reset(q3tts_engine* e, int slot) {
+    Q3Voc* v = e->voc;
+    if (!v) return Q3TTS_OK;
+    zero_hist(e, v->pre_in, slot);
+    for (auto& u : v->U) zero_hist(e, u.dw_in, slot);
+    zero_hist(e, v->dec_in_in, slot);
+    for (auto& b : v->Bk) { zero_hist(e, b.ct_in, slot); for (auto& r : b.res) zero_hist(e, r.c1_in, slot); }
+    zero_hist(e, v->out_in, slot);
+    v->frames_done[slot] = 0; v->last_flag[slot] = 0;
+    return Q3TTS_OK;
+}
+
+static void vgemm(hipStream_t s, const VConv& c, const float* x, size_t x_stride, int x_off, int ns, int T, float* y, size_t y_stride, int y_off,
+                  int epi = 0, const float* scale = nullptr, int scale_n = 1) {
+    VGemm g; g.x = x; g.x_stride = x_stride; g.x_off = x_off; g.T = T; g.M = ns * T; g.c = c; g.y = y; g.y_stride = y_stride; g.y_off = y_off;
+    g.scale = scale; g.scale_n = scale_n; g.epi = epi;
+    dim3 grid((c.nout + 63) / 64, (g.M + 127) / 128);
+    hipLaunchKernelGGL(k_vgemm, grid, dim3(256), 0, s, g);
+}
+static void hist(hipStream_t s, const VCall& cl, VBuf& b, int T, int save) {
+    if (b.H == 0) return;
+    const size_t n = (size_t)b.H * b.C;
+    hipLaunchKernelGGL(k_voc_hist, dim3((unsigned)std::min<size_t>((n + 255) / 256, 64), cl.ns), dim3(256), 0, s, cl, b.p, b.stride(), b.hist, b.H, b.C, T, save);
+}
+static void snake(hipStream_t s, int ns, const float* x, size_t x_stride, int x_off, int T, int C, const float* ea, const float* ib, VBuf& dst) {
+    const size_t n = (size_t)T * C;
+    hipLaunchKernelGGL(k_voc_snake, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024), ns), dim3(256), 0, s, x, x_stride, x_off, T, C, ea, ib,
+                       dst.p, dst.stride(), dst.H * dst.C);
+}
+
+// one batched streaming call: ns slots x nf new frames each (uniform nf <= VOC_FCAP)
+static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
+    Q3Voc* v = e->voc;
+    const q3tts_vocoder_config& c = v->c;
+    const int ns = cl.ns, nf = cl.nf, d = c.latent_dim, HH = c.n_head * c.head_dim, M = ns * nf;
+    // V1 + V2
+    hist(s, cl, v->pre_in, nf, 0);
+    hipLaunchKernelGGL(k_voc_embed, dim3(nf, ns), dim3(128), 0, s, cl, e->codes, e->cfg.max_steps_cap, e->cfg.model.n_codebooks, v->cb_dev,
+                       c.n_codebooks, c.codebook_size, c.codebook_dim, v->pre_in.p, v->pre_in.stride(), v->pre_in.H * v->pre_in.C);
+    vgemm(s, v->pre, v->pre_in.p, v->pre_in.stride(), v->pre_in.H * v->pre_in.C, ns, nf, v->x, (size_t)nf * d, 0);
+    hist(s, cl, v->pre_in, nf, 1);
+    // V3 transformer (rows m = s*nf + t)
+    for (int l = 0; l < c.n_layer; ++l) {
+        VLayer& L = v->L[l];
+        hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, L.in_norm, c.rms_eps, d, v->xn);
+        vgemm(s, L.q, v->xn, 0, 0, 1, M, v->q, 0, 0); vgemm(s, L.k, v->xn, 0, 0, 1, M, v->k, 0, 0); vgemm(s, L.v, v->xn, 0, 0, 1, M, v->v, 0, 0);
+        hipLaunchKernelGGL(k_voc_attn, dim3(c.n_head, ns), dim3(64), 0, s, cl, v->q, v->k, v->v, v->kring + (size_t)l * v->B * v->RW * HH,
+                           v->vring + (size_t)l * v->B * v->RW * HH, c.n_head, c.head_dim, v->RW, c.sliding_window, c.rope_theta, v->att);
+        vgemm(s, L.o, v->att, 0, 0, 1, M, v->x, 0, 0, 1, L.ls_attn, d);
+        hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, L.post_norm, c.rms_eps, d, v->xn);
+        vgemm(s, L.gate, v->xn, 0, 0, 1, M, v->g, 0, 0); vgemm(s, L.up, v->xn, 0, 0, 1, M, v->u, 0, 0);
+        hipLaunchKernelGGL(k_voc_swiglu, dim3((unsigned)std::min<size_t>(((size_t)M * c.d_ffn + 255) / 256, 2048)), dim3(256), 0, s, v->g, v->u, (size_t)M * c.d_ffn);
+        vgemm(s, L.down, v->g, 0, 0, 1, M, v->x, 0, 0, 1, L.ls_mlp, d);
+    }
+    hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, v->final_norm, c.rms_eps, d, v->xn);
+    // V5a upsample stages; cur = [ns][T][d] contiguous per slot (stride T*d)
+    const float* cur = v->xn; int T = nf; size_t cur_stride = (size_t)nf * d; int cur_off = 0;
+    for (auto& p : v->U) {
+        hist(s, cl, p.dw_in, T * p.r, 0);
+        vgemm(s, p.ct, cur, cur_stride, cur_off, ns, T, p.dw_in.p, p.dw_in.stride(), p.dw_in.H * d);  // [T][r*d] == [T*r][d]
+        T *= p.r;
+        hipLaunchKernelGGL(k_voc_dw_ln, dim3(T, ns), dim3(64), (size_t)d * 4, s, p.dw_in.p, p.dw_in.stride(), p.dw_in.H, T, d, p.dw_w, p.dw_b, p.ln_w, p.ln_b, v->t1);
+        hist(s, cl, p.dw_in, T, 1);  // history = the raw ConvTranspose output, saved before the in-place residual below
+        vgemm(s, p.pw1, v->t1, (size_t)T * d, 0, ns, T, v->t2, (size_t)T * 4 * d, 0, 3);
+        vgemm(s, p.pw2, v->t2, (size_t)T * 4 * d, 0, ns, T, p.dw_in.p, p.dw_in.stride(), p.dw_in.H * d, 1, p.gamma, d);  // residual in place
+        cur = p.dw_in.p; cur_stride = p.dw_in.stride(); cur_off = p.dw_in.H * d;
+    }
+    // V5b decoder
+    hist(s, cl, v->dec_in_in, T, 0);
+    hipMemcpy2DAsync(v->dec_in_in.p + (size_t)v->dec_in_in.H * d, v->dec_in_in.stride() * 4, cur + cur_off, cur_stride * 4, (size_t)T * d * 4, ns,
+                     hipMemcpyDeviceToDevice, s);
+    int ch = c.decoder_dim;
+    vgemm(s, v->dec_in, v->dec_in_in.p, v->dec_in_in.stride(), v->dec_in_in.H * d, ns, T, v->t1, (size_t)T * ch, 0);
+    hist(s, cl, v->dec_in_in, T, 1);
+    float* z = v->t1; float* o = v->t2; float* w2 = v->t3;
+    for (auto& k : v->Bk) {
+        hist(s, cl, k.ct_in, T, 0);
+        snake(s, ns, z, (size_t)T * k.cin, 0, T, k.cin, k.ea, k.ib, k.ct_in);
+        vgemm(s, k.ct, k.ct_in.p, k.ct_in.stride(), k.ct_in.H * k.cin, ns, T, o, (size_t)T * k.r * k.cout, 0);
+        hist(s, cl, k.ct_in, T, 1);
+        T *= k.r; ch = k.cout;
+        for (auto& r : k.res) {
+            hist(s, cl, r.c1_in, T, 0);
+            snake(s, ns, o, (size_t)T * ch, 0, T, ch, r.ea, r.ib, r.c1_in);
+            vgemm(s, r.c1, r.c1_in.p, r.c1_in.stride(), r.c1_in.H * ch, ns, T, w2, (size_t)T * ch, 0);
+            hist(s, cl, r.c1_in, T, 1);
+            VBuf tmp; tmp.p = z; tmp.H = 0; tmp.C = ch; tmp.Tcap = T;  // snake2 into z (plain [ns][T][ch])
+            snake(s, ns, w2, (size_t)T * ch, 0, T, ch, r.ea2, r.ib2, tmp);
+            vgemm(s, r.c2, z, (size_t)T * ch, 0, ns, T, o, (size_t)T * ch, 0, 2);  // o += conv k1
+        }
+        std::swap(z, o);  // block output now in z
+    }
+    // V6
+    hist(s, cl, v->out_in, T, 0);
+    snake(s, ns, z, (size_t)T * ch, 0, T, ch, v->oea, v->oib, v->out_in);
+    hipLaunchKernelGGL(k_voc_out, dim3((T + 255) / 256, ns), dim3(256), 0, s, cl, v->out_in.p, v->out_in.stride(), v->out_in.H, T, ch, v->out_w, v->out_b,
+                       v->pcm, v->pcm_stride, v->spf);
+    hist(s, cl, v->out_in, T, 1);
+    Q3_HIP(e, hipGetLastError());
+    return Q3TTS_OK;
+}
+
+// decode frames [f0, f0+nf) of ONE slot (codes already on the device); nf may exceed VOC_FCAP (split)
+int q3_voc_decode(q3tts_engine* e, int slot, int f0, int nf, int is_last, hipStream_t s) {
+    Q3Voc* v = e->voc;
+    if (!v) return q3_set_err(e, Q3TTS_ERR_STATE, "engine has no vocoder");
+    if (f0 != v->frames_done[slot]) return q3_set_err(e, Q3TTS_ERR_STATE, "vocoder frames must be consumed in order");
+    while (nf > 0) {
+        const int n = std::min(nf, VOC_FCAP);
+        VCall cl; memset(&cl, 0, sizeof(cl));
+        cl.ns = 1; cl.nf = n; cl.slot[0] = slot; cl.pos[0] = v->frames_done[slot];
+        VTRY(voc_call(e, cl, s));
+        v->frames_done[slot] += n; nf -= n;
+    }
+    if (is_last) v->last_flag[slot] = 1;
+    return Q3TTS_OK;
+}
+// batched variant: the same nf (<= VOC_FCAP) new frames for every listed slot
+int q3_voc_decode_batch(q3tts_engine* e, const int* slots, int ns, int nf, hipStream_t s) {
+    Q3Voc* v = e->voc;
+    if (!v) return q3_set_err(e, Q3TTS_ERR_STATE, "engine has no vocoder");
+    if (ns <= 0 || ns > VOC_MAX_NS || nf <= 0 || nf > VOC_FCAP) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder batch shape");
+    VCall cl; memset(&cl, 0, sizeof(cl));
+    cl.ns = ns; cl.nf = nf;
+    for (int i = 0; i < ns; ++i) { cl.slot[i] = slots[i]; cl.pos[i] = v->frames_done[slots[i]]; }
+    VTRY(voc_call(e, cl, s));
+    for (int i = 0; i < ns; ++i) v->frames_done[slots[i]] += nf;
+    return Q3TTS_OK;
+}
+void q3_voc_mark_last(q3tts_engine* e, int slot) { if (e->voc) e->voc->last_flag[slot] = 1; }
+
+float* q3_voc_pcm(q3tts_engine* e, int slot) { return e->voc->pcm + (size_t)slot * e->voc->pcm_stride; }
+// V4: frames are withheld by lookahead_frames until more input arrives or the slot is flushed with is_last
+int q3_voc_samples(q3tts_engine* e, int slot) {
+    Q3Voc* v = e->voc;
+    int fr = v->frames_done[slot];
+    if (!v->last_flag[slot]) fr = std::max(0, fr - v->c.lookahead_frames);
+    return fr * v->spf;
+}
+
+extern "C" int q3tts_k_vocoder(q3tts_engine* e, const int32_t* codes, int32_t n_frames, int32_t chunk_frames, float* pcm_out, int32_t* n_samples_out) {
+    if (!e || !codes || !pcm_out || !n_samples_out || n_frames <= 0) return q3_set_err(e, Q3TTS_ERR_INVALID, "null argument");
+    if (!e->voc) return q3_set_err(e, Q3TTS_ERR_STATE, "engine created with with_vocoder = 0");
+    if (n_frames > e->cfg.max_steps_cap) return q3_set_err(e, Q3TTS_ERR_INVALID, "n_frames exceeds max_steps_cap");
+    Q3_HIP(e, hipSetDevice(e->cfg.device));
+    const int ncb = e->cfg.model.n_codebooks;
+    hipStream_t s = e->stream;
+    Q3_HIP(e, hipMemcpyAsync(e->codes, codes, sizeof(int32_t) * (size_t)n_frames * ncb, hipMemcpyHostToDevice, s));  // slot 0
+    VTRY(q3_voc_reset(e, 0));
+    const int step = chunk_frames > 0 ? chunk_frames : n_frames;
+    for (int f = 0; f < n_frames; f += step) {
+        const int n = std::min(step, n_frames - f);
+        VTRY(q3_voc_decode(e, 0, f, n, f + n >= n_frames, s));
+    }
+    const int ns = q3_voc_samples(e, 0);
+    Q3_HIP(e, hipMemcpyAsync(pcm_out, q3_voc_pcm(e, 0), sizeof(float) * (size_t)ns, hipMemcpyDeviceToHost, s));
+    Q3_HIP(e, hipStreamSynchronize(s));
+    *n_samples_out = ns;
+    return Q3TTS_OK;
+}

@@ -184,7 +184,7 @@ def tiny_config(max_batch=4, n_ctx=256, with_vocoder=1):
     v.rope_theta, v.rms_eps, v.layer_scale_init = 10000.0, 1e-5, 0.01
     v.n_upsample = 2
     v.upsample_ratios[:] = [2, 2, 0, 0]
-    v.decoder_dim, v.n_dec_blocks = 64, 4
+    v.decoder_dim, v.n_dec_blocks = 512, 4
     v.dec_rates[:] = [8, 5, 4, 3, 0, 0, 0, 0]
     v.lookahead_frames, v.sample_rate = 0, 24000
     cfg.device, cfg.max_batch, cfg.n_ctx, cfg.max_steps_cap, cfg.with_vocoder = 0, max_batch, n_ctx, 64, with_vocoder

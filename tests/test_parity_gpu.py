@@ -223,9 +223,87 @@ def test_errors_are_loud(tiny):
     with pytest.raises(_abi.Q3Error):
         eng.generate(embd=np.zeros((cfg.n_ctx - 2, cfg.model.d_embed), dtype=np.float32), max_steps=16)  # prompt + steps > n_ctx
     with pytest.raises(_abi.Q3Error):
-        eng.generate(embd=np.zeros((4, cfg.model.d_embed), dtype=np.float32), max_steps=4, want_pcm=1)  # no vocoder in this engine
+        eng.generate(embd=np.zeros((4, cfg.model.d_embed), dtype=np.float32), max_steps=4, want_pcm=1)  # no vocoder in this engine (with_vocoder=0)
     bad = _abi.tiny_config()
     bad.model.t_head_dim = 64
     from q3tts import native
     with pytest.raises(_abi.Q3Error):
         native.NativeEngine(bad)
+
+
+# ---- vocoder (V1-V6): PCM within an RMS tolerance of the CPU restatement ------------------------------------------
+PCM_RMS_TOL = 2e-3  # of full scale (+-1.0); bf16 MFMA vs scalar f32 accumulation order + libm vs device sin/erf/exp
+
+
+@pytest.fixture(scope="module")
+def tiny_voc(oracle):
+    from q3tts import _abi, native
+    cfg = _abi.tiny_config(max_batch=4, n_ctx=256, with_vocoder=1)
+    eng = native.NativeEngine(cfg)
+    L = oracle.lib()
+    v = L.q3o_vocoder_create(C.byref(cfg.vocoder), 0, 4)
+    yield cfg, eng, v
+    eng.close()
+    L.q3o_vocoder_destroy(v)
+
+
+def _oracle_pcm(oracle, v, codes, spf=1920):
+    L = oracle.lib()
+    L.q3o_vocoder_reset(v)
+    pcm = np.zeros(codes.shape[0] * spf + 64, dtype=np.float32)
+    n = L.q3o_vocoder_decode(v, oracle.ptr(codes, oracle.i32p), codes.shape[0], 1, oracle.ptr(pcm, oracle.f32p), pcm.size)
+    return pcm[:n].copy()
+
+
+@pytest.mark.parametrize("n_frames", [1, 4, 7, 13])
+def test_vocoder_pcm_vs_oracle(oracle, tiny_voc, n_frames):
+    cfg, eng, v = tiny_voc
+    rng = np.random.default_rng(n_frames)
+    codes = rng.integers(0, cfg.vocoder.codebook_size, size=(n_frames, 16)).astype(np.int32)
+    ref = _oracle_pcm(oracle, v, codes)
+    out = eng.vocoder(codes)
+    assert out.shape == ref.shape == (n_frames * 1920,)
+    rms = float(np.sqrt(np.mean((out - ref) ** 2)))
+    assert rms <= PCM_RMS_TOL, rms
+    assert np.abs(out).max() <= 1.0
+
+
+def test_vocoder_streaming_equals_one_shot(tiny_voc):
+    """Causal convs + resident state: any chunking gives the same PCM as one call (bit for bit on the device)."""
+    cfg, eng, v = tiny_voc
+    codes = np.random.default_rng(3).integers(0, cfg.vocoder.codebook_size, size=(11, 16)).astype(np.int32)
+    one = eng.vocoder(codes, chunk_frames=0)
+    for ch in (1, 3, 4):
+        assert np.array_equal(eng.vocoder(codes, chunk_frames=ch), one), ch
+
+
+def test_vocoder_clamps_out_of_range_codes(oracle, tiny_voc):
+    """Codes outside [0, codebook_size) are clamped like the reference's vocoder thread (src/tts/engine.rs:515-519)."""
+    cfg, eng, v = tiny_voc
+    codes = np.random.default_rng(4).integers(0, cfg.vocoder.codebook_size, size=(4, 16)).astype(np.int32)
+    wild = codes.copy(); wild[0, 0] = 2150; wild[1, 3] = -7
+    clamped = np.clip(wild, 0, cfg.vocoder.codebook_size - 1)
+    assert np.array_equal(eng.vocoder(wild), eng.vocoder(clamped))
+
+
+def test_end_to_end_pcm_and_batch(oracle, tiny_voc):
+    """generate with want_pcm: ids equal the oracle, PCM within tolerance, batched == single."""
+    cfg, eng, v = tiny_voc
+    om = oracle.OracleModel(cfg.model, seed=0, n_ctx=256, n_threads=4)
+    reqs, refs = [], []
+    for i in range(6):
+        desc, keep = oracle.make_prompt_desc(np.arange(10 * i, 10 * i + 6 + i), spk_emb=_spk(cfg.model.d_embed))
+        pe = om.build_prompt(desc)
+        kw = dict(temperature=0.7, seed=77 + i, max_steps=16, min_frames=2 + 2 * i, force_eos_at=2 + 2 * i)
+        refs.append(om.generate(pe, **kw)[0])
+        reqs.append(dict(embd=pe, want_pcm=1, **kw))
+    outs = eng.generate_batch(reqs)
+    for i, (o, r) in enumerate(zip(outs, refs)):
+        assert np.array_equal(o.codes, r), i
+        ref_pcm = _oracle_pcm(oracle, v, np.clip(r, 0, cfg.vocoder.codebook_size - 1).astype(np.int32))
+        assert o.pcm.shape == ref_pcm.shape
+        assert float(np.sqrt(np.mean((o.pcm - ref_pcm) ** 2))) <= PCM_RMS_TOL, i
+    single = eng.generate(**reqs[4])
+    assert np.array_equal(single.pcm, outs[4].pcm)
+    assert single.first_chunk_ms > 0
+    om.close()
