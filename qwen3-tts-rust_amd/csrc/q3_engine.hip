@@ -129,6 +129,7 @@ static int init_tfm(q3tts_engine* e, Q3Tfm& t, int grp, int L, int d, int Hq, in
     TRY(dalloc(e, &t.out_norm, (size_t)d));
     q3_launch_fill_f32(t.out_norm, d, seed, Q3_TID(grp, Q3_L_MODEL, Q3WM_OUT_NORM), 1.0f, ns, 0, s);
     TRY(dalloc(e, &t.head, (size_t)head_n * d / 8));
+    t.weight_bytes += 2ull * (size_t)head_n * d;
     { Q3Fill f{}; f.seed = seed; f.scale = ms; f.dst = t.head; f.N = head_n; f.K = d; f.mode = 0; f.row0 = 0; f.rows = head_n;
       f.tid_a = Q3_TID(grp, Q3_L_MODEL, Q3WM_HEAD); q3_launch_fill_tiled(f, s); }
     t.layer_stride = (size_t)n_slots * Hkv * n_ctx * hd;
@@ -157,7 +158,8 @@ static int alloc_scratch(q3tts_engine* e, Q3Scratch& sc, int rows, int nqkv, int
 
 // K1-K8 of SURVEY.md §8a: one decoder block per iteration, 6 launches (norm+QKV, qk-prep, attention, O+residual,
 // norm+gate/up+SwiGLU, down+residual)
-static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, int rows, const int* row_pos, const int* row_slot, Q3Scratch& sc, hipStream_t s) {
+static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, int rows, const int* row_pos, const int* row_slot, Q3Scratch& sc, hipStream_t s,
+                       bool one_row_per_slot = false) {
     const float eps = e->cfg.model.rms_eps;
     for (int l = 0; l < t.L; ++l) {
         Q3Gemm g{};
@@ -166,9 +168,11 @@ static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, int rows, const int*
         Q3QkPrep qp{}; qp.qkv = sc.qkv; qp.ld = t.nqkv; qp.rows = rows; qp.Hq = t.Hq; qp.Hkv = t.Hkv; qp.hd = t.hd;
         qp.qnw = t.qn[l]; qp.knw = t.kn[l]; qp.eps = eps; qp.cs = t.cs; qp.sn = t.sn;
         qp.kc = t.kc + l * t.layer_stride; qp.vc = t.vc + l * t.layer_stride; qp.n_ctx = t.n_ctx; qp.row_pos = row_pos; qp.row_slot = row_slot;
-        q3_launch_qk_prep(qp, s);
+        const bool fused = one_row_per_slot && t.Hq / t.Hkv >= 2;
+        if (!fused) q3_launch_qk_prep(qp, s);
         Q3Attend at{}; at.qkv = sc.qkv; at.ld = t.nqkv; at.rows = rows; at.out = sc.att; at.ldo = t.nq; at.Hq = t.Hq; at.Hkv = t.Hkv; at.hd = t.hd;
         at.kc = qp.kc; at.vc = qp.vc; at.n_ctx = t.n_ctx; at.row_pos = row_pos; at.row_slot = row_slot;
+        at.fused = fused; at.prep = qp;
         q3_launch_attend(at, s);
         g = Q3Gemm{}; g.x = sc.att; g.ldx = t.nq; g.B = rows; g.w = t.wo[l]; g.K = t.nq; g.N = t.d; g.y = x; g.ldy = t.d; g.epi = Q3_EPI_RESID;
         q3_launch_gemm(g, s);
@@ -201,7 +205,7 @@ static void record_frame(q3tts_engine* e, hipStream_t s) {
         }
         Q3Gemm g{}; g.x = e->X; g.ldx = de; g.B = rows; g.w = e->proj_w; g.K = de; g.N = dp; g.bias = e->proj_b; g.y = e->px; g.ldy = dp;
         g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);  // H6: src/assets_manager.rs:383-399
-        run_layers(e, e->P, e->px, rows, q == 0 ? e->posA : e->pos_q + (size_t)q * B, q == 0 ? e->slotA : e->slot_id, e->sc_dec, s);
+        run_layers(e, e->P, e->px, rows, q == 0 ? e->posA : e->pos_q + (size_t)q * B, q == 0 ? e->slotA : e->slot_id, e->sc_dec, s, q > 0);
         g = Q3Gemm{}; g.x = q == 0 ? e->px + dp : e->px; g.ldx = q == 0 ? 2 * dp : dp; g.B = B; g.w = e->P.head + head_tile_stride * q;
         g.K = dp; g.N = cbs; g.norm_w = e->P.out_norm; g.eps = eps; g.xhat = e->sc_dec.xn; g.keys = e->keys + (q + 1); g.key_stride = ncb; g.epi = Q3_EPI_ARGMAX;
         q3_launch_gemm(g, s);
@@ -210,7 +214,7 @@ static void record_frame(q3tts_engine* e, hipStream_t s) {
       pn.slots = e->slots; pn.B = B; pn.codes = e->codes; pn.max_steps_cap = e->cfg.max_steps_cap; pn.fb = e->fb; pn.X = e->X;
       pn.tts_pad = e->tts_pad; pn.xT = e->xT; pn.row_pos_t = e->row_pos_t;
       q3_launch_pred_next(pn, s); }
-    run_layers(e, e->T, e->xT, B, e->row_pos_t, e->slot_id, e->sc_dec, s);
+    run_layers(e, e->T, e->xT, B, e->row_pos_t, e->slot_id, e->sc_dec, s, true);
     Q3Gemm g{}; g.x = e->xT; g.ldx = m.t_d_model; g.B = B; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab; g.norm_w = e->T.out_norm; g.eps = eps; g.xhat = e->sc_dec.xn;
     g.y = e->logits; g.ldy = m.t_vocab; g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);
 }

@@ -49,6 +49,8 @@ struct Q3Attend {
     int Hq, Hkv, hd;
     const uint16_t* kc; const uint16_t* vc; int n_ctx;
     const int* row_pos; const int* row_slot;
+    int fused;        // 1: every slot has exactly one row in this launch -> q/k prep + KV append done in-kernel (R >= 2)
+    Q3QkPrep prep;    // used when fused
 };
 void q3_launch_attend(const Q3Attend& a, hipStream_t s);
 

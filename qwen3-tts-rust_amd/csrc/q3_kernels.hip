@@ -84,55 +84,61 @@ void q3_launch_fill_f32(float* dst, size_t n, uint64_t seed, uint32_t tid, float
 // K cache layout: per (slot, kv head) blocks of 64 keys, [block][hd/8 chunks][64 keys][8] bf16,
 // so that the score kernel reads 1 KiB contiguous per wave-load with one key per lane. V is row-major [t][hd].
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_qk_prep(Q3QkPrep a) {
-    const int row = blockIdx.x, hx = blockIdx.y, lane = threadIdx.x;
-    const int pos = a.row_pos[row];
-    if (pos < 0) return;
-    const int slot = a.row_slot[row];
-    const int hd = a.hd, half = hd >> 1, nl = hd >> 2;  // nl lanes hold data
-    const bool isq = hx < a.Hq;
-    const int g = hx - a.Hq;
-    float* src = a.qkv + (size_t)row * a.ld + (size_t)(isq ? hx : a.Hq + g) * hd;
-    const float* nw = isq ? a.qnw : a.knw;
+// RMSNorm(hd) + RoPE of one head by one wave: lanes [0, hd/4) own 4 consecutive elements each; result in o[4]
+__device__ __forceinline__ void prep_head(const float* src, const float* nw, float eps, const float* cs, const float* sn, int hd,
+                                          int lane, float o[4]) {
+    const int nl = hd >> 2, hl = nl >> 1;
     float4 v = (float4){0.f, 0.f, 0.f, 0.f};
     if (lane < nl) v = ((const float4*)src)[lane];
     float acc = 0.0f;
     acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
     acc = wave_sum(acc);
-    const float rinv = 1.0f / sqrtf(acc / (float)hd + a.eps);
+    const float rinv = 1.0f / sqrtf(acc / (float)hd + eps);
     float4 w4 = (float4){0.f, 0.f, 0.f, 0.f};
     if (lane < nl) w4 = ((const float4*)nw)[lane];
-    float y[4] = {(v.x * rinv) * w4.x, (v.y * rinv) * w4.y, (v.z * rinv) * w4.z, (v.w * rinv) * w4.w};
+    const float y[4] = {(v.x * rinv) * w4.x, (v.y * rinv) * w4.y, (v.z * rinv) * w4.z, (v.w * rinv) * w4.w};
     // RoPE (NeoX pairing i <-> i + hd/2): lanes [0, nl/2) hold the first halves, partner lane = lane ^ (nl/2)
-    const int hl = nl >> 1;
-    float o[4];
-    {
-        const int i0 = 4 * (lane & (hl - 1));
-        float4 c4 = (float4){1.f, 1.f, 1.f, 1.f}, s4 = (float4){0.f, 0.f, 0.f, 0.f};
-        if (lane < nl) { c4 = *(const float4*)(a.cs + (size_t)pos * half + i0); s4 = *(const float4*)(a.sn + (size_t)pos * half + i0); }
-        const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+    const int i0 = 4 * (lane & (hl - 1));
+    float4 c4 = (float4){1.f, 1.f, 1.f, 1.f}, s4 = (float4){0.f, 0.f, 0.f, 0.f};
+    if (lane < nl) { c4 = *(const float4*)(cs + i0); s4 = *(const float4*)(sn + i0); }
+    const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float other = __shfl_xor(y[e], hl);
-            if (lane < hl) o[e] = fmaf(-other, ss[e], y[e] * cc[e]);   // x_i*c - x_{i+half}*s
-            else o[e] = fmaf(other, ss[e], y[e] * cc[e]);              // x_{i+half}*c + x_i*s
-        }
+    for (int e = 0; e < 4; ++e) {
+        const float other = __shfl_xor(y[e], hl);
+        if (lane < hl) o[e] = fmaf(-other, ss[e], y[e] * cc[e]);   // x_i*c - x_{i+half}*s
+        else o[e] = fmaf(other, ss[e], y[e] * cc[e]);              // x_{i+half}*c + x_i*s
     }
+}
+// bf16 K (key-interleaved blocks) and V (row-major) append of one kv head by lanes [0, hd/4)
+__device__ __forceinline__ void kv_append(uint16_t* kc, uint16_t* vc, size_t hb, int hd, int pos, int lane, const float o[4], const float4 vv) {
+    const int blk = pos >> 6, kl = pos & 63, c = lane >> 1, e0 = 4 * (lane & 1);
+    uint2 kk;
+    kk.x = (uint32_t)q3_bf16(o[0]) | ((uint32_t)q3_bf16(o[1]) << 16);
+    kk.y = (uint32_t)q3_bf16(o[2]) | ((uint32_t)q3_bf16(o[3]) << 16);
+    *(uint2*)(kc + hb * hd + ((size_t)(blk * (hd >> 3) + c) * 64 + kl) * 8 + e0) = kk;
+    uint2 vk;
+    vk.x = (uint32_t)q3_bf16(vv.x) | ((uint32_t)q3_bf16(vv.y) << 16);
+    vk.y = (uint32_t)q3_bf16(vv.z) | ((uint32_t)q3_bf16(vv.w) << 16);
+    *(uint2*)(vc + (hb + pos) * hd + 4 * lane) = vk;
+}
+
+__global__ __launch_bounds__(64) void k_qk_prep(Q3QkPrep a) {
+    const int row = blockIdx.x, hx = blockIdx.y, lane = threadIdx.x;
+    const int pos = a.row_pos[row];
+    if (pos < 0) return;
+    const int slot = a.row_slot[row];
+    const int hd = a.hd, half = hd >> 1, nl = hd >> 2;
+    const bool isq = hx < a.Hq;
+    const int g = hx - a.Hq;
+    float* src = a.qkv + (size_t)row * a.ld + (size_t)(isq ? hx : a.Hq + g) * hd;
+    float o[4];
+    prep_head(src, isq ? a.qnw : a.knw, a.eps, a.cs + (size_t)pos * half, a.sn + (size_t)pos * half, hd, lane, o);
     if (lane >= nl) return;
     if (isq) {
         ((float4*)src)[lane] = (float4){o[0], o[1], o[2], o[3]};
     } else {
-        const size_t hb = ((size_t)slot * a.Hkv + g) * a.n_ctx;
-        const int blk = pos >> 6, kl = pos & 63, c = lane >> 1, e0 = 4 * (lane & 1);
-        uint2 kk;
-        kk.x = (uint32_t)q3_bf16(o[0]) | ((uint32_t)q3_bf16(o[1]) << 16);
-        kk.y = (uint32_t)q3_bf16(o[2]) | ((uint32_t)q3_bf16(o[3]) << 16);
-        *(uint2*)(a.kc + hb * hd + ((size_t)(blk * (hd >> 3) + c) * 64 + kl) * 8 + e0) = kk;
         const float4 vv = ((const float4*)(a.qkv + (size_t)row * a.ld + (size_t)(a.Hq + a.Hkv + g) * hd))[lane];
-        uint2 vk;
-        vk.x = (uint32_t)q3_bf16(vv.x) | ((uint32_t)q3_bf16(vv.y) << 16);
-        vk.y = (uint32_t)q3_bf16(vv.z) | ((uint32_t)q3_bf16(vv.w) << 16);
-        *(uint2*)(a.vc + (hb + pos) * hd + 4 * lane) = vk;
+        kv_append(a.kc, a.vc, ((size_t)slot * a.Hkv + g) * a.n_ctx, hd, pos, lane, o, vv);
     }
 }
 void q3_launch_qk_prep(const Q3QkPrep& a, hipStream_t s) {
@@ -144,7 +150,9 @@ void q3_launch_qk_prep(const Q3QkPrep& a, hipStream_t s) {
 // head of the GQA group. Scores: one key per lane (256 virtual lanes = 4 waves), dot over d ascending.
 // PV: 16 key-partials (u = t mod 16: wave u/4, lane group u%4), 16 lanes x 8 dims per key.
 // ---------------------------------------------------------------------------------------------------
-template <int R>
+// FUSED (one row per slot, e.g. every decode step): the workgroup first does the q/k RMSNorm + RoPE + KV append of
+// its own row (k_qk_prep's work) and serves the newest key/value from LDS, saving one launch per layer.
+template <int R, bool FUSED>
 __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int g = blockIdx.x, row = blockIdx.y;
@@ -158,9 +166,31 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
     float* ow = qh + R * hd;                  // [R][4][hd]
     float* lw = ow + R * 4 * hd;              // [R][4]
     float* mw = lw + R * 4;                   // [R][4]
-    for (int i = tid; i < R * hd; i += R * 256) qh[i] = a.qkv[(size_t)row * a.ld + (size_t)g * R * hd + i];
-    __syncthreads();
+    float* kh = mw + R * 4;                   // [hd] newest key (bf16-rounded), FUSED only
+    float* vh = kh + hd;                      // [hd] newest value
     const size_t hb = ((size_t)slot * a.Hkv + g) * a.n_ctx;
+    if constexpr (FUSED) {
+        const Q3QkPrep& pr = a.prep;
+        const int half = hd >> 1, nl = hd >> 2;
+        const float* rowp = a.qkv + (size_t)row * a.ld;
+        float o[4];
+        if (sw == 0) {  // first wave of each query head: q-norm + RoPE -> LDS
+            prep_head(rowp + (size_t)(g * R + hh) * hd, pr.qnw, pr.eps, pr.cs + (size_t)pos * half, pr.sn + (size_t)pos * half, hd, lane, o);
+            if (lane < nl) *(float4*)(qh + hh * hd + 4 * lane) = (float4){o[0], o[1], o[2], o[3]};
+        }
+        if (wave == 1 || (R * 4 == 1)) {  // a second wave: k-norm + RoPE + append, v append
+            prep_head(rowp + (size_t)(a.Hq + g) * hd, pr.knw, pr.eps, pr.cs + (size_t)pos * half, pr.sn + (size_t)pos * half, hd, lane, o);
+            if (lane < nl) {
+                const float4 vv = ((const float4*)(rowp + (size_t)(a.Hq + a.Hkv + g) * hd))[lane];
+                kv_append(pr.kc, pr.vc, hb, hd, pos, lane, o, vv);
+                *(float4*)(kh + 4 * lane) = (float4){q3_round_bf16(o[0]), q3_round_bf16(o[1]), q3_round_bf16(o[2]), q3_round_bf16(o[3])};
+                *(float4*)(vh + 4 * lane) = (float4){q3_round_bf16(vv.x), q3_round_bf16(vv.y), q3_round_bf16(vv.z), q3_round_bf16(vv.w)};
+            }
+        }
+    } else {
+        for (int i = tid; i < R * hd; i += R * 256) qh[i] = a.qkv[(size_t)row * a.ld + (size_t)g * R * hd + i];
+    }
+    __syncthreads();
     const uint16_t* kb = a.kc + hb * hd;
     const uint16_t* vb = a.vc + hb * hd;
     const float scale = 1.0f / sqrtf((float)hd);
@@ -178,6 +208,10 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
             s = fmaf(qc[2], q3_u2f(kv.y << 16), s); s = fmaf(qc[3], q3_u2f(kv.y & 0xffff0000u), s);
             s = fmaf(qc[4], q3_u2f(kv.z << 16), s); s = fmaf(qc[5], q3_u2f(kv.z & 0xffff0000u), s);
             s = fmaf(qc[6], q3_u2f(kv.w << 16), s); s = fmaf(qc[7], q3_u2f(kv.w & 0xffff0000u), s);
+        }
+        if (FUSED && t == pos) {  // newest key: from LDS, same d-ascending chain
+            s = 0.0f;
+            for (int d = 0; d < hd; ++d) s = fmaf(q[d], kh[d], s);
         }
         s = s * scale;
         if (t < T) { p[t] = s; mloc = fmaxf(mloc, s); }
@@ -201,6 +235,11 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
     for (int t = 4 * sw + kg; t < T; t += 16) {
         const uint4 vv = *(const uint4*)(vb + (size_t)t * hd + dl * 8);
         const float pt = p[t];
+        if (FUSED && t == pos) {  // newest value: from LDS
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = fmaf(pt, vh[dl * 8 + e], o[e]);
+            continue;
+        }
         o[0] = fmaf(pt, q3_u2f(vv.x << 16), o[0]); o[1] = fmaf(pt, q3_u2f(vv.x & 0xffff0000u), o[1]);
         o[2] = fmaf(pt, q3_u2f(vv.y << 16), o[2]); o[3] = fmaf(pt, q3_u2f(vv.y & 0xffff0000u), o[3]);
         o[4] = fmaf(pt, q3_u2f(vv.z << 16), o[4]); o[5] = fmaf(pt, q3_u2f(vv.z & 0xffff0000u), o[5]);
@@ -227,11 +266,16 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
 }
 void q3_launch_attend(const Q3Attend& a, hipStream_t s) {
     const int R = a.Hq / a.Hkv;
-    const size_t lds = ((size_t)R * a.n_ctx + R * a.hd + R * 4 * a.hd + R * 8) * sizeof(float);
+    const size_t lds = ((size_t)R * a.n_ctx + R * a.hd + R * 4 * a.hd + R * 8 + 2 * a.hd) * sizeof(float);
     dim3 grid(a.Hkv, a.rows);
-    if (R == 1) hipLaunchKernelGGL((k_attend<1>), grid, dim3(256), lds, s, a);
-    else if (R == 2) hipLaunchKernelGGL((k_attend<2>), grid, dim3(512), lds, s, a);
-    else hipLaunchKernelGGL((k_attend<4>), grid, dim3(1024), lds, s, a);
+    if (a.fused) {
+        if (R == 2) hipLaunchKernelGGL((k_attend<2, true>), grid, dim3(512), lds, s, a);
+        else hipLaunchKernelGGL((k_attend<4, true>), grid, dim3(1024), lds, s, a);
+        return;
+    }
+    if (R == 1) hipLaunchKernelGGL((k_attend<1, false>), grid, dim3(256), lds, s, a);
+    else if (R == 2) hipLaunchKernelGGL((k_attend<2, false>), grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((k_attend<4, false>), grid, dim3(1024), lds, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -458,18 +502,46 @@ void q3_launch_copy_rows(float* dst, int ldd, const float* src, int lds, int row
     hipLaunchKernelGGL(k_copy_rows, dim3(rows), dim3(256), 0, s, dst, ldd, src, lds, cols);
 }
 
-__global__ __launch_bounds__(64) void k_rmsnorm_rows(const float* x, int ldx, const float* w, float eps, int d, float* out, int ldo) {
-    const int r = blockIdx.x, lane = threadIdx.x;
-    const float* xr = x + (size_t)r * ldx;
-    float acc = 0.0f;
-    for (int c = lane; c < (d >> 2); c += 64) {
-        const float4 v = ((const float4*)xr)[c];
-        acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+// One wave per row, 4 rows per workgroup. CPL = float4 chunks per lane (d = 256*CPL) held in registers so the row is
+// read once: all loads issue first, then the canonical per-lane fmaf chain (chunks lane, lane+64, ...), the butterfly
+// and one float4 store per chunk. CPL = 0: generic two-pass loop.
+template <int CPL>
+__global__ __launch_bounds__(256) void k_rmsnorm_rows(const float* x, int ldx, const float* w, float eps, int d, int rows, float* out, int ldo) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const float4* xr = (const float4*)(x + (size_t)r * ldx);
+    float4* orow = (float4*)(out + (size_t)r * ldo);
+    const float4* w4 = (const float4*)w;
+    if constexpr (CPL > 0) {
+        float4 v[CPL], g[CPL];
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) { v[i] = xr[lane + 64 * i]; g[i] = w4[lane + 64 * i]; }
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) { acc = fmaf(v[i].x, v[i].x, acc); acc = fmaf(v[i].y, v[i].y, acc); acc = fmaf(v[i].z, v[i].z, acc); acc = fmaf(v[i].w, v[i].w, acc); }
+        acc = wave_sum(acc);
+        const float rinv = 1.0f / sqrtf(acc / (float)d + eps);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i)
+            orow[lane + 64 * i] = make_float4((v[i].x * rinv) * g[i].x, (v[i].y * rinv) * g[i].y, (v[i].z * rinv) * g[i].z, (v[i].w * rinv) * g[i].w);
+    } else {
+        float acc = 0.0f;
+        for (int c = lane; c < (d >> 2); c += 64) {
+            const float4 v = xr[c];
+            acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+        }
+        acc = wave_sum(acc);
+        const float rinv = 1.0f / sqrtf(acc / (float)d + eps);
+        for (int c = lane; c < (d >> 2); c += 64) {
+            const float4 v = xr[c], g = w4[c];
+            orow[c] = make_float4((v.x * rinv) * g.x, (v.y * rinv) * g.y, (v.z * rinv) * g.z, (v.w * rinv) * g.w);
+        }
     }
-    acc = wave_sum(acc);
-    const float rinv = 1.0f / sqrtf(acc / (float)d + eps);
-    for (int i = lane; i < d; i += 64) out[(size_t)r * ldo + i] = (xr[i] * rinv) * w[i];
 }
 void q3_launch_rmsnorm_rows(const float* x, int ldx, const float* w, float eps, int d, int rows, float* out, int ldo, hipStream_t s) {
-    hipLaunchKernelGGL(k_rmsnorm_rows, dim3(rows), dim3(64), 0, s, x, ldx, w, eps, d, out, ldo);
+    dim3 grid((rows + 3) / 4);
+    if (d == 2048) hipLaunchKernelGGL((k_rmsnorm_rows<8>), grid, dim3(256), 0, s, x, ldx, w, eps, d, rows, out, ldo);
+    else if (d == 1024) hipLaunchKernelGGL((k_rmsnorm_rows<4>), grid, dim3(256), 0, s, x, ldx, w, eps, d, rows, out, ldo);
+    else if (d == 512) hipLaunchKernelGGL((k_rmsnorm_rows<2>), grid, dim3(256), 0, s, x, ldx, w, eps, d, rows, out, ldo);
+    else hipLaunchKernelGGL((k_rmsnorm_rows<0>), grid, dim3(256), 0, s, x, ldx, w, eps, d, rows, out, ldo);
 }
