@@ -30,19 +30,21 @@ def vivian():
         return np.asarray(json.load(f)["spk_emb"], dtype=np.float32)
 
 
-def make_workload(n, rank, spk, keepalive):
-    """n_text ~ U{8..64} (seed 1), n_frames ~ U{25..250} (seed 2, EOS forced at the target),
-    per-utterance sampler seed = 1000 + global index."""
+def make_workload(n_per_gpu, rank, world, spk, keepalive):
+    """the GLOBAL list of n_per_gpu*world utterances is a function of the global index
+    only (n_text ~ U{8..64}, n_frames ~ U{25..250} with EOS forced at the target, sampler seed 1000 + index);
+    rank r owns {i : i mod world == r}, so per-utterance results do not depend on the number of GPUs."""
+    from q3tts import dist as qd
     from q3tts.native import make_prompt_desc
-    r1, r2 = np.random.default_rng(1 + 7919 * rank), np.random.default_rng(2 + 7919 * rank)
     reqs, frames = [], []
-    for i in range(n):
-        n_text = int(r1.integers(8, 65))
-        ids = r1.integers(0, 151643, size=n_text)
-        target = int(r2.integers(25, 251))
+    for gi in qd.shard_indices(n_per_gpu * world, rank, world):
+        r = np.random.default_rng(977 * gi + 1)
+        n_text = int(r.integers(8, 65))
+        ids = r.integers(0, 151643, size=n_text)
+        target = int(r.integers(25, 251))
         desc, keep = make_prompt_desc(ids, spk_emb=spk)
         keepalive.append((desc, keep))
-        reqs.append(dict(desc=desc, temperature=0.7, top_k=40, top_p=0.9, seed=1000 + rank * n + i, max_steps=256,
+        reqs.append(dict(desc=desc, temperature=0.7, top_k=40, top_p=0.9, seed=qd.global_seed(1000, gi), max_steps=256,
                          min_frames=target, force_eos_at=target, want_pcm=1))
         frames.append(target)
     return reqs, frames
@@ -109,7 +111,7 @@ def main():
     eng = native.NativeEngine(cfg)
     spk = vivian()
     keepalive = []
-    reqs, frames = make_workload(args.batch, rank, spk, keepalive)
+    reqs, frames = make_workload(args.batch, rank, world, spk, keepalive)
     if args.no_vocoder:
         for r in reqs:
             r["want_pcm"] = 0
@@ -121,20 +123,13 @@ def main():
             dist.barrier()
 
     def gather_pcm(outs):
-        """RCCL over xGMI: lengths all-gather, then padded PCM gather to rank 0 (the only collective on the path)."""
+        """RCCL over xGMI: lengths all-gather + padded gather of the PCM to rank 0 (the only collective on the path)."""
         if dist is None:
             return
         import torch
-        lens = torch.tensor([0 if o.pcm is None else o.pcm.size for o in outs], dtype=torch.int32, device="cuda")
-        all_lens = [torch.empty_like(lens) for _ in range(world)]
-        dist.all_gather(all_lens, lens)
-        mx = int(torch.stack(all_lens).max().item())
-        buf = torch.zeros((len(outs), max(mx, 1)), dtype=torch.float16, device="cuda")
-        for i, o in enumerate(outs):
-            if o.pcm is not None and o.pcm.size:
-                buf[i, :o.pcm.size] = torch.from_numpy(o.pcm).to("cuda", non_blocking=True).half()
-        gl = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
-        dist.gather(buf, gl, dst=0)
+        from q3tts import dist as qd
+        qd.gather_pcm(dist, [o.pcm if o.pcm is not None else np.zeros(0, dtype=np.float32) for o in outs], rank, world,
+                      device="cuda", dtype=torch.float16)
 
     for _ in range(args.warmup):
         outs = eng.generate_batch(reqs)

@@ -1,0 +1,226 @@
+"""Host-side mirror of the reference crate's public API (names, argument meaning and error behaviour), over the C ABI.
+
+Reference surface (src/lib.rs:11-20): TtsEngine, SamplerConfig, VoiceFile, AudioSample, PromptBuilder, cleanup().
+The reference is Rust; Rust is not available in this image, so the host side above the C ABI is mirrored here in
+Python for the tests and in `rust/` as (uncompiled) binding source — see INTEGRATION.md.
+"""
+import ctypes as C
+import json
+import os
+import struct
+import wave
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import _abi, native
+
+LANG_ID_CHINESE = 2055  # hard-coded in the reference: src/tts/engine.rs:267,407,425
+
+
+@dataclass
+class SamplerConfig:
+    """src/tts/engine.rs:14-45 — defaults 0.7 / 40 / 0.9 / None."""
+    temperature: float = 0.7
+    top_k: int = 40
+    top_p: float = 0.9
+    seed: Optional[int] = None
+
+
+@dataclass
+class VoiceFile:
+    """src/utils/voice_file.rs:5-62 — serde JSON; `spk_emb` is an alias of `speaker_embedding`; unknown keys ignored."""
+    ref_text: str = ""
+    audio_codes: List[int] = field(default_factory=list)
+    speaker_embedding: List[float] = field(default_factory=list)
+    name: Optional[str] = None
+    gender: Optional[str] = None
+    age: Optional[str] = None
+    description: Optional[str] = None
+
+    @staticmethod
+    def new(ref_text, audio_codes, speaker_embedding):
+        return VoiceFile(ref_text, list(audio_codes), list(speaker_embedding))
+
+    def with_metadata(self, name=None, gender=None, age=None, description=None):
+        self.name, self.gender, self.age, self.description = name, gender, age, description
+        return self
+
+    @staticmethod
+    def load(path):
+        with open(path, "r", encoding="utf-8") as f:
+            d = json.load(f)
+        emb = d.get("speaker_embedding", d.get("spk_emb"))
+        if emb is None:
+            raise ValueError("missing field `speaker_embedding`")  # serde: the only non-default, non-Option field
+        return VoiceFile(d.get("ref_text", ""), list(d.get("audio_codes", [])), list(emb), d.get("name"), d.get("gender"),
+                         d.get("age"), d.get("description"))
+
+    def save(self, path):
+        with open(path, "w", encoding="utf-8") as f:
+            json.dump({"ref_text": self.ref_text, "audio_codes": self.audio_codes, "speaker_embedding": self.speaker_embedding,
+                       "name": self.name, "gender": self.gender, "age": self.age, "description": self.description}, f, indent=2)
+
+
+@dataclass
+class AudioSample:
+    """src/utils/audio.rs:4-46 — mono 24 kHz f32 container; WAV i/o is 16-bit."""
+    samples: np.ndarray
+    sample_rate: int = 24000
+    channels: int = 1
+
+    @staticmethod
+    def load_wav(path):
+        with wave.open(str(path), "rb") as w:
+            if w.getsampwidth() != 2:
+                raise ValueError("load_wav reads 16-bit PCM only (src/utils/audio.rs:14-17)")
+            raw = w.readframes(w.getnframes())
+            data = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+            return AudioSample(data, w.getframerate(), w.getnchannels())
+
+    def save_wav(self, path):
+        amp = np.clip(np.asarray(self.samples, dtype=np.float32) * np.float32(32767.0), -32768.0, 32767.0)
+        pcm = np.trunc(amp).astype("<i2")  # Rust `as i16` truncates toward zero (src/utils/audio.rs:35-37)
+        with wave.open(str(path), "wb") as w:
+            w.setnchannels(self.channels)
+            w.setsampwidth(2)
+            w.setframerate(self.sample_rate)
+            w.writeframes(pcm.tobytes())
+
+    def duration(self):
+        return len(self.samples) / float(self.sample_rate)
+
+
+# ref-audio cache `TTSC` v1 (src/utils/cache.rs:5-67): magic, u32 version, usize n + i64 codes, usize n + f32 emb
+def save_cache(path, codes: Sequence[int], emb: Sequence[float]):
+    with open(path, "wb") as f:
+        f.write(b"TTSC" + struct.pack("<I", 1))
+        f.write(struct.pack("<Q", len(codes)) + np.asarray(codes, dtype="<i8").tobytes())
+        f.write(struct.pack("<Q", len(emb)) + np.asarray(emb, dtype="<f4").tobytes())
+
+
+def load_cache(path):
+    with open(path, "rb") as f:
+        if f.read(4) != b"TTSC":
+            raise ValueError("Invalid magic bytes")
+        if struct.unpack("<I", f.read(4))[0] != 1:
+            raise ValueError("Unsupported version")
+        n = struct.unpack("<Q", f.read(8))[0]
+        codes = np.frombuffer(f.read(8 * n), dtype="<i8").tolist()
+        m = struct.unpack("<Q", f.read(8))[0]
+        emb = np.frombuffer(f.read(4 * m), dtype="<f4").tolist()
+    return codes, emb
+
+
+class TtsEngine:
+    """src/tts/engine.rs:53-72 — the engine owns weights, contexts and speakers; one utterance at a time per call
+    (`&mut self`), or a list through `generate_batch_with_voice` (continuous batching, an extension)."""
+
+    def __init__(self, cfg, tokenizer=None):
+        self._native = native.NativeEngine(cfg)
+        self.cfg = cfg
+        self.tokenizer = tokenizer
+        self.speakers = {}
+        self.max_steps = min(512, cfg.max_steps_cap)  # src/tts/engine.rs:152
+        self.sampler_config = SamplerConfig()
+
+    @classmethod
+    def new(cls, model_dir: Optional[str] = None, quant: str = "none", config=None):
+        """TtsEngine::new(model_dir, quant) (src/tts/engine.rs:84-169). There is no network here: with no weight
+        container under model_dir the engine uses seeded synthetic weights of the configured shape."""
+        cfg = config or _abi.default_config()
+        tok = None
+        if model_dir:
+            tj = os.path.join(model_dir, "tokenizer", "tokenizer.json")  # src/utils/tokenizer.rs:12
+            if os.path.exists(tj):
+                from tokenizers import Tokenizer as HfTokenizer
+                tok = HfTokenizer.from_file(tj)
+        eng = cls(cfg, tok)
+        for d in ([os.path.join(model_dir, "preset_speakers")] if model_dir else []) + ["speakers"]:  # :156-166
+            if os.path.isdir(d):
+                eng.load_speakers(d)
+                break
+        return eng
+
+    def close(self):
+        self._native.close()
+
+    def set_max_steps(self, steps: int):
+        self.max_steps = steps
+
+    def set_sampler_config(self, config: SamplerConfig):
+        self.sampler_config = config
+
+    def get_sampler_config(self) -> SamplerConfig:
+        return self.sampler_config
+
+    def load_speakers(self, speakers_dir):  # src/tts/engine.rs:187-208 (files that fail to parse are skipped)
+        for fn in sorted(os.listdir(speakers_dir)):
+            if fn.endswith(".json"):
+                try:
+                    self.speakers[os.path.splitext(fn)[0]] = VoiceFile.load(os.path.join(speakers_dir, fn))
+                except Exception:
+                    pass
+
+    def get_speaker(self, id_or_name: str) -> VoiceFile:  # src/tts/engine.rs:211-231
+        if id_or_name in self.speakers:
+            return self.speakers[id_or_name]
+        for v in self.speakers.values():
+            if v.name == id_or_name:
+                return v
+        if "vivian" in self.speakers:
+            return self.speakers["vivian"]
+        if not self.speakers:
+            raise RuntimeError("No speakers loaded in engine!")
+        return next(iter(self.speakers.values()))
+
+    def _encode(self, text: Union[str, Sequence[int]]):
+        if isinstance(text, str):
+            if self.tokenizer is None:
+                raise _abi.Q3Error("no tokenizer.json available: pass token ids instead of text")
+            return np.asarray(self.tokenizer.encode(text, add_special_tokens=False).ids, dtype=np.uint32)  # src/utils/tokenizer.rs:17-25
+        return np.asarray(text, dtype=np.uint32)
+
+    def _desc(self, text, voice: VoiceFile, instruct):
+        ids = self._encode(text)
+        ins = None if instruct is None else self._encode(instruct)
+        emb = np.asarray(voice.speaker_embedding, dtype=np.float32)
+        if emb.size != self.cfg.model.d_embed:
+            raise _abi.Q3Error(f"speaker_embedding has {emb.size} values, expected {self.cfg.model.d_embed}")
+        if len(voice.audio_codes) == 0:  # src/tts/engine.rs:398-412: x-vector-only prompt
+            return native.make_prompt_desc(ids, spk_emb=emb, lang_id=LANG_ID_CHINESE, instruct_ids=ins)
+        ref_ids = self._encode(voice.ref_text)  # :414-427: ICL clone prompt
+        return native.make_prompt_desc(ids, spk_emb=emb, lang_id=LANG_ID_CHINESE, instruct_ids=ins,
+                                       ref_codes=np.asarray(voice.audio_codes, dtype=np.int32), ref_text_ids=ref_ids)
+
+    def generate_with_voice(self, text, voice: VoiceFile, instruct=None) -> AudioSample:
+        """src/tts/engine.rs:390-435."""
+        return self.generate_batch_with_voice([text], [voice], [instruct])[0]
+
+    def generate_batch_with_voice(self, texts, voices, instructs=None, seeds=None):
+        sc = self.sampler_config
+        reqs, keep = [], []
+        for i, (t, v) in enumerate(zip(texts, voices)):
+            desc, k = self._desc(t, v, None if instructs is None else instructs[i])
+            keep.append(k)
+            seed = sc.seed if seeds is None else seeds[i]
+            reqs.append(dict(desc=desc, temperature=sc.temperature, top_k=sc.top_k, top_p=sc.top_p, seed=seed, max_steps=self.max_steps,
+                             want_pcm=1))
+        outs = self._native.generate_batch(reqs)
+        for o in outs:
+            if o.status != 0:
+                raise _abi.Q3Error(f"generation failed with status {o.status}")
+        sr = self.cfg.vocoder.sample_rate
+        return [AudioSample(o.pcm, sr, 1) for o in outs]
+
+    def create_voice_file(self, audio_path, ref_text):  # src/tts/engine.rs:324-387
+        raise _abi.Q3Error("AudioEncoder not loaded: the codec/speaker encoders are SURVEY.md §8(f) 'next' rows")
+
+    def generate(self, text, ref_audio_path, ref_text, instruct=None):  # src/tts/engine.rs:243-272
+        raise _abi.Q3Error("AudioEncoder not loaded (required for processing raw audio)")
+
+
+def cleanup():
+    """qwen3_tts::cleanup() (src/lib.rs:18-20): llama_backend_free in the reference; nothing global to free here."""
+    return None

@@ -1,0 +1,60 @@
+"""Multi-GPU plumbing: utterance sharding (no data-path collective) and the one PCM gather.
+
+The hot path shards over independent utterances: rank r of G owns the global indices
+{i : i mod G == r}; every utterance's sampler stream is a function of its GLOBAL index only, so results do not
+depend on G. The only collective is the gather of the variable-length PCM to rank 0 (RCCL over xGMI on the GPU
+box, gloo in the CPU tests): an all_gather of the lengths followed by a padded gather.
+"""
+import numpy as np
+
+
+def shard_indices(n_total, rank, world):
+    """Global utterance indices owned by `rank` (round-robin, order preserving)."""
+    return list(range(rank, n_total, world))
+
+
+def global_seed(base_seed, global_index):
+    """Per-utterance sampler seed: depends on the global index only (never on rank / world size)."""
+    return int(base_seed) + int(global_index)
+
+
+def gather_pcm(dist, pcm_list, rank, world, device="cpu", dtype=None):
+    """Gathers per-utterance PCM arrays of every rank to rank 0.
+
+    pcm_list: list of 1-D float32 numpy arrays (this rank's utterances, in shard order).
+    Returns on rank 0: list (over ranks) of lists of numpy arrays; on other ranks: None.
+    """
+    import torch
+    dtype = dtype or torch.float32
+    n_local = len(pcm_list)
+    lens = torch.tensor([a.size for a in pcm_list], dtype=torch.int64, device=device)
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([n_local], dtype=torch.int64, device=device))
+    max_n = int(max(int(c.item()) for c in counts))
+    lens_pad = torch.zeros(max_n, dtype=torch.int64, device=device)
+    lens_pad[:n_local] = lens
+    all_lens = [torch.zeros(max_n, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(all_lens, lens_pad)
+    max_len = max(1, int(torch.stack(all_lens).max().item()))
+    buf = torch.zeros((max_n, max_len), dtype=dtype, device=device)
+    for i, a in enumerate(pcm_list):
+        if a.size:
+            buf[i, :a.size] = torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dtype)
+    gathered = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, gathered, dst=0)
+    if rank != 0:
+        return None
+    out = []
+    for r in range(world):
+        n_r = int(counts[r].item())
+        out.append([gathered[r][i, :int(all_lens[r][i].item())].float().cpu().numpy() for i in range(n_r)])
+    return out
+
+
+def reassemble(gathered, n_total, world):
+    """Inverse of shard_indices on rank 0: list indexed by global utterance index."""
+    res = [None] * n_total
+    for r in range(world):
+        for j, gi in enumerate(shard_indices(n_total, r, world)):
+            res[gi] = gathered[r][j]
+    return res

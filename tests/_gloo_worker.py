@@ -1,0 +1,30 @@
+"""world_size-2 gloo worker for tests/test_host_cpu.py::test_pcm_gather_over_gloo_world2."""
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "qwen3-tts-rust_amd"))
+from q3tts import dist as qd  # noqa: E402
+
+
+def fake_pcm(gi):  # length and content are functions of the GLOBAL utterance index only
+    return (np.arange(100 + 37 * gi, dtype=np.float32) * 0.001 + gi).astype(np.float32)
+
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n_total = 7
+mine = [fake_pcm(gi) for gi in qd.shard_indices(n_total, rank, world)]
+g = qd.gather_pcm(dist, mine, rank, world)
+if rank == 0:
+    full = qd.reassemble(g, n_total, world)
+    assert all(np.array_equal(full[i], fake_pcm(i)) for i in range(n_total))
+    with open(os.environ["Q3_GLOO_OUT"], "w") as f:
+        f.write(f"ok {n_total}")
+else:
+    assert g is None
+dist.barrier()
+dist.destroy_process_group()

@@ -1,0 +1,103 @@
+"""CPU tests of the host logic: C-ABI export list, API mirror types (VoiceFile / AudioSample / TTSC cache / SamplerConfig),
+speaker presets, utterance sharding and the PCM gather over gloo (world_size 2)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+
+
+def test_abi_exports_every_declared_symbol():
+    from q3tts import _abi
+    hdr = open(os.path.join(REPO, "include", "q3tts.h")).read()
+    declared = sorted(set(re.findall(r"\b(q3tts_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == sorted(_abi.SYMBOLS)
+    lib = _abi.load_library()  # loads without a GPU; no compute call is made here
+    for s in declared:
+        assert hasattr(lib, s), s
+    cfg = _abi.default_config()
+    assert (cfg.model.t_n_layer, cfg.model.t_d_model, cfg.model.p_n_layer, cfg.model.n_codebooks, cfg.model.sample_limit) == (28, 2048, 5, 16, 2160)
+    py = _abi.full_config_py()
+    assert bytes(py.model) == bytes(cfg.model) and bytes(py.vocoder) == bytes(cfg.vocoder)
+
+
+def test_product_path_fails_loudly_without_gpu_or_library(tmp_path):
+    from q3tts import _abi, native
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_abi.Q3Error, match="no HIP device|hipGetDeviceCount|no CPU fallback"):
+        native.NativeEngine(_abi.tiny_config())
+    with pytest.raises(_abi.Q3Error, match="not found"):
+        _abi.load_library(str(tmp_path / "missing.so"))
+
+
+def test_voice_file_and_presets(tmp_path):
+    from q3tts.api import VoiceFile
+    v = VoiceFile.load(os.path.join(HERE, "golden", "speakers", "vivian.json"))  # preset: `spk_emb` alias, extra `spk_id` ignored
+    assert v.name == "vivian" and len(v.speaker_embedding) == 2048 and v.audio_codes == [] and v.ref_text == ""
+    emb = np.asarray(v.speaker_embedding, dtype=np.float32)
+    assert np.array_equal((emb.view(np.uint32) & 0xFFFF), np.zeros(2048, dtype=np.uint32))  # bf16-representable values
+    p = tmp_path / "v.json"
+    VoiceFile.new("hi", [1, 2, 3], [0.5, -1.0]).with_metadata(name="x").save(p)
+    w = VoiceFile.load(p)
+    assert (w.ref_text, w.audio_codes, w.speaker_embedding, w.name) == ("hi", [1, 2, 3], [0.5, -1.0], "x")
+    (tmp_path / "bad.json").write_text('{"name": "n"}')
+    with pytest.raises(ValueError):
+        VoiceFile.load(tmp_path / "bad.json")
+
+
+def test_audio_sample_wav_roundtrip(tmp_path):
+    from q3tts.api import AudioSample
+    s = np.array([0.0, 0.5, -0.5, 1.0, -1.0, 2.0, -2.0, 1e-5], dtype=np.float32)
+    a = AudioSample(s, 24000, 1)
+    a.save_wav(tmp_path / "a.wav")
+    b = AudioSample.load_wav(tmp_path / "a.wav")
+    want = np.trunc(np.clip(s * np.float32(32767.0), -32768, 32767)).astype(np.int16)  # src/utils/audio.rs:35-37
+    assert np.array_equal((b.samples * 32768.0).astype(np.int16), want)
+    assert b.sample_rate == 24000 and b.channels == 1 and abs(a.duration() - 8 / 24000) < 1e-9
+
+
+def test_ttsc_cache_roundtrip(tmp_path):
+    from q3tts.api import load_cache, save_cache
+    p = tmp_path / "ref.cache"
+    save_cache(p, [1, -2, 2047, 2 ** 40], [0.25, -3.5])
+    raw = p.read_bytes()
+    assert raw[:4] == b"TTSC" and raw[4:8] == (1).to_bytes(4, "little") and len(raw) == 8 + 8 + 4 * 8 + 8 + 2 * 4
+    assert load_cache(p) == ([1, -2, 2047, 2 ** 40], [0.25, -3.5])
+    p.write_bytes(b"XXXX" + raw[4:])
+    with pytest.raises(ValueError):
+        load_cache(p)
+
+
+def test_sampler_config_defaults():
+    from q3tts.api import SamplerConfig
+    c = SamplerConfig()
+    assert (c.temperature, c.top_k, c.top_p, c.seed) == (0.7, 40, 0.9, None)  # src/tts/engine.rs:25-34
+
+
+def test_sharding_is_a_partition_and_seeds_ignore_world_size():
+    from q3tts import dist
+    for n in (0, 1, 7, 64, 512):
+        for world in (1, 2, 4, 8):
+            parts = [dist.shard_indices(n, r, world) for r in range(world)]
+            assert sorted(sum(parts, [])) == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    assert [dist.global_seed(1000, i) for i in dist.shard_indices(8, 1, 2)] == [1001, 1003, 1005, 1007]
+    assert dist.global_seed(1000, 5) == 1005
+
+
+def test_pcm_gather_over_gloo_world2(tmp_path):
+    """The N > 1 path on CPU: 2 ranks, gloo, variable-length PCM gathered to rank 0 and re-assembled in global order."""
+    out = tmp_path / "ok"
+    env = dict(os.environ, Q3_GLOO_OUT=str(out), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", os.path.join(HERE, "_gloo_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert out.read_text() == "ok 7"

@@ -1,0 +1,240 @@
+"""CPU tests of the oracle (the checker itself): published known-answer vectors, hand-derived expectations from the
+cited reference lines, and committed golden self-vectors (tests/golden/oracle_tiny.json, made by make_golden.py).
+
+PARITY UNPINNED: the reference ships no tests / fixtures for this path; the only external vectors are
+the ChaCha block-function KATs below, everything else pins the restatement against the reference's source text.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _u32(a):
+    return np.asarray(a, dtype=np.uint32)
+
+
+def test_chacha20_rfc7539_block(oracle):
+    """RFC 7539 §2.3.2 block-function test vector (key 00..1f, counter 1, nonce 00:00:00:09:00:00:00:4a:00:00:00:00)."""
+    L = oracle.lib()
+    st = _u32([0x61707865, 0x3320646e, 0x79622d32, 0x6b206574] + [int.from_bytes(bytes(range(4 * i, 4 * i + 4)), "little") for i in range(8)] +
+              [1, 0x09000000, 0x4a000000, 0])
+    out = np.zeros(16, dtype=np.uint32)
+    L.q3o_chacha_block(oracle.ptr(st, oracle.u32p), 20, oracle.ptr(out, oracle.u32p))
+    assert out.tobytes().hex() == ("10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4e"
+                                   "d2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e")
+
+
+def test_chacha_zero_key_keystreams(oracle):
+    """Zero key / zero nonce keystream heads: ChaCha20 (the vector rand_chacha's own test suite uses) and ChaCha12."""
+    L = oracle.lib()
+    st = _u32([0x61707865, 0x3320646e, 0x79622d32, 0x6b206574] + [0] * 12)
+    out = np.zeros(16, dtype=np.uint32)
+    L.q3o_chacha_block(oracle.ptr(st, oracle.u32p), 20, oracle.ptr(out, oracle.u32p))
+    assert [int(x) for x in out[:8]] == [0xade0b876, 0x903df1a0, 0xe56a5d40, 0x28bd8653, 0xb819d2bd, 0x1aed8da0, 0xccef36a8, 0xc70d778b]
+    L.q3o_chacha_block(oracle.ptr(st, oracle.u32p), 12, oracle.ptr(out, oracle.u32p))
+    assert out.tobytes()[:32].hex() == "9bf49a6a0755f953811fce125f2683d50429c3bb49e074147e0089a52eae155f"
+
+
+def test_stdrng_stream_shape(oracle):
+    L = oracle.lib()
+    a = np.zeros(200, dtype=np.float32)
+    L.q3o_rng_f32(42, 200, oracle.ptr(a, oracle.f32p))
+    assert (a >= 0).all() and (a < 1).all()
+    assert np.all(a * 16777216.0 == np.floor(a * 16777216.0))  # 24-bit fractions: (u32 >> 8) * 2^-24
+    b = np.zeros(70, dtype=np.float32)
+    L.q3o_rng_f32(42, 70, oracle.ptr(b, oracle.f32p))
+    assert np.array_equal(a[:70], b)  # 64-word buffer refill boundary is seamless
+    c = np.zeros(8, dtype=np.float32)
+    L.q3o_rng_f32(43, 8, oracle.ptr(c, oracle.f32p))
+    assert not np.array_equal(a[:8], c)
+
+
+def test_positions_h2(oracle):
+    """qwen3_position: src/tts/engine.rs:306-314 — [t.. | h.. | w.. | 0..]."""
+    L = oracle.lib()
+    out = np.zeros(12, dtype=np.int32)
+    L.q3o_qwen3_position(5, 3, oracle.ptr(out, oracle.i32p))
+    assert out.tolist() == [5, 6, 7, 5, 6, 7, 5, 6, 7, 0, 0, 0]
+
+
+@pytest.mark.parametrize("n,expect", [(0, []), (1, [(1, 1)]), (3, [(3, 1)]), (4, [(4, 0)]), (5, [(4, 0), (1, 1)]), (8, [(4, 0), (4, 0)]),
+                                      (9, [(4, 0), (4, 0), (1, 1)])])
+def test_chunker_h8(oracle, n, expect):
+    """Vocoder-thread chunking: src/tts/engine.rs:507-541. Note n % 4 == 0: no call ever carries is_last (reference quirk)."""
+    L = oracle.lib()
+    cf, cl = np.zeros(16, dtype=np.int32), np.zeros(16, dtype=np.int32)
+    k = L.q3o_chunk_plan(n, oracle.ptr(cf, oracle.i32p), oracle.ptr(cl, oracle.i32p), 16)
+    assert [(int(cf[i]), int(cl[i])) for i in range(k)] == expect
+
+
+def _sample(oracle, logits, T, k, p, r):
+    lg = np.asarray(logits, dtype=np.float32)
+    return oracle.lib().q3o_sample(oracle.ptr(lg, oracle.f32p), lg.size, T, k, p, r)
+
+
+def test_sampler_h4_hand_cases(oracle):
+    """src/models/llama/mod.rs:666-772."""
+    # greedy: first max, strict '>' (:690-701)
+    assert _sample(oracle, [1.0, 5.0, 5.0, 2.0], 0.0, 40, 0.9, 0.0) == 1
+    assert _sample(oracle, [float("nan"), 1.0, 0.5], 0.0, 0, 1.0, 0.0) == 1  # NaN never wins
+    # probabilities 8/15, 4/15, 2/15, 1/15 for logits ln(1,2,4,8) at temperature 1
+    lg = np.log(np.array([1.0, 2.0, 4.0, 8.0]))
+    for r, want in [(0.0, 3), (0.5, 3), (0.6, 2), (0.79, 2), (0.85, 1), (0.95, 0), (0.9999, 0)]:
+        assert _sample(oracle, lg, 1.0, 0, 1.0, r) == want, r
+    assert _sample(oracle, lg, 1.0, 1, 1.0, 0.99) == 3            # top_k = 1 (:711-713)
+    assert _sample(oracle, lg, 1.0, 2, 1.0, 0.99) == 2            # renormalised over the top 2
+    assert _sample(oracle, lg, 1.0, 0, 0.7, 0.7) == 2             # top-p: cut after cumsum >= 0.7 (inclusive), renormalise
+    assert _sample(oracle, lg, 1.0, 0, 0.5, 0.99) == 3            # first candidate alone already reaches p
+    assert _sample(oracle, lg, 1.0, -1, 1.0, 0.95) == 0           # negative top_k: `as usize` -> disabled (:646)
+    assert _sample(oracle, lg, 0.01, 0, 1.0, 0.9999) == 3         # low temperature ~ greedy
+    # stable sort: equal logits keep index order (:708)
+    assert _sample(oracle, [2.0, 7.0, 7.0, 1.0], 1.0, 1, 1.0, 0.5) == 1
+    # r beyond the (rounded) cumulative sum falls back to the first candidate (:767-770)
+    assert _sample(oracle, lg, 1.0, 0, 1.0, 2.0) == 3
+
+
+def test_bf16_rounding_and_expf(oracle):
+    L = oracle.lib()
+    assert L.q3o_bf16(1.0) == 0x3F80
+    assert L.q3o_bf16(1.0 + 2.0 ** -8) == 0x3F80       # tie -> even
+    assert L.q3o_bf16(1.0 + 3 * 2.0 ** -8) == 0x3F82   # tie -> even (up)
+    assert L.q3o_bf16(-2.5) == 0xC020
+    xs = np.linspace(-80, 20, 4001, dtype=np.float32)
+    ys = np.array([L.q3o_expf(float(x)) for x in xs], dtype=np.float64)
+    rel = np.abs(ys - np.exp(xs.astype(np.float64))) / np.exp(xs.astype(np.float64))
+    assert rel.max() < 4e-7
+    assert L.q3o_expf(-100.0) == 0.0 and L.q3o_expf(0.0) == 1.0
+
+
+@pytest.fixture(scope="module")
+def tiny_model(oracle):
+    from q3tts import _abi
+    cfg = _abi.tiny_config()
+    m = oracle.OracleModel(cfg.model, seed=0, n_ctx=256, n_threads=4)
+    yield cfg, m
+    m.close()
+
+
+def _text(oracle, m, i, d):
+    out = np.zeros(d, dtype=np.float32)
+    oracle.lib().q3o_text_embedding(m.h, i, oracle.ptr(out, oracle.f32p))
+    return out
+
+
+def _codec(oracle, m, q, c, d):
+    out = np.zeros(d, dtype=np.float32)
+    oracle.lib().q3o_codec_embedding(m.h, q, c, oracle.ptr(out, oracle.f32p))
+    return out
+
+
+def test_prompt_layout_h1(oracle, tiny_model):
+    """src/tts/prompt.rs:141-277: row count and row contents of the x-vector prompt."""
+    cfg, m = tiny_model
+    d = cfg.model.d_embed
+    spk = ((np.arange(d) % 13 - 6) * 0.03125).astype(np.float32)
+    ids = [11, 22, 33, 44, 55]
+    desc, keep = oracle.make_prompt_desc(ids, spk_emb=spk)
+    pe = m.build_prompt(desc)
+    assert pe.shape == (len(ids) + 11, d)
+    marker, pad0 = _text(oracle, m, 151671, d), _codec(oracle, m, 0, 2148, d)
+    for r, tid in enumerate([151644, 77091, 198]):                       # role block :171-175
+        assert np.array_equal(pe[r], _text(oracle, m, tid, d))
+    for r, cid in zip(range(3, 7), [2154, 2156, 2055, 2157]):            # THINK, THINK_BOS, lang, THINK_EOS :180-191
+        assert np.array_equal(pe[r], marker + _codec(oracle, m, 0, cid, d))
+    assert np.array_equal(pe[7], marker + spk)                           # speaker embedding :215-222
+    assert np.array_equal(pe[8], _text(oracle, m, 151672, d) + pad0)     # BOS_TOKEN + PAD :229-239
+    for j, t in enumerate(ids):
+        assert np.array_equal(pe[9 + j], _text(oracle, m, t, d) + pad0)
+    assert np.array_equal(pe[9 + len(ids)], _text(oracle, m, 151673, d) + pad0)
+    assert np.array_equal(pe[10 + len(ids)], marker + _codec(oracle, m, 0, 2149, d))  # activation BOS :256-264
+    # variants: instruct block (+5+k rows), NOTHINK (3 control rows), preset speaker id, clone prompt
+    desc, keep = oracle.make_prompt_desc(ids, spk_emb=spk, instruct_ids=[7, 8])
+    assert m.build_prompt(desc).shape[0] == len(ids) + 11 + 5 + 2
+    desc, keep = oracle.make_prompt_desc(ids, spk_emb=spk, lang_id=-1)
+    assert m.build_prompt(desc).shape[0] == len(ids) + 10
+    desc, keep = oracle.make_prompt_desc(ids, spk_id=3065)
+    pe2 = m.build_prompt(desc)
+    assert np.array_equal(pe2[7], marker + _codec(oracle, m, 0, 3065, d))
+    codes = (np.arange(3 * 16) * 5) % 64
+    desc, keep = oracle.make_prompt_desc(ids, spk_emb=spk, ref_codes=codes, ref_text_ids=[1, 2])
+    pe3 = m.build_prompt(desc)
+    assert pe3.shape[0] == len(ids) + 11 + (2 + 2) + 1 + 3 + 1
+    fr = np.zeros(d, dtype=np.float32)
+    for q in range(16):
+        fr = fr + _codec(oracle, m, q, int(codes[16 + q]), d)
+    assert np.array_equal(pe3[8 + 4 + 1 + 1], marker + fr)               # second reference frame :79-96
+    # table edge rules: src/assets_manager.rs:419-460
+    assert np.all(_codec(oracle, m, 3, 999999, d) == 0) and np.array_equal(_codec(oracle, m, 0, -5, d), _codec(oracle, m, 0, 0, d))
+    fb = _text(oracle, m, 200000, d)
+    assert np.array_equal(fb, (np.mod((200000 * 17 + np.arange(d)).astype(np.float32), 2.0) - 1.0).astype(np.float32))
+
+
+def test_project_h6(oracle, tiny_model):
+    """y = W x + b (src/assets_manager.rs:383-399): canonical summation order, so compare against float64 with a tolerance."""
+    from q3tts import _abi  # noqa: F401
+    cfg, m = tiny_model
+    L = oracle.lib()
+    d, dp = cfg.model.d_embed, cfg.model.p_d_model
+    x = np.random.default_rng(0).standard_normal(d).astype(np.float32)
+    y = np.zeros(dp, dtype=np.float32)
+    L.q3o_project(m.h, oracle.ptr(x, oracle.f32p), oracle.ptr(y, oracle.f32p))
+    scale_w, scale_b = np.float32(0.02) / np.float32(37837.227), np.float32(0.02) / np.float32(37837.227)
+    tid_w, tid_b = (3 << 16) | 1, (3 << 16) | 2
+    W = np.array([[L.q3o_synth(0, tid_w, n * d + k, scale_w) for k in range(d)] for n in range(8)], dtype=np.float32)
+    Wb = (W.view(np.uint32).astype(np.uint64) + 0x7FFF + ((W.view(np.uint32) >> 16) & 1)) >> 16
+    Wf = (Wb.astype(np.uint32) << 16).view(np.float32)
+    b = np.array([L.q3o_synth(0, tid_b, n, scale_b) for n in range(8)], dtype=np.float32)
+    ref = Wf.astype(np.float64) @ x.astype(np.float64) + b
+    assert np.allclose(y[:8], ref, rtol=0, atol=2e-6)
+
+
+def test_golden_self_vectors(oracle, tiny_model):
+    """Regression pins produced by tests/golden/make_golden.py from this same restatement (self-vectors, labelled so)."""
+    cfg, m = tiny_model
+    with open(os.path.join(HERE, "golden", "oracle_tiny.json")) as f:
+        g = json.load(f)
+    L = oracle.lib()
+    r = np.zeros(len(g["rng_seed42"]), dtype=np.float32)
+    L.q3o_rng_f32(42, r.size, oracle.ptr(r, oracle.f32p))
+    assert r.view(np.uint32).tolist() == g["rng_seed42"]
+    spk = ((np.arange(cfg.model.d_embed) % 13 - 6) * 0.03125).astype(np.float32)
+    desc, keep = oracle.make_prompt_desc(g["text_ids"], spk_emb=spk)
+    pe = m.build_prompt(desc)
+    assert int(pe.view(np.uint32).astype(np.uint64).sum()) == g["prompt_bits_sum"]
+    hid, lg = m.talker_prefill(pe)
+    assert lg.view(np.uint32)[:8].tolist() == g["prefill_logits_bits_head"]
+    codes, eos = m.generate(pe, temperature=0.0, max_steps=g["max_steps"])
+    assert codes.tolist() == g["greedy_codes"]
+    codes, eos = m.generate(pe, temperature=0.7, top_k=40, top_p=0.9, seed=1234, max_steps=g["max_steps"])
+    assert codes.tolist() == g["sampled_codes_seed1234"]
+
+
+def test_vocoder_oracle_properties(oracle):
+    """Causality: chunked streaming == one call; look-ahead withholds frames until flushed (V4)."""
+    from q3tts import _abi
+    cfg = _abi.tiny_config()
+    L = oracle.lib()
+    codes = np.random.default_rng(0).integers(0, 64, size=(6, 16)).astype(np.int32)
+    v = L.q3o_vocoder_create(C.byref(cfg.vocoder), 0, 4)
+    pcm = np.zeros(6 * 1920 + 8, dtype=np.float32)
+    n = L.q3o_vocoder_decode(v, oracle.ptr(codes, oracle.i32p), 6, 1, oracle.ptr(pcm, oracle.f32p), pcm.size)
+    assert n == 6 * 1920 and np.abs(pcm).max() <= 1.0
+    L.q3o_vocoder_reset(v)
+    parts = []
+    for a, b, last in ((0, 4, 0), (4, 6, 1)):
+        buf = np.zeros(4 * 1920, dtype=np.float32)
+        k = L.q3o_vocoder_decode(v, oracle.ptr(codes[a:b].copy(), oracle.i32p), b - a, last, oracle.ptr(buf, oracle.f32p), buf.size)
+        parts.append(buf[:k].copy())
+    assert np.array_equal(np.concatenate(parts), pcm[:n])
+    L.q3o_vocoder_destroy(v)
+    cfg.vocoder.lookahead_frames = 2
+    v = L.q3o_vocoder_create(C.byref(cfg.vocoder), 0, 4)
+    buf = np.zeros(6 * 1920, dtype=np.float32)
+    assert L.q3o_vocoder_decode(v, oracle.ptr(codes[:4].copy(), oracle.i32p), 4, 0, oracle.ptr(buf, oracle.f32p), buf.size) == 2 * 1920
+    assert L.q3o_vocoder_decode(v, oracle.ptr(codes[4:].copy(), oracle.i32p), 2, 1, oracle.ptr(buf, oracle.f32p), buf.size) == 4 * 1920
+    L.q3o_vocoder_destroy(v)
