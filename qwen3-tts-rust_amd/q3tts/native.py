@@ -219,3 +219,23 @@ def k_rng_f32(seed, n):
     out = np.zeros(n, dtype=np.float32)
     lib.q3tts_k_rng_f32(seed, n, _ptr(out, f32p))
     return out
+
+
+def stream_chunks(engine: "NativeEngine", **kw):
+    """Generator over the streaming C ABI (q3tts_stream_begin / _poll / _end): yields (pcm_chunk, is_final); the final
+    StopIteration value is the GenResult with all codes and PCM."""
+    r, keep = engine.make_request(**kw)
+    h = C.c_void_p()
+    engine._check(engine.lib.q3tts_stream_begin(engine.h, C.byref(r), C.byref(h)), "q3tts_stream_begin")
+    chunk, n, fin = f32p(), C.c_int32(), C.c_int32()
+    try:
+        while True:
+            engine._check(engine.lib.q3tts_stream_poll(h, C.byref(chunk), C.byref(n), C.byref(fin)), "q3tts_stream_poll")
+            if n.value > 0:
+                yield np.ctypeslib.as_array(chunk, shape=(n.value,)).copy(), bool(fin.value)
+            if fin.value:
+                break
+    finally:
+        res = _abi.Result()
+        engine._check(engine.lib.q3tts_stream_end(h, C.byref(res)), "q3tts_stream_end")
+        engine.last_stream_result = engine._unpack(res)

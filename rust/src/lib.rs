@@ -1,0 +1,117 @@
+//! `extern "C"` declarations of include/q3tts.h and a safe wrapper that keeps the reference crate's names:
+//! `TtsEngine::{new, set_max_steps, set_sampler_config, generate_with_voice}`, `SamplerConfig`, `VoiceFile`,
+//! `AudioSample`. UNCOMPILED (no Rust toolchain in the image); field order mirrors the C header one to one.
+#![allow(non_camel_case_types)]
+use std::ffi::CStr;
+use std::os::raw::{c_char, c_float, c_int};
+
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct q3tts_model_config {
+    pub t_n_layer: i32, pub t_d_model: i32, pub t_n_head: i32, pub t_n_kv_head: i32, pub t_head_dim: i32, pub t_d_ffn: i32, pub t_vocab: i32,
+    pub t_rope_theta: c_float, pub t_mrope_sections: [i32; 4],
+    pub p_n_layer: i32, pub p_d_model: i32, pub p_n_head: i32, pub p_n_kv_head: i32, pub p_head_dim: i32, pub p_d_ffn: i32,
+    pub p_rope_theta: c_float, pub n_codebooks: i32, pub codebook_size: i32, pub rms_eps: c_float,
+    pub d_embed: i32, pub text_vocab: i32, pub codec0_rows: i32, pub codecq_rows: i32,
+    pub sample_limit: i32, pub eos_code: i32, pub tts_pad_id: i32,
+}
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct q3tts_vocoder_config {
+    pub n_codebooks: i32, pub codebook_size: i32, pub codebook_dim: i32, pub latent_dim: i32, pub pre_conv_kernel: i32,
+    pub n_layer: i32, pub n_head: i32, pub head_dim: i32, pub d_ffn: i32, pub sliding_window: i32,
+    pub rope_theta: c_float, pub rms_eps: c_float, pub layer_scale_init: c_float,
+    pub n_upsample: i32, pub upsample_ratios: [i32; 4], pub decoder_dim: i32, pub n_dec_blocks: i32, pub dec_rates: [i32; 8],
+    pub lookahead_frames: i32, pub sample_rate: i32,
+}
+#[repr(C)]
+pub struct q3tts_engine_config {
+    pub model: q3tts_model_config, pub vocoder: q3tts_vocoder_config,
+    pub device: i32, pub max_batch: i32, pub n_ctx: i32, pub max_steps_cap: i32, pub with_vocoder: i32,
+    pub synth_seed: u64, pub weights_path: *const c_char,
+}
+#[repr(C)]
+pub struct q3tts_prompt_desc {
+    pub text_ids: *const u32, pub n_text: i32, pub instruct_ids: *const u32, pub n_instruct: i32,
+    pub lang_id: i32, pub spk_id: i32, pub spk_emb: *const c_float,
+    pub ref_codes: *const i32, pub n_ref_frames: i32, pub ref_text_ids: *const u32, pub n_ref_text: i32,
+}
+#[repr(C)]
+pub struct q3tts_request {
+    pub prompt_embd: *const c_float, pub n_tok: i32, pub prompt: *const q3tts_prompt_desc, pub use_engine_sampler: i32,
+    pub temperature: c_float, pub top_k: i32, pub top_p: c_float, pub has_seed: i32, pub seed: u64,
+    pub max_steps: i32, pub min_frames: i32, pub force_eos_at: i32, pub want_pcm: i32,
+}
+#[repr(C)]
+pub struct q3tts_result {
+    pub status: i32, pub n_frames: i32, pub hit_eos: i32, pub codes: *mut i32, pub pcm: *mut c_float,
+    pub n_samples: i32, pub sample_rate: i32, pub first_chunk_ms: c_float, pub total_ms: c_float,
+}
+pub enum q3tts_engine {}
+
+#[link(name = "q3tts")]
+extern "C" {
+    pub fn q3tts_default_config(cfg: *mut q3tts_engine_config);
+    pub fn q3tts_engine_create(cfg: *const q3tts_engine_config, out: *mut *mut q3tts_engine) -> c_int;
+    pub fn q3tts_engine_destroy(e: *mut q3tts_engine);
+    pub fn q3tts_last_error(e: *const q3tts_engine) -> *const c_char;
+    pub fn q3tts_set_sampler(e: *mut q3tts_engine, temperature: c_float, top_k: i32, top_p: c_float, has_seed: i32, seed: u64) -> c_int;
+    pub fn q3tts_set_max_steps(e: *mut q3tts_engine, max_steps: i32) -> c_int;
+    pub fn q3tts_generate(e: *mut q3tts_engine, req: *const q3tts_request, out: *mut q3tts_result) -> c_int;
+    pub fn q3tts_generate_batch(e: *mut q3tts_engine, reqs: *const q3tts_request, n: i32, outs: *mut q3tts_result) -> c_int;
+    pub fn q3tts_result_free(r: *mut q3tts_result);
+}
+
+// ---- the reference crate's public names on top of the C ABI (src/lib.rs:11-20) ------------------------------------
+#[derive(Debug, Clone)]
+pub struct SamplerConfig { pub temperature: f32, pub top_k: i32, pub top_p: f32, pub seed: Option<u64> }
+impl Default for SamplerConfig { fn default() -> Self { Self { temperature: 0.7, top_k: 40, top_p: 0.9, seed: None } } }
+
+pub struct VoiceFile { pub ref_text: String, pub audio_codes: Vec<i64>, pub speaker_embedding: Vec<f32> }
+pub struct AudioSample { pub samples: Vec<f32>, pub sample_rate: u32, pub channels: u16 }
+
+pub struct TtsEngine { raw: *mut q3tts_engine, sampler: SamplerConfig, max_steps: usize }
+
+impl TtsEngine {
+    /// TtsEngine::new(model_dir, quant) — src/tts/engine.rs:84. `model_dir` would carry a Q3TW weight container.
+    pub fn new(_model_dir: &str, _quant: &str) -> Result<Self, String> {
+        unsafe {
+            let mut cfg: q3tts_engine_config = std::mem::zeroed();
+            q3tts_default_config(&mut cfg);
+            let mut raw = std::ptr::null_mut();
+            let rc = q3tts_engine_create(&cfg, &mut raw);
+            if rc != 0 { return Err(CStr::from_ptr(q3tts_last_error(std::ptr::null())).to_string_lossy().into_owned()); }
+            Ok(Self { raw, sampler: SamplerConfig::default(), max_steps: 512 })
+        }
+    }
+    pub fn set_max_steps(&mut self, steps: usize) { self.max_steps = steps; }
+    pub fn set_sampler_config(&mut self, c: SamplerConfig) { self.sampler = c; }
+    pub fn get_sampler_config(&self) -> &SamplerConfig { &self.sampler }
+
+    /// generate_with_voice — src/tts/engine.rs:390. `text_ids` = tokenizer.encode(text) (the tokenizer stays in Rust).
+    pub fn generate_with_voice(&mut self, text_ids: &[u32], voice: &VoiceFile, instruct_ids: Option<&[u32]>) -> Result<AudioSample, String> {
+        let codes32: Vec<i32> = voice.audio_codes.iter().map(|&c| c as i32).collect();
+        let desc = q3tts_prompt_desc {
+            text_ids: text_ids.as_ptr(), n_text: text_ids.len() as i32,
+            instruct_ids: instruct_ids.map_or(std::ptr::null(), |s| s.as_ptr()), n_instruct: instruct_ids.map_or(0, |s| s.len() as i32),
+            lang_id: 2055, spk_id: -1, spk_emb: voice.speaker_embedding.as_ptr(),
+            ref_codes: if codes32.is_empty() { std::ptr::null() } else { codes32.as_ptr() }, n_ref_frames: (codes32.len() / 16) as i32,
+            ref_text_ids: std::ptr::null(), n_ref_text: 0, // tokenizer.encode(&voice.ref_text) in the real crate
+        };
+        let req = q3tts_request {
+            prompt_embd: std::ptr::null(), n_tok: 0, prompt: &desc, use_engine_sampler: 0,
+            temperature: self.sampler.temperature, top_k: self.sampler.top_k, top_p: self.sampler.top_p,
+            has_seed: self.sampler.seed.is_some() as i32, seed: self.sampler.seed.unwrap_or(0),
+            max_steps: self.max_steps as i32, min_frames: 0, force_eos_at: -1, want_pcm: 1,
+        };
+        unsafe {
+            let mut out: q3tts_result = std::mem::zeroed();
+            let rc = q3tts_generate(self.raw, &req, &mut out);
+            if rc != 0 { return Err(CStr::from_ptr(q3tts_last_error(self.raw)).to_string_lossy().into_owned()); }
+            let samples = std::slice::from_raw_parts(out.pcm, out.n_samples as usize).to_vec();
+            q3tts_result_free(&mut out);
+            Ok(AudioSample { samples, sample_rate: 24000, channels: 1 })
+        }
+    }
+}
+impl Drop for TtsEngine { fn drop(&mut self) { unsafe { q3tts_engine_destroy(self.raw) } } }
+/// qwen3_tts::cleanup() (src/lib.rs:18-20): nothing global to free.
+pub fn cleanup() {}

@@ -307,3 +307,33 @@ def test_end_to_end_pcm_and_batch(oracle, tiny_voc):
     assert np.array_equal(single.pcm, outs[4].pcm)
     assert single.first_chunk_ms > 0
     om.close()
+
+
+def test_streaming_api_chunks(oracle, tiny_voc):
+    """q3tts_stream_*: 4-frame chunks (src/tts/engine.rs:507-541) concatenate to exactly the non-streaming PCM."""
+    from q3tts import native
+    cfg, eng, v = tiny_voc
+    desc, keep = oracle.make_prompt_desc(np.arange(40, 52), spk_emb=_spk(cfg.model.d_embed))
+    kw = dict(desc=desc, temperature=0.7, seed=5, max_steps=16, min_frames=10, force_eos_at=10)
+    whole = eng.generate(want_pcm=1, **kw)
+    chunks = list(native.stream_chunks(eng, want_pcm=1, **kw))
+    assert [c.size for c, _ in chunks] == [4 * 1920, 4 * 1920, 2 * 1920] and [f for _, f in chunks] == [False, False, True]
+    assert np.array_equal(np.concatenate([c for c, _ in chunks]), whole.pcm)
+    assert np.array_equal(eng.last_stream_result.codes, whole.codes)
+
+
+def test_api_mirror_generate_with_voice(tiny_voc, tmp_path):
+    """TtsEngine / VoiceFile / SamplerConfig / AudioSample mirror over the same engine handle (token ids in, WAV out)."""
+    from q3tts import api
+    cfg, eng, v = tiny_voc
+    te = api.TtsEngine.__new__(api.TtsEngine)
+    te._native, te.cfg, te.tokenizer, te.speakers, te.max_steps, te.sampler_config = eng, cfg, None, {}, 6, api.SamplerConfig(0.0, 40, 0.9, 7)
+    voice = api.VoiceFile.new("", [], _spk(cfg.model.d_embed).tolist())
+    a = te.generate_with_voice(list(range(100, 110)), voice)
+    assert a.sample_rate == 24000 and a.channels == 1 and len(a.samples) == 6 * 1920
+    a.save_wav(tmp_path / "o.wav")
+    assert api.AudioSample.load_wav(tmp_path / "o.wav").samples.size == 6 * 1920
+    te.speakers = {"vivian": voice}
+    assert te.get_speaker("nobody") is voice  # fallback chain: id -> name -> vivian (src/tts/engine.rs:211-231)
+    with pytest.raises(Exception):
+        te.generate_with_voice("plain text needs a tokenizer.json", voice)
