@@ -23,6 +23,7 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 
 FRAME_SEC = 0.08  # 1 frame = 16 codes = 1920 samples @ 24 kHz (reference: src/tts/engine.rs:509-512,653)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+F32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32 dense peak
 
 
 def vivian():
@@ -137,7 +138,7 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     step_frames = 0
-    dec_ms = steps_dev = bytes_step = 0
+    dec_ms = steps_dev = bytes_step = flops_step = live = 0
     for _ in range(args.steps):
         outs = eng.generate_batch(reqs)
         gather_pcm(outs)
@@ -145,7 +146,7 @@ def main():
         tm = eng.timings()
         dec_ms += tm.decode_ms
         steps_dev += tm.frame_steps
-        bytes_step = tm.algo_bytes_per_step
+        bytes_step, flops_step, live = tm.algo_bytes_per_step, tm.algo_flops_per_step, tm.mean_live_slots
     sync_all()
     elapsed = time.perf_counter() - t0
     assert all(o.status == 0 for o in outs)
@@ -165,7 +166,10 @@ def main():
         audio_sec = total_frames * FRAME_SEC
         value = audio_sec / elapsed
         frame_step_ms = dec_ms / max(1, steps_dev)
-        achieved = bytes_step / (frame_step_ms * 1e-3) / 1e9 if frame_step_ms > 0 else 0.0
+        hbm_gbs = bytes_step / (frame_step_ms * 1e-3) / 1e9 if frame_step_ms > 0 else 0.0
+        mfma_tf = flops_step / (frame_step_ms * 1e-3) / 1e12 if frame_step_ms > 0 else 0.0
+        # arithmetic intensity = flops/bytes; the f32-input MFMA ridge is 157.3 TF / 8 TB/s = 19.7 flop/B
+        mfma_bound = bytes_step > 0 and flops_step / bytes_step > F32_MFMA_PEAK_TF * 1e3 / HBM_PEAK_GBS
         tm = eng.timings()
         line = {
             "metric": "audio_sec_per_s", "value": round(value, 2), "unit": "audio-sec/s", "n_gpus": world, "steps": args.steps,
@@ -179,10 +183,17 @@ def main():
             "rtf_per_utterance": round(frame_step_ms / 80.0, 5),
             "frame_step_ms": round(frame_step_ms, 4),
             "stage_ms_last_step": {"prefill": round(tm.prefill_ms, 2), "decode": round(tm.decode_ms, 2), "vocoder_host_wait": round(tm.vocoder_ms, 2)},
-            "roofline": {"bound": "hbm", "kernel": "frame-step graph replay (sample + 15 Predictor passes + Talker step; k_gemm dominant)",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "algorithmic_bytes_per_launch": int(bytes_step), "launch_ms": round(frame_step_ms, 4), "traffic": None},
+            "roofline": ({"bound": "mfma", "achieved": round(mfma_tf, 2), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                          "frac": round(mfma_tf / F32_MFMA_PEAK_TF, 4)} if mfma_bound else
+                         {"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(hbm_gbs / HBM_PEAK_GBS, 4)}),
         }
+        line["roofline"].update({
+            "kernel": "frame step = one replay of the decoder graph(s): sample + 15 Predictor passes + Talker step (k_gemm_ring / k_gemm_small dominant)",
+            "peak_note": "f32-input MFMA dense peak 157.3 TF (MI355X_MICROARCH.md); the exact decoder accumulates on v_mfma_f32_16x16x4_f32",
+            "algorithmic_flops_per_launch": int(flops_step), "algorithmic_bytes_per_launch": int(bytes_step), "mean_live_utterances": round(live, 2),
+            "launch_ms": round(frame_step_ms, 4), "hbm_GBs_same_launch": round(hbm_gbs, 1), "hbm_frac_of_8TBs": round(hbm_gbs / HBM_PEAK_GBS, 4),
+            "lanes": int(tm.n_lanes), "traffic": None})
         if args.no_vocoder:
             line["invalid"] = "diagnostic run without the vocoder"
 

@@ -177,6 +177,9 @@ typedef struct q3tts_timings {
     float talker_gemm_ms;     /* mean device time of the dominant kernel family per frame step */
     int64_t frame_steps;      /* graph replays timed */
     int64_t algo_bytes_per_step; /* SURVEY.md §8(d) algorithmic bytes of one frame step at the batch run */
+    int64_t algo_flops_per_step; /* 2 * (W_T + 15 W_P + 15 h + 16 pj) * mean live utterances per step (decoder GEMMs) */
+    float mean_live_slots;       /* utterances generating, averaged over the timed frame steps */
+    float n_lanes;               /* concurrent slot groups (streams) the engine replays */
 } q3tts_timings;
 int q3tts_get_timings(const q3tts_engine* e, q3tts_timings* out);
 

@@ -26,6 +26,19 @@ struct Q3Scratch {
     int rows = 0;
 };
 
+// one lane = rows [0, nb) <-> slots [b0, b0 + nb): per-row buffers, its own stream and frame-step graph
+struct Q3Lane {
+    int b0 = 0, nb = 0;
+    hipStream_t stream = nullptr;
+    float *xT = nullptr, *logits = nullptr, *X = nullptr, *fb = nullptr, *px = nullptr;
+    unsigned long long* keys = nullptr;
+    int *row_pos_t = nullptr, *slot_id = nullptr, *posA = nullptr, *slotA = nullptr, *pos_q = nullptr;
+    Q3Scratch sc;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+};
+
 struct q3tts_engine {
     q3tts_engine_config cfg;
     std::string err;
@@ -38,24 +51,20 @@ struct q3tts_engine {
     uint4* proj_w = nullptr;
     float* proj_b = nullptr;
     float* tts_pad = nullptr;             // = text[tts_pad_id]
-    // decode state (B = max_batch rows)
+    // decode state: B = max_batch slots, split over `lanes` (independent slot groups replayed concurrently on their
+    // own HIP streams so that one group's latency-bound kernel chain fills the other's gaps)
     int B = 0;
-    Q3Slot* slots = nullptr;              // device
-    Q3Slot* slots_host = nullptr;         // pinned mirror
-    float *xT = nullptr, *logits = nullptr, *X = nullptr, *fb = nullptr, *px = nullptr;
-    unsigned long long* keys = nullptr;
+    Q3Slot* slots = nullptr;              // device [B]
+    Q3Slot* slots_host = nullptr;         // pinned mirror [B] + staging [B]
     int* codes = nullptr;                 // [B][max_steps_cap][ncb]
     float* rng = nullptr;                 // [B][max_steps_cap]
-    int *row_pos_t = nullptr, *slot_id = nullptr, *posA = nullptr, *slotA = nullptr, *pos_q = nullptr;
-    Q3Scratch sc_dec, sc_pre;
+    std::vector<Q3Lane> lanes;
+    Q3Scratch sc_pre;
     // prefill
     float* xp = nullptr;                  // [n_ctx][d]
     int *pf_pos = nullptr, *pf_slot = nullptr;
     Q3PromptRow* prow_dev = nullptr; int prow_cap = 0;
     float* spk_dev = nullptr; int* refcodes_dev = nullptr;
-    // graph of one frame step
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
     // sampler defaults (SamplerConfig::default: src/tts/engine.rs:25-34)
     float temperature = 0.7f; int top_k = 40; float top_p = 0.9f; int has_seed = 0; uint64_t seed = 0;
     int max_steps = 512;

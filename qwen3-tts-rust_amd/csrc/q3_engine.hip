@@ -183,40 +183,40 @@ static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, int rows, const int*
     }
 }
 
-// one frame: src/tts/engine.rs:545-642 for all B slots
-static void record_frame(q3tts_engine* e, hipStream_t s) {
+// one frame: src/tts/engine.rs:545-642 for the slots [b0, b0 + nb) of one lane
+static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s) {
     const q3tts_model_config& m = e->cfg.model;
-    const int B = e->B, ncb = m.n_codebooks, cbs = m.codebook_size, dp = m.p_d_model, de = m.d_embed;
+    const int B = L.nb, ncb = m.n_codebooks, cbs = m.codebook_size, dp = m.p_d_model, de = m.d_embed, cap = e->cfg.max_steps_cap;
     const float eps = m.rms_eps;
-    Q3Sample sa{}; sa.logits = e->logits; sa.ld = m.t_vocab; sa.limit = m.sample_limit; sa.eos = m.eos_code; sa.slots = e->slots; sa.B = B;
-    sa.rng = e->rng; sa.codes = e->codes; sa.max_steps_cap = e->cfg.max_steps_cap; sa.ncb = ncb; sa.keys = e->keys;
+    Q3Slot* slots = e->slots + L.b0;
+    int* codes = e->codes + (size_t)L.b0 * cap * ncb;
+    Q3Sample sa{}; sa.logits = L.logits; sa.ld = m.t_vocab; sa.limit = m.sample_limit; sa.eos = m.eos_code; sa.slots = slots; sa.B = B;
+    sa.rng = e->rng; sa.codes = codes; sa.max_steps_cap = cap; sa.ncb = ncb; sa.keys = L.keys;
     q3_launch_sample(sa, s);
-    Q3PredInput pi{}; pi.xT = e->xT; pi.out_norm = e->T.out_norm; pi.eps = eps; pi.d = de; pi.codec0 = e->codec[0]; pi.codec0_rows = m.codec0_rows;
-    pi.slots = e->slots; pi.X = e->X; pi.fb = e->fb; pi.B = B;
+    Q3PredInput pi{}; pi.xT = L.xT; pi.out_norm = e->T.out_norm; pi.eps = eps; pi.d = de; pi.codec0 = e->codec[0]; pi.codec0_rows = m.codec0_rows;
+    pi.slots = slots; pi.X = L.X; pi.fb = L.fb; pi.B = B;
     q3_launch_pred_input(pi, s);
     const size_t head_tile_stride = (size_t)(cbs / 16) * (dp / 32) * 64;  // uint4 per predictor head
+    auto pred_next = [&](int q) {
+        Q3PredNext pn{}; pn.keys = L.keys; pn.q = q; pn.ncb = ncb; pn.codec_q = e->codec[q]; pn.rows_q = m.codecq_rows; pn.d = de;
+        pn.slots = slots; pn.B = B; pn.codes = codes; pn.max_steps_cap = cap; pn.fb = L.fb; pn.X = L.X;
+        pn.tts_pad = e->tts_pad; pn.xT = L.xT; pn.row_pos_t = L.row_pos_t;
+        q3_launch_pred_next(pn, s);
+    };
     for (int q = 0; q < ncb - 1; ++q) {  // pass q produces code_{q+1}
         const int rows = q == 0 ? 2 * B : B;
-        if (q > 0) {
-            Q3PredNext pn{}; pn.keys = e->keys; pn.q = q; pn.ncb = ncb; pn.codec_q = e->codec[q]; pn.rows_q = m.codecq_rows; pn.d = de;
-            pn.slots = e->slots; pn.B = B; pn.codes = e->codes; pn.max_steps_cap = e->cfg.max_steps_cap; pn.fb = e->fb; pn.X = e->X;
-            pn.tts_pad = e->tts_pad; pn.xT = e->xT; pn.row_pos_t = e->row_pos_t;
-            q3_launch_pred_next(pn, s);
-        }
-        Q3Gemm g{}; g.x = e->X; g.ldx = de; g.B = rows; g.w = e->proj_w; g.K = de; g.N = dp; g.bias = e->proj_b; g.y = e->px; g.ldy = dp;
+        if (q > 0) pred_next(q);
+        Q3Gemm g{}; g.x = L.X; g.ldx = de; g.B = rows; g.w = e->proj_w; g.K = de; g.N = dp; g.bias = e->proj_b; g.y = L.px; g.ldy = dp;
         g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);  // H6: src/assets_manager.rs:383-399
-        run_layers(e, e->P, e->px, rows, q == 0 ? e->posA : e->pos_q + (size_t)q * B, q == 0 ? e->slotA : e->slot_id, e->sc_dec, s, q > 0);
-        g = Q3Gemm{}; g.x = q == 0 ? e->px + dp : e->px; g.ldx = q == 0 ? 2 * dp : dp; g.B = B; g.w = e->P.head + head_tile_stride * q;
-        g.K = dp; g.N = cbs; g.norm_w = e->P.out_norm; g.eps = eps; g.xhat = e->sc_dec.xn; g.keys = e->keys + (q + 1); g.key_stride = ncb; g.epi = Q3_EPI_ARGMAX;
+        run_layers(e, e->P, L.px, rows, q == 0 ? L.posA : L.pos_q + (size_t)q * B, q == 0 ? L.slotA : L.slot_id, L.sc, s, q > 0);
+        g = Q3Gemm{}; g.x = q == 0 ? L.px + dp : L.px; g.ldx = q == 0 ? 2 * dp : dp; g.B = B; g.w = e->P.head + head_tile_stride * q;
+        g.K = dp; g.N = cbs; g.norm_w = e->P.out_norm; g.eps = eps; g.xhat = L.sc.xn; g.keys = L.keys + (q + 1); g.key_stride = ncb; g.epi = Q3_EPI_ARGMAX;
         q3_launch_gemm(g, s);
     }
-    { Q3PredNext pn{}; pn.keys = e->keys; pn.q = ncb - 1; pn.ncb = ncb; pn.codec_q = e->codec[ncb - 1]; pn.rows_q = m.codecq_rows; pn.d = de;
-      pn.slots = e->slots; pn.B = B; pn.codes = e->codes; pn.max_steps_cap = e->cfg.max_steps_cap; pn.fb = e->fb; pn.X = e->X;
-      pn.tts_pad = e->tts_pad; pn.xT = e->xT; pn.row_pos_t = e->row_pos_t;
-      q3_launch_pred_next(pn, s); }
-    run_layers(e, e->T, e->xT, B, e->row_pos_t, e->slot_id, e->sc_dec, s, true);
-    Q3Gemm g{}; g.x = e->xT; g.ldx = m.t_d_model; g.B = B; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab; g.norm_w = e->T.out_norm; g.eps = eps; g.xhat = e->sc_dec.xn;
-    g.y = e->logits; g.ldy = m.t_vocab; g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);
+    pred_next(ncb - 1);
+    run_layers(e, e->T, L.xT, B, L.row_pos_t, L.slot_id, L.sc, s, true);
+    Q3Gemm g{}; g.x = L.xT; g.ldx = m.t_d_model; g.B = B; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab; g.norm_w = e->T.out_norm; g.eps = eps; g.xhat = L.sc.xn;
+    g.y = L.logits; g.ldy = m.t_vocab; g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);
 }
 
 extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine** out) {
@@ -269,25 +269,36 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
     TRYC(dalloc(e, &e->slots, (size_t)B));
     HIPC(hipHostMalloc((void**)&e->slots_host, sizeof(Q3Slot) * 2 * B, hipHostMallocDefault));
     memset(e->slots_host, 0, sizeof(Q3Slot) * 2 * B);
-    TRYC(dalloc(e, &e->xT, (size_t)B * m.t_d_model)); TRYC(dalloc(e, &e->logits, (size_t)B * m.t_vocab));
-    TRYC(dalloc(e, &e->X, (size_t)2 * B * m.d_embed)); TRYC(dalloc(e, &e->fb, (size_t)B * m.d_embed));
-    TRYC(dalloc(e, &e->px, (size_t)2 * B * m.p_d_model)); TRYC(dalloc(e, &e->keys, (size_t)B * m.n_codebooks));
     TRYC(dalloc(e, &e->codes, (size_t)B * cfg->max_steps_cap * m.n_codebooks)); TRYC(dalloc(e, &e->rng, (size_t)B * cfg->max_steps_cap));
-    TRYC(dalloc(e, &e->row_pos_t, (size_t)B)); TRYC(dalloc(e, &e->slot_id, (size_t)B));
-    TRYC(dalloc(e, &e->posA, (size_t)2 * B)); TRYC(dalloc(e, &e->slotA, (size_t)2 * B)); TRYC(dalloc(e, &e->pos_q, (size_t)m.n_codebooks * B));
     {
-        std::vector<int> sid(B), pa(2 * B), sla(2 * B), pq((size_t)m.n_codebooks * B), rp(B, -1);
-        for (int b = 0; b < B; ++b) { sid[b] = b; pa[2 * b] = 0; pa[2 * b + 1] = 1; sla[2 * b] = sla[2 * b + 1] = b; }
-        for (int q = 0; q < m.n_codebooks; ++q) for (int b = 0; b < B; ++b) pq[(size_t)q * B + b] = q + 1;  // src/tts/engine.rs:604
-        HIPC(hipMemcpyAsync(e->slot_id, sid.data(), B * 4, hipMemcpyHostToDevice, s));
-        HIPC(hipMemcpyAsync(e->posA, pa.data(), 2 * B * 4, hipMemcpyHostToDevice, s));
-        HIPC(hipMemcpyAsync(e->slotA, sla.data(), 2 * B * 4, hipMemcpyHostToDevice, s));
-        HIPC(hipMemcpyAsync(e->pos_q, pq.data(), pq.size() * 4, hipMemcpyHostToDevice, s));
-        HIPC(hipMemcpyAsync(e->row_pos_t, rp.data(), B * 4, hipMemcpyHostToDevice, s));
-        HIPC(hipStreamSynchronize(s));
+        int n_lanes = 1;  // measured on MI355X: 2 or 4 lanes do not beat 1 (kernels fill the chip; Q3TTS_LANES overrides)
+        if (getenv("Q3TTS_LANES")) n_lanes = atoi(getenv("Q3TTS_LANES"));
+        if (n_lanes < 1 || n_lanes > 8 || B % n_lanes) n_lanes = 1;
+        const int nb = B / n_lanes;
+        const int nqkv_max = std::max(e->T.nqkv, e->P.nqkv), nq_max = std::max(e->T.nq, e->P.nq), F_max = std::max(e->T.F, e->P.F);
+        e->lanes.resize(n_lanes);
+        for (int li = 0; li < n_lanes; ++li) {
+            Q3Lane& L = e->lanes[li];
+            L.b0 = li * nb; L.nb = nb;
+            HIPC(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+            HIPC(hipEventCreate(&L.ev_begin)); HIPC(hipEventCreate(&L.ev_end));
+            TRYC(dalloc(e, &L.xT, (size_t)nb * m.t_d_model)); TRYC(dalloc(e, &L.logits, (size_t)nb * m.t_vocab));
+            TRYC(dalloc(e, &L.X, (size_t)2 * nb * m.d_embed)); TRYC(dalloc(e, &L.fb, (size_t)nb * m.d_embed));
+            TRYC(dalloc(e, &L.px, (size_t)2 * nb * m.p_d_model)); TRYC(dalloc(e, &L.keys, (size_t)nb * m.n_codebooks));
+            TRYC(dalloc(e, &L.row_pos_t, (size_t)nb)); TRYC(dalloc(e, &L.slot_id, (size_t)nb));
+            TRYC(dalloc(e, &L.posA, (size_t)2 * nb)); TRYC(dalloc(e, &L.slotA, (size_t)2 * nb)); TRYC(dalloc(e, &L.pos_q, (size_t)m.n_codebooks * nb));
+            std::vector<int> sid(nb), pa(2 * nb), sla(2 * nb), pq((size_t)m.n_codebooks * nb), rp(nb, -1);
+            for (int b = 0; b < nb; ++b) { sid[b] = L.b0 + b; pa[2 * b] = 0; pa[2 * b + 1] = 1; sla[2 * b] = sla[2 * b + 1] = L.b0 + b; }
+            for (int q = 0; q < m.n_codebooks; ++q) for (int b = 0; b < nb; ++b) pq[(size_t)q * nb + b] = q + 1;  // src/tts/engine.rs:604
+            HIPC(hipMemcpyAsync(L.slot_id, sid.data(), nb * 4, hipMemcpyHostToDevice, s));
+            HIPC(hipMemcpyAsync(L.posA, pa.data(), 2 * nb * 4, hipMemcpyHostToDevice, s));
+            HIPC(hipMemcpyAsync(L.slotA, sla.data(), 2 * nb * 4, hipMemcpyHostToDevice, s));
+            HIPC(hipMemcpyAsync(L.pos_q, pq.data(), pq.size() * 4, hipMemcpyHostToDevice, s));
+            HIPC(hipMemcpyAsync(L.row_pos_t, rp.data(), nb * 4, hipMemcpyHostToDevice, s));
+            HIPC(hipStreamSynchronize(s));
+            TRYC(alloc_scratch(e, L.sc, 2 * nb, nqkv_max, nq_max, F_max, std::max(m.t_d_model, m.p_d_model)));
+        }
     }
-    const int nqkv_max = std::max(e->T.nqkv, e->P.nqkv), nq_max = std::max(e->T.nq, e->P.nq), F_max = std::max(e->T.F, e->P.F);
-    TRYC(alloc_scratch(e, e->sc_dec, 2 * B, nqkv_max, nq_max, F_max, std::max(m.t_d_model, m.p_d_model)));
     TRYC(alloc_scratch(e, e->sc_pre, cfg->n_ctx, e->T.nqkv, e->T.nq, e->T.F, m.t_d_model));
     TRYC(dalloc(e, &e->xp, (size_t)cfg->n_ctx * m.t_d_model));
     TRYC(dalloc(e, &e->pf_pos, (size_t)cfg->n_ctx)); TRYC(dalloc(e, &e->pf_slot, (size_t)cfg->n_ctx));
@@ -300,14 +311,16 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
         TRYC(q3_voc_create(e));
         HIPC(hipHostMalloc((void**)&e->first_chunk_host, sizeof(float) * 4 * (size_t)q3_voc_samples_per_frame(e), hipHostMallocDefault));
     }
-    // capture the frame step once; every later frame is a replay (Q3TTS_NO_GRAPH=1: eager launches, for profilers)
+    // capture each lane's frame step once; every later frame is a replay (Q3TTS_NO_GRAPH=1: eager launches, for profilers)
     HIPC(hipStreamSynchronize(s));
     if (!(getenv("Q3TTS_NO_GRAPH") && atoi(getenv("Q3TTS_NO_GRAPH")))) {
-        HIPC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        record_frame(e, s);
-        HIPC(hipStreamEndCapture(s, &e->graph));
-        HIPC(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
-        HIPC(hipStreamSynchronize(s));
+        for (auto& L : e->lanes) {
+            HIPC(hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal));
+            record_frame(e, L, L.stream);
+            HIPC(hipStreamEndCapture(L.stream, &L.graph));
+            HIPC(hipGraphInstantiate(&L.graph_exec, L.graph, nullptr, nullptr, 0));
+            HIPC(hipStreamSynchronize(L.stream));
+        }
     }
     // algorithmic bytes of one frame step, context term added per run
     e->tm.algo_bytes_per_step = 0;
@@ -324,14 +337,21 @@ extern "C" void q3tts_engine_destroy(q3tts_engine* e) {
     if (e->vstream) hipStreamSynchronize(e->vstream);
     if (e->voc) q3_voc_destroy(e);
     if (e->first_chunk_host) hipHostFree(e->first_chunk_host);
-    if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
-    if (e->graph) hipGraphDestroy(e->graph);
+    for (auto& L : e->lanes) {
+        if (L.stream) hipStreamSynchronize(L.stream);
+        if (L.graph_exec) hipGraphExecDestroy(L.graph_exec);
+        if (L.graph) hipGraphDestroy(L.graph);
+        hipFree(L.xT); hipFree(L.logits); hipFree(L.X); hipFree(L.fb); hipFree(L.px); hipFree(L.keys);
+        hipFree(L.row_pos_t); hipFree(L.slot_id); hipFree(L.posA); hipFree(L.slotA); hipFree(L.pos_q);
+        hipFree(L.sc.qkv); hipFree(L.sc.att); hipFree(L.sc.h); hipFree(L.sc.xn);
+        if (L.ev_begin) hipEventDestroy(L.ev_begin); if (L.ev_end) hipEventDestroy(L.ev_end);
+        if (L.stream) hipStreamDestroy(L.stream);
+    }
     free_tfm(e->T); free_tfm(e->P);
     hipFree(e->text); for (auto p : e->codec) hipFree(p); hipFree((void*)e->codec_dev); hipFree(e->proj_w); hipFree(e->proj_b);
     hipFree(e->slots); if (e->slots_host) hipHostFree(e->slots_host);
-    hipFree(e->xT); hipFree(e->logits); hipFree(e->X); hipFree(e->fb); hipFree(e->px); hipFree(e->keys); hipFree(e->codes); hipFree(e->rng);
-    hipFree(e->row_pos_t); hipFree(e->slot_id); hipFree(e->posA); hipFree(e->slotA); hipFree(e->pos_q);
-    hipFree(e->sc_dec.qkv); hipFree(e->sc_dec.att); hipFree(e->sc_dec.h); hipFree(e->sc_dec.xn); hipFree(e->sc_pre.xn); hipFree(e->sc_pre.qkv); hipFree(e->sc_pre.att); hipFree(e->sc_pre.h);
+    hipFree(e->codes); hipFree(e->rng);
+    hipFree(e->sc_pre.xn); hipFree(e->sc_pre.qkv); hipFree(e->sc_pre.att); hipFree(e->sc_pre.h);
     hipFree(e->xp); hipFree(e->pf_pos); hipFree(e->pf_slot); hipFree(e->prow_dev); hipFree(e->spk_dev); hipFree(e->refcodes_dev);
     if (e->ev0) hipEventDestroy(e->ev0); if (e->ev1) hipEventDestroy(e->ev1); if (e->ev2) hipEventDestroy(e->ev2); if (e->ev3) hipEventDestroy(e->ev3);
     if (e->stream) hipStreamDestroy(e->stream);
@@ -426,9 +446,36 @@ extern "C" int q3tts_build_prompt(q3tts_engine* e, const q3tts_prompt_desc* p, f
 // ------------------------------------------------------------------------------------------------
 // generation
 // ------------------------------------------------------------------------------------------------
-static int launch_frame(q3tts_engine* e, hipStream_t s) {
-    if (e->graph_exec) { Q3_HIP(e, hipGraphLaunch(e->graph_exec, s)); }
-    else { record_frame(e, s); Q3_HIP(e, hipGetLastError()); }
+static inline Q3Lane& lane_of(q3tts_engine* e, int b) { return e->lanes[b / e->lanes[0].nb]; }
+
+// CH frame steps on every lane in `mask`, concurrently; afterwards the main stream has the slot mirror on the host.
+// Returns the device time of the slowest lane (ms).
+static int run_chunk(q3tts_engine* e, unsigned mask, int CH, float* dev_ms) {
+    hipStream_t s = e->stream;
+    Q3_HIP(e, hipEventRecord(e->ev1, s));  // admissions (prefill, state uploads) precede the frames
+    for (size_t li = 0; li < e->lanes.size(); ++li) {
+        if (!(mask & (1u << li))) continue;
+        Q3Lane& L = e->lanes[li];
+        Q3_HIP(e, hipStreamWaitEvent(L.stream, e->ev1, 0));
+        Q3_HIP(e, hipEventRecord(L.ev_begin, L.stream));
+        for (int i = 0; i < CH; ++i) {
+            if (L.graph_exec) { Q3_HIP(e, hipGraphLaunch(L.graph_exec, L.stream)); }
+            else { record_frame(e, L, L.stream); Q3_HIP(e, hipGetLastError()); }
+        }
+        Q3_HIP(e, hipEventRecord(L.ev_end, L.stream));
+        Q3_HIP(e, hipStreamWaitEvent(s, L.ev_end, 0));
+    }
+    Q3_HIP(e, hipEventRecord(e->ev3, s));  // the vocoder stream waits on this
+    Q3_HIP(e, hipMemcpyAsync(e->slots_host, e->slots, sizeof(Q3Slot) * e->B, hipMemcpyDeviceToHost, s));
+    Q3_HIP(e, hipStreamSynchronize(s));
+    float worst = 0.0f;
+    for (size_t li = 0; li < e->lanes.size(); ++li) {
+        if (!(mask & (1u << li))) continue;
+        float ms = 0.0f;
+        hipEventElapsedTime(&ms, e->lanes[li].ev_begin, e->lanes[li].ev_end);
+        worst = std::max(worst, ms);
+    }
+    if (dev_ms) *dev_ms = worst;
     return Q3TTS_OK;
 }
 
@@ -436,45 +483,90 @@ static uint64_t wall_seed() {
     return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
 }
 
-// Talker prefill of one request into slot b (src/tts/engine.rs:455-462) + slot state
-static int admit(q3tts_engine* e, int b, const q3tts_request* r) {
+// Talker prefill (src/tts/engine.rs:455-462) of several requests at once: their prompt rows are concatenated into one
+// batch (row -> (slot, position) maps), so the weights stream once for all of them; then per request the last row
+// seeds the slot (logits, state, sampler draws). rc[i] receives the per-request status.
+struct Adm { int b; const q3tts_request* r; int n, row0, max_steps; };
+
+static int admit_group(q3tts_engine* e, std::vector<Adm>& grp, int total) {
     const q3tts_model_config& m = e->cfg.model;
     hipStream_t s = e->stream;
-    int n = 0;
-    if (r->prompt_embd) {
-        n = r->n_tok;
-        if (n <= 0 || n > e->cfg.n_ctx) return q3_set_err(e, Q3TTS_ERR_INVALID, "n_tok out of range");
-        Q3_HIP(e, hipMemcpyAsync(e->xp, r->prompt_embd, (size_t)n * m.d_embed * 4, hipMemcpyHostToDevice, s));
-    } else if (r->prompt) {
-        TRY(build_prompt_dev(e, r->prompt, e->xp, e->cfg.n_ctx, &n));
-    } else return q3_set_err(e, Q3TTS_ERR_INVALID, "request has neither prompt_embd nor prompt");
-    int max_steps = r->max_steps > 0 ? r->max_steps : e->max_steps;
-    if (max_steps > e->cfg.max_steps_cap) return q3_set_err(e, Q3TTS_ERR_INVALID, "max_steps exceeds max_steps_cap");
-    if (n + max_steps > e->cfg.n_ctx) return q3_set_err(e, Q3TTS_ERR_INVALID, "prompt + max_steps exceeds n_ctx");
-    Q3_HIP(e, hipMemsetD32Async((hipDeviceptr_t)e->pf_slot, b, n, s));
-    run_layers(e, e->T, e->xp, n, e->pf_pos, e->pf_slot, e->sc_pre, s);
-    q3_launch_copy_rows(e->xT + (size_t)b * m.t_d_model, m.t_d_model, e->xp + (size_t)(n - 1) * m.t_d_model, m.t_d_model, 1, m.t_d_model, s);
-    Q3Gemm g{}; g.x = e->xT + (size_t)b * m.t_d_model; g.ldx = m.t_d_model; g.B = 1; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab;
-    g.norm_w = e->T.out_norm; g.eps = m.rms_eps; g.xhat = e->sc_dec.xn; g.y = e->logits + (size_t)b * m.t_vocab; g.ldy = m.t_vocab; g.epi = Q3_EPI_STORE;
-    q3_launch_gemm(g, s);
-    // sampler stream (src/tts/engine.rs:473-485)
-    float temperature = e->temperature, top_p = e->top_p; int top_k = e->top_k, has_seed = e->has_seed; uint64_t seed = e->seed;
-    if (!r->use_engine_sampler) { temperature = r->temperature; top_k = r->top_k; top_p = r->top_p; has_seed = r->has_seed; seed = r->seed; }
-    if (!has_seed) seed = wall_seed();
-    if (temperature > 0.0f) {
-        std::vector<float> draws(max_steps);
-        q3_stdrng_f32(seed, max_steps, draws.data());
-        Q3_HIP(e, hipMemcpyAsync(e->rng + (size_t)b * e->cfg.max_steps_cap, draws.data(), (size_t)max_steps * 4, hipMemcpyHostToDevice, s));
-        Q3_HIP(e, hipStreamSynchronize(s));
+    if (grp.empty()) return Q3TTS_OK;
+    std::vector<int> pos(total), slot(total);
+    for (const Adm& a : grp) for (int i = 0; i < a.n; ++i) { pos[a.row0 + i] = i; slot[a.row0 + i] = a.b; }
+    Q3_HIP(e, hipMemcpyAsync(e->pf_pos, pos.data(), (size_t)total * 4, hipMemcpyHostToDevice, s));
+    Q3_HIP(e, hipMemcpyAsync(e->pf_slot, slot.data(), (size_t)total * 4, hipMemcpyHostToDevice, s));
+    Q3_HIP(e, hipStreamSynchronize(s));  // pos/slot are locals
+    run_layers(e, e->T, e->xp, total, e->pf_pos, e->pf_slot, e->sc_pre, s);
+    for (const Adm& a : grp) {
+        const q3tts_request* r = a.r;
+        const int b = a.b;
+        Q3Lane& L = lane_of(e, b);
+        const int row = b - L.b0;
+        q3_launch_copy_rows(L.xT + (size_t)row * m.t_d_model, m.t_d_model, e->xp + (size_t)(a.row0 + a.n - 1) * m.t_d_model, m.t_d_model, 1, m.t_d_model, s);
+        Q3Gemm g{}; g.x = L.xT + (size_t)row * m.t_d_model; g.ldx = m.t_d_model; g.B = 1; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab;
+        g.norm_w = e->T.out_norm; g.eps = m.rms_eps; g.xhat = e->sc_pre.xn; g.y = L.logits + (size_t)row * m.t_vocab; g.ldy = m.t_vocab; g.epi = Q3_EPI_STORE;
+        q3_launch_gemm(g, s);
+        // sampler stream (src/tts/engine.rs:473-485)
+        float temperature = e->temperature, top_p = e->top_p; int top_k = e->top_k, has_seed = e->has_seed; uint64_t seed = e->seed;
+        if (!r->use_engine_sampler) { temperature = r->temperature; top_k = r->top_k; top_p = r->top_p; has_seed = r->has_seed; seed = r->seed; }
+        if (!has_seed) seed = wall_seed();
+        if (temperature > 0.0f) {
+            std::vector<float> draws(a.max_steps);
+            q3_stdrng_f32(seed, a.max_steps, draws.data());
+            Q3_HIP(e, hipMemcpyAsync(e->rng + (size_t)b * e->cfg.max_steps_cap, draws.data(), (size_t)a.max_steps * 4, hipMemcpyHostToDevice, s));
+            Q3_HIP(e, hipStreamSynchronize(s));
+        }
+        Q3Slot* st = e->slots_host + e->B + b;  // pinned staging half
+        memset(st, 0, sizeof(*st));
+        st->active = 1; st->cur_pos = a.n; st->n_frames = 0; st->max_steps = a.max_steps; st->min_frames = r->min_frames;
+        st->force_eos_at = r->force_eos_at; st->top_k = top_k; st->temperature = temperature; st->top_p = top_p;
+        st->rng_base = b * e->cfg.max_steps_cap;
+        Q3_HIP(e, hipMemcpyAsync(e->slots + b, st, sizeof(Q3Slot), hipMemcpyHostToDevice, s));
+        if (e->voc) TRY(q3_voc_reset(e, b));
     }
-    Q3Slot* st = e->slots_host + e->B + b;  // pinned staging half
-    memset(st, 0, sizeof(*st));
-    st->active = 1; st->cur_pos = n; st->n_frames = 0; st->max_steps = max_steps; st->min_frames = r->min_frames;
-    st->force_eos_at = r->force_eos_at; st->top_k = top_k; st->temperature = temperature; st->top_p = top_p;
-    st->rng_base = b * e->cfg.max_steps_cap;
-    Q3_HIP(e, hipMemcpyAsync(e->slots + b, st, sizeof(Q3Slot), hipMemcpyHostToDevice, s));
-    if (e->voc) TRY(q3_voc_reset(e, b));
     return Q3TTS_OK;
+}
+
+// slots[i] <- reqs[i]; rc[i] = status of request i (a failing request does not stop the others)
+static int admit_many(q3tts_engine* e, const int* slots, const q3tts_request* const* reqs, int count, int* rc) {
+    const q3tts_model_config& m = e->cfg.model;
+    hipStream_t s = e->stream;
+    std::vector<Adm> grp;
+    int total = 0;
+    for (int i = 0; i < count; ++i) {
+        const q3tts_request* r = reqs[i];
+        rc[i] = Q3TTS_OK;
+        const int max_steps = r->max_steps > 0 ? r->max_steps : e->max_steps;
+        if (max_steps > e->cfg.max_steps_cap) { rc[i] = q3_set_err(e, Q3TTS_ERR_INVALID, "max_steps exceeds max_steps_cap"); continue; }
+        int n = 0;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const int room = e->cfg.n_ctx - total;
+            if (r->prompt_embd) {
+                n = r->n_tok;
+                if (n <= 0 || n > e->cfg.n_ctx) { rc[i] = q3_set_err(e, Q3TTS_ERR_INVALID, "n_tok out of range"); break; }
+                if (n > room) { if (total == 0) { rc[i] = q3_set_err(e, Q3TTS_ERR_INVALID, "n_tok out of range"); break; } }
+                else { Q3_HIP(e, hipMemcpyAsync(e->xp + (size_t)total * m.d_embed, r->prompt_embd, (size_t)n * m.d_embed * 4, hipMemcpyHostToDevice, s)); break; }
+            } else if (r->prompt) {
+                const int brc = build_prompt_dev(e, r->prompt, e->xp + (size_t)total * m.d_embed, room, &n);
+                if (brc == Q3TTS_OK) break;
+                if (total == 0) { rc[i] = brc; break; }
+            } else { rc[i] = q3_set_err(e, Q3TTS_ERR_INVALID, "request has neither prompt_embd nor prompt"); break; }
+            TRY(admit_group(e, grp, total));  // batch full: flush, then retry this request in an empty batch
+            grp.clear(); total = 0;
+        }
+        if (rc[i] != Q3TTS_OK) continue;
+        if (n + max_steps > e->cfg.n_ctx) { rc[i] = q3_set_err(e, Q3TTS_ERR_INVALID, "prompt + max_steps exceeds n_ctx"); continue; }
+        grp.push_back(Adm{slots[i], r, n, total, max_steps});
+        total += n;
+    }
+    return admit_group(e, grp, total);
+}
+
+static int admit(q3tts_engine* e, int b, const q3tts_request* r) {
+    int rc = Q3TTS_OK;
+    int st = admit_many(e, &b, &r, 1, &rc);
+    return st != Q3TTS_OK ? st : rc;
 }
 
 static double now_ms() {
@@ -520,31 +612,34 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
     int next = 0, done = 0;
     const double t0 = now_ms();
     double dec_ms = 0, pre_ms = 0, voc_ms = 0;
-    long long steps = 0, ctx_tokens = 0;
+    long long steps = 0, ctx_tokens = 0, live_slot_steps = 0;
     hipStream_t s = e->stream;
     while (done < n) {
         bool admitted = false;
-        for (int b = 0; b < B && next < n; ++b)
-            if (run[b].req < 0) {
-                if (!admitted) Q3_HIP(e, hipEventRecord(e->ev0, s));
+        {
+            std::vector<int> as, ai; std::vector<const q3tts_request*> ar;
+            for (int b = 0; b < B && next < n; ++b)
+                if (run[b].req < 0) { as.push_back(b); ar.push_back(&reqs[next]); ai.push_back(next++); }
+            if (!as.empty()) {
+                Q3_HIP(e, hipEventRecord(e->ev0, s));
                 admitted = true;
-                int rc = admit(e, b, &reqs[next]);
-                if (rc != Q3TTS_OK) { outs[next].status = rc; ++next; ++done; --b; continue; }
-                run[b] = SlotRun{}; run[b].req = next++;
+                std::vector<int> rcs(as.size());
+                TRY(admit_many(e, as.data(), ar.data(), (int)as.size(), rcs.data()));
+                for (size_t i = 0; i < as.size(); ++i) {
+                    if (rcs[i] != Q3TTS_OK) { outs[ai[i]].status = rcs[i]; ++done; }
+                    else { run[as[i]] = SlotRun{}; run[as[i]].req = ai[i]; }
+                }
             }
-        if (admitted) { Q3_HIP(e, hipEventRecord(e->ev1, s)); }
-        bool any = false;
-        for (int b = 0; b < B; ++b) any |= run[b].req >= 0;
-        if (!any) break;
-        Q3_HIP(e, hipEventRecord(e->ev2, s));
-        for (int i = 0; i < CH; ++i) TRY(launch_frame(e, s));
-        Q3_HIP(e, hipEventRecord(e->ev3, s));
-        Q3_HIP(e, hipMemcpyAsync(e->slots_host, e->slots, sizeof(Q3Slot) * B, hipMemcpyDeviceToHost, s));
-        Q3_HIP(e, hipStreamSynchronize(s));
+        }
+        if (admitted) { Q3_HIP(e, hipEventRecord(e->ev2, s)); }
+        unsigned mask = 0;
+        for (int b = 0; b < B; ++b) if (run[b].req >= 0) mask |= 1u << (b / e->lanes[0].nb);
+        if (!mask) break;
         float ms = 0;
-        if (admitted) { hipEventElapsedTime(&ms, e->ev0, e->ev1); pre_ms += ms; }
-        hipEventElapsedTime(&ms, e->ev2, e->ev3); dec_ms += ms; steps += CH;
-        for (int b = 0; b < B; ++b) if (run[b].req >= 0) ctx_tokens += (long long)e->slots_host[b].cur_pos * CH;
+        TRY(run_chunk(e, mask, CH, &ms));
+        dec_ms += ms; steps += CH;
+        if (admitted) { hipEventElapsedTime(&ms, e->ev0, e->ev2); pre_ms += ms; }
+        for (int b = 0; b < B; ++b) if (run[b].req >= 0) { ctx_tokens += (long long)e->slots_host[b].cur_pos * CH; live_slot_steps += CH; }
         // H8: the vocoder consumes 4-frame chunks (src/tts/engine.rs:507-541). It runs on its own stream behind an
         // event, batched over every slot that has a chunk ready, so chunk k's PCM overlaps the decoding of chunk k+1.
         if (e->voc) {
@@ -601,6 +696,9 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
         const long long kv_per_tok = 2ll * m.t_n_layer * 2 * m.t_n_kv_head * m.t_head_dim;
         const long long fixed = wt + (m.n_codebooks - 1) * (wp_layers + head1) + m.n_codebooks * pj;
         e->tm.algo_bytes_per_step = fixed + (steps ? kv_per_tok * (ctx_tokens / steps) : 0);
+        e->tm.mean_live_slots = steps ? (float)((double)live_slot_steps / (double)steps) : 0.0f;
+        e->tm.algo_flops_per_step = (long long)((double)fixed * (double)e->tm.mean_live_slots);  // 2 flop per bf16 weight (2 bytes) per live row
+        e->tm.n_lanes = (float)e->lanes.size();
     }
     return Q3TTS_OK;
 }
@@ -658,9 +756,7 @@ extern "C" int q3tts_stream_poll(q3tts_stream* st, const float** chunk, int32_t*
     for (;;) {
         const Q3Slot& sl = e->slots_host[0];
         if (!st->finished) {
-            for (int i = 0; i < 4; ++i) TRY(launch_frame(e, s));
-            Q3_HIP(e, hipMemcpyAsync(e->slots_host, e->slots, sizeof(Q3Slot), hipMemcpyDeviceToHost, s));
-            Q3_HIP(e, hipStreamSynchronize(s));
+            TRY(run_chunk(e, 1u, 4, nullptr));
             if (!sl.active) st->finished = true;
         }
         int nf = 0, last = 0;
@@ -810,10 +906,10 @@ extern "C" int q3tts_k_talker_prefill(q3tts_engine* e, const float* embd, int32_
     const q3tts_model_config& m = e->cfg.model;
     hipStream_t s = e->stream;
     if (hidden_out) {
-        q3_launch_rmsnorm_rows(e->xT, m.t_d_model, e->T.out_norm, m.rms_eps, m.t_d_model, 1, e->X, m.t_d_model, s);
-        Q3_HIP(e, hipMemcpyAsync(hidden_out, e->X, (size_t)m.t_d_model * 4, hipMemcpyDeviceToHost, s));
+        q3_launch_rmsnorm_rows(e->lanes[0].xT, m.t_d_model, e->T.out_norm, m.rms_eps, m.t_d_model, 1, e->lanes[0].X, m.t_d_model, s);
+        Q3_HIP(e, hipMemcpyAsync(hidden_out, e->lanes[0].X, (size_t)m.t_d_model * 4, hipMemcpyDeviceToHost, s));
     }
-    if (logits_out) Q3_HIP(e, hipMemcpyAsync(logits_out, e->logits, (size_t)m.t_vocab * 4, hipMemcpyDeviceToHost, s));
+    if (logits_out) Q3_HIP(e, hipMemcpyAsync(logits_out, e->lanes[0].logits, (size_t)m.t_vocab * 4, hipMemcpyDeviceToHost, s));
     Q3Slot* stage = e->slots_host + e->B; memset(stage, 0, sizeof(Q3Slot));
     Q3_HIP(e, hipMemcpyAsync(e->slots, stage, sizeof(Q3Slot), hipMemcpyHostToDevice, s));  // retire the slot again
     Q3_HIP(e, hipStreamSynchronize(s));

@@ -19,6 +19,8 @@
 //   k_gemm_ring (larger batches, MFMA-bound): 8 waves x 2 adjacent slices; x fragments ride a register ring XPF
 //        blocks deep issued BEFORE the weight refill of the same block; each wave reuses its x fragments for NT
 //        column tiles (x traffic from L2 is the co-bottleneck at B = 64); RMSNorm runs as a pre-kernel.
+#include <cstdlib>
+
 #include "q3_kernels.h"
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(1024) void k_gemm_small(Q3Gemm g) {
 // BPS = K/512 blocks per slice (0 = runtime).
 // ---------------------------------------------------------------------------------------------------------------
 template <int RT, int NT, int BPS>
-__global__ __launch_bounds__(512) void k_gemm_ring(Q3Gemm g) {
+__global__ __launch_bounds__(512, (RT <= 2 && NT == 1 && BPS > 0 && BPS <= 2) ? 4 : 2) void k_gemm_ring(Q3Gemm g) {
     __shared__ float red[8 * RT * 16 * (NT * 16 + 1)];
     __shared__ float sums[RT * 16 * NT * 16];
     constexpr int WPF = NT == 1 ? 8 : 4;
@@ -327,8 +329,10 @@ void q3_launch_gemm(const Q3Gemm& gin, hipStream_t s) {
     const int tiles = g.N / 16;
     int NT = 1;
     if (g.B > 16) {
-        if (tiles >= 768 && tiles % 3 == 0) NT = 3;
-        else if (tiles >= 512 && tiles % 2 == 0) NT = 2;
+        // x-fragment traffic from L2 scales with 1/NT and is the co-bottleneck at B = 64: widest NT that still
+        // gives every CU a workgroup (2 row chunks of 32 rows each)
+        if (tiles >= 384 && tiles % 3 == 0) NT = 3;
+        else if (tiles >= 256 && tiles % 2 == 0) NT = 2;
     }
     if (NT > 1) {
         dim3 grid(tiles / NT, (g.B + 31) / 32);
@@ -338,6 +342,8 @@ void q3_launch_gemm(const Q3Gemm& gin, hipStream_t s) {
     int RT = 1;
     if (g.B > 16) {
         RT = g.B > 32 ? 4 : 2;
+        static const int rtmax = getenv("Q3_RTMAX") ? atoi(getenv("Q3_RTMAX")) : 4;  // tuning knob
+        if (RT > rtmax) RT = rtmax;
         while (RT > 1 && (long)tiles * ((g.B + RT * 16 - 1) / (RT * 16)) < 256) RT >>= 1;
     }
     dim3 grid(tiles, (g.B + RT * 16 - 1) / (RT * 16));

@@ -147,6 +147,90 @@ __global__ __launch_bounds__(256) void k_vgemm(VGemm g) {
         }
 }
 
+// LDS-tiled variant for the big-M convolutions (the decoder blocks: thousands of rows per slot): workgroup tile
+// 128 x 128, K step 32, 4 waves of 64 x 64 (4 x 4 MFMA tiles). A (f32 -> bf16) and W tiles are staged through
+// registers into double-buffered LDS one step ahead; rows are padded to 40 bf16 (80 B) so that the 16 lanes of a
+// ds_read_b128 group hit 16 distinct 4-bank slots. Conv taps are just extra K steps with a shifted row pointer.
+#define VT_LD 40
+__global__ __launch_bounds__(256) void k_vgemm_lds(VGemm g) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][128 * VT_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][128 * VT_LD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int cin = g.c.cin, nout = g.c.nout, kpt = cin >> 5, steps = g.c.ntap * kpt;
+    const int ldr = tid >> 1, half = tid & 1;  // loader: row/col ldr, 16 k-elements at half*16
+    const float* xrow;
+    {
+        int m = m0 + ldr; if (m >= g.M) m = g.M - 1;
+        const int s = m / g.T, t = m - s * g.T;
+        xrow = g.x + (size_t)s * g.x_stride + g.x_off + (size_t)t * cin + half * 16;
+    }
+    const uint16_t* wrow;
+    { int n = n0 + ldr; if (n >= nout) n = nout - 1; wrow = g.c.w + (size_t)n * cin + half * 16; }
+    float4 ra0, ra1, ra2, ra3; uint4 rb0, rb1;
+    auto gload = [&](int step) {
+        const int tap = step / kpt, k0 = (step - tap * kpt) << 5;
+        const float* p = xrow - (long)(g.c.ntap - 1 - tap) * g.c.dil * cin + k0;
+        ra0 = ((const float4*)p)[0]; ra1 = ((const float4*)p)[1]; ra2 = ((const float4*)p)[2]; ra3 = ((const float4*)p)[3];
+        const uint16_t* q = wrow + (size_t)tap * nout * cin + k0;
+        rb0 = ((const uint4*)q)[0]; rb1 = ((const uint4*)q)[1];
+    };
+    auto sstore = [&](int buf) {
+        bf16x8 lo, hi;
+        lo[0] = (__bf16)ra0.x; lo[1] = (__bf16)ra0.y; lo[2] = (__bf16)ra0.z; lo[3] = (__bf16)ra0.w;
+        lo[4] = (__bf16)ra1.x; lo[5] = (__bf16)ra1.y; lo[6] = (__bf16)ra1.z; lo[7] = (__bf16)ra1.w;
+        hi[0] = (__bf16)ra2.x; hi[1] = (__bf16)ra2.y; hi[2] = (__bf16)ra2.z; hi[3] = (__bf16)ra2.w;
+        hi[4] = (__bf16)ra3.x; hi[5] = (__bf16)ra3.y; hi[6] = (__bf16)ra3.z; hi[7] = (__bf16)ra3.w;
+        __bf16* ap = &As[buf][ldr * VT_LD + half * 16];
+        *(bf16x8*)ap = lo; *(bf16x8*)(ap + 8) = hi;
+        uint4* bp = (uint4*)&Bs[buf][ldr * VT_LD + half * 16];
+        bp[0] = rb0; bp[1] = rb1;
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    gload(0); sstore(0);
+    __syncthreads();
+    for (int step = 0; step < steps; ++step) {
+        const int buf = step & 1;
+        if (step + 1 < steps) gload(step + 1);
+        bf16x8 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)&As[buf][(wm * 64 + i * 16 + lr) * VT_LD + kq * 8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8*)&Bs[buf][(wn * 64 + j * 16 + lr) * VT_LD + kq * 8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        if (step + 1 < steps) sstore(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = m0 + wm * 64 + i * 16 + 4 * kq + e;
+            if (m >= g.M) continue;
+            const int s = m / g.T, t = m - s * g.T;
+            float* yrow = g.y + (size_t)s * g.y_stride + g.y_off + (size_t)t * nout;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + lr;
+                if (n >= nout) continue;
+                float v = acc[i][j][e];
+                if (g.c.b) v += g.c.b[n % g.c.bias_n];
+                if (g.epi == 0) yrow[n] = v;
+                else if (g.epi == 1) yrow[n] = yrow[n] + g.scale[n % g.scale_n] * v;
+                else if (g.epi == 2) yrow[n] = yrow[n] + v;
+                else yrow[n] = gelu_erf(v);
+            }
+        }
+}
+
 __global__ void k_voc_embed(VCall cl, const int* codes, int max_steps_cap, int ncb_model, const float* const* cb, int ncb, int cbs, int cd,
                             float* out, size_t out_stride, int out_off) {
     const int s = blockIdx.y, t = blockIdx.x;
@@ -274,23 +358,36 @@ __global__ void k_voc_snake(const float* x, size_t x_stride, int x_off, int T, i
     }
 }
 
-// V6: Conv k7 C -> 1 over the snaked input (with history) + clamp -> PCM of the slot
-__global__ void k_voc_out(VCall cl, const float* x, size_t x_stride, int H, int T, int C, const float* w, const float* b, float* pcm,
-                          size_t pcm_stride, int spf) {
-    const int s = blockIdx.y, slot = cl.slot[s];
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= T) return;
-    const float* xp = x + (size_t)s * x_stride + (size_t)(H + t) * C;
-    float acc = 0.0f;
+// V6: Conv k7 C -> 1 over the snaked input (with history) + clamp -> PCM of the slot. A block produces 64 samples:
+// the 70-row input window is staged in LDS with coalesced loads (rows padded to C+1 floats: the per-thread row
+// stride then walks all banks), weights in LDS too; same summation order as before (per tap, channels ascending).
+__global__ __launch_bounds__(256) void k_voc_out(VCall cl, const float* x, size_t x_stride, int H, int T, int C, const float* w, const float* b,
+                                                 float* pcm, size_t pcm_stride, int spf) {
+    extern __shared__ float sm[];  // win[70][C+1] | wl[7*C]
+    const int s = blockIdx.y, slot = cl.slot[s], t0 = blockIdx.x * 64, tid = threadIdx.x, CP = C + 1;
+    float* win = sm; float* wl = sm + 70 * CP;
+    const float* xp = x + (size_t)s * x_stride + (size_t)(H + t0 - 6) * C;  // window row 0 = t0 - 6
+    const int nrow = min(70, T - t0 + 6);
+    for (int i = tid; i < nrow * C; i += 256) { const int r = i / C, c = i - r * C; win[r * CP + c] = q3_round_bf16(xp[i]); }
+    for (int i = tid; i < 7 * C; i += 256) wl[i] = w[i];
+    __syncthreads();
+    // 4 threads per output sample split the channels; partial sums are combined in a fixed order
+    const int o = tid >> 2, part = tid & 3, t = t0 + o;
+    float acc[7];
+#pragma unroll
     for (int tap = 0; tap < 7; ++tap) {
-        const float* xr = xp + (long)(tap - 6) * C;
         float a = 0.0f;
-        for (int i = 0; i < C; ++i) a += q3_round_bf16(xr[i]) * w[tap * C + i];
-        acc += a;
+        if (t < T) for (int i = part; i < C; i += 4) a += win[(o + tap) * CP + i] * wl[tap * C + i];
+        a += __shfl_xor(a, 1); a += __shfl_xor(a, 2);
+        acc[tap] = a;
     }
-    acc += b[0];
-    acc = fminf(1.0f, fmaxf(-1.0f, acc));
-    pcm[(size_t)slot * pcm_stride + (size_t)cl.pos[s] * spf + t] = acc;
+    if (t < T && part == 0) {
+        float r = 0.0f;
+#pragma unroll
+        for (int tap = 0; tap < 7; ++tap) r += acc[tap];
+        r += b[0];
+        pcm[(size_t)slot * pcm_stride + (size_t)cl.pos[s] * spf + t] = fminf(1.0f, fmaxf(-1.0f, r));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -336,8 +433,10 @@ static int gen_snake(q3tts_engine* e, Q3Voc* v, uint32_t ta, uint32_t tb, int C,
         a[i] = (float)exp((double)al); b[i] = (float)(1.0 / (exp((double)be) + 1e-9));
     }
     VTRY(valloc(e, v, ea, (size_t)C)); VTRY(valloc(e, v, ib, (size_t)C));
-    Q3_HIP(e, hipMemcpy(*ea, a.data(), (size_t)C * 4, hipMemcpyHostToDevice));
-    Q3_HIP(e, hipMemcpy(*ib, b.data(), (size_t)C * 4, hipMemcpyHostToDevice));
+    // same stream as valloc's zero-fill (a null-stream copy could be overtaken by that memset), synced: a/b are locals
+    Q3_HIP(e, hipMemcpyAsync(*ea, a.data(), (size_t)C * 4, hipMemcpyHostToDevice, e->stream));
+    Q3_HIP(e, hipMemcpyAsync(*ib, b.data(), (size_t)C * 4, hipMemcpyHostToDevice, e->stream));
+    Q3_HIP(e, hipStreamSynchronize(e->stream));
     return Q3TTS_OK;
 }
 static int mk_buf(q3tts_engine* e, Q3Voc* v, VBuf* b, int H, int C, int Tcap) {
@@ -371,7 +470,8 @@ int q3_voc_create(q3tts_engine* e) {
                            (1.0f / sqrtf(16.0f)) / Q3_IH4_STD, 1, e->stream);
     }
     { float** cd = nullptr; VTRY(valloc(e, v, &cd, (size_t)16)); v->cb_dev = (const float**)cd;
-      Q3_HIP(e, hipMemcpy((void*)cd, v->cb.data(), sizeof(float*) * c.n_codebooks, hipMemcpyHostToDevice)); }
+      Q3_HIP(e, hipMemcpyAsync((void*)cd, v->cb.data(), sizeof(float*) * c.n_codebooks, hipMemcpyHostToDevice, e->stream));
+      Q3_HIP(e, hipStreamSynchronize(e->stream)); }
     VTRY(gen_conv(e, v, &v->pre, VC_PRE, VW_W, VW_B, c.pre_conv_kernel, 1, c.codebook_dim, d, d, 1.0f));
     VTRY(mk_buf(e, v, &v->pre_in, c.pre_conv_kernel - 1, c.codebook_dim, VOC_FCAP));
     v->L.resize(c.n_layer);
@@ -469,6 +569,11 @@ static void vgemm(hipStream_t s, const VConv& c, const float* x, size_t x_stride
                   int epi = 0, const float* scale = nullptr, int scale_n = 1) {
     VGemm g; g.x = x; g.x_stride = x_stride; g.x_off = x_off; g.T = T; g.M = ns * T; g.c = c; g.y = y; g.y_stride = y_stride; g.y_off = y_off;
     g.scale = scale; g.scale_n = scale_n; g.epi = epi;
+    if (g.M >= 256) {  // both kernels accumulate the same 32-wide K steps in the same order: identical results
+        dim3 grid((c.nout + 127) / 128, (g.M + 127) / 128);
+        hipLaunchKernelGGL(k_vgemm_lds, grid, dim3(256), 0, s, g);
+        return;
+    }
     dim3 grid((c.nout + 63) / 64, (g.M + 127) / 128);
     hipLaunchKernelGGL(k_vgemm, grid, dim3(256), 0, s, g);
 }
@@ -548,7 +653,7 @@ static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
     // V6
     hist(s, cl, v->out_in, T, 0);
     snake(s, ns, z, (size_t)T * ch, 0, T, ch, v->oea, v->oib, v->out_in);
-    hipLaunchKernelGGL(k_voc_out, dim3((T + 255) / 256, ns), dim3(256), 0, s, cl, v->out_in.p, v->out_in.stride(), v->out_in.H, T, ch, v->out_w, v->out_b,
+    hipLaunchKernelGGL(k_voc_out, dim3((T + 63) / 64, ns), dim3(256), (size_t)(70 * (ch + 1) + 7 * ch) * 4, s, cl, v->out_in.p, v->out_in.stride(), v->out_in.H, T, ch, v->out_w, v->out_b,
                        v->pcm, v->pcm_stride, v->spf);
     hist(s, cl, v->out_in, T, 1);
     Q3_HIP(e, hipGetLastError());

@@ -89,7 +89,8 @@ class Timings(C.Structure):
     _fields_ = [
         ("prefill_ms", C.c_float), ("decode_ms", C.c_float), ("vocoder_ms", C.c_float), ("total_ms", C.c_float),
         ("frame_step_ms", C.c_float), ("talker_gemm_ms", C.c_float),
-        ("frame_steps", C.c_int64), ("algo_bytes_per_step", C.c_int64),
+        ("frame_steps", C.c_int64), ("algo_bytes_per_step", C.c_int64), ("algo_flops_per_step", C.c_int64),
+        ("mean_live_slots", C.c_float), ("n_lanes", C.c_float),
     ]
 
 
