@@ -148,7 +148,7 @@ typedef struct q3tts_result {
     int32_t n_frames;      /* frames kept (EOS frame excluded, as src/tts/engine.rs:558-562) */
     int32_t hit_eos;
     int32_t* codes;        /* [n_frames][n_codebooks] raw ids (unclamped) */
-    float* pcm;            /* [n_samples] mono f32, or NULL */
+    float* pcm;            /* [n_samples] mono f32, or NULL; pinned host memory: release with q3tts_result_free only */
     int32_t n_samples;
     int32_t sample_rate;
     float first_chunk_ms;  /* entry -> first 4-frame PCM chunk resident on host (0 if none) */

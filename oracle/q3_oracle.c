@@ -154,6 +154,38 @@ static void gemm_t(const float* xh, int B, int ldx, int K, const uint16_t* Wt, i
     }
 }
 
+/* Fused RMSNorm of a NORM GEMM (q3_gemm.hip): the row scale commutes out of the K-sum,
+ *   y[r][n] = s_r * SUM_canonical((x[r][k] * nw[k]) * W[n][k]),  s_r = 1 / sqrtf(ss_r / K + eps),
+ * with ss_r summed in the GEMM's own order: per (slice, kq) an fmaf chain over ascending k,
+ * S_slice = (c0 + c1) + (c2 + c3), Q_w = S_2w + S_2w+1, ss = ((Q_0 + Q_1) + ...) + Q_7.
+ * Writes xh = x * nw and the row scale. */
+static float norm_gemm_row(const float* x, int K, const float* nw, float eps, float* xh) {
+    const int bps = K / (32 * NSLICE);
+    float tot = 0.0f, pair = 0.0f;
+    for (int s = 0; s < NSLICE; ++s) {
+        float c[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int kb = s * bps; kb < (s + 1) * bps; ++kb)
+            for (int h = 0; h < 2; ++h)
+                for (int kq = 0; kq < 4; ++kq)
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = kb * 32 + h * 16 + kq * 4 + e;
+                        c[kq] = __builtin_fmaf(x[k], x[k], c[kq]);
+                    }
+        const float S = (c[0] + c[1]) + (c[2] + c[3]);
+        if ((s & 1) == 0) pair = S;
+        else {
+            const float q = pair + S;
+            tot = (s == 1) ? q : tot + q;
+        }
+    }
+    for (int k = 0; k < K; ++k) xh[k] = x[k] * nw[k];
+    return 1.0f / sqrtf(tot / (float)K + eps);
+}
+static void scale_rows(float* y, int n, int ncols, int ldy, const float* sc) {
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < ncols; ++c) y[(size_t)r * ldy + c] = y[(size_t)r * ldy + c] * sc[r];
+}
+
 static inline uint64_t argmax_key(float v, uint32_t n) {
     if (v != v) return 0; /* NaN never wins (reference: `val > max_val` is false) */
     if (v == 0.0f) v = 0.0f;
@@ -176,8 +208,9 @@ void q3o_gemm_exact(const float* x, int32_t B, int32_t K, const uint16_t* w, int
                     const float* bias, int32_t epilogue, float* y, uint64_t* keys) {
     uint16_t* wt = transpose_bf16(w, N, K);
     float* xh = (float*)malloc((size_t)B * K * 4);
+    float* sc = (float*)malloc((size_t)B * 4);
     for (int b = 0; b < B; ++b) {
-        if (norm_w) q3o_rmsnorm(x + (size_t)b * K, K, norm_w, eps, xh + (size_t)b * K);
+        if (norm_w) sc[b] = norm_gemm_row(x + (size_t)b * K, K, norm_w, eps, xh + (size_t)b * K);
         else memcpy(xh + (size_t)b * K, x + (size_t)b * K, (size_t)K * 4);
     }
     float* raw = (float*)malloc((size_t)B * N * 4);
@@ -185,6 +218,8 @@ void q3o_gemm_exact(const float* x, int32_t B, int32_t K, const uint16_t* w, int
     if (g_threads <= 0) g_threads = 4;
     gemm_t(xh, B, K, K, wt, N, 0, N, raw, N);
     g_threads = saved;
+    if (norm_w) scale_rows(raw, B, N, N, sc);
+    free(sc);
     if (epilogue == 0) {
         for (int b = 0; b < B; ++b)
             for (int n = 0; n < N; ++n) y[(size_t)b * N + n] = bias ? raw[(size_t)b * N + n] + bias[n] : raw[(size_t)b * N + n];
@@ -515,21 +550,25 @@ static void tfm_layers(tfm* t, float* x, int n, int pos0, float eps) {
     float* g = malloc((size_t)n * F * 4);
     float* u = malloc((size_t)n * F * 4);
     float* y = malloc((size_t)n * d * 4);
+    float* sc = malloc((size_t)n * 4);
     for (int l = 0; l < t->L; ++l) {
-        for (int r = 0; r < n; ++r) q3o_rmsnorm(x + (size_t)r * d, d, t->attn_norm[l], eps, xh + (size_t)r * d);
+        for (int r = 0; r < n; ++r) sc[r] = norm_gemm_row(x + (size_t)r * d, d, t->attn_norm[l], eps, xh + (size_t)r * d);
         gemm_t(xh, n, d, d, t->wqkv_t[l], nqkv, 0, nqkv, qkv, nqkv);
+        scale_rows(qkv, n, nqkv, nqkv, sc);
         size_t co = (size_t)l * t->Hkv * t->n_ctx * t->hd;
         attn_rows(qkv, n, pos0, t->Hq, t->Hkv, t->hd, t->qn[l], t->kn[l], eps, t->cs, t->sn, t->kc + co, t->vc + co, t->n_ctx, att);
         gemm_t(att, n, nq, nq, t->wo_t[l], d, 0, d, y, d);
         for (size_t i = 0; i < (size_t)n * d; ++i) x[i] = x[i] + y[i];
-        for (int r = 0; r < n; ++r) q3o_rmsnorm(x + (size_t)r * d, d, t->ffn_norm[l], eps, xh + (size_t)r * d);
+        for (int r = 0; r < n; ++r) sc[r] = norm_gemm_row(x + (size_t)r * d, d, t->ffn_norm[l], eps, xh + (size_t)r * d);
         gemm_t(xh, n, d, d, t->wg_t[l], F, 0, F, g, F);
         gemm_t(xh, n, d, d, t->wu_t[l], F, 0, F, u, F);
+        scale_rows(g, n, F, F, sc);
+        scale_rows(u, n, F, F, sc);
         for (size_t i = 0; i < (size_t)n * F; ++i) g[i] = swiglu(g[i], u[i]);
         gemm_t(g, n, F, F, t->wd_t[l], d, 0, d, y, d);
         for (size_t i = 0; i < (size_t)n * d; ++i) x[i] = x[i] + y[i];
     }
-    free(xh); free(qkv); free(att); free(g); free(u); free(y);
+    free(xh); free(qkv); free(att); free(g); free(u); free(y); free(sc);
 }
 
 q3o_model* q3o_create(const q3o_model_config* c, uint64_t seed, int32_t n_ctx, int32_t n_threads) {
@@ -637,9 +676,10 @@ int32_t q3o_build_prompt(const q3o_model* m, const q3o_prompt_desc* p, float* ou
 /* final norm + lm_head (optionally a column slice) of ONE row */
 static void head_row(tfm* t, const float* xrow, float eps, int col0, int ncols, float* hidden_out, float* logits) {
     float* xh = malloc((size_t)t->d * 4);
-    q3o_rmsnorm(xrow, t->d, t->out_norm, eps, xh);
-    if (hidden_out) memcpy(hidden_out, xh, (size_t)t->d * 4);
+    if (hidden_out) q3o_rmsnorm(xrow, t->d, t->out_norm, eps, hidden_out); /* standalone canonical RMSNorm (§4.2) */
+    const float sc = norm_gemm_row(xrow, t->d, t->out_norm, eps, xh);
     gemm_t(xh, 1, t->d, t->d, t->head_t, t->head_n, col0, ncols, logits, ncols);
+    scale_rows(logits, 1, ncols, ncols, &sc);
     free(xh);
 }
 

@@ -22,7 +22,7 @@ struct Q3Tfm {
 };
 
 struct Q3Scratch {
-    float *qkv = nullptr, *att = nullptr, *h = nullptr, *xn = nullptr;  // xn: RMSNorm pre-kernel output [rows][d]
+    float *qkv = nullptr, *att = nullptr, *h = nullptr;
     int rows = 0;
 };
 
@@ -70,6 +70,7 @@ struct q3tts_engine {
     int max_steps = 512;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    std::vector<hipEvent_t> fin_ev;     // per slot: PCM of a finished utterance copied to the host (vocoder stream)
     q3tts_timings tm{};
     Q3Voc* voc = nullptr;
     float* first_chunk_host = nullptr;  // pinned landing buffer of the first 4-frame PCM chunk (first-chunk latency)

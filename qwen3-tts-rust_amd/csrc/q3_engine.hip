@@ -152,7 +152,6 @@ static void free_tfm(Q3Tfm& t) {
 static int alloc_scratch(q3tts_engine* e, Q3Scratch& sc, int rows, int nqkv, int nq, int F, int dmax) {
     sc.rows = rows;
     TRY(dalloc(e, &sc.qkv, (size_t)rows * nqkv)); TRY(dalloc(e, &sc.att, (size_t)rows * nq)); TRY(dalloc(e, &sc.h, (size_t)rows * F));
-    TRY(dalloc(e, &sc.xn, (size_t)rows * dmax));
     return Q3TTS_OK;
 }
 
@@ -163,7 +162,7 @@ static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, int rows, const int*
     const float eps = e->cfg.model.rms_eps;
     for (int l = 0; l < t.L; ++l) {
         Q3Gemm g{};
-        g.x = x; g.ldx = t.d; g.B = rows; g.w = t.wqkv[l]; g.K = t.d; g.N = t.nqkv; g.norm_w = t.attn_norm[l]; g.eps = eps; g.xhat = sc.xn;
+        g.x = x; g.ldx = t.d; g.B = rows; g.w = t.wqkv[l]; g.K = t.d; g.N = t.nqkv; g.norm_w = t.attn_norm[l]; g.eps = eps;
         g.y = sc.qkv; g.ldy = t.nqkv; g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);
         Q3QkPrep qp{}; qp.qkv = sc.qkv; qp.ld = t.nqkv; qp.rows = rows; qp.Hq = t.Hq; qp.Hkv = t.Hkv; qp.hd = t.hd;
         qp.qnw = t.qn[l]; qp.knw = t.kn[l]; qp.eps = eps; qp.cs = t.cs; qp.sn = t.sn;
@@ -176,7 +175,7 @@ static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, int rows, const int*
         q3_launch_attend(at, s);
         g = Q3Gemm{}; g.x = sc.att; g.ldx = t.nq; g.B = rows; g.w = t.wo[l]; g.K = t.nq; g.N = t.d; g.y = x; g.ldy = t.d; g.epi = Q3_EPI_RESID;
         q3_launch_gemm(g, s);
-        g = Q3Gemm{}; g.x = x; g.ldx = t.d; g.B = rows; g.w = t.wgu[l]; g.K = t.d; g.N = 2 * t.F; g.norm_w = t.ffn_norm[l]; g.eps = eps; g.xhat = sc.xn;
+        g = Q3Gemm{}; g.x = x; g.ldx = t.d; g.B = rows; g.w = t.wgu[l]; g.K = t.d; g.N = 2 * t.F; g.norm_w = t.ffn_norm[l]; g.eps = eps;
         g.y = sc.h; g.ldy = t.F; g.epi = Q3_EPI_SWIGLU; q3_launch_gemm(g, s);
         g = Q3Gemm{}; g.x = sc.h; g.ldx = t.F; g.B = rows; g.w = t.wd[l]; g.K = t.F; g.N = t.d; g.y = x; g.ldy = t.d; g.epi = Q3_EPI_RESID;
         q3_launch_gemm(g, s);
@@ -210,12 +209,12 @@ static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s) {
         g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);  // H6: src/assets_manager.rs:383-399
         run_layers(e, e->P, L.px, rows, q == 0 ? L.posA : L.pos_q + (size_t)q * B, q == 0 ? L.slotA : L.slot_id, L.sc, s, q > 0);
         g = Q3Gemm{}; g.x = q == 0 ? L.px + dp : L.px; g.ldx = q == 0 ? 2 * dp : dp; g.B = B; g.w = e->P.head + head_tile_stride * q;
-        g.K = dp; g.N = cbs; g.norm_w = e->P.out_norm; g.eps = eps; g.xhat = L.sc.xn; g.keys = L.keys + (q + 1); g.key_stride = ncb; g.epi = Q3_EPI_ARGMAX;
+        g.K = dp; g.N = cbs; g.norm_w = e->P.out_norm; g.eps = eps; g.keys = L.keys + (q + 1); g.key_stride = ncb; g.epi = Q3_EPI_ARGMAX;
         q3_launch_gemm(g, s);
     }
     pred_next(ncb - 1);
     run_layers(e, e->T, L.xT, B, L.row_pos_t, L.slot_id, L.sc, s, true);
-    Q3Gemm g{}; g.x = L.xT; g.ldx = m.t_d_model; g.B = B; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab; g.norm_w = e->T.out_norm; g.eps = eps; g.xhat = L.sc.xn;
+    Q3Gemm g{}; g.x = L.xT; g.ldx = m.t_d_model; g.B = B; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab; g.norm_w = e->T.out_norm; g.eps = eps;
     g.y = L.logits; g.ldy = m.t_vocab; g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);
 }
 
@@ -236,8 +235,12 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
 #define HIPC(call) do { hipError_t er__ = (call); if (er__ != hipSuccess) { q3_set_err(e, Q3TTS_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(er__)); return fail(Q3TTS_ERR_DEVICE); } } while (0)
     HIPC(hipSetDevice(cfg->device));
     HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    HIPC(hipStreamCreateWithFlags(&e->vstream, hipStreamNonBlocking));
+    // Q3TTS_VOC_SERIAL=1: the vocoder shares the decoder stream (no overlap): isolates its kernels in a profile
+    if (getenv("Q3TTS_VOC_SERIAL") && atoi(getenv("Q3TTS_VOC_SERIAL"))) e->vstream = e->stream;
+    else HIPC(hipStreamCreateWithFlags(&e->vstream, hipStreamNonBlocking));
     HIPC(hipEventCreate(&e->ev0)); HIPC(hipEventCreate(&e->ev1)); HIPC(hipEventCreate(&e->ev2)); HIPC(hipEventCreate(&e->ev3));
+    e->fin_ev.resize(cfg->max_batch, nullptr);
+    for (auto& ev : e->fin_ev) HIPC(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     const q3tts_model_config& m = cfg->model;
     const int B = cfg->max_batch;
     e->B = B;
@@ -343,7 +346,7 @@ extern "C" void q3tts_engine_destroy(q3tts_engine* e) {
         if (L.graph) hipGraphDestroy(L.graph);
         hipFree(L.xT); hipFree(L.logits); hipFree(L.X); hipFree(L.fb); hipFree(L.px); hipFree(L.keys);
         hipFree(L.row_pos_t); hipFree(L.slot_id); hipFree(L.posA); hipFree(L.slotA); hipFree(L.pos_q);
-        hipFree(L.sc.qkv); hipFree(L.sc.att); hipFree(L.sc.h); hipFree(L.sc.xn);
+        hipFree(L.sc.qkv); hipFree(L.sc.att); hipFree(L.sc.h);
         if (L.ev_begin) hipEventDestroy(L.ev_begin); if (L.ev_end) hipEventDestroy(L.ev_end);
         if (L.stream) hipStreamDestroy(L.stream);
     }
@@ -351,11 +354,12 @@ extern "C" void q3tts_engine_destroy(q3tts_engine* e) {
     hipFree(e->text); for (auto p : e->codec) hipFree(p); hipFree((void*)e->codec_dev); hipFree(e->proj_w); hipFree(e->proj_b);
     hipFree(e->slots); if (e->slots_host) hipHostFree(e->slots_host);
     hipFree(e->codes); hipFree(e->rng);
-    hipFree(e->sc_pre.xn); hipFree(e->sc_pre.qkv); hipFree(e->sc_pre.att); hipFree(e->sc_pre.h);
+    hipFree(e->sc_pre.qkv); hipFree(e->sc_pre.att); hipFree(e->sc_pre.h);
     hipFree(e->xp); hipFree(e->pf_pos); hipFree(e->pf_slot); hipFree(e->prow_dev); hipFree(e->spk_dev); hipFree(e->refcodes_dev);
+    for (auto ev : e->fin_ev) if (ev) hipEventDestroy(ev);
     if (e->ev0) hipEventDestroy(e->ev0); if (e->ev1) hipEventDestroy(e->ev1); if (e->ev2) hipEventDestroy(e->ev2); if (e->ev3) hipEventDestroy(e->ev3);
     if (e->stream) hipStreamDestroy(e->stream);
-    if (e->vstream) hipStreamDestroy(e->vstream);
+    if (e->vstream && e->vstream != e->stream) hipStreamDestroy(e->vstream);
     delete e;
 }
 
@@ -505,7 +509,7 @@ static int admit_group(q3tts_engine* e, std::vector<Adm>& grp, int total) {
         const int row = b - L.b0;
         q3_launch_copy_rows(L.xT + (size_t)row * m.t_d_model, m.t_d_model, e->xp + (size_t)(a.row0 + a.n - 1) * m.t_d_model, m.t_d_model, 1, m.t_d_model, s);
         Q3Gemm g{}; g.x = L.xT + (size_t)row * m.t_d_model; g.ldx = m.t_d_model; g.B = 1; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab;
-        g.norm_w = e->T.out_norm; g.eps = m.rms_eps; g.xhat = e->sc_pre.xn; g.y = L.logits + (size_t)row * m.t_vocab; g.ldy = m.t_vocab; g.epi = Q3_EPI_STORE;
+        g.norm_w = e->T.out_norm; g.eps = m.rms_eps; g.y = L.logits + (size_t)row * m.t_vocab; g.ldy = m.t_vocab; g.epi = Q3_EPI_STORE;
         q3_launch_gemm(g, s);
         // sampler stream (src/tts/engine.rs:473-485)
         float temperature = e->temperature, top_p = e->top_p; int top_k = e->top_k, has_seed = e->has_seed; uint64_t seed = e->seed;
@@ -575,7 +579,12 @@ static double now_ms() {
 
 struct SlotRun { int req = -1; int voc_frames = 0; double t_first = 0; };
 
-static int finalize(q3tts_engine* e, int b, const q3tts_request* r, q3tts_result* o, const SlotRun& sr, double t0) {
+// Results of a finished slot. The codes come back on the decoder stream at once; the PCM (pinned host buffer) is copied
+// on the vocoder stream. With `defer` the call does not wait for the vocoder: the copy is enqueued behind the slot's last
+// vocoder chunk, `fin_ev` is recorded after it and the caller completes the result later (complete_result), so the next
+// decode chunk is launched while the vocoder is still working.
+static int finalize(q3tts_engine* e, int b, const q3tts_request* r, q3tts_result* o, const SlotRun& sr, double t0, bool defer = false,
+                    hipEvent_t fin_ev = nullptr) {
     const int ncb = e->cfg.model.n_codebooks;
     const Q3Slot& st = e->slots_host[b];
     o->n_frames = st.n_frames; o->hit_eos = st.hit_eos;
@@ -588,13 +597,24 @@ static int finalize(q3tts_engine* e, int b, const q3tts_request* r, q3tts_result
     if (r->want_pcm && e->voc) {
         const int ns = q3_voc_samples(e, b);
         o->n_samples = ns;
-        o->pcm = (float*)malloc(sizeof(float) * (size_t)std::max(1, ns));
-        if (!o->pcm) return q3_set_err(e, Q3TTS_ERR_OOM, "malloc");
-        Q3_HIP(e, hipStreamSynchronize(e->vstream));
-        if (ns > 0) Q3_HIP(e, hipMemcpyAsync(o->pcm, q3_voc_pcm(e, b), sizeof(float) * (size_t)ns, hipMemcpyDeviceToHost, e->stream));
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, sizeof(float) * (size_t)std::max(1, ns), hipHostMallocDefault) != hipSuccess) return q3_set_err(e, Q3TTS_ERR_OOM, "hipHostMalloc");
+        o->pcm = (float*)hp;
+        if (ns > 0) Q3_HIP(e, hipMemcpyAsync(o->pcm, q3_voc_pcm(e, b), sizeof(float) * (size_t)ns, hipMemcpyDeviceToHost, e->vstream));
+        if (defer) Q3_HIP(e, hipEventRecord(fin_ev, e->vstream));
+        else Q3_HIP(e, hipStreamSynchronize(e->vstream));
+    } else if (defer) {
+        Q3_HIP(e, hipEventRecord(fin_ev, e->vstream));
     }
     Q3_HIP(e, hipStreamSynchronize(e->stream));
     o->first_chunk_ms = sr.t_first > 0 ? (float)(sr.t_first - t0) : 0.0f;
+    o->total_ms = (float)(now_ms() - t0);
+    o->status = defer ? Q3TTS_ERR_STATE : Q3TTS_OK;  // a deferred result becomes OK in complete_result
+    return Q3TTS_OK;
+}
+
+static int complete_result(q3tts_engine* e, q3tts_result* o, hipEvent_t fin_ev, double t0) {
+    Q3_HIP(e, hipEventSynchronize(fin_ev));
     o->total_ms = (float)(now_ms() - t0);
     o->status = Q3TTS_OK;
     return Q3TTS_OK;
@@ -609,8 +629,13 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
     const int B = e->B, CH = 4;  // 4-frame chunks: src/tts/engine.rs:509-512
     const int spf = e->voc ? q3_voc_samples_per_frame(e) : 0;
     std::vector<SlotRun> run(B);
-    int next = 0, done = 0;
     const double t0 = now_ms();
+    std::vector<int> pending(B, -1);  // request whose PCM copy is still in flight on the vocoder stream, per slot
+    auto drain = [&](int b) -> int {
+        if (pending[b] >= 0) { TRY(complete_result(e, &outs[pending[b]], e->fin_ev[b], t0)); pending[b] = -1; }
+        return Q3TTS_OK;
+    };
+    int next = 0, done = 0;
     double dec_ms = 0, pre_ms = 0, voc_ms = 0;
     long long steps = 0, ctx_tokens = 0, live_slot_steps = 0;
     hipStream_t s = e->stream;
@@ -619,7 +644,7 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
         {
             std::vector<int> as, ai; std::vector<const q3tts_request*> ar;
             for (int b = 0; b < B && next < n; ++b)
-                if (run[b].req < 0) { as.push_back(b); ar.push_back(&reqs[next]); ai.push_back(next++); }
+                if (run[b].req < 0) { TRY(drain(b)); as.push_back(b); ar.push_back(&reqs[next]); ai.push_back(next++); }
             if (!as.empty()) {
                 Q3_HIP(e, hipEventRecord(e->ev0, s));
                 admitted = true;
@@ -681,10 +706,15 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
         for (int b = 0; b < B; ++b) {
             if (run[b].req < 0 || e->slots_host[b].active) continue;
             if (e->voc) q3_voc_mark_last(e, b);
-            TRY(finalize(e, b, &reqs[run[b].req], &outs[run[b].req], run[b], t0));
+            // hand the slot's results over without waiting for the vocoder (completed at slot reuse / at the end)
+            for (int j = 0; j < B; ++j)
+                if (pending[j] >= 0 && hipEventQuery(e->fin_ev[j]) == hipSuccess) TRY(drain(j));
+            TRY(finalize(e, b, &reqs[run[b].req], &outs[run[b].req], run[b], t0, true, e->fin_ev[b]));
+            pending[b] = run[b].req;
             run[b].req = -1; ++done;
         }
     }
+    for (int b = 0; b < B; ++b) TRY(drain(b));
     e->tm.prefill_ms = (float)pre_ms; e->tm.decode_ms = (float)dec_ms; e->tm.vocoder_ms = (float)voc_ms;
     e->tm.total_ms = (float)(now_ms() - t0); e->tm.frame_steps = steps; e->tm.frame_step_ms = steps ? (float)(dec_ms / steps) : 0.0f;
     // bytes = 2*W_T + 15*2*W_P(layers) + 15*2*h + 16*2*pj + KV bytes of the live context + gathers
@@ -711,7 +741,8 @@ extern "C" int q3tts_generate(q3tts_engine* e, const q3tts_request* req, q3tts_r
 
 extern "C" void q3tts_result_free(q3tts_result* r) {
     if (!r) return;
-    free(r->codes); free(r->pcm);
+    free(r->codes);
+    if (r->pcm) hipHostFree(r->pcm);  // pinned: filled by an asynchronous device-to-host copy
     r->codes = nullptr; r->pcm = nullptr;
 }
 
@@ -819,8 +850,7 @@ extern "C" int q3tts_k_gemm_exact(int32_t device, const float* x, int32_t B, int
     HK(hipSetDevice(device));
     const int F = N / 2;
     const size_t ny = epi == Q3_EPI_SWIGLU ? (size_t)B * F : (size_t)B * N;
-    DevBuf dx, dw, dwt, dn, db, dy, dk, dxh;
-    if (dxh.alloc((size_t)B * K * 4)) return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
+    DevBuf dx, dw, dwt, dn, db, dy, dk;
     if (dx.alloc((size_t)B * K * 4) || dw.alloc((size_t)N * K * 2) || dwt.alloc((size_t)N * K * 2) || dn.alloc((size_t)K * 4) ||
         db.alloc((size_t)N * 4) || dy.alloc(ny * 4) || dk.alloc((size_t)B * 8))
         return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
@@ -834,7 +864,7 @@ extern "C" int q3tts_k_gemm_exact(int32_t device, const float* x, int32_t B, int
     else { f.mode = 0; f.row0 = 0; f.rows = N; f.src_a = (const uint16_t*)dw.p; }
     q3_launch_fill_tiled(f, nullptr);
     Q3Gemm g{}; g.x = (const float*)dx.p; g.ldx = K; g.B = B; g.w = (const uint4*)dwt.p; g.K = K; g.N = N;
-    g.norm_w = norm_w ? (const float*)dn.p : nullptr; g.eps = eps; g.bias = bias ? (const float*)db.p : nullptr; g.xhat = (float*)dxh.p;
+    g.norm_w = norm_w ? (const float*)dn.p : nullptr; g.eps = eps; g.bias = bias ? (const float*)db.p : nullptr;
     g.y = (float*)dy.p; g.ldy = epi == Q3_EPI_SWIGLU ? F : N; g.keys = (unsigned long long*)dk.p; g.key_stride = 1; g.epi = epi;
     q3_launch_gemm(g, nullptr);
     HK(hipDeviceSynchronize());

@@ -15,10 +15,16 @@
 // vmcnt is ONE in-order queue: waiting on a young L2 load also waits for every older HBM load. Hence:
 //   k_gemm_small (rows*K <= 12288 floats; the latency-critical B = 1..6 decode case): 16 waves = 16 slices, the
 //        workgroup stages x and the norm weights in LDS once (their loads are issued BEFORE the weight stream), so
-//        the main loop's vmcnt only ever counts weights; RMSNorm is fused (stats from LDS).
+//        the main loop's vmcnt only ever counts weights.
 //   k_gemm_ring (larger batches, MFMA-bound): 8 waves x 2 adjacent slices; x fragments ride a register ring XPF
 //        blocks deep issued BEFORE the weight refill of the same block; each wave reuses its x fragments for NT
-//        column tiles (x traffic from L2 is the co-bottleneck at B = 64); RMSNorm runs as a pre-kernel.
+//        column tiles (x traffic from L2 is the co-bottleneck at B = 64).
+//
+// Fused RMSNorm: the row scale commutes out of the K-sum, so a NORM GEMM computes
+//   y[r][n] = s_r * SUM_canonical((x[r][k] * nw[k]) * W[n][k]),   s_r = 1 / sqrtf(ss_r / K + eps),
+// and ss_r is accumulated from the very fragments the MFMAs consume, in the GEMM's own order: per (slice, kq) an
+// fmaf chain over ascending k, S_slice = (c0 + c1) + (c2 + c3), Q_w = S_2w + S_2w+1, ss = Q_0 + Q_1 + ... + Q_7.
+// No pre-kernel, no second pass over x, no normalised copy in HBM.
 #include <cstdlib>
 
 #include "q3_kernels.h"
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(1024) void k_gemm_small(Q3Gemm g) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];  // x[nrows][K] then norm_w[K]
     __shared__ float red[16 * 16 * 17];
     __shared__ float sums[16 * 16];
-    __shared__ float rinv_s[16];
+    __shared__ float ssred[16 * 16];
     constexpr int WPF = 8;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nb = blockIdx.x, nrows = g.B;
@@ -124,20 +130,10 @@ __global__ __launch_bounds__(1024) void k_gemm_small(Q3Gemm g) {
         if (tid + 1024 < K4) ((float4*)nwl)[tid + 1024] = nv1;
     }
     __syncthreads();
-    if (NORM) {
-        for (int r = wave; r < nrows; r += 16) {
-            const float4* xr = (const float4*)(dsm + (size_t)r * K);
-            float a = 0.0f;
-            for (int c = lane; c < K4; c += 64) a = sq4(xr[c], a);
-            a = wsum(a);
-            if (lane == 0) rinv_s[r] = 1.0f / sqrtf(a / (float)K + g.eps);
-        }
-        __syncthreads();
-    }
     const int lr = li < nrows ? li : nrows - 1;  // padding rows replicate the last row; their results are dropped
     const float* xa = dsm + (size_t)lr * K + koff;
     const float* nwa = nwl + koff;
-    const float ri0 = NORM ? rinv_s[lr] : 1.0f;
+    float ss = 0.0f;  // NORM: this lane's (slice, kq) chain of the row's sum of squares
     for (int kb0 = 0; kb0 < bps; kb0 += WPF) {
 #pragma unroll
         for (int j = 0; j < WPF; ++j) {
@@ -153,8 +149,9 @@ __global__ __launch_bounds__(1024) void k_gemm_small(Q3Gemm g) {
                 if (NORM) {
                     const float4 n0 = *(const float4*)(nwa + kb * 32), n1 = *(const float4*)(nwa + kb * 32 + 16);
                     const float nw[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+                    ss = sq4(x0, ss); ss = sq4(x1, ss);
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) a[t] = (a[t] * ri0) * nw[t];
+                    for (int t = 0; t < 8; ++t) a[t] = a[t] * nw[t];
                 }
 #pragma unroll
                 for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], acc, 0, 0, 0);
@@ -164,6 +161,11 @@ __global__ __launch_bounds__(1024) void k_gemm_small(Q3Gemm g) {
     // D layout: lane holds rows 4*(lane>>4)+j, column lane&15
 #pragma unroll
     for (int j = 0; j < 4; ++j) red[(wave * 16 + 4 * kq + j) * 17 + li] = acc[j];
+    if (NORM) {
+        ss = ss + __shfl_xor(ss, 16);
+        ss = ss + __shfl_xor(ss, 32);  // (c0 + c1) + (c2 + c3): this slice's share of row li
+        if (kq == 0) ssred[wave * 16 + li] = ss;
+    }
     __syncthreads();
     if (tid < 256) {
         const int row = tid >> 4, col = tid & 15;
@@ -171,6 +173,12 @@ __global__ __launch_bounds__(1024) void k_gemm_small(Q3Gemm g) {
             float s = red[row * 17 + col] + red[(16 + row) * 17 + col];
 #pragma unroll
             for (int w = 1; w < 8; ++w) s = s + (red[(2 * w * 16 + row) * 17 + col] + red[((2 * w + 1) * 16 + row) * 17 + col]);
+            if (NORM) {
+                float tot = ssred[row] + ssred[16 + row];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) tot = tot + (ssred[2 * w * 16 + row] + ssred[(2 * w + 1) * 16 + row]);
+                s = s * (1.0f / sqrtf(tot / (float)K + g.eps));
+            }
             store_elem(g, sums, s, (size_t)row, nb * 16 + col, row, col, 16);
         }
     }
@@ -181,12 +189,15 @@ __global__ __launch_bounds__(1024) void k_gemm_small(Q3Gemm g) {
 // ring kernel: 512 threads, wave w = slices 2w and 2w+1 (adjacent in k), RT row tiles x NT column tiles per wave.
 // BPS = K/512 blocks per slice (0 = runtime).
 // ---------------------------------------------------------------------------------------------------------------
-template <int RT, int NT, int BPS>
+template <int RT, int NT, int BPS, bool NORM>
 __global__ __launch_bounds__(512, (RT <= 2 && NT == 1 && BPS > 0 && BPS <= 2) ? 4 : 2) void k_gemm_ring(Q3Gemm g) {
+    extern __shared__ __attribute__((aligned(16))) float nwl[];  // NORM: norm_w[K]
     __shared__ float red[8 * RT * 16 * (NT * 16 + 1)];
     __shared__ float sums[RT * 16 * NT * 16];
+    __shared__ float ssred[NORM ? 8 * RT * 16 : 1];
+    __shared__ float srow[NORM ? RT * 16 : 1];
     constexpr int WPF = NT == 1 ? 8 : 4;
-    constexpr int XPF = RT == 4 ? 2 : (RT == 2 ? 4 : 8);
+    constexpr int XPF = (RT == 4 || (NORM && RT * NT >= 6)) ? 2 : (RT == 2 ? 4 : 8);  // NORM keeps a[] apart from the ring: shallower ring for the widest tile
     constexpr int CP = NT * 16 + 1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nbt = blockIdx.x, row0 = blockIdx.y * (RT * 16);
@@ -201,7 +212,24 @@ __global__ __launch_bounds__(512, (RT <= 2 && NT == 1 && BPS > 0 && BPS <= 2) ? 
     uint4 wq[WPF][NT];
     float4 xq[XPF][RT][2];
     f32x4 acc[RT][NT], accA[RT][NT];
+    float ss[RT], ssA[RT];  // NORM: (slice, kq) chains of the rows' sums of squares
     const float* xr[RT];
+    // NORM: the norm weights go to LDS once; their loads are the OLDEST in the queue
+    const int K4 = K >> 2;
+    const float4* nsrc = (const float4*)(NORM ? g.norm_w : g.x);
+    float4 nv0, nv1;
+    if (NORM) { nv0 = nsrc[min(tid, K4 - 1)]; nv1 = nsrc[min(tid + 512, K4 - 1)]; }
+    // RESID: the residual operand is fetched up front instead of at the very end
+    constexpr int NOUT = (RT * 16 * NT * 16 + 511) / 512;
+    float yres[NOUT];
+    if (g.epi == Q3_EPI_RESID) {
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) {
+            const int o = tid + i * 512;
+            const int row = o / (NT * 16), col = o - row * (NT * 16);
+            yres[i] = (o < RT * 16 * NT * 16 && row < nrows) ? g.y[(size_t)(row0 + row) * g.ldy + nbt * NT * 16 + col] : 0.0f;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
         int lrw = r * 16 + li;
@@ -209,6 +237,7 @@ __global__ __launch_bounds__(512, (RT <= 2 && NT == 1 && BPS > 0 && BPS <= 2) ? 
         xr[r] = g.x + (size_t)(row0 + lrw) * g.ldx + koff;
 #pragma unroll
         for (int c = 0; c < NT; ++c) { acc[r][c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; accA[r][c] = acc[r][c]; }
+        ss[r] = 0.0f; ssA[r] = 0.0f;
     }
 #pragma unroll
     for (int j = 0; j < XPF; ++j)
@@ -224,6 +253,13 @@ __global__ __launch_bounds__(512, (RT <= 2 && NT == 1 && BPS > 0 && BPS <= 2) ? 
             for (int c = 0; c < NT; ++c) wq[j][c] = ntload16(wp + c * tile_stride + (size_t)j * 64);
         }
     __builtin_amdgcn_sched_barrier(0);
+    if (NORM) {
+        if (tid < K4) ((float4*)nwl)[tid] = nv0;
+        if (tid + 512 < K4) ((float4*)nwl)[tid + 512] = nv1;
+        for (int i = tid + 1024; i < K4; i += 512) ((float4*)nwl)[i] = nsrc[i];
+        __syncthreads();
+    }
+    const float* nwa = nwl + koff;
     for (int kb0 = 0; kb0 < nblk; kb0 += WPF) {
 #pragma unroll
         for (int j = 0; j < WPF; ++j) {
@@ -231,9 +267,11 @@ __global__ __launch_bounds__(512, (RT <= 2 && NT == 1 && BPS > 0 && BPS <= 2) ? 
             if (kb < nblk) {
                 if (kb == bps) {  // slice 2w done: park its partial, start slice 2w+1 from +0
 #pragma unroll
-                    for (int r = 0; r < RT; ++r)
+                    for (int r = 0; r < RT; ++r) {
 #pragma unroll
                         for (int c = 0; c < NT; ++c) { accA[r][c] = acc[r][c]; acc[r][c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
+                        ssA[r] = ss[r]; ss[r] = 0.0f;
+                    }
                 }
                 float b[NT][8];
 #pragma unroll
@@ -243,6 +281,15 @@ __global__ __launch_bounds__(512, (RT <= 2 && NT == 1 && BPS > 0 && BPS <= 2) ? 
                 for (int r = 0; r < RT; ++r) {
                     const float4 x0 = xq[j % XPF][r][0], x1 = xq[j % XPF][r][1];
                     a[r][0] = x0.x; a[r][1] = x0.y; a[r][2] = x0.z; a[r][3] = x0.w; a[r][4] = x1.x; a[r][5] = x1.y; a[r][6] = x1.z; a[r][7] = x1.w;
+                    if (NORM) { ss[r] = sq4(x0, ss[r]); ss[r] = sq4(x1, ss[r]); }
+                }
+                if (NORM) {
+                    const float4 n0 = *(const float4*)(nwa + kb * 32), n1 = *(const float4*)(nwa + kb * 32 + 16);
+                    const float nw[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) a[r][t] = a[r][t] * nw[t];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (kb + XPF < nblk) {  // activations first: they must stay OLDER than the weight refill below
@@ -274,14 +321,35 @@ __global__ __launch_bounds__(512, (RT <= 2 && NT == 1 && BPS > 0 && BPS <= 2) ? 
         for (int c = 0; c < NT; ++c)
 #pragma unroll
             for (int j = 0; j < 4; ++j) red[((wave * RT + r) * 16 + 4 * kq + j) * CP + c * 16 + li] = accA[r][c][j] + acc[r][c][j];
+    if (NORM) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            float sa = ssA[r] + __shfl_xor(ssA[r], 16), sb = ss[r] + __shfl_xor(ss[r], 16);
+            sa = sa + __shfl_xor(sa, 32); sb = sb + __shfl_xor(sb, 32);  // S_2w, S_2w+1 = (c0 + c1) + (c2 + c3)
+            if (kq == 0) ssred[(wave * RT + r) * 16 + li] = sa + sb;
+        }
+    }
     __syncthreads();
-    for (int o = tid; o < RT * 16 * NT * 16; o += 512) {
+    if (NORM) {
+        if (tid < RT * 16) {
+            float tot = ssred[tid];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) tot = tot + ssred[w * RT * 16 + tid];
+            srow[tid] = 1.0f / sqrtf(tot / (float)K + g.eps);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) {
+        const int o = tid + i * 512;
         const int row = o / (NT * 16), col = o - row * (NT * 16);
-        if (row >= nrows) continue;
+        if (o >= RT * 16 * NT * 16 || row >= nrows) continue;
         float s = red[row * CP + col];
 #pragma unroll
         for (int w = 1; w < 8; ++w) s = s + red[(w * RT * 16 + row) * CP + col];
-        store_elem(g, sums, s, (size_t)(row0 + row), nbt * NT * 16 + col, row, col, NT * 16);
+        if (NORM) s = s * srow[row];
+        if (g.epi == Q3_EPI_RESID) g.y[(size_t)(row0 + row) * g.ldy + nbt * NT * 16 + col] = yres[i] + s;
+        else store_elem(g, sums, s, (size_t)(row0 + row), nbt * NT * 16 + col, row, col, NT * 16);
     }
     epilogue<RT * 16, NT * 16>(g, sums, tid, 512, row0, nrows, nbt * NT * 16);
 }
@@ -301,30 +369,33 @@ static void launch_small(const Q3Gemm& g, dim3 grid, size_t lds, hipStream_t s) 
 }
 template <int RT, int NT>
 static void launch_ring(const Q3Gemm& g, dim3 grid, hipStream_t s) {
-#define L(BPS_) hipLaunchKernelGGL((k_gemm_ring<RT, NT, BPS_>), grid, dim3(512), 0, s, g)
-    switch (g.K >> 9) {
+    const bool norm = g.norm_w != nullptr;
+    const size_t lds = norm ? (size_t)g.K * 4 : 0;
+#define L(BPS_)                                                                                              \
+    do {                                                                                                     \
+        if (norm) hipLaunchKernelGGL((k_gemm_ring<RT, NT, BPS_, true>), grid, dim3(512), lds, s, g);         \
+        else hipLaunchKernelGGL((k_gemm_ring<RT, NT, BPS_, false>), grid, dim3(512), 0, s, g);               \
+    } while (0)
+#define LN(BPS_) hipLaunchKernelGGL((k_gemm_ring<RT, NT, BPS_, false>), grid, dim3(512), 0, s, g)
+    switch (g.K >> 9) {  // norm GEMMs have K = d_model: 1, 2, 4 (anything else: the runtime-K instance)
         case 1: L(1); break;
         case 2: L(2); break;
-        case 4: L(4); break;
-        case 6: L(6); break;
-        case 12: L(12); break;
+        case 4: if (norm && RT == 4) L(0); else L(4); break;  // the unrolled K = 2048 NORM instance of RT = 4 spills
+        case 6: if (norm) L(0); else LN(6); break;
+        case 12: if (norm) L(0); else LN(12); break;
         default: L(0); break;
     }
 #undef L
+#undef LN
 }
 
-void q3_launch_gemm(const Q3Gemm& gin, hipStream_t s) {
-    Q3Gemm g = gin;
+void q3_launch_gemm(const Q3Gemm& g, hipStream_t s) {
     const bool norm = g.norm_w != nullptr;
     if (g.B <= 16 && g.ldx == g.K && (size_t)g.B * g.K <= XLDS_MAX_FLOATS && g.K <= 8192) {
         const size_t lds = ((size_t)g.B * g.K + (norm ? g.K : 0)) * 4;
         dim3 grid(g.N / 16);
         if (norm) launch_small<true>(g, grid, lds, s); else launch_small<false>(g, grid, lds, s);
         return;
-    }
-    if (norm) {  // RMSNorm as a pre-kernel: xhat = (x * rinv) * w, canonical order of DESIGN.md §4.2
-        q3_launch_rmsnorm_rows(g.x, g.ldx, g.norm_w, g.eps, g.K, g.B, g.xhat, g.K, s);
-        g.x = g.xhat; g.ldx = g.K; g.norm_w = nullptr;
     }
     const int tiles = g.N / 16;
     int NT = 1;

@@ -13,7 +13,6 @@ struct Q3Gemm {
     const float* norm_w; float eps;   // RMSNorm fused into the prologue when norm_w != nullptr
     const float* bias;                // STORE only
     float* y; int ldy;                // SWIGLU writes [B][N/2]
-    float* xhat;                      // [B][K] scratch for the RMSNorm pre-kernel (batches beyond the fused small-batch path)
     unsigned long long* keys; int key_stride;  // ARGMAX: atomicMax(keys[row*key_stride])
     int epi;
 };

@@ -37,7 +37,8 @@ struct VConv { int ntap = 1, dil = 1, cin = 0, nout = 0, bias_n = 0; uint16_t* w
 // work buffer of a conv input: [VOC_MAX_NS][H + Tcap][C] (slot-major) + per-slot history [B][H][C]
 struct VBuf { float* p = nullptr; float* hist = nullptr; int H = 0, C = 0, Tcap = 0; size_t stride() const { return (size_t)(H + Tcap) * C; } };
 
-struct VLayer { float *in_norm, *post_norm, *ls_attn, *ls_mlp; VConv q, k, v, o, gate, up, down; };
+struct VLayer { float *in_norm, *post_norm, *ls_attn, *ls_mlp; VConv q, k, v, o, gate, up, down;
+                VConv qkv, gu; };  // fused launches: qkv = rows of q | k | v; gu = 16-row groups of gate and up alternating
 struct VUp { VConv ct, pw1, pw2; float *dw_w, *dw_b, *ln_w, *ln_b, *gamma; int r; VBuf dw_in; };
 struct VRes { float *ea, *ib, *ea2, *ib2; VConv c1, c2; VBuf c1_in; };
 struct VBlk { float *ea, *ib; VConv ct; VRes res[3]; int r, cin, cout; VBuf ct_in; };
@@ -53,7 +54,7 @@ struct Q3Voc {
     std::vector<VBlk> Bk;
     float *oea = nullptr, *oib = nullptr, *out_w = nullptr, *out_b = nullptr; VBuf out_in; int out_c = 0;
     float *kring = nullptr, *vring = nullptr;  // [n_layer][B][RW][HH]
-    float *x = nullptr, *xn = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *att = nullptr, *g = nullptr, *u = nullptr;  // transformer scratch [M][.]
+    float *x = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *g = nullptr;  // transformer scratch [M][.]
     float *t1 = nullptr, *t2 = nullptr, *t3 = nullptr;  // generic scratch (largest stage)
     float* pcm = nullptr; size_t pcm_stride = 0;         // [B][max_steps_cap * spf]
     std::vector<int> frames_done, last_flag;
@@ -67,99 +68,129 @@ struct VGemm {
     const float* x; size_t x_stride; int x_off;   // row (s, t) tap 0 shift 0 at x + s*x_stride + x_off + t*cin
     int T, M;                                     // rows per slot, total rows = ns*T
     VConv c;
-    float* y; size_t y_stride; int y_off;         // out row (s,t) at y + s*y_stride + y_off + t*nout
-    const float* scale;                           // epilogue 1: y += scale[n % bias_n'] * (acc + bias)
+    float* y; size_t y_stride; int y_off;         // out row (s,t) at y + s*y_stride + y_off + t*nout (t*nout/2 for epi 4)
+    const float* scale;                           // epilogue 1: y += scale[n % scale_n] * (acc + bias)
     int scale_n;
-    int epi;                                      // 0 store, 1 y += scale*(.), 2 y += (.), 3 gelu
+    int epi;                                      // 0 store, 1 y += scale*(.), 2 y += (.), 3 gelu, 4 swiglu (16-column tiles alternate gate / up)
+    int store;                                    // 0: the primary output is not written (only y2 is wanted)
+    float* y2; size_t y2_stride; int y2_off;      // optional second output: SnakeBeta(v) with the NEXT layer's parameters,
+    const float *ea, *ib; int snake_n;            //   written straight into that layer's conv-input work buffer
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-// workgroup = 4 waves, tile 128 rows x 64 cols; wave = 32 rows x 64 cols = 2 x 4 MFMA tiles. Fragments load straight
-// from global/L2 (A: 32 B of f32 per lane -> bf16x8; B: 16 B of bf16 per lane), no LDS.
-__global__ __launch_bounds__(256) void k_vgemm(VGemm g) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int m0 = blockIdx.y * 128 + wave * 32, n0 = blockIdx.x * 64;
-    const int lr = lane & 15, kq = lane >> 4;
-    const int cin = g.c.cin, nout = g.c.nout;
-    f32x4 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* xrow[2]; int trow[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int m = m0 + i * 16 + lr;
-        if (m >= g.M) m = g.M - 1;
-        const int s = m / g.T, t = m - s * g.T;
-        trow[i] = t;
-        xrow[i] = g.x + (size_t)s * g.x_stride + g.x_off + (size_t)t * cin + kq * 8;
+// shared epilogue of one output element (row (s, t), column n)
+__device__ __forceinline__ void vepi(const VGemm& g, float v, int s, int t, int n) {
+    const int nout = g.c.nout;
+    if (g.c.b) v += g.c.b[n % g.c.bias_n];
+    float* yp = g.y + (size_t)s * g.y_stride + g.y_off + (size_t)t * nout + n;
+    if (g.epi == 1) v = *yp + g.scale[n % g.scale_n] * v;
+    else if (g.epi == 2) v = *yp + v;
+    else if (g.epi == 3) v = gelu_erf(v);
+    if (g.store) *yp = v;
+    if (g.y2) {
+        const int c = n % g.snake_n;
+        const float sn = __sinf(v * g.ea[c]);
+        g.y2[(size_t)s * g.y2_stride + g.y2_off + (size_t)t * nout + n] = v + g.ib[c] * (sn * sn);
     }
-    const uint16_t* wrow[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int n = n0 + j * 16 + lr;
-        if (n >= nout) n = nout - 1;
-        wrow[j] = g.c.w + (size_t)n * cin + kq * 8;
-    }
-    for (int tap = 0; tap < g.c.ntap; ++tap) {
-        const long shift = (long)(g.c.ntap - 1 - tap) * g.c.dil * cin;
-        const size_t woff = (size_t)tap * nout * cin;
-        for (int k0 = 0; k0 < cin; k0 += 32) {
-            bf16x8 a[2], b[4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float* p = xrow[i] - shift + k0;
-                const float4 v0 = *(const float4*)p, v1 = *(const float4*)(p + 4);
-                a[i][0] = (__bf16)v0.x; a[i][1] = (__bf16)v0.y; a[i][2] = (__bf16)v0.z; a[i][3] = (__bf16)v0.w;
-                a[i][4] = (__bf16)v1.x; a[i][5] = (__bf16)v1.y; a[i][6] = (__bf16)v1.z; a[i][7] = (__bf16)v1.w;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8*)(wrow[j] + woff + k0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-    }
-    (void)trow;
-    // D layout: lane holds rows 4*(lane>>4)+e, column lane&15
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int m = m0 + i * 16 + 4 * kq + e;
-            if (m >= g.M) continue;
-            const int s = m / g.T, t = m - s * g.T;
-            float* yrow = g.y + (size_t)s * g.y_stride + g.y_off + (size_t)t * nout;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + j * 16 + lr;
-                if (n >= nout) continue;
-                float v = acc[i][j][e];
-                if (g.c.b) v += g.c.b[n % g.c.bias_n];
-                if (g.epi == 0) yrow[n] = v;
-                else if (g.epi == 1) yrow[n] = yrow[n] + g.scale[n % g.scale_n] * v;
-                else if (g.epi == 2) yrow[n] = yrow[n] + v;
-                else yrow[n] = gelu_erf(v);
-            }
-        }
 }
 
-// LDS-tiled variant for the big-M convolutions (the decoder blocks: thousands of rows per slot): workgroup tile
-// 128 x 128, K step 32, 4 waves of 64 x 64 (4 x 4 MFMA tiles). A (f32 -> bf16) and W tiles are staged through
-// registers into double-buffered LDS one step ahead; rows are padded to 40 bf16 (80 B) so that the 16 lanes of a
-// ds_read_b128 group hit 16 distinct 4-bank slots. Conv taps are just extra K steps with a shifted row pointer.
+// Small-M GEMM (M <= 512 rows: the 12.5 Hz transformer, the first up-sampling stages, the drain phase of a batch):
+// workgroup tile 64 x 32, wave = 16 rows x 32 cols (2 MFMA tiles), no LDS and no barriers. The few rows cannot hide
+// memory latency with MFMA work, so fragments ride a 4-deep register ring (A: 32 B of f32 per lane -> bf16x8,
+// B: 16 B of bf16 per lane per column tile) and the grid is cut fine enough to put a workgroup on every CU.
+#define VS_PF 4
+__global__ __launch_bounds__(256) void k_vgemm_small(VGemm g) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m0 = blockIdx.y * 64 + wave * 16, n0 = blockIdx.x * 32;
+    if (m0 >= g.M) return;
+    const int lr = lane & 15, kq = lane >> 4;
+    const int cin = g.c.cin, nout = g.c.nout, kpt = cin >> 5, steps = g.c.ntap * kpt;
+    const float* xrow;
+    {
+        int m = m0 + lr; if (m >= g.M) m = g.M - 1;
+        const int s = m / g.T, t = m - s * g.T;
+        xrow = g.x + (size_t)s * g.x_stride + g.x_off + (size_t)t * cin + kq * 8;
+    }
+    const uint16_t* wrow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { int n = n0 + j * 16 + lr; if (n >= nout) n = nout - 1; wrow[j] = g.c.w + (size_t)n * cin + kq * 8; }
+    float4 ra[VS_PF][2]; uint4 rb[VS_PF][2];
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    // (no branch inside the ring: loads past the end re-read the last step and their A fragment is zeroed, so the
+    //  compiler can count outstanding loads exactly: vmcnt(12) at each consumption instead of vmcnt(0))
+#define VS_ISSUE(slot_, step_)                                                                        \
+    do {                                                                                              \
+        const int st__ = min((step_), steps - 1);                                                     \
+        const int tap__ = st__ / kpt, k0__ = (st__ - tap__ * kpt) << 5;                               \
+        const float* p__ = xrow - (long)(g.c.ntap - 1 - tap__) * g.c.dil * cin + k0__;                \
+        ra[slot_][0] = *(const float4*)p__; ra[slot_][1] = *(const float4*)(p__ + 4);                 \
+        const size_t wo__ = (size_t)tap__ * nout * cin + k0__;                                        \
+        rb[slot_][0] = *(const uint4*)(wrow[0] + wo__); rb[slot_][1] = *(const uint4*)(wrow[1] + wo__); \
+    } while (0)
+#pragma unroll
+    for (int j = 0; j < VS_PF; ++j) VS_ISSUE(j, j);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int s0 = 0; s0 < steps; s0 += VS_PF) {
+#pragma unroll
+        for (int j = 0; j < VS_PF; ++j) {
+            const int step = s0 + j;
+            const float live = step < steps ? 1.0f : 0.0f;
+            bf16x8 a;
+            const float4 v0 = ra[j][0], v1 = ra[j][1];
+            a[0] = (__bf16)(v0.x * live); a[1] = (__bf16)(v0.y * live); a[2] = (__bf16)(v0.z * live); a[3] = (__bf16)(v0.w * live);
+            a[4] = (__bf16)(v1.x * live); a[5] = (__bf16)(v1.y * live); a[6] = (__bf16)(v1.z * live); a[7] = (__bf16)(v1.w * live);
+            const uint4 u0 = rb[j][0], u1 = rb[j][1];
+            const bf16x8 b0 = *(const bf16x8*)&u0, b1 = *(const bf16x8*)&u1;
+            __builtin_amdgcn_sched_barrier(0);
+            VS_ISSUE(j, step + VS_PF);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[1], 0, 0, 0);
+        }
+    }
+#undef VS_ISSUE
+    // D layout: lane holds rows 4*(lane>>4)+e, column lane&15
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int m = m0 + 4 * kq + e;
+        if (m >= g.M) continue;
+        const int s = m / g.T, t = m - s * g.T;
+        if (g.epi == 4) {  // column tile 0 = gate, tile 1 = the matching up columns (interleaved weight rows)
+            const int n = blockIdx.x * 16 + lr;
+            if (n0 + 16 + lr < nout) {
+                const float gt = acc[0][e], up = acc[1][e];
+                g.y[(size_t)s * g.y_stride + g.y_off + (size_t)t * (nout >> 1) + n] = (gt / (1.0f + expf(-gt))) * up;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + j * 16 + lr;
+                if (n < nout) vepi(g, acc[j][e], s, t, n);
+            }
+        }
+    }
+}
+
+// LDS-tiled GEMM for the big-M convolutions (the decoder blocks: thousands of rows per slot): workgroup tile
+// 128 x (NJ*32), K step 32, 2 x 2 waves of 64 x (NJ*16) (4 x NJ MFMA tiles); NJ = 3 serves the 96- and 192-channel
+// blocks without padding waste. A (f32 -> bf16) and W tiles go through registers into double-buffered LDS; the
+// registers run two K steps ahead of the LDS copy (three ahead of the MFMAs), rows are padded to 40 bf16 (80 B) so
+// that the 16 lanes of a ds_read_b128 group hit 16 distinct 4-bank slots. Conv taps are just extra K steps with a
+// shifted row pointer.
 #define VT_LD 40
+struct VStage { float4 a0, a1, a2, a3; uint4 b0, b1; float live; };
+template <int NJ>
 __global__ __launch_bounds__(256) void k_vgemm_lds(VGemm g) {
+    constexpr int BN = NJ * 32;
     __shared__ __attribute__((aligned(16))) __bf16 As[2][128 * VT_LD];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][128 * VT_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * VT_LD];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, kq = lane >> 4;
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * BN;
     const int cin = g.c.cin, nout = g.c.nout, kpt = cin >> 5, steps = g.c.ntap * kpt;
     const int ldr = tid >> 1, half = tid & 1;  // loader: row/col ldr, 16 k-elements at half*16
+    const bool bload = ldr < BN;
     const float* xrow;
     {
         int m = m0 + ldr; if (m >= g.M) m = g.M - 1;
@@ -168,45 +199,53 @@ __global__ __launch_bounds__(256) void k_vgemm_lds(VGemm g) {
     }
     const uint16_t* wrow;
     { int n = n0 + ldr; if (n >= nout) n = nout - 1; wrow = g.c.w + (size_t)n * cin + half * 16; }
-    float4 ra0, ra1, ra2, ra3; uint4 rb0, rb1;
-    auto gload = [&](int step) {
+    auto gload = [&](VStage& r, int step_) {  // steps past the end re-read the last tile; their A part is zeroed
+        const int step = min(step_, steps - 1);
         const int tap = step / kpt, k0 = (step - tap * kpt) << 5;
         const float* p = xrow - (long)(g.c.ntap - 1 - tap) * g.c.dil * cin + k0;
-        ra0 = ((const float4*)p)[0]; ra1 = ((const float4*)p)[1]; ra2 = ((const float4*)p)[2]; ra3 = ((const float4*)p)[3];
-        const uint16_t* q = wrow + (size_t)tap * nout * cin + k0;
-        rb0 = ((const uint4*)q)[0]; rb1 = ((const uint4*)q)[1];
+        r.a0 = ((const float4*)p)[0]; r.a1 = ((const float4*)p)[1]; r.a2 = ((const float4*)p)[2]; r.a3 = ((const float4*)p)[3];
+        if (bload) { const uint16_t* q = wrow + (size_t)tap * nout * cin + k0; r.b0 = ((const uint4*)q)[0]; r.b1 = ((const uint4*)q)[1]; }
+        r.live = step_ < steps ? 1.0f : 0.0f;
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](const VStage& r, int buf) {
         bf16x8 lo, hi;
-        lo[0] = (__bf16)ra0.x; lo[1] = (__bf16)ra0.y; lo[2] = (__bf16)ra0.z; lo[3] = (__bf16)ra0.w;
-        lo[4] = (__bf16)ra1.x; lo[5] = (__bf16)ra1.y; lo[6] = (__bf16)ra1.z; lo[7] = (__bf16)ra1.w;
-        hi[0] = (__bf16)ra2.x; hi[1] = (__bf16)ra2.y; hi[2] = (__bf16)ra2.z; hi[3] = (__bf16)ra2.w;
-        hi[4] = (__bf16)ra3.x; hi[5] = (__bf16)ra3.y; hi[6] = (__bf16)ra3.z; hi[7] = (__bf16)ra3.w;
+        const float lv = r.live;
+        lo[0] = (__bf16)(r.a0.x * lv); lo[1] = (__bf16)(r.a0.y * lv); lo[2] = (__bf16)(r.a0.z * lv); lo[3] = (__bf16)(r.a0.w * lv);
+        lo[4] = (__bf16)(r.a1.x * lv); lo[5] = (__bf16)(r.a1.y * lv); lo[6] = (__bf16)(r.a1.z * lv); lo[7] = (__bf16)(r.a1.w * lv);
+        hi[0] = (__bf16)(r.a2.x * lv); hi[1] = (__bf16)(r.a2.y * lv); hi[2] = (__bf16)(r.a2.z * lv); hi[3] = (__bf16)(r.a2.w * lv);
+        hi[4] = (__bf16)(r.a3.x * lv); hi[5] = (__bf16)(r.a3.y * lv); hi[6] = (__bf16)(r.a3.z * lv); hi[7] = (__bf16)(r.a3.w * lv);
         __bf16* ap = &As[buf][ldr * VT_LD + half * 16];
         *(bf16x8*)ap = lo; *(bf16x8*)(ap + 8) = hi;
-        uint4* bp = (uint4*)&Bs[buf][ldr * VT_LD + half * 16];
-        bp[0] = rb0; bp[1] = rb1;
+        if (bload) { uint4* bp = (uint4*)&Bs[buf][ldr * VT_LD + half * 16]; bp[0] = r.b0; bp[1] = r.b1; }
     };
-    f32x4 acc[4][4];
+    f32x4 acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    gload(0); sstore(0);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define VT_COMPUTE(buf_)                                                                                              \
+    do {                                                                                                              \
+        bf16x8 a__[4], b__[NJ];                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) a__[i] = *(const bf16x8*)&As[buf_][(wm * 64 + i * 16 + lr) * VT_LD + kq * 8];     \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) b__[j] = *(const bf16x8*)&Bs[buf_][(wn * NJ * 16 + j * 16 + lr) * VT_LD + kq * 8]; \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+            _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                            \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a__[i], b__[j], acc[i][j], 0, 0, 0);              \
+    } while (0)
+    // at the top of step k: LDS[k & 1] holds tile k, R0/R1 (alternating) hold tiles k+1 and k+2
+    VStage R0, R1;
+    gload(R0, 0); sstore(R0, 0);
+    gload(R0, 1);
+    gload(R1, 2);
     __syncthreads();
-    for (int step = 0; step < steps; ++step) {
-        const int buf = step & 1;
-        if (step + 1 < steps) gload(step + 1);
-        bf16x8 a[4], b[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)&As[buf][(wm * 64 + i * 16 + lr) * VT_LD + kq * 8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8*)&Bs[buf][(wn * 64 + j * 16 + lr) * VT_LD + kq * 8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        if (step + 1 < steps) sstore(buf ^ 1);
+    for (int step = 0; step < steps; step += 2) {  // an odd tail runs one zeroed tile: the loop body has no branch
+        sstore(R0, 1);       // tile step+1 -> LDS[1] (last read before the previous barrier)
+        gload(R0, step + 3);
+        VT_COMPUTE(0);
+        __syncthreads();
+        sstore(R1, 0);       // tile step+2 -> LDS[0]
+        gload(R1, step + 4);
+        VT_COMPUTE(1);
         __syncthreads();
     }
 #pragma unroll
@@ -216,17 +255,10 @@ __global__ __launch_bounds__(256) void k_vgemm_lds(VGemm g) {
             const int m = m0 + wm * 64 + i * 16 + 4 * kq + e;
             if (m >= g.M) continue;
             const int s = m / g.T, t = m - s * g.T;
-            float* yrow = g.y + (size_t)s * g.y_stride + g.y_off + (size_t)t * nout;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn * 64 + j * 16 + lr;
-                if (n >= nout) continue;
-                float v = acc[i][j][e];
-                if (g.c.b) v += g.c.b[n % g.c.bias_n];
-                if (g.epi == 0) yrow[n] = v;
-                else if (g.epi == 1) yrow[n] = yrow[n] + g.scale[n % g.scale_n] * v;
-                else if (g.epi == 2) yrow[n] = yrow[n] + v;
-                else yrow[n] = gelu_erf(v);
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n0 + wn * NJ * 16 + j * 16 + lr;
+                if (n < nout) vepi(g, acc[i][j][e], s, t, n);
             }
         }
 }
@@ -270,7 +302,7 @@ __global__ __launch_bounds__(64) void k_voc_rmsnorm(const float* x, const float*
 }
 
 // RoPE + ring append + sliding-window attention; one workgroup (64 threads) per (slot, head), tokens in order
-__global__ __launch_bounds__(64) void k_voc_attn(VCall cl, const float* q, const float* k, const float* v, float* kring, float* vring,
+__global__ __launch_bounds__(64) void k_voc_attn(VCall cl, const float* qkv, float* kring, float* vring,
                                                  int H, int hd, int RW, int W, float theta, float* att) {
     __shared__ float sc[512];
     __shared__ float qs[128];
@@ -282,16 +314,18 @@ __global__ __launch_bounds__(64) void k_voc_attn(VCall cl, const float* q, const
     for (int t = 0; t < T; ++t) {
         const int pos = cl.pos[s] + t;
         const size_t row = ((size_t)s * T + t) * HH + h * hd;
+        const float* qp = qkv + ((size_t)s * T + t) * 3 * HH + h * hd;  // q | k | v of this row inside the fused [M][3*HH] buffer
+        const float* kp0 = qp + HH; const float* vp = qp + 2 * HH;
         if (lane < half) {
             const double inv = pow((double)theta, -2.0 * (double)lane / (double)hd), ang = (double)pos * inv;
             const float cs = (float)cos(ang), sn = (float)sin(ang);
-            float a = q[row + lane], b = q[row + lane + half];
+            float a = qp[lane], b = qp[lane + half];
             qs[lane] = a * cs - b * sn; qs[lane + half] = b * cs + a * sn;
-            a = k[row + lane]; b = k[row + lane + half];
+            a = kp0[lane]; b = kp0[lane + half];
             float* kd = kr + (size_t)(pos % RW) * HH;
             kd[lane] = a * cs - b * sn; kd[lane + half] = b * cs + a * sn;
         }
-        for (int i = lane; i < hd; i += 64) vr[(size_t)(pos % RW) * HH + i] = v[row + i];
+        for (int i = lane; i < hd; i += 64) vr[(size_t)(pos % RW) * HH + i] = vp[i];
         __syncthreads();
         const int j0 = pos - W + 1 > 0 ? pos - W + 1 : 0, nk = pos - j0 + 1;
         for (int j = lane; j < nk; j += 64) {
@@ -342,20 +376,6 @@ __global__ __launch_bounds__(64) void k_voc_dw_ln(const float* x, size_t x_strid
     const float rinv = 1.0f / sqrtf(var / (float)C + 1e-6f);
     float* yp = y + ((size_t)s * T + t) * C;
     for (int i = lane; i < C; i += 64) yp[i] = ((row[i] - mean) * rinv) * ln_w[i] + ln_b[i];
-}
-
-// SnakeBeta: y = x + ib[c] * sin(x * ea[c])^2 ; x rows [s][t] contiguous (x_stride per slot), y into a work buffer
-__global__ void k_voc_snake(const float* x, size_t x_stride, int x_off, int T, int C, const float* ea, const float* ib, float* y,
-                            size_t y_stride, int y_off) {
-    const int s = blockIdx.y;
-    const size_t n = (size_t)T * C;
-    const float* xp = x + (size_t)s * x_stride + x_off;
-    float* yp = y + (size_t)s * y_stride + y_off;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const float v = xp[i], sn = sinf(v * ea[c]);
-        yp[i] = v + ib[c] * (sn * sn);
-    }
 }
 
 // V6: Conv k7 C -> 1 over the snaked input (with history) + clamp -> PCM of the slot. A block produces 64 samples:
@@ -453,6 +473,7 @@ int q3_voc_create(q3tts_engine* e) {
 #define REQ(cond) do { if (!(cond)) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder config check failed: " #cond); } while (0)
     REQ(c.n_codebooks >= 1 && c.n_codebooks <= 16 && c.n_codebooks <= e->cfg.model.n_codebooks);
     REQ(c.codebook_dim % 32 == 0 && c.latent_dim % 32 == 0 && c.d_ffn % 32 == 0 && (c.n_head * c.head_dim) % 32 == 0);
+    REQ(c.d_ffn % 16 == 0);
     REQ(c.head_dim <= 128 && c.head_dim % 2 == 0 && c.sliding_window >= 1 && c.sliding_window + VOC_FCAP <= 512);
     REQ(c.n_upsample >= 0 && c.n_upsample <= Q3TTS_MAX_UPSAMPLE && c.n_dec_blocks >= 1 && c.n_dec_blocks <= Q3TTS_MAX_DEC_BLOCKS);
     REQ(c.pre_conv_kernel >= 1 && c.lookahead_frames >= 0);
@@ -485,6 +506,16 @@ int q3_voc_create(q3tts_engine* e) {
         VTRY(gen_conv(e, v, &y.v, comp, VW_V, 0, 1, 1, d, HH, 0, 1.0f)); VTRY(gen_conv(e, v, &y.o, comp, VW_O, 0, 1, 1, HH, d, 0, 1.0f));
         VTRY(gen_conv(e, v, &y.gate, comp, VW_GATE, 0, 1, 1, d, c.d_ffn, 0, 1.0f)); VTRY(gen_conv(e, v, &y.up, comp, VW_UP, 0, 1, 1, d, c.d_ffn, 0, 1.0f));
         VTRY(gen_conv(e, v, &y.down, comp, VW_DOWN, 0, 1, 1, c.d_ffn, d, 0, 1.0f));
+        // fused copies (same bf16 values, rearranged rows)
+        y.qkv = y.q; y.qkv.nout = 3 * HH;
+        VTRY(valloc(e, v, &y.qkv.w, (size_t)3 * HH * d));
+        Q3_HIP(e, hipMemcpyAsync(y.qkv.w, y.q.w, (size_t)HH * d * 2, hipMemcpyDeviceToDevice, e->stream));
+        Q3_HIP(e, hipMemcpyAsync(y.qkv.w + (size_t)HH * d, y.k.w, (size_t)HH * d * 2, hipMemcpyDeviceToDevice, e->stream));
+        Q3_HIP(e, hipMemcpyAsync(y.qkv.w + (size_t)2 * HH * d, y.v.w, (size_t)HH * d * 2, hipMemcpyDeviceToDevice, e->stream));
+        y.gu = y.gate; y.gu.nout = 2 * c.d_ffn;
+        VTRY(valloc(e, v, &y.gu.w, (size_t)2 * c.d_ffn * d));
+        Q3_HIP(e, hipMemcpy2DAsync(y.gu.w, (size_t)32 * d * 2, y.gate.w, (size_t)16 * d * 2, (size_t)16 * d * 2, c.d_ffn / 16, hipMemcpyDeviceToDevice, e->stream));
+        Q3_HIP(e, hipMemcpy2DAsync(y.gu.w + (size_t)16 * d, (size_t)32 * d * 2, y.up.w, (size_t)16 * d * 2, (size_t)16 * d * 2, c.d_ffn / 16, hipMemcpyDeviceToDevice, e->stream));
     }
     VTRY(gen_vec(e, v, &v->final_norm, VTID(VC_FINAL_NORM, VW_W), d, 1.0f, 0.05f));
     int rows = VOC_FCAP;  // rows per slot at the current stage
@@ -531,8 +562,8 @@ int q3_voc_create(q3tts_engine* e) {
     VTRY(mk_buf(e, v, &v->out_in, 6, ch, rows));
     // transformer scratch [VOC_MAX_NS * VOC_FCAP][.]
     const size_t M = (size_t)VOC_MAX_NS * VOC_FCAP;
-    VTRY(valloc(e, v, &v->x, M * d)); VTRY(valloc(e, v, &v->xn, M * d)); VTRY(valloc(e, v, &v->q, M * HH)); VTRY(valloc(e, v, &v->k, M * HH));
-    VTRY(valloc(e, v, &v->v, M * HH)); VTRY(valloc(e, v, &v->att, M * HH)); VTRY(valloc(e, v, &v->g, M * c.d_ffn)); VTRY(valloc(e, v, &v->u, M * c.d_ffn));
+    VTRY(valloc(e, v, &v->x, M * d)); VTRY(valloc(e, v, &v->xn, M * d)); VTRY(valloc(e, v, &v->qkv, M * 3 * HH));
+    VTRY(valloc(e, v, &v->att, M * HH)); VTRY(valloc(e, v, &v->g, M * c.d_ffn));
     VTRY(valloc(e, v, &v->kring, (size_t)c.n_layer * v->B * v->RW * HH)); VTRY(valloc(e, v, &v->vring, (size_t)c.n_layer * v->B * v->RW * HH));
     VTRY(valloc(e, v, &v->t1, (size_t)VOC_MAX_NS * scratch)); VTRY(valloc(e, v, &v->t2, (size_t)VOC_MAX_NS * scratch)); VTRY(valloc(e, v, &v->t3, (size_t)VOC_MAX_NS * scratch));
     v->pcm_stride = (size_t)e->cfg.max_steps_cap * v->spf;
@@ -565,29 +596,33 @@ int q3_voc_reset(q3tts_engine* e, int slot) {
     return Q3TTS_OK;
 }
 
+struct VSnake { float* y2 = nullptr; size_t stride = 0; int off = 0; const float* ea = nullptr; const float* ib = nullptr; int n = 1; };
+static VSnake snake_into(const VBuf& dst, const float* ea, const float* ib, int C) {
+    VSnake k; k.y2 = dst.p; k.stride = dst.stride(); k.off = dst.H * dst.C; k.ea = ea; k.ib = ib; k.n = C; return k;
+}
 static void vgemm(hipStream_t s, const VConv& c, const float* x, size_t x_stride, int x_off, int ns, int T, float* y, size_t y_stride, int y_off,
-                  int epi = 0, const float* scale = nullptr, int scale_n = 1) {
+                  int epi = 0, const float* scale = nullptr, int scale_n = 1, const VSnake* sk = nullptr, int store = 1) {
     VGemm g; g.x = x; g.x_stride = x_stride; g.x_off = x_off; g.T = T; g.M = ns * T; g.c = c; g.y = y; g.y_stride = y_stride; g.y_off = y_off;
-    g.scale = scale; g.scale_n = scale_n; g.epi = epi;
-    if (g.M >= 256) {  // both kernels accumulate the same 32-wide K steps in the same order: identical results
+    g.scale = scale; g.scale_n = scale_n; g.epi = epi; g.store = store;
+    g.y2 = nullptr; g.y2_stride = 0; g.y2_off = 0; g.ea = g.ib = nullptr; g.snake_n = 1;
+    if (sk) { g.y2 = sk->y2; g.y2_stride = sk->stride; g.y2_off = sk->off; g.ea = sk->ea; g.ib = sk->ib; g.snake_n = sk->n; }
+    // every kernel accumulates the same 32-wide K steps in the same order: the choice never changes a result
+    if (g.M <= 512 || epi == 4) {
+        dim3 grid((c.nout + 31) / 32, (g.M + 63) / 64);
+        hipLaunchKernelGGL(k_vgemm_small, grid, dim3(256), 0, s, g);
+    } else if (c.nout % 128 != 0 && c.nout % 96 == 0) {
+        dim3 grid(c.nout / 96, (g.M + 127) / 128);
+        hipLaunchKernelGGL((k_vgemm_lds<3>), grid, dim3(256), 0, s, g);
+    } else {
         dim3 grid((c.nout + 127) / 128, (g.M + 127) / 128);
-        hipLaunchKernelGGL(k_vgemm_lds, grid, dim3(256), 0, s, g);
-        return;
+        hipLaunchKernelGGL((k_vgemm_lds<4>), grid, dim3(256), 0, s, g);
     }
-    dim3 grid((c.nout + 63) / 64, (g.M + 127) / 128);
-    hipLaunchKernelGGL(k_vgemm, grid, dim3(256), 0, s, g);
 }
 static void hist(hipStream_t s, const VCall& cl, VBuf& b, int T, int save) {
     if (b.H == 0) return;
     const size_t n = (size_t)b.H * b.C;
     hipLaunchKernelGGL(k_voc_hist, dim3((unsigned)std::min<size_t>((n + 255) / 256, 64), cl.ns), dim3(256), 0, s, cl, b.p, b.stride(), b.hist, b.H, b.C, T, save);
 }
-static void snake(hipStream_t s, int ns, const float* x, size_t x_stride, int x_off, int T, int C, const float* ea, const float* ib, VBuf& dst) {
-    const size_t n = (size_t)T * C;
-    hipLaunchKernelGGL(k_voc_snake, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024), ns), dim3(256), 0, s, x, x_stride, x_off, T, C, ea, ib,
-                       dst.p, dst.stride(), dst.H * dst.C);
-}
-
 // one batched streaming call: ns slots x nf new frames each (uniform nf <= VOC_FCAP)
 static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
     Q3Voc* v = e->voc;
@@ -603,13 +638,12 @@ static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
     for (int l = 0; l < c.n_layer; ++l) {
         VLayer& L = v->L[l];
         hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, L.in_norm, c.rms_eps, d, v->xn);
-        vgemm(s, L.q, v->xn, 0, 0, 1, M, v->q, 0, 0); vgemm(s, L.k, v->xn, 0, 0, 1, M, v->k, 0, 0); vgemm(s, L.v, v->xn, 0, 0, 1, M, v->v, 0, 0);
-        hipLaunchKernelGGL(k_voc_attn, dim3(c.n_head, ns), dim3(64), 0, s, cl, v->q, v->k, v->v, v->kring + (size_t)l * v->B * v->RW * HH,
+        vgemm(s, L.qkv, v->xn, 0, 0, 1, M, v->qkv, 0, 0);
+        hipLaunchKernelGGL(k_voc_attn, dim3(c.n_head, ns), dim3(64), 0, s, cl, v->qkv, v->kring + (size_t)l * v->B * v->RW * HH,
                            v->vring + (size_t)l * v->B * v->RW * HH, c.n_head, c.head_dim, v->RW, c.sliding_window, c.rope_theta, v->att);
         vgemm(s, L.o, v->att, 0, 0, 1, M, v->x, 0, 0, 1, L.ls_attn, d);
         hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, L.post_norm, c.rms_eps, d, v->xn);
-        vgemm(s, L.gate, v->xn, 0, 0, 1, M, v->g, 0, 0); vgemm(s, L.up, v->xn, 0, 0, 1, M, v->u, 0, 0);
-        hipLaunchKernelGGL(k_voc_swiglu, dim3((unsigned)std::min<size_t>(((size_t)M * c.d_ffn + 255) / 256, 2048)), dim3(256), 0, s, v->g, v->u, (size_t)M * c.d_ffn);
+        vgemm(s, L.gu, v->xn, 0, 0, 1, M, v->g, 0, 0, 4);  // gate | up in one launch, SwiGLU in the epilogue
         vgemm(s, L.down, v->g, 0, 0, 1, M, v->x, 0, 0, 1, L.ls_mlp, d);
     }
     hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, v->final_norm, c.rms_eps, d, v->xn);
@@ -630,29 +664,40 @@ static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
     hipMemcpy2DAsync(v->dec_in_in.p + (size_t)v->dec_in_in.H * d, v->dec_in_in.stride() * 4, cur + cur_off, cur_stride * 4, (size_t)T * d * 4, ns,
                      hipMemcpyDeviceToDevice, s);
     int ch = c.decoder_dim;
-    vgemm(s, v->dec_in, v->dec_in_in.p, v->dec_in_in.stride(), v->dec_in_in.H * d, ns, T, v->t1, (size_t)T * ch, 0);
+    // Every SnakeBeta runs in the epilogue of the convolution that produces its input and lands directly in the
+    // work buffer of the convolution that consumes it: dec_in -> blk0.ct_in; ct -> res0.c1_in; c1 -> (snake2) -> c2's
+    // input; c2 -> next unit's c1_in / next block's ct_in / the final conv's window.
+    hist(s, cl, v->Bk[0].ct_in, T, 0);
+    {
+        const VSnake sk = snake_into(v->Bk[0].ct_in, v->Bk[0].ea, v->Bk[0].ib, ch);
+        vgemm(s, v->dec_in, v->dec_in_in.p, v->dec_in_in.stride(), v->dec_in_in.H * d, ns, T, v->t1, (size_t)T * ch, 0, 0, nullptr, 1, &sk, 0);
+    }
     hist(s, cl, v->dec_in_in, T, 1);
-    float* z = v->t1; float* o = v->t2; float* w2 = v->t3;
-    for (auto& k : v->Bk) {
-        hist(s, cl, k.ct_in, T, 0);
-        snake(s, ns, z, (size_t)T * k.cin, 0, T, k.cin, k.ea, k.ib, k.ct_in);
-        vgemm(s, k.ct, k.ct_in.p, k.ct_in.stride(), k.ct_in.H * k.cin, ns, T, o, (size_t)T * k.r * k.cout, 0);
+    float* z = v->t1; float* o = v->t2;
+    for (size_t bi = 0; bi < v->Bk.size(); ++bi) {
+        VBlk& k = v->Bk[bi];
+        hist(s, cl, k.res[0].c1_in, T * k.r, 0);
+        {
+            const VSnake sk = snake_into(k.res[0].c1_in, k.res[0].ea, k.res[0].ib, k.cout);
+            vgemm(s, k.ct, k.ct_in.p, k.ct_in.stride(), k.ct_in.H * k.cin, ns, T, o, (size_t)T * k.r * k.cout, 0, 0, nullptr, 1, &sk, 1);
+        }
         hist(s, cl, k.ct_in, T, 1);
         T *= k.r; ch = k.cout;
-        for (auto& r : k.res) {
-            hist(s, cl, r.c1_in, T, 0);
-            snake(s, ns, o, (size_t)T * ch, 0, T, ch, r.ea, r.ib, r.c1_in);
-            vgemm(s, r.c1, r.c1_in.p, r.c1_in.stride(), r.c1_in.H * ch, ns, T, w2, (size_t)T * ch, 0);
+        for (int u = 0; u < 3; ++u) {
+            VRes& r = k.res[u];
+            {
+                VSnake sk; sk.y2 = z; sk.stride = (size_t)T * ch; sk.off = 0; sk.ea = r.ea2; sk.ib = r.ib2; sk.n = ch;  // snake2 -> z
+                vgemm(s, r.c1, r.c1_in.p, r.c1_in.stride(), r.c1_in.H * ch, ns, T, z, (size_t)T * ch, 0, 0, nullptr, 1, &sk, 0);
+            }
             hist(s, cl, r.c1_in, T, 1);
-            VBuf tmp; tmp.p = z; tmp.H = 0; tmp.C = ch; tmp.Tcap = T;  // snake2 into z (plain [ns][T][ch])
-            snake(s, ns, w2, (size_t)T * ch, 0, T, ch, r.ea2, r.ib2, tmp);
-            vgemm(s, r.c2, z, (size_t)T * ch, 0, ns, T, o, (size_t)T * ch, 0, 2);  // o += conv k1
+            VSnake sk;
+            if (u < 2) { hist(s, cl, k.res[u + 1].c1_in, T, 0); sk = snake_into(k.res[u + 1].c1_in, k.res[u + 1].ea, k.res[u + 1].ib, ch); }
+            else if (bi + 1 < v->Bk.size()) { VBlk& nx = v->Bk[bi + 1]; hist(s, cl, nx.ct_in, T, 0); sk = snake_into(nx.ct_in, nx.ea, nx.ib, ch); }
+            else { hist(s, cl, v->out_in, T, 0); sk = snake_into(v->out_in, v->oea, v->oib, ch); }
+            vgemm(s, r.c2, z, (size_t)T * ch, 0, ns, T, o, (size_t)T * ch, 0, 2, nullptr, 1, &sk, u < 2 ? 1 : 0);  // o += conv k1
         }
-        std::swap(z, o);  // block output now in z
     }
     // V6
-    hist(s, cl, v->out_in, T, 0);
-    snake(s, ns, z, (size_t)T * ch, 0, T, ch, v->oea, v->oib, v->out_in);
     hipLaunchKernelGGL(k_voc_out, dim3((T + 63) / 64, ns), dim3(256), (size_t)(70 * (ch + 1) + 7 * ch) * 4, s, cl, v->out_in.p, v->out_in.stride(), v->out_in.H, T, ch, v->out_w, v->out_b,
                        v->pcm, v->pcm_stride, v->spf);
     hist(s, cl, v->out_in, T, 1);
