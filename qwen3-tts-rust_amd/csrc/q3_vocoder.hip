@@ -80,12 +80,12 @@ struct VGemm {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
 // shared epilogue of one output element (row (s, t), column n)
-__device__ __forceinline__ void vepi(const VGemm& g, float v, int s, int t, int n) {
+__device__ __forceinline__ void vepi(const VGemm& g, float v, int s, int t, int n, float yold) {
     const int nout = g.c.nout;
     if (g.c.b) v += g.c.b[n % g.c.bias_n];
     float* yp = g.y + (size_t)s * g.y_stride + g.y_off + (size_t)t * nout + n;
-    if (g.epi == 1) v = *yp + g.scale[n % g.scale_n] * v;
-    else if (g.epi == 2) v = *yp + v;
+    if (g.epi == 1) v = yold + g.scale[n % g.scale_n] * v;
+    else if (g.epi == 2) v = yold + v;
     else if (g.epi == 3) v = gelu_erf(v);
     if (g.store) *yp = v;
     if (g.y2) {
@@ -166,7 +166,10 @@ __global__ __launch_bounds__(256) void k_vgemm_small(VGemm g) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n = n0 + j * 16 + lr;
-                if (n < nout) vepi(g, acc[j][e], s, t, n);
+                if (n < nout) {
+                    const float yold = (g.epi == 1 || g.epi == 2) ? g.y[(size_t)s * g.y_stride + g.y_off + (size_t)t * nout + n] : 0.0f;
+                    vepi(g, acc[j][e], s, t, n, yold);
+                }
             }
         }
     }
@@ -248,8 +251,20 @@ __global__ __launch_bounds__(256) void k_vgemm_lds(VGemm g) {
         VT_COMPUTE(1);
         __syncthreads();
     }
+    const bool rmw = g.epi == 1 || g.epi == 2;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+        float yv[4][NJ];  // residual operands of this row tile: one batch of loads, not a round trip per element
+        if (rmw) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = min(m0 + wm * 64 + i * 16 + 4 * kq + e, g.M - 1);
+                const int s = m / g.T, t = m - s * g.T;
+                const float* yp = g.y + (size_t)s * g.y_stride + g.y_off + (size_t)t * nout;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) yv[e][j] = yp[min(n0 + wn * NJ * 16 + j * 16 + lr, nout - 1)];
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int m = m0 + wm * 64 + i * 16 + 4 * kq + e;
@@ -258,7 +273,157 @@ __global__ __launch_bounds__(256) void k_vgemm_lds(VGemm g) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int n = n0 + wn * NJ * 16 + j * 16 + lr;
-                if (n < nout) vepi(g, acc[i][j][e], s, t, n);
+                if (n < nout) vepi(g, acc[i][j][e], s, t, n, rmw ? yv[e][j] : 0.0f);
+            }
+        }
+    }
+}
+
+// Fused residual unit of the narrow decoder blocks (C <= 192 channels, where everything is HBM-bound):
+//   o += conv1x1(snake2(conv7_dil(xin)))  and  next_in = snake_next(o)
+// in ONE pass: the workgroup stages its R + 6*dil input rows in LDS as bf16 once (the seven taps read LDS, not HBM),
+// streams the weight chunks through a double-buffered LDS ring, keeps the intermediate (snake2 output) as a bf16 tile
+// in LDS for the 1x1 convolution and finishes with the residual read-modify-write. HBM traffic per unit: read xin,
+// read/write o, write next_in: the un-fused chain moved the activations three more times. Arithmetic per output element
+// is the same as k_vgemm_lds + vepi (32-wide K steps in order, bf16 operands, f32 accumulate).
+struct VResUnit {
+    const float* xin; size_t xin_stride;  // work buffer [H + T][C] per slot, H = 6*dil history rows in front
+    int T, dil;
+    const uint16_t *w1, *w2; const float *b1, *b2;  // conv k7 [7][C][C], conv k1 [C][C]
+    const float *ea2, *ib2;               // snake between the convolutions
+    float* o; size_t o_stride; int store_o;
+    float* y2; size_t y2_stride; int y2_off; const float *ea3, *ib3;  // snake of the consumer, written into its work buffer
+};
+template <int NT, int MT>
+__global__ __launch_bounds__(256) void k_voc_resunit(VResUnit g) {
+    constexpr int C = NT * 16, KS = C / 32, R = 64 * MT, LDA = C + 8, S1 = 7 * KS, S = 8 * KS;
+    constexpr int BPASS = (C + 63) / 64;  // weight-chunk loader passes: 64 rows x 64 B per pass
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
+    const int halo = 6 * g.dil;
+    __bf16* At = lds;                                  // [R + halo][LDA]
+    __bf16* Zt = lds;                                  // [R][LDA]: reuses the input tile once conv1 has consumed it
+    __bf16* Bs = At + (size_t)(R + halo) * LDA;         // [2][C][VT_LD]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+    const int sidx = blockIdx.y, t0 = blockIdx.x * R, T = g.T;
+    // weight chunk pipeline: chunk c < S1 is (tap, ks) of conv1, chunk S1 + ks is conv2
+    const int bn = tid >> 2, bpart = tid & 3;
+    uint4 rb0, rb1, rb2;  // (named scalars: an indexed array lands in scratch here)
+    rb1 = rb2 = make_uint4(0, 0, 0, 0);
+#define VR_GLOADB(step_)                                                                                                 \
+    do {                                                                                                                \
+        const int st__ = min((step_), S - 1);                                                                           \
+        const uint16_t* base__ = (st__ < S1 ? g.w1 + (size_t)(st__ / KS) * C * C + (st__ % KS) * 32 : g.w2 + (st__ - S1) * 32) + bpart * 8; \
+        rb0 = *(const uint4*)(base__ + (size_t)min(bn, C - 1) * C);                                                      \
+        if (BPASS > 1) rb1 = *(const uint4*)(base__ + (size_t)min(bn + 64, C - 1) * C);                                  \
+        if (BPASS > 2) rb2 = *(const uint4*)(base__ + (size_t)min(bn + 128, C - 1) * C);                                 \
+    } while (0)
+#define VR_SSTOREB(buf_)                                                                                                \
+    do {                                                                                                                \
+        __bf16* d__ = &Bs[((size_t)(buf_) * C + bn) * VT_LD + bpart * 8];                                               \
+        if (bn < C) *(uint4*)d__ = rb0;                                                                                 \
+        if (BPASS > 1 && bn + 64 < C) *(uint4*)(d__ + 64 * VT_LD) = rb1;                                                \
+        if (BPASS > 2 && bn + 128 < C) *(uint4*)(d__ + 128 * VT_LD) = rb2;                                              \
+    } while (0)
+    VR_GLOADB(0);
+    // stage the input rows (f32 -> bf16), rows past T are zero
+    {
+        const float* xp = g.xin + (size_t)sidx * g.xin_stride + (size_t)t0 * C;  // buffer row t0 = output row t0 - halo
+        const int nrow = R + halo, c4 = C / 4, total = nrow * c4;
+        for (int base = tid; base < total; base += 8 * 256) {  // 8 loads in flight per thread, then convert + store
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(base + u * 256, total - 1), r = i / c4, c = (i - r * c4) * 4;
+                v[u] = *(const float4*)(xp + (size_t)min(r, T + halo - 1 - t0) * C + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256;
+                if (i < total) {
+                    const int r = i / c4, c = (i - r * c4) * 4;
+                    const bool live = t0 + r < T + halo;
+                    __bf16* d = At + (size_t)r * LDA + c;
+                    d[0] = (__bf16)(live ? v[u].x : 0.f); d[1] = (__bf16)(live ? v[u].y : 0.f);
+                    d[2] = (__bf16)(live ? v[u].z : 0.f); d[3] = (__bf16)(live ? v[u].w : 0.f);
+                }
+            }
+        }
+    }
+    VR_SSTOREB(0);
+    VR_GLOADB(1);
+    __syncthreads();
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wrow0 = wave * MT * 16;
+#define VR_STEP(step_, SRC_, ROWOFF_, KOFF_)                                                                             \
+    do {                                                                                                                \
+        const int buf__ = (step_) & 1;                                                                                  \
+        bf16x8 a__[MT], b__[NT];                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                  \
+            a__[i] = *(const bf16x8*)&SRC_[(size_t)(wrow0 + i * 16 + lr + (ROWOFF_)) * LDA + (KOFF_) + kq * 8];         \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                  \
+            b__[j] = *(const bf16x8*)&Bs[((size_t)buf__ * C + j * 16 + lr) * VT_LD + kq * 8];                           \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                  \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                              \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a__[i], b__[j], acc[i][j], 0, 0, 0);                \
+        VR_SSTOREB(buf__ ^ 1);                                                                                          \
+        VR_GLOADB((step_) + 2);                                                                                         \
+        __syncthreads();                                                                                                \
+    } while (0)
+    for (int step = 0; step < S1; ++step) {
+        const int tap = step / KS, ks = step - tap * KS;
+        VR_STEP(step, At, tap * g.dil, ks * 32);
+    }
+    // the residual operand is fetched now and consumed after the second convolution (one batch of loads in flight,
+    // not one round trip per element)
+    float ov[MT][4][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int t = min(t0 + wrow0 + i * 16 + 4 * kq + e, T - 1);
+            const float* op = g.o + (size_t)sidx * g.o_stride + (size_t)t * C;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) ov[i][e][j] = op[j * 16 + lr];
+        }
+    // snake2(conv1 + bias) -> bf16 tile (D layout: lane holds rows 4*kq+e, column lr of every tile)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = j * 16 + lr;
+            const float bb = g.b1[n], ea = g.ea2[n], ib = g.ib2[n];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = acc[i][j][e] + bb;
+                const float sn = __sinf(v * ea);
+                Zt[(size_t)(wrow0 + i * 16 + 4 * kq + e) * LDA + n] = (__bf16)(v + ib * (sn * sn));
+                acc[i][j][e] = 0.0f;
+            }
+        }
+    __syncthreads();
+    for (int step = S1; step < S; ++step) VR_STEP(step, Zt, 0, (step - S1) * 32);
+#undef VR_STEP
+#undef VR_GLOADB
+#undef VR_SSTOREB
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int t = t0 + wrow0 + i * 16 + 4 * kq + e;
+            if (t >= T) continue;
+            float* op = g.o + (size_t)sidx * g.o_stride + (size_t)t * C;
+            float* yp = g.y2 + (size_t)sidx * g.y2_stride + g.y2_off + (size_t)t * C;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = j * 16 + lr;
+                const float v = ov[i][e][j] + (acc[i][j][e] + g.b2[n]);
+                if (g.store_o) op[n] = v;
+                const float sn = __sinf(v * g.ea3[n]);
+                yp[n] = v + g.ib3[n] * (sn * sn);
             }
         }
 }
@@ -618,6 +783,32 @@ static void vgemm(hipStream_t s, const VConv& c, const float* x, size_t x_stride
         hipLaunchKernelGGL((k_vgemm_lds<4>), grid, dim3(256), 0, s, g);
     }
 }
+static bool resunit_ok(int C) {
+    static const int off = getenv("Q3TTS_VOC_NOFUSE") ? atoi(getenv("Q3TTS_VOC_NOFUSE")) : 0;
+    return !off && (C == 32 || C == 64 || C == 96 || C == 128 || C == 192);
+}
+template <int NT, int MT>
+static void launch_resunit_t(hipStream_t s, const VResUnit& g, int ns) {
+    constexpr int C = NT * 16, R = 64 * MT, LDA = C + 8;
+    const size_t lds = ((size_t)(R + 6 * g.dil) * LDA + (size_t)2 * C * VT_LD) * 2;
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute((const void*)k_voc_resunit<NT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr_set = true; }
+    hipLaunchKernelGGL((k_voc_resunit<NT, MT>), dim3((g.T + R - 1) / R, ns), dim3(256), lds, s, g);
+}
+static void launch_resunit(hipStream_t s, const VRes& r, int ns, int T, int C, float* o, int store_o, const VSnake& sk) {
+    VResUnit g;
+    g.xin = r.c1_in.p; g.xin_stride = r.c1_in.stride(); g.T = T; g.dil = r.c1.dil;
+    g.w1 = r.c1.w; g.w2 = r.c2.w; g.b1 = r.c1.b; g.b2 = r.c2.b; g.ea2 = r.ea2; g.ib2 = r.ib2;
+    g.o = o; g.o_stride = (size_t)T * C; g.store_o = store_o;
+    g.y2 = sk.y2; g.y2_stride = sk.stride; g.y2_off = sk.off; g.ea3 = sk.ea; g.ib3 = sk.ib;
+    switch (C) {
+        case 32: launch_resunit_t<2, 4>(s, g, ns); break;
+        case 64: launch_resunit_t<4, 3>(s, g, ns); break;
+        case 96: launch_resunit_t<6, 2>(s, g, ns); break;
+        case 128: launch_resunit_t<8, 1>(s, g, ns); break;
+        default: launch_resunit_t<12, 1>(s, g, ns); break;
+    }
+}
 static void hist(hipStream_t s, const VCall& cl, VBuf& b, int T, int save) {
     if (b.H == 0) return;
     const size_t n = (size_t)b.H * b.C;
@@ -685,6 +876,15 @@ static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
         T *= k.r; ch = k.cout;
         for (int u = 0; u < 3; ++u) {
             VRes& r = k.res[u];
+            if (resunit_ok(ch)) {  // narrow blocks: the whole residual unit in one pass over HBM
+                VSnake sk;
+                if (u < 2) { hist(s, cl, k.res[u + 1].c1_in, T, 0); sk = snake_into(k.res[u + 1].c1_in, k.res[u + 1].ea, k.res[u + 1].ib, ch); }
+                else if (bi + 1 < v->Bk.size()) { VBlk& nx = v->Bk[bi + 1]; hist(s, cl, nx.ct_in, T, 0); sk = snake_into(nx.ct_in, nx.ea, nx.ib, ch); }
+                else { hist(s, cl, v->out_in, T, 0); sk = snake_into(v->out_in, v->oea, v->oib, ch); }
+                launch_resunit(s, r, ns, T, ch, o, u < 2 ? 1 : 0, sk);
+                hist(s, cl, r.c1_in, T, 1);
+                continue;
+            }
             {
                 VSnake sk; sk.y2 = z; sk.stride = (size_t)T * ch; sk.off = 0; sk.ea = r.ea2; sk.ib = r.ib2; sk.n = ch;  // snake2 -> z
                 vgemm(s, r.c1, r.c1_in.p, r.c1_in.stride(), r.c1_in.H * ch, ns, T, z, (size_t)T * ch, 0, 0, nullptr, 1, &sk, 0);
