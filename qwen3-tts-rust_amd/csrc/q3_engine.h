@@ -1,5 +1,6 @@
 // q3_engine.h — internal engine state of libq3tts (host side, C++). The public surface is include/q3tts.h.
 #pragma once
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -26,16 +27,16 @@ struct Q3Scratch {
     int rows = 0;
 };
 
-// one lane = rows [0, nb) <-> slots [b0, b0 + nb): per-row buffers, its own stream and frame-step graph
+// the decode rows: per-row buffers, the row -> slot map and one captured frame-step graph per row-count bucket
 struct Q3Lane {
-    int b0 = 0, nb = 0;
+    int nb = 0;                       // row capacity = max_batch
     hipStream_t stream = nullptr;
-    float *xT = nullptr, *logits = nullptr, *X = nullptr, *fb = nullptr, *px = nullptr;
+    float *xT = nullptr, *logits = nullptr, *logits_tmp = nullptr, *X = nullptr, *fb = nullptr, *px = nullptr;
     unsigned long long* keys = nullptr;
-    int *row_pos_t = nullptr, *slot_id = nullptr, *posA = nullptr, *slotA = nullptr, *pos_q = nullptr;
+    int *row_pos_t = nullptr, *slot_id = nullptr, *posA = nullptr, *slotA = nullptr, *pos_q = nullptr, *perm = nullptr;
     Q3Scratch sc;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
+    std::vector<hipGraph_t> graphs;          // per bucket
+    std::vector<hipGraphExec_t> execs;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
 };
 
@@ -51,9 +52,12 @@ struct q3tts_engine {
     uint4* proj_w = nullptr;
     float* proj_b = nullptr;
     float* tts_pad = nullptr;             // = text[tts_pad_id]
-    // decode state: B = max_batch slots, split over `lanes` (independent slot groups replayed concurrently on their
-    // own HIP streams so that one group's latency-bound kernel chain fills the other's gaps)
+    // decode state: B = max_batch slots. A frame step runs on `rows` = the smallest bucket (1, 2, 4, ... B) that holds
+    // the live slots: rows [0, n_live) carry the live slots, the rest carry distinct idle slots (row -> slot map on the
+    // device), so a draining batch stops paying for rows it no longer has.
     int B = 0;
+    std::vector<int> buckets; int cur_bucket = -1;
+    std::vector<int> row_of_slot, slot_of_row;
     Q3Slot* slots = nullptr;              // device [B]
     Q3Slot* slots_host = nullptr;         // pinned mirror [B] + staging [B]
     int* codes = nullptr;                 // [B][max_steps_cap][ncb]

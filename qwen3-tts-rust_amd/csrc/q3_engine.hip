@@ -183,22 +183,22 @@ static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, int rows, const int*
 }
 
 // one frame: src/tts/engine.rs:545-642 for the slots [b0, b0 + nb) of one lane
-static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s) {
+static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
     const q3tts_model_config& m = e->cfg.model;
-    const int B = L.nb, ncb = m.n_codebooks, cbs = m.codebook_size, dp = m.p_d_model, de = m.d_embed, cap = e->cfg.max_steps_cap;
+    const int ncb = m.n_codebooks, cbs = m.codebook_size, dp = m.p_d_model, de = m.d_embed, cap = e->cfg.max_steps_cap;
     const float eps = m.rms_eps;
-    Q3Slot* slots = e->slots + L.b0;
-    int* codes = e->codes + (size_t)L.b0 * cap * ncb;
-    Q3Sample sa{}; sa.logits = L.logits; sa.ld = m.t_vocab; sa.limit = m.sample_limit; sa.eos = m.eos_code; sa.slots = slots; sa.B = B;
+    Q3Slot* slots = e->slots;
+    int* codes = e->codes;
+    Q3Sample sa{}; sa.logits = L.logits; sa.ld = m.t_vocab; sa.limit = m.sample_limit; sa.eos = m.eos_code; sa.slots = slots; sa.B = B; sa.row_slot = L.slot_id;
     sa.rng = e->rng; sa.codes = codes; sa.max_steps_cap = cap; sa.ncb = ncb; sa.keys = L.keys;
     q3_launch_sample(sa, s);
     Q3PredInput pi{}; pi.xT = L.xT; pi.out_norm = e->T.out_norm; pi.eps = eps; pi.d = de; pi.codec0 = e->codec[0]; pi.codec0_rows = m.codec0_rows;
-    pi.slots = slots; pi.X = L.X; pi.fb = L.fb; pi.B = B;
+    pi.slots = slots; pi.row_slot = L.slot_id; pi.X = L.X; pi.fb = L.fb; pi.B = B;
     q3_launch_pred_input(pi, s);
     const size_t head_tile_stride = (size_t)(cbs / 16) * (dp / 32) * 64;  // uint4 per predictor head
     auto pred_next = [&](int q) {
         Q3PredNext pn{}; pn.keys = L.keys; pn.q = q; pn.ncb = ncb; pn.codec_q = e->codec[q]; pn.rows_q = m.codecq_rows; pn.d = de;
-        pn.slots = slots; pn.B = B; pn.codes = codes; pn.max_steps_cap = cap; pn.fb = L.fb; pn.X = L.X;
+        pn.slots = slots; pn.row_slot = L.slot_id; pn.B = B; pn.codes = codes; pn.max_steps_cap = cap; pn.fb = L.fb; pn.X = L.X;
         pn.tts_pad = e->tts_pad; pn.xT = L.xT; pn.row_pos_t = L.row_pos_t;
         q3_launch_pred_next(pn, s);
     };
@@ -207,7 +207,7 @@ static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s) {
         if (q > 0) pred_next(q);
         Q3Gemm g{}; g.x = L.X; g.ldx = de; g.B = rows; g.w = e->proj_w; g.K = de; g.N = dp; g.bias = e->proj_b; g.y = L.px; g.ldy = dp;
         g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);  // H6: src/assets_manager.rs:383-399
-        run_layers(e, e->P, L.px, rows, q == 0 ? L.posA : L.pos_q + (size_t)q * B, q == 0 ? L.slotA : L.slot_id, L.sc, s, q > 0);
+        run_layers(e, e->P, L.px, rows, q == 0 ? L.posA : L.pos_q + (size_t)q * L.nb, q == 0 ? L.slotA : L.slot_id, L.sc, s, q > 0);
         g = Q3Gemm{}; g.x = q == 0 ? L.px + dp : L.px; g.ldx = q == 0 ? 2 * dp : dp; g.B = B; g.w = e->P.head + head_tile_stride * q;
         g.K = dp; g.N = cbs; g.norm_w = e->P.out_norm; g.eps = eps; g.keys = L.keys + (q + 1); g.key_stride = ncb; g.epi = Q3_EPI_ARGMAX;
         q3_launch_gemm(g, s);
@@ -274,33 +274,32 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
     memset(e->slots_host, 0, sizeof(Q3Slot) * 2 * B);
     TRYC(dalloc(e, &e->codes, (size_t)B * cfg->max_steps_cap * m.n_codebooks)); TRYC(dalloc(e, &e->rng, (size_t)B * cfg->max_steps_cap));
     {
-        int n_lanes = 1;  // measured on MI355X: 2 or 4 lanes do not beat 1 (kernels fill the chip; Q3TTS_LANES overrides)
-        if (getenv("Q3TTS_LANES")) n_lanes = atoi(getenv("Q3TTS_LANES"));
-        if (n_lanes < 1 || n_lanes > 8 || B % n_lanes) n_lanes = 1;
-        const int nb = B / n_lanes;
+        const int nb = B;
         const int nqkv_max = std::max(e->T.nqkv, e->P.nqkv), nq_max = std::max(e->T.nq, e->P.nq), F_max = std::max(e->T.F, e->P.F);
-        e->lanes.resize(n_lanes);
-        for (int li = 0; li < n_lanes; ++li) {
-            Q3Lane& L = e->lanes[li];
-            L.b0 = li * nb; L.nb = nb;
-            HIPC(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
-            HIPC(hipEventCreate(&L.ev_begin)); HIPC(hipEventCreate(&L.ev_end));
-            TRYC(dalloc(e, &L.xT, (size_t)nb * m.t_d_model)); TRYC(dalloc(e, &L.logits, (size_t)nb * m.t_vocab));
-            TRYC(dalloc(e, &L.X, (size_t)2 * nb * m.d_embed)); TRYC(dalloc(e, &L.fb, (size_t)nb * m.d_embed));
-            TRYC(dalloc(e, &L.px, (size_t)2 * nb * m.p_d_model)); TRYC(dalloc(e, &L.keys, (size_t)nb * m.n_codebooks));
-            TRYC(dalloc(e, &L.row_pos_t, (size_t)nb)); TRYC(dalloc(e, &L.slot_id, (size_t)nb));
-            TRYC(dalloc(e, &L.posA, (size_t)2 * nb)); TRYC(dalloc(e, &L.slotA, (size_t)2 * nb)); TRYC(dalloc(e, &L.pos_q, (size_t)m.n_codebooks * nb));
-            std::vector<int> sid(nb), pa(2 * nb), sla(2 * nb), pq((size_t)m.n_codebooks * nb), rp(nb, -1);
-            for (int b = 0; b < nb; ++b) { sid[b] = L.b0 + b; pa[2 * b] = 0; pa[2 * b + 1] = 1; sla[2 * b] = sla[2 * b + 1] = L.b0 + b; }
-            for (int q = 0; q < m.n_codebooks; ++q) for (int b = 0; b < nb; ++b) pq[(size_t)q * nb + b] = q + 1;  // src/tts/engine.rs:604
-            HIPC(hipMemcpyAsync(L.slot_id, sid.data(), nb * 4, hipMemcpyHostToDevice, s));
-            HIPC(hipMemcpyAsync(L.posA, pa.data(), 2 * nb * 4, hipMemcpyHostToDevice, s));
-            HIPC(hipMemcpyAsync(L.slotA, sla.data(), 2 * nb * 4, hipMemcpyHostToDevice, s));
-            HIPC(hipMemcpyAsync(L.pos_q, pq.data(), pq.size() * 4, hipMemcpyHostToDevice, s));
-            HIPC(hipMemcpyAsync(L.row_pos_t, rp.data(), nb * 4, hipMemcpyHostToDevice, s));
-            HIPC(hipStreamSynchronize(s));
-            TRYC(alloc_scratch(e, L.sc, 2 * nb, nqkv_max, nq_max, F_max, std::max(m.t_d_model, m.p_d_model)));
-        }
+        e->lanes.resize(1);
+        Q3Lane& L = e->lanes[0];
+        L.nb = nb;
+        HIPC(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        HIPC(hipEventCreate(&L.ev_begin)); HIPC(hipEventCreate(&L.ev_end));
+        TRYC(dalloc(e, &L.xT, (size_t)nb * m.t_d_model)); TRYC(dalloc(e, &L.logits, (size_t)nb * m.t_vocab)); TRYC(dalloc(e, &L.logits_tmp, (size_t)nb * std::max(m.t_vocab, m.t_d_model)));
+        TRYC(dalloc(e, &L.X, (size_t)2 * nb * m.d_embed)); TRYC(dalloc(e, &L.fb, (size_t)nb * m.d_embed));
+        TRYC(dalloc(e, &L.px, (size_t)2 * nb * m.p_d_model)); TRYC(dalloc(e, &L.keys, (size_t)nb * m.n_codebooks));
+        TRYC(dalloc(e, &L.row_pos_t, (size_t)nb)); TRYC(dalloc(e, &L.slot_id, (size_t)nb)); TRYC(dalloc(e, &L.perm, (size_t)nb));
+        TRYC(dalloc(e, &L.posA, (size_t)2 * nb)); TRYC(dalloc(e, &L.slotA, (size_t)2 * nb)); TRYC(dalloc(e, &L.pos_q, (size_t)m.n_codebooks * nb));
+        std::vector<int> sid(nb), pa(2 * nb), sla(2 * nb), pq((size_t)m.n_codebooks * nb), rp(nb, -1);
+        for (int b = 0; b < nb; ++b) { sid[b] = b; pa[2 * b] = 0; pa[2 * b + 1] = 1; sla[2 * b] = sla[2 * b + 1] = b; }
+        for (int q = 0; q < m.n_codebooks; ++q) for (int b = 0; b < nb; ++b) pq[(size_t)q * nb + b] = q + 1;  // src/tts/engine.rs:604
+        HIPC(hipMemcpyAsync(L.slot_id, sid.data(), nb * 4, hipMemcpyHostToDevice, s));
+        HIPC(hipMemcpyAsync(L.posA, pa.data(), 2 * nb * 4, hipMemcpyHostToDevice, s));
+        HIPC(hipMemcpyAsync(L.slotA, sla.data(), 2 * nb * 4, hipMemcpyHostToDevice, s));
+        HIPC(hipMemcpyAsync(L.pos_q, pq.data(), pq.size() * 4, hipMemcpyHostToDevice, s));
+        HIPC(hipMemcpyAsync(L.row_pos_t, rp.data(), nb * 4, hipMemcpyHostToDevice, s));
+        HIPC(hipStreamSynchronize(s));
+        TRYC(alloc_scratch(e, L.sc, 2 * nb, nqkv_max, nq_max, F_max, std::max(m.t_d_model, m.p_d_model)));
+        for (int r = 1; r < nb; r *= 2) e->buckets.push_back(r);
+        e->buckets.push_back(nb);
+        e->cur_bucket = (int)e->buckets.size() - 1;
+        e->row_of_slot = sid; e->slot_of_row = sid;
     }
     TRYC(alloc_scratch(e, e->sc_pre, cfg->n_ctx, e->T.nqkv, e->T.nq, e->T.F, m.t_d_model));
     TRYC(dalloc(e, &e->xp, (size_t)cfg->n_ctx * m.t_d_model));
@@ -314,14 +313,17 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
         TRYC(q3_voc_create(e));
         HIPC(hipHostMalloc((void**)&e->first_chunk_host, sizeof(float) * 4 * (size_t)q3_voc_samples_per_frame(e), hipHostMallocDefault));
     }
-    // capture each lane's frame step once; every later frame is a replay (Q3TTS_NO_GRAPH=1: eager launches, for profilers)
+    // capture the frame step once per row-count bucket; every later frame is a replay (Q3TTS_NO_GRAPH=1: eager launches,
+    // for profilers)
     HIPC(hipStreamSynchronize(s));
     if (!(getenv("Q3TTS_NO_GRAPH") && atoi(getenv("Q3TTS_NO_GRAPH")))) {
-        for (auto& L : e->lanes) {
+        Q3Lane& L = e->lanes[0];
+        L.graphs.resize(e->buckets.size(), nullptr); L.execs.resize(e->buckets.size(), nullptr);
+        for (size_t bi = 0; bi < e->buckets.size(); ++bi) {
             HIPC(hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal));
-            record_frame(e, L, L.stream);
-            HIPC(hipStreamEndCapture(L.stream, &L.graph));
-            HIPC(hipGraphInstantiate(&L.graph_exec, L.graph, nullptr, nullptr, 0));
+            record_frame(e, L, L.stream, e->buckets[bi]);
+            HIPC(hipStreamEndCapture(L.stream, &L.graphs[bi]));
+            HIPC(hipGraphInstantiate(&L.execs[bi], L.graphs[bi], nullptr, nullptr, 0));
             HIPC(hipStreamSynchronize(L.stream));
         }
     }
@@ -342,8 +344,9 @@ extern "C" void q3tts_engine_destroy(q3tts_engine* e) {
     if (e->first_chunk_host) hipHostFree(e->first_chunk_host);
     for (auto& L : e->lanes) {
         if (L.stream) hipStreamSynchronize(L.stream);
-        if (L.graph_exec) hipGraphExecDestroy(L.graph_exec);
-        if (L.graph) hipGraphDestroy(L.graph);
+        for (auto ge : L.execs) if (ge) hipGraphExecDestroy(ge);
+        for (auto gr : L.graphs) if (gr) hipGraphDestroy(gr);
+        hipFree(L.logits_tmp); hipFree(L.perm);
         hipFree(L.xT); hipFree(L.logits); hipFree(L.X); hipFree(L.fb); hipFree(L.px); hipFree(L.keys);
         hipFree(L.row_pos_t); hipFree(L.slot_id); hipFree(L.posA); hipFree(L.slotA); hipFree(L.pos_q);
         hipFree(L.sc.qkv); hipFree(L.sc.att); hipFree(L.sc.h);
@@ -450,36 +453,57 @@ extern "C" int q3tts_build_prompt(q3tts_engine* e, const q3tts_prompt_desc* p, f
 // ------------------------------------------------------------------------------------------------
 // generation
 // ------------------------------------------------------------------------------------------------
-static inline Q3Lane& lane_of(q3tts_engine* e, int b) { return e->lanes[b / e->lanes[0].nb]; }
-
-// CH frame steps on every lane in `mask`, concurrently; afterwards the main stream has the slot mirror on the host.
-// Returns the device time of the slowest lane (ms).
-static int run_chunk(q3tts_engine* e, unsigned mask, int CH, float* dev_ms) {
+// Map the live slots onto rows [0, n) of the smallest bucket that holds them (idle slots fill the rest: every row keeps
+// a distinct, valid slot). Row-indexed state that outlives a frame (the Talker logits) moves with its slot.
+static int plan_rows(q3tts_engine* e, const std::vector<int>& live_in) {
+    Q3Lane& L = e->lanes[0];
+    const int B = e->B;
+    std::vector<int> live(live_in);
+    std::sort(live.begin(), live.end());
+    int bi = 0;
+    while (bi + 1 < (int)e->buckets.size() && e->buckets[bi] < (int)live.size()) ++bi;
+    bool ok = bi == e->cur_bucket;
+    if (ok) for (int b : live) if (e->row_of_slot[b] >= e->buckets[bi]) { ok = false; break; }
+    if (ok) return Q3TTS_OK;
+    std::vector<int> slot_of_row(B, -1), perm(B), used(B, 0), sla(2 * (size_t)B);
+    int r = 0;
+    for (int b : live) { slot_of_row[r++] = b; used[b] = 1; }
+    for (int b = 0; b < B && r < B; ++b) if (!used[b]) slot_of_row[r++] = b;
+    for (r = 0; r < B; ++r) { perm[r] = e->row_of_slot[slot_of_row[r]]; sla[2 * r] = sla[2 * r + 1] = slot_of_row[r]; }
     hipStream_t s = e->stream;
+    Q3_HIP(e, hipMemcpyAsync(L.perm, perm.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+    Q3_HIP(e, hipMemcpyAsync(L.slot_id, slot_of_row.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+    Q3_HIP(e, hipMemcpyAsync(L.slotA, sla.data(), (size_t)2 * B * 4, hipMemcpyHostToDevice, s));
+    // row state that outlives a frame: the Talker logits (sampled at the next frame) and its last hidden row (the
+    // Predictor's first input)
+    q3_launch_gather_rows(L.logits_tmp, L.logits, L.perm, B, e->cfg.model.t_vocab, s);
+    Q3_HIP(e, hipMemcpyAsync(L.logits, L.logits_tmp, (size_t)B * e->cfg.model.t_vocab * 4, hipMemcpyDeviceToDevice, s));
+    q3_launch_gather_rows(L.logits_tmp, L.xT, L.perm, B, e->cfg.model.t_d_model, s);
+    Q3_HIP(e, hipMemcpyAsync(L.xT, L.logits_tmp, (size_t)B * e->cfg.model.t_d_model * 4, hipMemcpyDeviceToDevice, s));
+    Q3_HIP(e, hipStreamSynchronize(s));  // the uploads read locals
+    for (r = 0; r < B; ++r) e->row_of_slot[slot_of_row[r]] = r;
+    e->slot_of_row = slot_of_row;
+    e->cur_bucket = bi;
+    return Q3TTS_OK;
+}
+
+// CH frame steps over the current row bucket; afterwards the slot mirror is on the host. Returns the device time (ms).
+static int run_chunk(q3tts_engine* e, int CH, float* dev_ms) {
+    hipStream_t s = e->stream;
+    Q3Lane& L = e->lanes[0];
     Q3_HIP(e, hipEventRecord(e->ev1, s));  // admissions (prefill, state uploads) precede the frames
-    for (size_t li = 0; li < e->lanes.size(); ++li) {
-        if (!(mask & (1u << li))) continue;
-        Q3Lane& L = e->lanes[li];
-        Q3_HIP(e, hipStreamWaitEvent(L.stream, e->ev1, 0));
-        Q3_HIP(e, hipEventRecord(L.ev_begin, L.stream));
-        for (int i = 0; i < CH; ++i) {
-            if (L.graph_exec) { Q3_HIP(e, hipGraphLaunch(L.graph_exec, L.stream)); }
-            else { record_frame(e, L, L.stream); Q3_HIP(e, hipGetLastError()); }
-        }
-        Q3_HIP(e, hipEventRecord(L.ev_end, L.stream));
-        Q3_HIP(e, hipStreamWaitEvent(s, L.ev_end, 0));
+    Q3_HIP(e, hipStreamWaitEvent(L.stream, e->ev1, 0));
+    Q3_HIP(e, hipEventRecord(L.ev_begin, L.stream));
+    for (int i = 0; i < CH; ++i) {
+        if (!L.execs.empty()) { Q3_HIP(e, hipGraphLaunch(L.execs[e->cur_bucket], L.stream)); }
+        else { record_frame(e, L, L.stream, e->buckets[e->cur_bucket]); Q3_HIP(e, hipGetLastError()); }
     }
+    Q3_HIP(e, hipEventRecord(L.ev_end, L.stream));
+    Q3_HIP(e, hipStreamWaitEvent(s, L.ev_end, 0));
     Q3_HIP(e, hipEventRecord(e->ev3, s));  // the vocoder stream waits on this
     Q3_HIP(e, hipMemcpyAsync(e->slots_host, e->slots, sizeof(Q3Slot) * e->B, hipMemcpyDeviceToHost, s));
     Q3_HIP(e, hipStreamSynchronize(s));
-    float worst = 0.0f;
-    for (size_t li = 0; li < e->lanes.size(); ++li) {
-        if (!(mask & (1u << li))) continue;
-        float ms = 0.0f;
-        hipEventElapsedTime(&ms, e->lanes[li].ev_begin, e->lanes[li].ev_end);
-        worst = std::max(worst, ms);
-    }
-    if (dev_ms) *dev_ms = worst;
+    if (dev_ms) { *dev_ms = 0.0f; hipEventElapsedTime(dev_ms, L.ev_begin, L.ev_end); }
     return Q3TTS_OK;
 }
 
@@ -505,8 +529,8 @@ static int admit_group(q3tts_engine* e, std::vector<Adm>& grp, int total) {
     for (const Adm& a : grp) {
         const q3tts_request* r = a.r;
         const int b = a.b;
-        Q3Lane& L = lane_of(e, b);
-        const int row = b - L.b0;
+        Q3Lane& L = e->lanes[0];
+        const int row = e->row_of_slot[b];
         q3_launch_copy_rows(L.xT + (size_t)row * m.t_d_model, m.t_d_model, e->xp + (size_t)(a.row0 + a.n - 1) * m.t_d_model, m.t_d_model, 1, m.t_d_model, s);
         Q3Gemm g{}; g.x = L.xT + (size_t)row * m.t_d_model; g.ldx = m.t_d_model; g.B = 1; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab;
         g.norm_w = e->T.out_norm; g.eps = m.rms_eps; g.y = L.logits + (size_t)row * m.t_vocab; g.ldy = m.t_vocab; g.epi = Q3_EPI_STORE;
@@ -645,6 +669,11 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
             std::vector<int> as, ai; std::vector<const q3tts_request*> ar;
             for (int b = 0; b < B && next < n; ++b)
                 if (run[b].req < 0) { TRY(drain(b)); as.push_back(b); ar.push_back(&reqs[next]); ai.push_back(next++); }
+            {
+                std::vector<int> live(as);
+                for (int b = 0; b < B; ++b) if (run[b].req >= 0) live.push_back(b);
+                TRY(plan_rows(e, live));
+            }
             if (!as.empty()) {
                 Q3_HIP(e, hipEventRecord(e->ev0, s));
                 admitted = true;
@@ -657,11 +686,11 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
             }
         }
         if (admitted) { Q3_HIP(e, hipEventRecord(e->ev2, s)); }
-        unsigned mask = 0;
-        for (int b = 0; b < B; ++b) if (run[b].req >= 0) mask |= 1u << (b / e->lanes[0].nb);
-        if (!mask) break;
+        bool any = false;
+        for (int b = 0; b < B; ++b) if (run[b].req >= 0) any = true;
+        if (!any) break;
         float ms = 0;
-        TRY(run_chunk(e, mask, CH, &ms));
+        TRY(run_chunk(e, CH, &ms));
         dec_ms += ms; steps += CH;
         if (admitted) { hipEventElapsedTime(&ms, e->ev0, e->ev2); pre_ms += ms; }
         for (int b = 0; b < B; ++b) if (run[b].req >= 0) { ctx_tokens += (long long)e->slots_host[b].cur_pos * CH; live_slot_steps += CH; }
@@ -728,7 +757,7 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
         e->tm.algo_bytes_per_step = fixed + (steps ? kv_per_tok * (ctx_tokens / steps) : 0);
         e->tm.mean_live_slots = steps ? (float)((double)live_slot_steps / (double)steps) : 0.0f;
         e->tm.algo_flops_per_step = (long long)((double)fixed * (double)e->tm.mean_live_slots);  // 2 flop per bf16 weight (2 bytes) per live row
-        e->tm.n_lanes = (float)e->lanes.size();
+        e->tm.n_lanes = 1.0f;
     }
     return Q3TTS_OK;
 }
@@ -771,7 +800,8 @@ extern "C" int q3tts_stream_begin(q3tts_engine* e, const q3tts_request* req, q3t
     Q3_HIP(e, hipSetDevice(e->cfg.device));
     q3tts_stream* st = new q3tts_stream();
     st->e = e; st->req = *req; st->t0 = now_ms();
-    int rc = admit(e, 0, req);
+    int rc = plan_rows(e, std::vector<int>{0});
+    if (rc == Q3TTS_OK) rc = admit(e, 0, req);
     if (rc != Q3TTS_OK) { delete st; return rc; }
     *out = st;
     return Q3TTS_OK;
@@ -787,7 +817,7 @@ extern "C" int q3tts_stream_poll(q3tts_stream* st, const float** chunk, int32_t*
     for (;;) {
         const Q3Slot& sl = e->slots_host[0];
         if (!st->finished) {
-            TRY(run_chunk(e, 1u, 4, nullptr));
+            TRY(run_chunk(e, 4, nullptr));
             if (!sl.active) st->finished = true;
         }
         int nf = 0, last = 0;
@@ -932,6 +962,7 @@ extern "C" int q3tts_k_talker_prefill(q3tts_engine* e, const float* embd, int32_
     if (!e || !embd || n_tok <= 0) return q3_set_err(e, Q3TTS_ERR_INVALID, "null argument");
     Q3_HIP(e, hipSetDevice(e->cfg.device));
     q3tts_request r{}; r.prompt_embd = embd; r.n_tok = n_tok; r.use_engine_sampler = 0; r.temperature = 0; r.max_steps = 1;
+    TRY(plan_rows(e, std::vector<int>{0}));
     TRY(admit(e, 0, &r));
     const q3tts_model_config& m = e->cfg.model;
     hipStream_t s = e->stream;

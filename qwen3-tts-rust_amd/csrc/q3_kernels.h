@@ -56,7 +56,8 @@ void q3_launch_attend(const Q3Attend& a, hipStream_t s);
 // Talker sampler + frame bookkeeping (H4/H5). One workgroup per slot.
 struct Q3Sample {
     float* logits; int ld; int limit; int eos;
-    Q3Slot* slots; int B;
+    Q3Slot* slots; int B;             // slots: ALL slots of the engine; row b works for slot row_slot[b]
+    const int* row_slot;
     const float* rng;                 // per-slot draws: rng[slot.rng_base + step]
     int* codes; int max_steps_cap; int ncb;
     unsigned long long* keys;         // [B][ncb] argmax keys, zeroed here for the frame
@@ -70,7 +71,7 @@ void q3_launch_sample_rows(const float* logits, int n, int ld, int limit, float 
 struct Q3PredInput {
     const float* xT; const float* out_norm; float eps; int d;
     const float* codec0; int codec0_rows;
-    const Q3Slot* slots; float* X; float* fb; int B;
+    const Q3Slot* slots; const int* row_slot; float* X; float* fb; int B;
 };
 void q3_launch_pred_input(const Q3PredInput& a, hipStream_t s);
 
@@ -79,7 +80,7 @@ void q3_launch_pred_input(const Q3PredInput& a, hipStream_t s);
 struct Q3PredNext {
     const unsigned long long* keys; int q; int ncb;
     const float* codec_q; int rows_q; int d;
-    Q3Slot* slots; int B;
+    Q3Slot* slots; const int* row_slot; int B;
     int* codes; int max_steps_cap;
     float* fb; float* X; const float* tts_pad; float* xT; int* row_pos_t;
 };
@@ -96,4 +97,5 @@ void q3_launch_prompt_ref_frames(const int* codes, int n_frames, const float* ma
 void q3_launch_copy_rows(float* dst, int ldd, const float* src, int lds, int rows, int cols, hipStream_t s);
 
 // canonical RMSNorm of rows (test hook / hidden read-back)
+void q3_launch_gather_rows(float* dst, const float* src, const int* perm, int rows, int cols, hipStream_t s);
 void q3_launch_rmsnorm_rows(const float* x, int ldx, const float* w, float eps, int d, int rows, float* out, int ldo, hipStream_t s);

@@ -346,8 +346,8 @@ __device__ int sample_row(const float* logits, int limit, float temperature, int
 __global__ __launch_bounds__(256) void k_sample(Q3Sample a) {
     __shared__ unsigned long long keys[SAMP_MAX];
     __shared__ float probs[SAMP_MAX];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    Q3Slot* sl = a.slots + b;
+    const int b = blockIdx.x, tid = threadIdx.x, slot = a.row_slot[b];
+    Q3Slot* sl = a.slots + slot;
     if (!sl->active) return;
     if (tid < a.ncb) a.keys[(size_t)b * a.ncb + tid] = 0ull;
     const int step = sl->n_frames;
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void k_sample(Q3Sample a) {
     __syncthreads();
     if (tid == 0) {
         if (code0 == a.eos) { sl->hit_eos = 1; sl->active = 0; }  // :558-561
-        else { a.codes[((size_t)b * a.max_steps_cap + step) * a.ncb] = code0; sl->code0 = code0; }
+        else { a.codes[((size_t)slot * a.max_steps_cap + step) * a.ncb] = code0; sl->code0 = code0; }
     }
 }
 void q3_launch_sample(const Q3Sample& a, hipStream_t s) { hipLaunchKernelGGL(k_sample, dim3(a.B), dim3(256), 0, s, a); }
@@ -393,7 +393,7 @@ void q3_launch_sample_rows(const float* logits, int n, int ld, int limit, float 
 __global__ __launch_bounds__(256) void k_pred_input(Q3PredInput a) {
     __shared__ float rinv_s;
     const int b = blockIdx.x, tid = threadIdx.x, d = a.d;
-    const Q3Slot* sl = a.slots + b;
+    const Q3Slot* sl = a.slots + a.row_slot[b];
     if (!sl->active) return;
     const float* x = a.xT + (size_t)b * d;
     if (tid < 64) {
@@ -420,8 +420,8 @@ __global__ __launch_bounds__(256) void k_pred_input(Q3PredInput a) {
 void q3_launch_pred_input(const Q3PredInput& a, hipStream_t s) { hipLaunchKernelGGL(k_pred_input, dim3(a.B), dim3(256), 0, s, a); }
 
 __global__ __launch_bounds__(256) void k_pred_next(Q3PredNext a) {
-    const int b = blockIdx.x, tid = threadIdx.x, d = a.d;
-    Q3Slot* sl = a.slots + b;
+    const int b = blockIdx.x, tid = threadIdx.x, d = a.d, slot = a.row_slot[b];
+    Q3Slot* sl = a.slots + slot;
     const bool last = a.q == a.ncb - 1;
     if (!sl->active) {
         if (last && tid == 0) a.row_pos_t[b] = -1;
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void k_pred_next(Q3PredNext a) {
     const bool ok = code >= 0 && code < a.rows_q;
     const float* e = a.codec_q + (size_t)(ok ? code : 0) * d;
     const int frame = sl->n_frames;
-    if (tid == 0) a.codes[((size_t)b * a.max_steps_cap + frame) * a.ncb + a.q] = code;
+    if (tid == 0) a.codes[((size_t)slot * a.max_steps_cap + frame) * a.ncb + a.q] = code;
     for (int i = tid; i < d; i += 256) {
         const float ev = ok ? e[i] : 0.0f;
         float f = a.fb[(size_t)b * d + i] + ev;
@@ -497,6 +497,15 @@ void q3_launch_prompt_ref_frames(const int* codes, int n_frames, const float* ma
 __global__ void k_copy_rows(float* dst, int ldd, const float* src, int lds, int cols) {
     const int r = blockIdx.x;
     for (int i = threadIdx.x; i < cols; i += blockDim.x) dst[(size_t)r * ldd + i] = src[(size_t)r * lds + i];
+}
+// dst[r] = src[perm[r]] (row compaction of the decode rows)
+__global__ void k_gather_rows(float* dst, const float* src, const int* perm, int cols) {
+    const int r = blockIdx.y;
+    const float* sp = src + (size_t)perm[r] * cols;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cols; i += gridDim.x * blockDim.x) dst[(size_t)r * cols + i] = sp[i];
+}
+void q3_launch_gather_rows(float* dst, const float* src, const int* perm, int rows, int cols, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_rows, dim3((cols + 255) / 256, rows), dim3(256), 0, s, dst, src, perm, cols);
 }
 void q3_launch_copy_rows(float* dst, int ldd, const float* src, int lds, int rows, int cols, hipStream_t s) {
     hipLaunchKernelGGL(k_copy_rows, dim3(rows), dim3(256), 0, s, dst, ldd, src, lds, cols);
