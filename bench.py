@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--no-vocoder", action="store_true", help="codes only (diagnostic; the JSON line is then marked invalid)")
     ap.add_argument("--no-single", action="store_true", help="skip the batch=1 RTF / first-chunk leg")
     ap.add_argument("--n-ctx", type=int, default=4096)
+    ap.add_argument("--no-probe", action="store_true", help="skip the in-situ dominant-kernel measurement (roofline.achieved falls back to the whole frame step)")
+    ap.add_argument("--probe-only", action="store_true", help="run only the probe leg (the command profiled for profiles/*/probe_kernel_stats.csv)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -131,6 +133,30 @@ def main():
         from q3tts import dist as qd
         qd.gather_pcm(dist, [o.pcm if o.pcm is not None else np.zeros(0, dtype=np.float32) for o in outs], rank, world,
                       device="cuda", dtype=torch.float16)
+
+    def probe_leg():
+        """Dominant kernel, in situ: the same batch of 64 utterances for 24 forced frames (codes only, so nothing else
+        shares the GPU), frame steps launched eagerly with HIP events on the decode stream around the Predictor gate/up
+        GEMM of pass 1 / layer 0 (k_gemm_ring<2, 3, 2, true> at M = 64, K = 1024, N = 6144)."""
+        eng.probe(True)
+        preqs = [dict(r, min_frames=24, force_eos_at=24, max_steps=32, want_pcm=0) for r in reqs]
+        for _ in range(2):
+            pouts = eng.generate_batch(preqs)
+        ptm = eng.timings()
+        eng.probe(False)
+        assert all(o.status == 0 and o.n_frames == 24 for o in pouts)
+        m = cfg.model
+        rows, K, N = len(preqs), m.p_d_model, 2 * m.p_d_ffn
+        flops = 2.0 * rows * K * N
+        nbytes = 2.0 * N * K + 4.0 * rows * K + 4.0 * rows * (N // 2)
+        return {"kernel_ms": ptm.probe_kernel_ms, "empty_ms": ptm.probe_empty_ms, "launches": int(ptm.probe_count), "rows": rows, "K": K, "N": N, "flops": flops, "bytes": nbytes}
+
+    if args.probe_only:
+        pr = probe_leg()
+        if rank == 0:
+            print(json.dumps({"probe": pr}), flush=True)
+        eng.close()
+        return
 
     for _ in range(args.warmup):
         outs = eng.generate_batch(reqs)
@@ -183,17 +209,39 @@ def main():
             "rtf_per_utterance": round(frame_step_ms / 80.0, 5),
             "frame_step_ms": round(frame_step_ms, 4),
             "stage_ms_last_step": {"prefill": round(tm.prefill_ms, 2), "decode": round(tm.decode_ms, 2), "vocoder_host_wait": round(tm.vocoder_ms, 2)},
-            "roofline": ({"bound": "mfma", "achieved": round(mfma_tf, 2), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                          "frac": round(mfma_tf / F32_MFMA_PEAK_TF, 4)} if mfma_bound else
-                         {"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": round(hbm_gbs / HBM_PEAK_GBS, 4)}),
+            "frame_step": {
+                "what": "one frame step = sample + 15 Predictor passes + Talker step over the live row bucket (graph replay)",
+                "ms": round(frame_step_ms, 4), "mean_live_utterances": round(live, 2), "mean_rows": round(tm.mean_rows, 2),
+                "algorithmic_flops": int(flops_step), "algorithmic_bytes": int(bytes_step),
+                "tflops": round(mfma_tf, 2), "frac_of_f32_mfma_peak": round(mfma_tf / F32_MFMA_PEAK_TF, 4),
+                "hbm_GBs": round(hbm_gbs, 1), "frac_of_8TBs": round(hbm_gbs / HBM_PEAK_GBS, 4), "mfma_bound": bool(mfma_bound)},
         }
-        line["roofline"].update({
-            "kernel": "frame step = one replay of the decoder graph(s): sample + 15 Predictor passes + Talker step (k_gemm_ring / k_gemm_small dominant)",
-            "peak_note": "f32-input MFMA dense peak 157.3 TF (MI355X_MICROARCH.md); the exact decoder accumulates on v_mfma_f32_16x16x4_f32",
-            "algorithmic_flops_per_launch": int(flops_step), "algorithmic_bytes_per_launch": int(bytes_step), "mean_live_utterances": round(live, 2),
-            "launch_ms": round(frame_step_ms, 4), "hbm_GBs_same_launch": round(hbm_gbs, 1), "hbm_frac_of_8TBs": round(hbm_gbs / HBM_PEAK_GBS, 4),
-            "lanes": int(tm.n_lanes), "traffic": None})
+        if not args.no_probe:
+            pr = probe_leg()
+            k_ms = pr["kernel_ms"] - pr["empty_ms"]  # an empty event bracket on the same stream costs empty_ms: not kernel time
+            k_tf = pr["flops"] / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+            traffic = None
+            tpath = os.path.join(REPO, "profiles", "r01", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f).get("hbm_bytes_per_launch")
+            line["roofline"] = {
+                "bound": "mfma", "achieved": round(k_tf, 2), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(k_tf / F32_MFMA_PEAK_TF, 4),
+                "traffic": traffic,
+                "kernel": "k_gemm_ring<2, 3, 2, true>: Predictor gate/up GEMM + fused RMSNorm + SwiGLU, M=%d K=%d N=%d (largest share of kernel time "
+                          "in profiles/r01/bench_b64_eager_kernel_stats.csv)" % (pr["rows"], pr["K"], pr["N"]),
+                "launch_us": round(k_ms * 1e3, 2), "launch_us_raw_bracket": round(pr["kernel_ms"] * 1e3, 2),
+                "empty_bracket_us": round(pr["empty_ms"] * 1e3, 2), "launches_timed": pr["launches"],
+                "algorithmic_flops_per_launch": int(pr["flops"]), "algorithmic_bytes_per_launch": int(pr["bytes"]),
+                "how": "HIP events on the decode stream around every launch of this kernel in pass 1 / layer 0, eager frame steps, "
+                       "64 live utterances, codes only (q3tts_k_probe); rocprofv3 of the same leg: profiles/r01/probe_kernel_stats.csv",
+                "peak_note": "f32-input MFMA dense peak 157.3 TF (MI355X_MICROARCH.md); the exact decoder accumulates on v_mfma_f32_16x16x4_f32; "
+                             "arithmetic intensity %.0f flop/B > ridge 19.7" % (pr["flops"] / pr["bytes"])}
+        else:
+            line["roofline"] = {"bound": "mfma" if mfma_bound else "hbm", "achieved": round(mfma_tf if mfma_bound else hbm_gbs, 2),
+                                "peak": F32_MFMA_PEAK_TF if mfma_bound else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                                "frac": round(mfma_tf / F32_MFMA_PEAK_TF if mfma_bound else hbm_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                "kernel": "whole frame step (no per-kernel probe in this run)"}
         if args.no_vocoder:
             line["invalid"] = "diagnostic run without the vocoder"
 

@@ -174,12 +174,14 @@ int q3tts_write_weights(q3tts_engine* e, const char* path);
 typedef struct q3tts_timings {
     float prefill_ms, decode_ms, vocoder_ms, total_ms;
     float frame_step_ms;      /* mean device time of one frame-step graph replay */
-    float talker_gemm_ms;     /* mean device time of the dominant kernel family per frame step */
+    float probe_kernel_ms;    /* q3tts_k_probe: mean in-situ device time of the probed kernel (Predictor gate/up GEMM, full batch) */
     int64_t frame_steps;      /* graph replays timed */
     int64_t algo_bytes_per_step; /* SURVEY.md §8(d) algorithmic bytes of one frame step at the batch run */
     int64_t algo_flops_per_step; /* 2 * (W_T + 15 W_P + 15 h + 16 pj) * mean live utterances per step (decoder GEMMs) */
     float mean_live_slots;       /* utterances generating, averaged over the timed frame steps */
-    float n_lanes;               /* concurrent slot groups (streams) the engine replays */
+    float mean_rows;             /* decode rows per frame step (row bucket), averaged over the timed frame steps */
+    int64_t probe_count;         /* launches behind probe_kernel_ms */
+    float probe_empty_ms;        /* mean elapsed time of an EMPTY event bracket on the same stream (event overhead) */
 } q3tts_timings;
 int q3tts_get_timings(const q3tts_engine* e, q3tts_timings* out);
 
@@ -201,6 +203,10 @@ int q3tts_k_talker_prefill(q3tts_engine* e, const float* embd, int32_t n_tok, fl
 /* Vocoder: codes [n_frames][n_codebooks] -> pcm; chunk_frames frames per streaming call (0 = one call) */
 int q3tts_k_vocoder(q3tts_engine* e, const int32_t* codes, int32_t n_frames, int32_t chunk_frames, float* pcm_out,
                     int32_t* n_samples_out);
+/* Measurement mode for bench.py: frame steps are launched eagerly (no graph replay) and the Predictor gate/up GEMM of
+ * pass 1 / layer 0 is bracketed by HIP events on its own stream; q3tts_timings.probe_kernel_ms / probe_count report it
+ * for the frame steps that ran at the full row count. enable = 0 restores graph replay. */
+int q3tts_k_probe(q3tts_engine* e, int32_t enable);
 /* rand 0.8 StdRng (ChaCha12) stream: seed_from_u64(seed) then n x gen::<f32>() */
 int q3tts_k_rng_f32(uint64_t seed, int32_t n, float* out);
 

@@ -77,6 +77,11 @@ struct q3tts_engine {
     std::vector<hipEvent_t> fin_ev;     // per slot: PCM of a finished utterance copied to the host (vocoder stream)
     q3tts_timings tm{};
     Q3Voc* voc = nullptr;
+    // q3tts_k_probe: eager frame steps, events around the Predictor gate/up GEMM (pass 1, layer 0) of every frame
+    int probe = 0;
+    std::vector<hipEvent_t> probe_ev;   // 2 per frame of a chunk
+    int probe_i = 0;
+    double probe_ms = 0, probe_empty_ms = 0; long long probe_cnt = 0, probe_empty_cnt = 0, row_steps = 0;
     float* first_chunk_host = nullptr;  // pinned landing buffer of the first 4-frame PCM chunk (first-chunk latency)
 };
 

@@ -158,7 +158,7 @@ static int alloc_scratch(q3tts_engine* e, Q3Scratch& sc, int rows, int nqkv, int
 // K1-K8 of SURVEY.md §8a: one decoder block per iteration, 6 launches (norm+QKV, qk-prep, attention, O+residual,
 // norm+gate/up+SwiGLU, down+residual)
 static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, int rows, const int* row_pos, const int* row_slot, Q3Scratch& sc, hipStream_t s,
-                       bool one_row_per_slot = false) {
+                       bool one_row_per_slot = false, hipEvent_t* probe = nullptr) {
     const float eps = e->cfg.model.rms_eps;
     for (int l = 0; l < t.L; ++l) {
         Q3Gemm g{};
@@ -176,7 +176,10 @@ static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, int rows, const int*
         g = Q3Gemm{}; g.x = sc.att; g.ldx = t.nq; g.B = rows; g.w = t.wo[l]; g.K = t.nq; g.N = t.d; g.y = x; g.ldy = t.d; g.epi = Q3_EPI_RESID;
         q3_launch_gemm(g, s);
         g = Q3Gemm{}; g.x = x; g.ldx = t.d; g.B = rows; g.w = t.wgu[l]; g.K = t.d; g.N = 2 * t.F; g.norm_w = t.ffn_norm[l]; g.eps = eps;
-        g.y = sc.h; g.ldy = t.F; g.epi = Q3_EPI_SWIGLU; q3_launch_gemm(g, s);
+        g.y = sc.h; g.ldy = t.F; g.epi = Q3_EPI_SWIGLU;
+        if (probe && l == 0) hipEventRecord(probe[0], s);
+        q3_launch_gemm(g, s);
+        if (probe && l == 0) hipEventRecord(probe[1], s);
         g = Q3Gemm{}; g.x = sc.h; g.ldx = t.F; g.B = rows; g.w = t.wd[l]; g.K = t.F; g.N = t.d; g.y = x; g.ldy = t.d; g.epi = Q3_EPI_RESID;
         q3_launch_gemm(g, s);
     }
@@ -207,7 +210,9 @@ static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
         if (q > 0) pred_next(q);
         Q3Gemm g{}; g.x = L.X; g.ldx = de; g.B = rows; g.w = e->proj_w; g.K = de; g.N = dp; g.bias = e->proj_b; g.y = L.px; g.ldy = dp;
         g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);  // H6: src/assets_manager.rs:383-399
-        run_layers(e, e->P, L.px, rows, q == 0 ? L.posA : L.pos_q + (size_t)q * L.nb, q == 0 ? L.slotA : L.slot_id, L.sc, s, q > 0);
+        hipEvent_t* pe = nullptr;
+        if (e->probe && q == 1 && B == L.nb && e->probe_i + 2 <= 8) { pe = &e->probe_ev[e->probe_i]; e->probe_i += 2; }
+        run_layers(e, e->P, L.px, rows, q == 0 ? L.posA : L.pos_q + (size_t)q * L.nb, q == 0 ? L.slotA : L.slot_id, L.sc, s, q > 0, pe);
         g = Q3Gemm{}; g.x = q == 0 ? L.px + dp : L.px; g.ldx = q == 0 ? 2 * dp : dp; g.B = B; g.w = e->P.head + head_tile_stride * q;
         g.K = dp; g.N = cbs; g.norm_w = e->P.out_norm; g.eps = eps; g.keys = L.keys + (q + 1); g.key_stride = ncb; g.epi = Q3_EPI_ARGMAX;
         q3_launch_gemm(g, s);
@@ -360,6 +365,7 @@ extern "C" void q3tts_engine_destroy(q3tts_engine* e) {
     hipFree(e->sc_pre.qkv); hipFree(e->sc_pre.att); hipFree(e->sc_pre.h);
     hipFree(e->xp); hipFree(e->pf_pos); hipFree(e->pf_slot); hipFree(e->prow_dev); hipFree(e->spk_dev); hipFree(e->refcodes_dev);
     for (auto ev : e->fin_ev) if (ev) hipEventDestroy(ev);
+    for (auto ev : e->probe_ev) if (ev) hipEventDestroy(ev);
     if (e->ev0) hipEventDestroy(e->ev0); if (e->ev1) hipEventDestroy(e->ev1); if (e->ev2) hipEventDestroy(e->ev2); if (e->ev3) hipEventDestroy(e->ev3);
     if (e->stream) hipStreamDestroy(e->stream);
     if (e->vstream && e->vstream != e->stream) hipStreamDestroy(e->vstream);
@@ -494,16 +500,27 @@ static int run_chunk(q3tts_engine* e, int CH, float* dev_ms) {
     Q3_HIP(e, hipEventRecord(e->ev1, s));  // admissions (prefill, state uploads) precede the frames
     Q3_HIP(e, hipStreamWaitEvent(L.stream, e->ev1, 0));
     Q3_HIP(e, hipEventRecord(L.ev_begin, L.stream));
+    e->probe_i = 0;
+    if (e->probe) { hipEventRecord(e->probe_ev[8], L.stream); hipEventRecord(e->probe_ev[9], L.stream); }  // empty bracket
     for (int i = 0; i < CH; ++i) {
-        if (!L.execs.empty()) { Q3_HIP(e, hipGraphLaunch(L.execs[e->cur_bucket], L.stream)); }
+        if (!L.execs.empty() && !e->probe) { Q3_HIP(e, hipGraphLaunch(L.execs[e->cur_bucket], L.stream)); }
         else { record_frame(e, L, L.stream, e->buckets[e->cur_bucket]); Q3_HIP(e, hipGetLastError()); }
     }
+    e->row_steps += (long long)CH * e->buckets[e->cur_bucket];
     Q3_HIP(e, hipEventRecord(L.ev_end, L.stream));
     Q3_HIP(e, hipStreamWaitEvent(s, L.ev_end, 0));
     Q3_HIP(e, hipEventRecord(e->ev3, s));  // the vocoder stream waits on this
     Q3_HIP(e, hipMemcpyAsync(e->slots_host, e->slots, sizeof(Q3Slot) * e->B, hipMemcpyDeviceToHost, s));
     Q3_HIP(e, hipStreamSynchronize(s));
     if (dev_ms) { *dev_ms = 0.0f; hipEventElapsedTime(dev_ms, L.ev_begin, L.ev_end); }
+    for (int i = 0; i + 1 < e->probe_i; i += 2) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, e->probe_ev[i], e->probe_ev[i + 1]) == hipSuccess) { e->probe_ms += ms; ++e->probe_cnt; }
+    }
+    if (e->probe) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, e->probe_ev[8], e->probe_ev[9]) == hipSuccess) { e->probe_empty_ms += ms; ++e->probe_empty_cnt; }
+    }
     return Q3TTS_OK;
 }
 
@@ -662,6 +679,7 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
     int next = 0, done = 0;
     double dec_ms = 0, pre_ms = 0, voc_ms = 0;
     long long steps = 0, ctx_tokens = 0, live_slot_steps = 0;
+    e->probe_ms = 0; e->probe_cnt = 0; e->row_steps = 0; e->probe_empty_ms = 0; e->probe_empty_cnt = 0;
     hipStream_t s = e->stream;
     while (done < n) {
         bool admitted = false;
@@ -757,7 +775,10 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
         e->tm.algo_bytes_per_step = fixed + (steps ? kv_per_tok * (ctx_tokens / steps) : 0);
         e->tm.mean_live_slots = steps ? (float)((double)live_slot_steps / (double)steps) : 0.0f;
         e->tm.algo_flops_per_step = (long long)((double)fixed * (double)e->tm.mean_live_slots);  // 2 flop per bf16 weight (2 bytes) per live row
-        e->tm.n_lanes = 1.0f;
+        e->tm.mean_rows = steps ? (float)((double)e->row_steps / (double)steps) : 0.0f;
+        e->tm.probe_kernel_ms = e->probe_cnt ? (float)(e->probe_ms / (double)e->probe_cnt) : 0.0f;
+        e->tm.probe_count = e->probe_cnt;
+        e->tm.probe_empty_ms = e->probe_empty_cnt ? (float)(e->probe_empty_ms / (double)e->probe_empty_cnt) : 0.0f;
     }
     return Q3TTS_OK;
 }
@@ -974,6 +995,17 @@ extern "C" int q3tts_k_talker_prefill(q3tts_engine* e, const float* embd, int32_
     Q3Slot* stage = e->slots_host + e->B; memset(stage, 0, sizeof(Q3Slot));
     Q3_HIP(e, hipMemcpyAsync(e->slots, stage, sizeof(Q3Slot), hipMemcpyHostToDevice, s));  // retire the slot again
     Q3_HIP(e, hipStreamSynchronize(s));
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_k_probe(q3tts_engine* e, int32_t enable) {
+    if (!e) return Q3TTS_ERR_INVALID;
+    Q3_HIP(e, hipSetDevice(e->cfg.device));
+    if (enable && e->probe_ev.empty()) {
+        e->probe_ev.resize(10, nullptr);  // 4 frames x 2 + one empty bracket per chunk (event overhead calibration)
+        for (auto& ev : e->probe_ev) Q3_HIP(e, hipEventCreate(&ev));
+    }
+    e->probe = enable ? 1 : 0;
     return Q3TTS_OK;
 }
 

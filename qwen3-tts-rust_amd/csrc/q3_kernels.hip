@@ -299,11 +299,38 @@ __device__ int sample_row(const float* logits, int limit, float temperature, int
         __syncthreads();
         return q3_argmax_idx(b);
     }
+    const bool select = top_k_i > 0 && top_k_i <= 256 && top_k_i < limit;
+    if (select) {
+        // top-k by selection: only the k largest keys are ever read below (:711-713), and the k-th round's block-wide
+        // maximum IS the k-th entry of the sorted list (keys are unique: the index is part of the key). Each thread
+        // keeps its 16 candidates in registers; a round = local max, wave max, 4-way max through LDS, owner removes it.
+        unsigned long long loc[SAMP_MAX / 256];
+#pragma unroll
+        for (int j = 0; j < SAMP_MAX / 256; ++j) { const int i = tid + j * 256; loc[j] = i < limit ? q3_argmax_key(logits[i], (uint32_t)i) : 0ull; }
+        for (int r = 0; r < top_k_i; ++r) {
+            unsigned long long best = 0;
+#pragma unroll
+            for (int j = 0; j < SAMP_MAX / 256; ++j) best = loc[j] > best ? loc[j] : best;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(best, m); best = o > best ? o : best; }
+            if ((tid & 63) == 0) wbest[tid >> 6] = best;
+            __syncthreads();
+            unsigned long long b = wbest[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) b = wbest[w] > b ? wbest[w] : b;
+            if (tid == 0) keys[r] = b;
+#pragma unroll
+            for (int j = 0; j < SAMP_MAX / 256; ++j) loc[j] = (loc[j] == b) ? 0ull : loc[j];
+            __syncthreads();
+        }
+    }
     int NP = 64;
     while (NP < limit) NP <<= 1;
+    if (!select) {
     for (int i = tid; i < NP; i += 256) keys[i] = i < limit ? q3_argmax_key(logits[i], (uint32_t)i) : 0ull;
     __syncthreads();
-    for (int k = 2; k <= NP; k <<= 1)
+    }
+    for (int k = 2; !select && k <= NP; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < NP; i += 256) {
                 const int ixj = i ^ j;

@@ -88,9 +88,9 @@ class Result(C.Structure):
 class Timings(C.Structure):
     _fields_ = [
         ("prefill_ms", C.c_float), ("decode_ms", C.c_float), ("vocoder_ms", C.c_float), ("total_ms", C.c_float),
-        ("frame_step_ms", C.c_float), ("talker_gemm_ms", C.c_float),
+        ("frame_step_ms", C.c_float), ("probe_kernel_ms", C.c_float),
         ("frame_steps", C.c_int64), ("algo_bytes_per_step", C.c_int64), ("algo_flops_per_step", C.c_int64),
-        ("mean_live_slots", C.c_float), ("n_lanes", C.c_float),
+        ("mean_live_slots", C.c_float), ("mean_rows", C.c_float), ("probe_count", C.c_int64), ("probe_empty_ms", C.c_float),
     ]
 
 
@@ -100,7 +100,7 @@ SYMBOLS = [
     "q3tts_set_max_steps", "q3tts_build_prompt", "q3tts_free", "q3tts_generate", "q3tts_generate_batch",
     "q3tts_result_free", "q3tts_stream_begin", "q3tts_stream_poll", "q3tts_stream_end", "q3tts_write_weights",
     "q3tts_get_timings", "q3tts_k_gemm_exact", "q3tts_k_attention", "q3tts_k_sample", "q3tts_k_talker_prefill",
-    "q3tts_k_vocoder", "q3tts_k_rng_f32",
+    "q3tts_k_vocoder", "q3tts_k_rng_f32", "q3tts_k_probe",
 ]
 
 
@@ -154,6 +154,7 @@ def load_library(path=None):
     lib.q3tts_k_talker_prefill.argtypes = [vp, f32p, C.c_int32, f32p, f32p]
     lib.q3tts_k_vocoder.argtypes = [vp, i32p, C.c_int32, C.c_int32, f32p, i32p]
     lib.q3tts_k_rng_f32.argtypes = [C.c_uint64, C.c_int32, f32p]
+    lib.q3tts_k_probe.argtypes = [C.c_void_p, C.c_int32]
     if path is None:
         _lib = lib
     return lib

@@ -141,6 +141,10 @@ class NativeEngine:
         self._check(self.lib.q3tts_get_timings(self.h, C.byref(t)), "q3tts_get_timings")
         return t
 
+    def probe(self, enable):
+        """Measurement mode (bench.py): eager frame steps with HIP events around the Predictor gate/up GEMM."""
+        self._check(self.lib.q3tts_k_probe(self.h, int(bool(enable))), "q3tts_k_probe")
+
     def talker_prefill(self, embd):
         e = np.ascontiguousarray(embd, dtype=np.float32)
         hid = np.zeros(self.cfg.model.t_d_model, dtype=np.float32)
