@@ -784,7 +784,8 @@ static void vgemm(hipStream_t s, const VConv& c, const float* x, size_t x_stride
     }
 }
 static bool resunit_ok(int C) {
-    static const int off = getenv("Q3TTS_VOC_NOFUSE") ? atoi(getenv("Q3TTS_VOC_NOFUSE")) : 0;
+    const char* ev = getenv("Q3TTS_VOC_NOFUSE");  // (read per call: the tests compare both paths in one process)
+    const int off = ev ? atoi(ev) : 0;
     return !off && (C == 32 || C == 64 || C == 96 || C == 128 || C == 192);
 }
 template <int NT, int MT>

@@ -58,7 +58,11 @@ def test_gemm_exact_store_bias(oracle, native, B, K, N):
     assert np.array_equal(_bits(y), _bits(y_ref))
 
 
-@pytest.mark.parametrize("B,K,N", [(1, 2048, 64), (5, 1024, 32), (12, 1024, 32), (13, 1024, 32), (40, 512, 64), (64, 2048, 12288)])
+# fused RMSNorm through every launcher branch: small path, ring RT = 1/2/4 x NT = 1/2/3, unrolled and
+# runtime-K instances (K = 512/1024/2048 vs 1536/3072), ragged last row tile, SwiGLU / argmax epilogues below
+@pytest.mark.parametrize("B,K,N", [(1, 2048, 64), (5, 1024, 32), (12, 1024, 32), (13, 1024, 32), (40, 512, 64), (64, 2048, 12288),
+                                   (64, 1024, 6144), (64, 1024, 4096), (64, 2048, 4096), (64, 2048, 3072), (32, 1024, 6144), (17, 1024, 96),
+                                   (128, 1024, 6144), (100, 2048, 4096), (37, 1536, 4096), (64, 3072, 6144), (200, 512, 48), (64, 1024, 2048)])
 def test_gemm_exact_norm_prologue(oracle, native, B, K, N):
     rng = np.random.default_rng(7 + B)
     x = _rand(rng, (B, K), 3.0)
@@ -284,6 +288,57 @@ def test_vocoder_clamps_out_of_range_codes(oracle, tiny_voc):
     wild = codes.copy(); wild[0, 0] = 2150; wild[1, 3] = -7
     clamped = np.clip(wild, 0, cfg.vocoder.codebook_size - 1)
     assert np.array_equal(eng.vocoder(wild), eng.vocoder(clamped))
+
+
+def test_vocoder_narrow_block_kernels(oracle):
+    """A vocoder shaped so the narrow-block kernels run (fused residual units at C = 192 / 96, the 96-wide LDS tile,
+    the small-M ring): PCM vs the oracle, chunked == one-shot, and the un-fused path gives the same bits."""
+    import os
+    from q3tts import _abi, native
+    cfg = _abi.tiny_config(max_batch=2, n_ctx=128, with_vocoder=1)
+    vc = cfg.vocoder
+    vc.decoder_dim, vc.n_dec_blocks = 768, 3
+    for i, r in enumerate((8, 5, 3)):
+        vc.dec_rates[i] = r
+    spf = 2 * 2 * 8 * 5 * 3
+    L = oracle.lib()
+    v = L.q3o_vocoder_create(C.byref(vc), 0, 4)
+    eng = native.NativeEngine(cfg)
+    try:
+        codes = np.random.default_rng(21).integers(0, vc.codebook_size, size=(9, 16)).astype(np.int32)
+        ref = _oracle_pcm(oracle, v, codes, spf=spf)
+        one = eng.vocoder(codes)
+        assert one.shape == ref.shape == (9 * spf,)
+        assert float(np.sqrt(np.mean((one - ref) ** 2))) <= PCM_RMS_TOL
+        for ch in (1, 4):
+            assert np.array_equal(eng.vocoder(codes, chunk_frames=ch), one), ch
+        os.environ["Q3TTS_VOC_NOFUSE"] = "1"   # conv k7 -> snake -> conv k1 as separate GEMM launches
+        try:
+            assert np.array_equal(eng.vocoder(codes), one)
+        finally:
+            del os.environ["Q3TTS_VOC_NOFUSE"]
+    finally:
+        eng.close()
+        L.q3o_vocoder_destroy(v)
+
+
+def test_batch_with_pcm_crosses_row_buckets(oracle, tiny_voc):
+    """Mixed lengths on 4 slots with the vocoder on: rows are re-packed 4 -> 2 -> 1 mid-utterance, slots are re-used."""
+    cfg, eng, v = tiny_voc
+    om = oracle.OracleModel(cfg.model, seed=0, n_ctx=256, n_threads=4)
+    reqs, refs = [], []
+    for i in range(7):
+        desc, keep = oracle.make_prompt_desc(np.arange(7 * i, 7 * i + 5 + 2 * i), spk_emb=_spk(cfg.model.d_embed))
+        pe = om.build_prompt(desc)
+        kw = dict(temperature=0.7, top_k=40, top_p=0.9, seed=500 + i, max_steps=24, min_frames=3 + 3 * i, force_eos_at=3 + 3 * i)
+        refs.append(om.generate(pe, **kw)[0])
+        reqs.append(dict(embd=pe, want_pcm=1, **kw))
+    outs = eng.generate_batch(reqs)
+    for i, (o, r) in enumerate(zip(outs, refs)):
+        assert o.status == 0 and np.array_equal(o.codes, r), i
+        ref_pcm = _oracle_pcm(oracle, v, np.clip(r, 0, cfg.vocoder.codebook_size - 1).astype(np.int32))
+        assert o.pcm.shape == ref_pcm.shape and float(np.sqrt(np.mean((o.pcm - ref_pcm) ** 2))) <= PCM_RMS_TOL, i
+    om.close()
 
 
 def test_end_to_end_pcm_and_batch(oracle, tiny_voc):
