@@ -104,8 +104,9 @@ void q3_voc_destroy(q3tts_engine* e);
 int q3_voc_reset(q3tts_engine* e, int slot);
 // decode frames [f0, f0+nf) of slot (codes already on device in e->codes) into the slot's PCM buffer on stream
 int q3_voc_decode(q3tts_engine* e, int slot, int f0, int nf, int is_last, hipStream_t s);
-// batched: the same nf (<= 4) new frames for every listed slot, one set of launches for all of them
-int q3_voc_decode_batch(q3tts_engine* e, const int* slots, int ns, int nf, hipStream_t s);
+// batched: nf (<= 4) frames for every listed slot in one set of launches; real[i] <= nf of them are real for slot i (the
+// rest are throw-away padding behind a finished utterance's last frame)
+int q3_voc_decode_batch(q3tts_engine* e, const int* slots, const int* real, int ns, int nf, hipStream_t s);
 void q3_voc_mark_last(q3tts_engine* e, int slot);
 // PCM buffer of a slot (device) and samples produced so far
 float* q3_voc_pcm(q3tts_engine* e, int slot);

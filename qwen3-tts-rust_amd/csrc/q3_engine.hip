@@ -719,24 +719,21 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
             hipStream_t vs = e->vstream;
             bool waited = false, first = false;
             auto ensure_wait = [&]() -> int { if (!waited) { Q3_HIP(e, hipStreamWaitEvent(vs, e->ev3, 0)); waited = true; } return Q3TTS_OK; };
-            int list[64];
-            for (;;) {  // full chunks
+            // ONE batched call per chunk: every slot with new frames runs nf = 4. A finished utterance whose tail is
+            // shorter is padded with throw-away frames: the vocoder is causal, so they cannot change the samples already
+            // due, their own samples are never reported, and the slot's vocoder state is reset at its next admission.
+            int list[64], real[64];
+            for (;;) {
                 int ns = 0;
-                for (int b = 0; b < B; ++b)
-                    if (run[b].req >= 0 && reqs[run[b].req].want_pcm && e->slots_host[b].n_frames - run[b].voc_frames >= 4) list[ns++] = b;
+                for (int b = 0; b < B; ++b) {
+                    if (run[b].req < 0 || !reqs[run[b].req].want_pcm) continue;
+                    const int pend = e->slots_host[b].n_frames - run[b].voc_frames;
+                    if (pend >= 4 || (pend > 0 && !e->slots_host[b].active)) { real[ns] = std::min(pend, 4); list[ns++] = b; }
+                }
                 if (!ns) break;
                 TRY(ensure_wait());
-                TRY(q3_voc_decode_batch(e, list, ns, 4, vs));
-                for (int i = 0; i < ns; ++i) { if (run[list[i]].voc_frames == 0) first = true; run[list[i]].voc_frames += 4; }
-            }
-            for (int nf = 3; nf >= 1; --nf) {  // tails of finished utterances (flushed: nothing is silently dropped)
-                int ns = 0;
-                for (int b = 0; b < B; ++b)
-                    if (run[b].req >= 0 && reqs[run[b].req].want_pcm && !e->slots_host[b].active && e->slots_host[b].n_frames - run[b].voc_frames == nf) list[ns++] = b;
-                if (!ns) continue;
-                TRY(ensure_wait());
-                TRY(q3_voc_decode_batch(e, list, ns, nf, vs));
-                for (int i = 0; i < ns; ++i) { if (run[list[i]].voc_frames == 0) first = true; run[list[i]].voc_frames += nf; }
+                TRY(q3_voc_decode_batch(e, list, real, ns, 4, vs));
+                for (int i = 0; i < ns; ++i) { if (run[list[i]].voc_frames == 0) first = true; run[list[i]].voc_frames += real[i]; }
             }
             if (first) {  // first-chunk latency: the first chunk's PCM resident on the host
                 for (int b = 0; b < B; ++b)

@@ -97,9 +97,9 @@ __device__ __forceinline__ void vepi(const VGemm& g, float v, int s, int t, int 
 
 // Small-M GEMM (M <= 512 rows: the 12.5 Hz transformer, the first up-sampling stages, the drain phase of a batch):
 // workgroup tile 64 x 32, wave = 16 rows x 32 cols (2 MFMA tiles), no LDS and no barriers. The few rows cannot hide
-// memory latency with MFMA work, so fragments ride a 4-deep register ring (A: 32 B of f32 per lane -> bf16x8,
+// memory latency with MFMA work, so fragments ride an 8-deep register ring (A: 32 B of f32 per lane -> bf16x8,
 // B: 16 B of bf16 per lane per column tile) and the grid is cut fine enough to put a workgroup on every CU.
-#define VS_PF 4
+#define VS_PF 8
 __global__ __launch_bounds__(256) void k_vgemm_small(VGemm g) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int m0 = blockIdx.y * 64 + wave * 16, n0 = blockIdx.x * 32;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k_vgemm_small(VGemm g) {
     float4 ra[VS_PF][2]; uint4 rb[VS_PF][2];
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     // (no branch inside the ring: loads past the end re-read the last step and their A fragment is zeroed, so the
-    //  compiler can count outstanding loads exactly: vmcnt(12) at each consumption instead of vmcnt(0))
+    //  compiler can count outstanding loads exactly: vmcnt(28) at each consumption instead of vmcnt(0))
 #define VS_ISSUE(slot_, step_)                                                                        \
     do {                                                                                              \
         const int st__ = min((step_), steps - 1);                                                     \
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void k_voc_resunit(VResUnit g) {
 __global__ void k_voc_embed(VCall cl, const int* codes, int max_steps_cap, int ncb_model, const float* const* cb, int ncb, int cbs, int cd,
                             float* out, size_t out_stride, int out_off) {
     const int s = blockIdx.y, t = blockIdx.x;
-    const int slot = cl.slot[s], frame = cl.pos[s] + t;
+    const int slot = cl.slot[s], frame = min(cl.pos[s] + t, max_steps_cap - 1);  // (padding frames may point past the last row)
     const int* cp = codes + ((size_t)slot * max_steps_cap + frame) * ncb_model;
     for (int i = threadIdx.x; i < cd; i += blockDim.x) {
         float acc = 0.0f;
@@ -500,13 +500,19 @@ __global__ __launch_bounds__(64) void k_voc_attn(VCall cl, const float* qkv, flo
             sc[j] = a * scale;
         }
         __syncthreads();
+        // softmax weights once per key (lane j), max and sum by wave reductions; then P.V with the weights from LDS
         float m = -INFINITY;
-        for (int j = 0; j < nk; ++j) m = fmaxf(m, sc[j]);
+        for (int j = lane; j < nk; j += 64) m = fmaxf(m, sc[j]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         float l = 0.0f;
-        for (int j = 0; j < nk; ++j) l += expf(sc[j] - m);
+        for (int j = lane; j < nk; j += 64) { const float pj = expf(sc[j] - m); sc[j] = pj; l += pj; }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) l += __shfl_xor(l, o);
+        __syncthreads();
         for (int i = lane; i < hd; i += 64) {
             float o = 0.0f;
-            for (int j = 0; j < nk; ++j) o += expf(sc[j] - m) * vr[(size_t)((j0 + j) % RW) * HH + i];
+            for (int j = 0; j < nk; ++j) o += sc[j] * vr[(size_t)((j0 + j) % RW) * HH + i];
             att[row + i] = o / l;
         }
         __syncthreads();
@@ -731,7 +737,7 @@ int q3_voc_create(q3tts_engine* e) {
     VTRY(valloc(e, v, &v->att, M * HH)); VTRY(valloc(e, v, &v->g, M * c.d_ffn));
     VTRY(valloc(e, v, &v->kring, (size_t)c.n_layer * v->B * v->RW * HH)); VTRY(valloc(e, v, &v->vring, (size_t)c.n_layer * v->B * v->RW * HH));
     VTRY(valloc(e, v, &v->t1, (size_t)VOC_MAX_NS * scratch)); VTRY(valloc(e, v, &v->t2, (size_t)VOC_MAX_NS * scratch)); VTRY(valloc(e, v, &v->t3, (size_t)VOC_MAX_NS * scratch));
-    v->pcm_stride = (size_t)e->cfg.max_steps_cap * v->spf;
+    v->pcm_stride = (size_t)(e->cfg.max_steps_cap + VOC_FCAP) * v->spf;  // + padding frames behind a finished utterance
     VTRY(valloc(e, v, &v->pcm, (size_t)v->B * v->pcm_stride));
     v->frames_done.assign(v->B, 0); v->last_flag.assign(v->B, 0);
     Q3_HIP(e, hipStreamSynchronize(e->stream));
@@ -922,7 +928,7 @@ int q3_voc_decode(q3tts_engine* e, int slot, int f0, int nf, int is_last, hipStr
     return Q3TTS_OK;
 }
 // batched variant: the same nf (<= VOC_FCAP) new frames for every listed slot
-int q3_voc_decode_batch(q3tts_engine* e, const int* slots, int ns, int nf, hipStream_t s) {
+int q3_voc_decode_batch(q3tts_engine* e, const int* slots, const int* real, int ns, int nf, hipStream_t s) {
     Q3Voc* v = e->voc;
     if (!v) return q3_set_err(e, Q3TTS_ERR_STATE, "engine has no vocoder");
     if (ns <= 0 || ns > VOC_MAX_NS || nf <= 0 || nf > VOC_FCAP) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder batch shape");
@@ -930,7 +936,7 @@ int q3_voc_decode_batch(q3tts_engine* e, const int* slots, int ns, int nf, hipSt
     cl.ns = ns; cl.nf = nf;
     for (int i = 0; i < ns; ++i) { cl.slot[i] = slots[i]; cl.pos[i] = v->frames_done[slots[i]]; }
     VTRY(voc_call(e, cl, s));
-    for (int i = 0; i < ns; ++i) v->frames_done[slots[i]] += nf;
+    for (int i = 0; i < ns; ++i) v->frames_done[slots[i]] += real ? real[i] : nf;
     return Q3TTS_OK;
 }
 void q3_voc_mark_last(q3tts_engine* e, int slot) { if (e->voc) e->voc->last_flag[slot] = 1; }
