@@ -93,7 +93,12 @@ typedef struct q3tts_engine_config {
     int32_t max_steps_cap; /* upper bound accepted by q3tts_set_max_steps (reference default 512) */
     int32_t with_vocoder;  /* 0: codes only (no vocoder weights allocated) */
     uint64_t synth_seed;   /* seeded synthetic weights when weights_path == NULL */
-    const char* weights_path; /* NULL -> synthetic; else a Q3TW container written by q3tts_write_weights */
+    const char* weights_path; /* NULL -> synthetic. Else the reference's quant directory (src/tts/engine.rs:91-131):
+                               * qwen3_tts_talker.gguf + qwen3_tts_predictor.gguf (llama.cpp qwen3 tensor names; F32, F16,
+                               * BF16 or Q8_0, converted to bf16 at load) and qwen3_assets.gguf or its NPY fallback
+                               * (src/assets_manager.rs:14-26). Shapes must match `model`; the table row counts
+                               * (text_vocab, codec0_rows, codecq_rows) are taken from the files. The vocoder stays
+                               * synthetic: the reference ships it as ONNX only. */
 } q3tts_engine_config;
 
 typedef struct q3tts_engine q3tts_engine;
@@ -203,6 +208,10 @@ int q3tts_k_talker_prefill(q3tts_engine* e, const float* embd, int32_t n_tok, fl
 /* Vocoder: codes [n_frames][n_codebooks] -> pcm; chunk_frames frames per streaming call (0 = one call) */
 int q3tts_k_vocoder(q3tts_engine* e, const int32_t* codes, int32_t n_frames, int32_t chunk_frames, float* pcm_out,
                     int32_t* n_samples_out);
+/* Host-only: one tensor of a GGUF file (or the array of an .npy file; `tensor` is then ignored) as f32, through the same
+ * reader the engine uses for weights_path. out may be NULL to query nelem / dims (ggml order: dims4[0] is the row length)
+ * / ggml type (0 F32, 1 F16, 8 Q8_0, 30 BF16). Needs no GPU. */
+int q3tts_k_gguf_read(const char* path, const char* tensor, float* out, int64_t cap, int64_t* nelem, int64_t* dims4, int32_t* ggml_type);
 /* Measurement mode for bench.py: frame steps are launched eagerly (no graph replay) and the Predictor gate/up GEMM of
  * pass 1 / layer 0 is bracketed by HIP events on its own stream; q3tts_timings.probe_kernel_ms / probe_count report it
  * for the frame steps that ran at the full row count. enable = 0 restores graph replay. */

@@ -73,6 +73,18 @@ enum { WM_OUT_NORM = 0, WM_HEAD = 1 };
 enum { WA_TEXT = 0, WA_PROJ_W = 1, WA_PROJ_B = 2 };
 #define L_MODEL 255
 
+/* out[i] = base + synth(seed, tensor, i, std / IH4_STD), optionally rounded to bf16 — the generator behind every synthetic
+ * tensor, exported so that tests can write the same model into GGUF / NPY files (loader parity) */
+void q3o_synth_fill(uint64_t seed, uint32_t tensor, uint64_t n, float base, float std, int32_t round_to_bf16, float* out) {
+    const float scale = std / IH4_STD;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        float v = base + q3o_synth(seed, tensor, (uint64_t)i, scale);
+        if (round_to_bf16) { uint32_t u = (uint32_t)q3o_bf16(v) << 16; memcpy(&v, &u, 4); }
+        out[i] = v;
+    }
+}
+
 static float butterfly64(float* v) {
     float t[64];
     for (int m = 32; m >= 1; m >>= 1) {
@@ -707,7 +719,9 @@ int32_t q3o_generate(q3o_model* m, const float* prompt, int32_t n_tok, float tem
     float* pin = malloc((size_t)2 * dp * 4);
     float* px = malloc((size_t)2 * dp * 4);
     stdrng rng; stdrng_seed_u64(&rng, seed); /* :473-485 */
-    q3o_text_embedding(m, c->tts_pad_id, pad); /* tts_pad: src/assets_manager.rs:244-249 */
+    /* tts_pad: row 151671 of the text table when the table is that large, else zeros (src/assets_manager.rs:244-249) */
+    if (c->tts_pad_id < c->text_vocab) q3o_text_embedding(m, c->tts_pad_id, pad);
+    else memset(pad, 0, (size_t)de * 4);
     q3o_talker_prefill(m, prompt, n_tok, hidden, logits); /* :455-462 */
     int cur_pos = n_tok, n_frames = 0;
     *hit_eos = 0;

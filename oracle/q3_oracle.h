@@ -77,6 +77,7 @@ void q3o_destroy(q3o_model* m);
 float q3o_expf(float x);
 float q3o_synth(uint64_t seed, uint32_t tensor, uint64_t idx, float scale);
 uint16_t q3o_bf16(float x);
+void q3o_synth_fill(uint64_t seed, uint32_t tensor, uint64_t n, float base, float std, int32_t round_to_bf16, float* out);
 /* y = gemm_exact(norm?(x), W[N][K] bf16) ; epilogue 0 store(+bias) 1 residual 2 swiglu 3 argmax keys */
 void q3o_gemm_exact(const float* x, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, const float* norm_w,
                     float eps, const float* bias, int32_t epilogue, float* y, uint64_t* argmax_keys);

@@ -51,7 +51,8 @@ struct q3tts_engine {
     const float** codec_dev = nullptr;    // device array of the same pointers
     uint4* proj_w = nullptr;
     float* proj_b = nullptr;
-    float* tts_pad = nullptr;             // = text[tts_pad_id]
+    float* tts_pad = nullptr;             // = text[tts_pad_id] (or tts_pad_own: zeros, when the loaded text table is too small)
+    float* tts_pad_own = nullptr;
     // decode state: B = max_batch slots. A frame step runs on `rows` = the smallest bucket (1, 2, 4, ... B) that holds
     // the live slots: rows [0, n_live) carry the live slots, the rest carry distinct idle slots (row -> slot map on the
     // device), so a draining batch stops paying for rows it no longer has.

@@ -4,6 +4,7 @@
 // sample -> 15 predictor passes -> feedback -> Talker step, no host round trip (the reference crosses the
 // host<->backend boundary >= 33 times per frame).
 #include "q3_engine.h"
+#include "q3_gguf.h"
 
 #include <chrono>
 #include <cmath>
@@ -97,8 +98,53 @@ static void rope_tables(int n_pos, int hd, float theta, const int* sections, std
         }
 }
 
+// ---- real weights: llama.cpp's tensor names for the qwen3 architecture --------------------------
+struct GgSrc {
+    q3tts_engine* e; const Q3Gguf* g; const char* file;
+    std::vector<uint16_t> host; uint16_t* dev[2] = {nullptr, nullptr}; size_t dev_cap[2] = {0, 0};
+    ~GgSrc() { for (auto p : dev) if (p) hipFree(p); }
+    int fail(const std::string& msg) { return q3_set_err(e, Q3TTS_ERR_INVALID, std::string(file) + ": " + msg); }
+    const Q3GgufTensor* need(const std::string& name, uint64_t ne0, uint64_t ne1, int* rc) {
+        const Q3GgufTensor* t = g->find(name);
+        if (!t) { *rc = fail("tensor '" + name + "' is missing"); return nullptr; }
+        const uint64_t d1 = t->dims.size() > 1 ? t->dims[1] : 1;
+        if (t->dims[0] != ne0 || d1 != ne1 || t->dims.size() > 2) {
+            *rc = fail("tensor '" + name + "' has shape [" + std::to_string(d1) + "][" + std::to_string(t->dims[0]) + "], the configuration needs [" +
+                       std::to_string(ne1) + "][" + std::to_string(ne0) + "]");
+            return nullptr;
+        }
+        *rc = Q3TTS_OK;
+        return t;
+    }
+    // f32 vector -> device
+    int vec(const std::string& name, size_t n, float* dst) {
+        int rc; const Q3GgufTensor* t = need(name, n, 1, &rc);
+        if (!t) return rc;
+        std::vector<float> h(n); std::string err;
+        if (q3_gguf_to_f32(*t, h.data(), err)) return fail(err);
+        Q3_HIP(e, hipMemcpy(dst, h.data(), n * 4, hipMemcpyHostToDevice));
+        return Q3TTS_OK;
+    }
+    // [N][K] matrix -> bf16 row-major staging buffer `which` on the device
+    int mat(const std::string& name, size_t N, size_t K, int which) {
+        int rc; const Q3GgufTensor* t = need(name, K, N, &rc);
+        if (!t) return rc;
+        host.resize(N * K); std::string err;
+        if (q3_gguf_to_bf16(*t, host.data(), err)) return fail(err);
+        if (dev_cap[which] < N * K) {
+            if (dev[which]) hipFree(dev[which]);
+            dev[which] = nullptr; dev_cap[which] = 0;
+            void* p = nullptr;
+            if (hipMalloc(&p, N * K * 2) != hipSuccess) return q3_set_err(e, Q3TTS_ERR_OOM, "hipMalloc (weight staging)");
+            dev[which] = (uint16_t*)p; dev_cap[which] = N * K;
+        }
+        Q3_HIP(e, hipMemcpy(dev[which], host.data(), N * K * 2, hipMemcpyHostToDevice));
+        return Q3TTS_OK;
+    }
+};
+
 static int init_tfm(q3tts_engine* e, Q3Tfm& t, int grp, int L, int d, int Hq, int Hkv, int hd, int F, int head_n, float theta,
-                    const int* sections, int n_ctx, int n_slots) {
+                    const int* sections, int n_ctx, int n_slots, GgSrc* gg = nullptr) {
     t.L = L; t.d = d; t.Hq = Hq; t.Hkv = Hkv; t.hd = hd; t.F = F; t.nq = Hq * hd; t.nkv = Hkv * hd; t.nqkv = t.nq + 2 * t.nkv;
     t.head_n = head_n; t.n_ctx = n_ctx; t.n_slots = n_slots;
     const uint64_t seed = e->cfg.synth_seed;
@@ -109,6 +155,33 @@ static int init_tfm(q3tts_engine* e, Q3Tfm& t, int grp, int L, int d, int Hq, in
     for (int l = 0; l < L; ++l) {
         TRY(dalloc(e, &t.attn_norm[l], (size_t)d)); TRY(dalloc(e, &t.ffn_norm[l], (size_t)d));
         TRY(dalloc(e, &t.qn[l], (size_t)hd)); TRY(dalloc(e, &t.kn[l], (size_t)hd));
+        if (gg) {  // blk.N.* of a llama.cpp qwen3 GGUF (weights [out][in], NeoX RoPE: no q/k permutation)
+            const std::string b = "blk." + std::to_string(l) + ".";
+            Q3_HIP(e, hipStreamSynchronize(s));
+            TRY(gg->vec(b + "attn_norm.weight", d, t.attn_norm[l])); TRY(gg->vec(b + "ffn_norm.weight", d, t.ffn_norm[l]));
+            TRY(gg->vec(b + "attn_q_norm.weight", hd, t.qn[l])); TRY(gg->vec(b + "attn_k_norm.weight", hd, t.kn[l]));
+            TRY(dalloc(e, &t.wqkv[l], (size_t)t.nqkv * d / 8)); TRY(dalloc(e, &t.wo[l], (size_t)d * t.nq / 8));
+            TRY(dalloc(e, &t.wgu[l], (size_t)2 * F * d / 8)); TRY(dalloc(e, &t.wd[l], (size_t)d * F / 8));
+            Q3Fill f{}; f.mode = 0;
+            auto put = [&](const std::string& name, uint4* dst, int Ntot, int K, int row0, int rows) -> int {
+                TRY(gg->mat(name, rows, K, 0));
+                f.dst = dst; f.N = Ntot; f.K = K; f.mode = 0; f.row0 = row0; f.rows = rows; f.src_a = gg->dev[0]; f.src_b = nullptr;
+                q3_launch_fill_tiled(f, s);
+                Q3_HIP(e, hipStreamSynchronize(s));  // the staging buffer is reused by the next tensor
+                return Q3TTS_OK;
+            };
+            TRY(put(b + "attn_q.weight", t.wqkv[l], t.nqkv, d, 0, t.nq));
+            TRY(put(b + "attn_k.weight", t.wqkv[l], t.nqkv, d, t.nq, t.nkv));
+            TRY(put(b + "attn_v.weight", t.wqkv[l], t.nqkv, d, t.nq + t.nkv, t.nkv));
+            TRY(put(b + "attn_output.weight", t.wo[l], d, t.nq, 0, d));
+            TRY(gg->mat(b + "ffn_gate.weight", F, d, 0)); TRY(gg->mat(b + "ffn_up.weight", F, d, 1));
+            f.dst = t.wgu[l]; f.N = 2 * F; f.K = d; f.mode = 1; f.src_a = gg->dev[0]; f.src_b = gg->dev[1];
+            q3_launch_fill_tiled(f, s);
+            Q3_HIP(e, hipStreamSynchronize(s));
+            TRY(put(b + "ffn_down.weight", t.wd[l], d, F, 0, d));
+            t.weight_bytes += 2ull * ((size_t)t.nqkv * d + (size_t)d * t.nq + 3ull * F * d);
+            continue;
+        }
         q3_launch_fill_f32(t.attn_norm[l], d, seed, Q3_TID(grp, l, Q3W_ATTN_NORM), 1.0f, ns, 0, s);
         q3_launch_fill_f32(t.ffn_norm[l], d, seed, Q3_TID(grp, l, Q3W_FFN_NORM), 1.0f, ns, 0, s);
         q3_launch_fill_f32(t.qn[l], hd, seed, Q3_TID(grp, l, Q3W_QNORM), 1.0f, ns, 0, s);
@@ -127,11 +200,20 @@ static int init_tfm(q3tts_engine* e, Q3Tfm& t, int grp, int L, int d, int Hq, in
         t.weight_bytes += 2ull * ((size_t)t.nqkv * d + (size_t)d * t.nq + 3ull * F * d);
     }
     TRY(dalloc(e, &t.out_norm, (size_t)d));
-    q3_launch_fill_f32(t.out_norm, d, seed, Q3_TID(grp, Q3_L_MODEL, Q3WM_OUT_NORM), 1.0f, ns, 0, s);
     TRY(dalloc(e, &t.head, (size_t)head_n * d / 8));
     t.weight_bytes += 2ull * (size_t)head_n * d;
-    { Q3Fill f{}; f.seed = seed; f.scale = ms; f.dst = t.head; f.N = head_n; f.K = d; f.mode = 0; f.row0 = 0; f.rows = head_n;
-      f.tid_a = Q3_TID(grp, Q3_L_MODEL, Q3WM_HEAD); q3_launch_fill_tiled(f, s); }
+    if (gg) {
+        Q3_HIP(e, hipStreamSynchronize(s));
+        TRY(gg->vec("output_norm.weight", d, t.out_norm));
+        TRY(gg->mat("output.weight", head_n, d, 0));
+        Q3Fill f{}; f.dst = t.head; f.N = head_n; f.K = d; f.mode = 0; f.row0 = 0; f.rows = head_n; f.src_a = gg->dev[0];
+        q3_launch_fill_tiled(f, s);
+        Q3_HIP(e, hipStreamSynchronize(s));
+    } else {
+        q3_launch_fill_f32(t.out_norm, d, seed, Q3_TID(grp, Q3_L_MODEL, Q3WM_OUT_NORM), 1.0f, ns, 0, s);
+        Q3Fill f{}; f.seed = seed; f.scale = ms; f.dst = t.head; f.N = head_n; f.K = d; f.mode = 0; f.row0 = 0; f.rows = head_n;
+        f.tid_a = Q3_TID(grp, Q3_L_MODEL, Q3WM_HEAD); q3_launch_fill_tiled(f, s);
+    }
     t.layer_stride = (size_t)n_slots * Hkv * n_ctx * hd;
     TRY(dalloc(e, &t.kc, t.layer_stride * L)); TRY(dalloc(e, &t.vc, t.layer_stride * L));
     std::vector<float> cs, sn;
@@ -223,11 +305,100 @@ static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
     g.y = L.logits; g.ldy = m.t_vocab; g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);
 }
 
+static bool file_exists(const std::string& p) { FILE* f = fopen(p.c_str(), "rb"); if (f) fclose(f); return f != nullptr; }
+static uint16_t host_bf16(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static int upload_table(q3tts_engine* e, float** dst, const float* host, size_t n) {
+    TRY(dalloc(e, dst, n));
+    Q3_HIP(e, hipMemcpy(*dst, host, n * 4, hipMemcpyHostToDevice));
+    return Q3TTS_OK;
+}
+static int upload_proj(q3tts_engine* e, const float* w, const float* b) {
+    const q3tts_model_config& m = e->cfg.model;
+    const size_t n = (size_t)m.p_d_model * m.d_embed;
+    std::vector<uint16_t> h(n);
+    for (size_t i = 0; i < n; ++i) h[i] = host_bf16(w[i]);  // the projection runs on the bf16 GEMM (documented deviation)
+    void* stage = nullptr;
+    if (hipMalloc(&stage, n * 2) != hipSuccess) return q3_set_err(e, Q3TTS_ERR_OOM, "hipMalloc (projection staging)");
+    hipError_t er = hipMemcpy(stage, h.data(), n * 2, hipMemcpyHostToDevice);
+    int rc = Q3TTS_OK;
+    if (er == hipSuccess) rc = dalloc(e, &e->proj_w, n / 8);
+    if (er == hipSuccess && rc == Q3TTS_OK) {
+        Q3Fill f{}; f.dst = e->proj_w; f.N = m.p_d_model; f.K = m.d_embed; f.mode = 0; f.row0 = 0; f.rows = m.p_d_model; f.src_a = (const uint16_t*)stage;
+        q3_launch_fill_tiled(f, e->stream);
+        er = hipStreamSynchronize(e->stream);
+    }
+    hipFree(stage);
+    if (er != hipSuccess) return q3_set_err(e, Q3TTS_ERR_DEVICE, hipGetErrorString(er));
+    TRY(rc);
+    return upload_table(e, &e->proj_b, b, (size_t)m.p_d_model);
+}
+// Assets::load (src/assets_manager.rs:14-26): qwen3_assets.gguf if present, else the NPY files. Table row counts come from
+// the files (they define the out-of-range rules, :419-460); a missing text table means "every id is out of range".
+static int load_assets_files(q3tts_engine* e, const std::string& dir) {
+    q3tts_model_config& m = e->cfg.model;
+    const size_t d = (size_t)m.d_embed;
+    std::vector<std::vector<float>> tabs(1 + m.n_codebooks);  // text, codec 0..
+    std::vector<size_t> rows(1 + m.n_codebooks, 0);
+    std::vector<float> pw, pb;
+    std::string err;
+    const std::string gpath = dir + "/qwen3_assets.gguf";
+    if (file_exists(gpath)) {
+        Q3Gguf g;
+        if (g.open(gpath, err)) return q3_set_err(e, Q3TTS_ERR_INVALID, err);
+        auto fetch = [&](const std::string& name, uint64_t ne0, bool required, std::vector<float>& out, size_t* nrows) -> int {
+            const Q3GgufTensor* t = g.find(name);
+            if (!t) return required ? q3_set_err(e, Q3TTS_ERR_INVALID, gpath + ": " + name + " (tensor) missing") : Q3TTS_OK;
+            if (t->dims[0] != ne0 || t->dims.size() > 2) return q3_set_err(e, Q3TTS_ERR_INVALID, gpath + ": tensor '" + name + "' has the wrong row length");
+            out.resize(t->nelem);
+            if (q3_gguf_to_f32(*t, out.data(), err)) return q3_set_err(e, Q3TTS_ERR_INVALID, gpath + ": " + err);
+            if (nrows) *nrows = t->dims.size() > 1 ? (size_t)t->dims[1] : 1;
+            return Q3TTS_OK;
+        };
+        size_t pr = 0;
+        TRY(fetch("proj.weight", d, true, pw, &pr));
+        if (pr != (size_t)m.p_d_model) return q3_set_err(e, Q3TTS_ERR_INVALID, gpath + ": proj.weight does not have p_d_model rows");
+        TRY(fetch("proj.bias", (uint64_t)m.p_d_model, true, pb, nullptr));
+        TRY(fetch("text_embd", d, false, tabs[0], &rows[0]));
+        for (int q = 0; q < m.n_codebooks; ++q) TRY(fetch("codec_embd." + std::to_string(q), d, true, tabs[1 + q], &rows[1 + q]));
+    } else {
+        auto fetch = [&](const std::string& file, bool required, std::vector<float>& out, size_t* nrows, size_t row_len) -> int {
+            const std::string path = dir + "/" + file;
+            if (!file_exists(path)) return required ? q3_set_err(e, Q3TTS_ERR_INVALID, "neither qwen3_assets.gguf nor " + file + " in " + dir) : Q3TTS_OK;
+            std::vector<size_t> shape;
+            if (q3_npy_load_f32(path, out, shape, err)) return q3_set_err(e, Q3TTS_ERR_INVALID, err);
+            if (out.size() % row_len) return q3_set_err(e, Q3TTS_ERR_INVALID, path + ": size is not a multiple of the row length");
+            if (nrows) *nrows = out.size() / row_len;
+            return Q3TTS_OK;
+        };
+        size_t pr = 0, br = 0;
+        TRY(fetch("proj_weight.npy", true, pw, &pr, d));
+        TRY(fetch("proj_bias.npy", true, pb, &br, 1));
+        if (pr != (size_t)m.p_d_model || br != (size_t)m.p_d_model) return q3_set_err(e, Q3TTS_ERR_INVALID, dir + ": projection shape does not match p_d_model");
+        TRY(fetch("text_embedding_projected.npy", false, tabs[0], &rows[0], d));
+        for (int q = 0; q < m.n_codebooks; ++q) TRY(fetch("codec_embedding_" + std::to_string(q) + ".npy", true, tabs[1 + q], &rows[1 + q], d));
+    }
+    for (int q = 2; q < m.n_codebooks; ++q)
+        if (rows[1 + q] != rows[2]) return q3_set_err(e, Q3TTS_ERR_INVALID, dir + ": codec tables 1.." + std::to_string(m.n_codebooks - 1) + " differ in size");
+    m.text_vocab = (int32_t)rows[0]; m.codec0_rows = (int32_t)rows[1];
+    if (m.n_codebooks > 1) m.codecq_rows = (int32_t)rows[2];
+    if (rows[0]) TRY(upload_table(e, &e->text, tabs[0].data(), tabs[0].size()));
+    e->codec.resize(m.n_codebooks);
+    for (int q = 0; q < m.n_codebooks; ++q) TRY(upload_table(e, &e->codec[q], tabs[1 + q].data(), tabs[1 + q].size()));
+    TRY(upload_proj(e, pw.data(), pb.data()));
+    // tts_pad = row 151671 of the text table when it is that large, else zeros (src/assets_manager.rs:244-249)
+    if ((size_t)m.tts_pad_id < rows[0]) e->tts_pad = e->text + (size_t)m.tts_pad_id * d;
+    else { TRY(dalloc(e, &e->tts_pad_own, d)); Q3_HIP(e, hipMemset(e->tts_pad_own, 0, d * 4)); e->tts_pad = e->tts_pad_own; }
+    return Q3TTS_OK;
+}
+
 extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine** out) {
     if (!cfg || !out) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "null argument");
     std::string why;
     if (validate(*cfg, why) != Q3TTS_OK) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, why);
-    if (cfg->weights_path) return q3_set_err(nullptr, Q3TTS_ERR_UNSUPPORTED, "weights_path: Q3TW loader not built in this round; use synthetic weights");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return q3_set_err(nullptr, Q3TTS_ERR_DEVICE, "no HIP device: libq3tts has no CPU fallback");
@@ -246,17 +417,31 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
     HIPC(hipEventCreate(&e->ev0)); HIPC(hipEventCreate(&e->ev1)); HIPC(hipEventCreate(&e->ev2)); HIPC(hipEventCreate(&e->ev3));
     e->fin_ev.resize(cfg->max_batch, nullptr);
     for (auto& ev : e->fin_ev) HIPC(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    const q3tts_model_config& m = cfg->model;
+    q3tts_model_config& m = e->cfg.model;  // (table row counts follow the files when weights_path is given)
     const int B = cfg->max_batch;
     e->B = B;
     hipStream_t s = e->stream;
+    // weights_path = the reference's quant directory (src/tts/engine.rs:91-131): qwen3_tts_talker.gguf,
+    // qwen3_tts_predictor.gguf, qwen3_assets.gguf (or the NPY fallback). NULL: seeded synthetic weights.
+    const std::string wdir = cfg->weights_path ? cfg->weights_path : "";
+    Q3Gguf gt, gp;
+    GgSrc st{e, &gt, "qwen3_tts_talker.gguf"}, sp{e, &gp, "qwen3_tts_predictor.gguf"};
+    if (!wdir.empty()) {
+        std::string er;
+        if (gt.open(wdir + "/qwen3_tts_talker.gguf", er) || gp.open(wdir + "/qwen3_tts_predictor.gguf", er)) { q3_set_err(e, Q3TTS_ERR_INVALID, er); return fail(Q3TTS_ERR_INVALID); }
+    }
     TRYC(init_tfm(e, e->T, Q3G_TALKER, m.t_n_layer, m.t_d_model, m.t_n_head, m.t_n_kv_head, m.t_head_dim, m.t_d_ffn, m.t_vocab,
-                  m.t_rope_theta, m.t_mrope_sections, cfg->n_ctx, B));
+                  m.t_rope_theta, m.t_mrope_sections, cfg->n_ctx, B, wdir.empty() ? nullptr : &st));
     TRYC(init_tfm(e, e->P, Q3G_PRED, m.p_n_layer, m.p_d_model, m.p_n_head, m.p_n_kv_head, m.p_head_dim, m.p_d_ffn,
-                  (m.n_codebooks - 1) * m.codebook_size, m.p_rope_theta, nullptr, 64, B));
+                  (m.n_codebooks - 1) * m.codebook_size, m.p_rope_theta, nullptr, 64, B, wdir.empty() ? nullptr : &sp));
     // assets (F32 tables like qwen3_assets.gguf: src/assets_manager.rs:212-241; values bf16-representable)
     const uint64_t seed = cfg->synth_seed;
     const float es = 0.05f / Q3_IH4_STD;
+    if (!wdir.empty()) {
+        TRYC(load_assets_files(e, wdir));
+        { void* cd = nullptr; HIPC(hipMalloc(&cd, sizeof(float*) * 16)); e->codec_dev = (const float**)cd; }
+        HIPC(hipMemcpyAsync((void*)e->codec_dev, e->codec.data(), sizeof(float*) * m.n_codebooks, hipMemcpyHostToDevice, s));
+    } else {
     TRYC(dalloc(e, &e->text, (size_t)m.text_vocab * m.d_embed));
     q3_launch_fill_f32(e->text, (size_t)m.text_vocab * m.d_embed, seed, Q3_TID(Q3G_ASSET, 0, Q3WA_TEXT), 0.0f, es, 1, s);
     e->codec.resize(m.n_codebooks);
@@ -273,6 +458,7 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
     TRYC(dalloc(e, &e->proj_b, (size_t)m.p_d_model));
     q3_launch_fill_f32(e->proj_b, m.p_d_model, seed, Q3_TID(Q3G_ASSET, 0, Q3WA_PROJ_B), 0.0f, 0.02f / Q3_IH4_STD, 0, s);
     e->tts_pad = e->text + (size_t)m.tts_pad_id * m.d_embed;  // src/assets_manager.rs:244-249
+    }
     // decode state
     TRYC(dalloc(e, &e->slots, (size_t)B));
     HIPC(hipHostMalloc((void**)&e->slots_host, sizeof(Q3Slot) * 2 * B, hipHostMallocDefault));
@@ -360,6 +546,7 @@ extern "C" void q3tts_engine_destroy(q3tts_engine* e) {
     }
     free_tfm(e->T); free_tfm(e->P);
     hipFree(e->text); for (auto p : e->codec) hipFree(p); hipFree((void*)e->codec_dev); hipFree(e->proj_w); hipFree(e->proj_b);
+    hipFree(e->tts_pad_own);
     hipFree(e->slots); if (e->slots_host) hipHostFree(e->slots_host);
     hipFree(e->codes); hipFree(e->rng);
     hipFree(e->sc_pre.qkv); hipFree(e->sc_pre.att); hipFree(e->sc_pre.h);
@@ -992,6 +1179,33 @@ extern "C" int q3tts_k_talker_prefill(q3tts_engine* e, const float* embd, int32_
     Q3Slot* stage = e->slots_host + e->B; memset(stage, 0, sizeof(Q3Slot));
     Q3_HIP(e, hipMemcpyAsync(e->slots, stage, sizeof(Q3Slot), hipMemcpyHostToDevice, s));  // retire the slot again
     Q3_HIP(e, hipStreamSynchronize(s));
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_k_gguf_read(const char* path, const char* tensor, float* out, int64_t cap, int64_t* nelem, int64_t* dims4, int32_t* ggml_type) {
+    if (!path || !tensor || !nelem) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "null argument");
+    std::string err;
+    const std::string p = path;
+    if (p.size() > 4 && p.compare(p.size() - 4, 4, ".npy") == 0) {
+        std::vector<float> v; std::vector<size_t> shape;
+        if (q3_npy_load_f32(p, v, shape, err)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, err);
+        *nelem = (int64_t)v.size();
+        if (dims4) for (int i = 0; i < 4; ++i) dims4[i] = i < (int)shape.size() ? (int64_t)shape[i] : 0;
+        if (ggml_type) *ggml_type = Q3_GGML_F32;
+        if (out) { if (cap < *nelem) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "output buffer too small"); memcpy(out, v.data(), v.size() * 4); }
+        return Q3TTS_OK;
+    }
+    Q3Gguf g;
+    if (g.open(p, err)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, err);
+    const Q3GgufTensor* t = g.find(tensor);
+    if (!t) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, std::string("tensor '") + tensor + "' is missing");
+    *nelem = (int64_t)t->nelem;
+    if (dims4) for (int i = 0; i < 4; ++i) dims4[i] = i < (int)t->dims.size() ? (int64_t)t->dims[i] : 0;
+    if (ggml_type) *ggml_type = (int32_t)t->type;
+    if (out) {
+        if (cap < *nelem) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "output buffer too small");
+        if (q3_gguf_to_f32(*t, out, err)) return q3_set_err(nullptr, Q3TTS_ERR_UNSUPPORTED, err);
+    }
     return Q3TTS_OK;
 }
 

@@ -415,7 +415,8 @@ void q3_launch_gemm(const Q3Gemm& g, hipStream_t s) {
         RT = g.B > 32 ? 4 : 2;
         static const int rtmax = getenv("Q3_RTMAX") ? atoi(getenv("Q3_RTMAX")) : 4;  // tuning knob
         if (RT > rtmax) RT = rtmax;
-        while (RT > 1 && (long)tiles * ((g.B + RT * 16 - 1) / (RT * 16)) < 256) RT >>= 1;
+        static const int minwg = getenv("Q3_MINWG") ? atoi(getenv("Q3_MINWG")) : 256;  // tuning knob
+        while (RT > 1 && (long)tiles * ((g.B + RT * 16 - 1) / (RT * 16)) < minwg) RT >>= 1;
     }
     dim3 grid(tiles, (g.B + RT * 16 - 1) / (RT * 16));
     if (RT == 4) launch_ring<4, 1>(g, grid, s);

@@ -1,5 +1,6 @@
 """Thin object wrapper over the C ABI (include/q3tts.h). No arithmetic happens in Python."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -216,6 +217,24 @@ def k_sample(logits, limit, temperature, top_k, top_p, r=None, device=0):
     if rc != 0:
         raise _abi.Q3Error(f"q3tts_k_sample failed ({rc}): {lib.q3tts_last_error(None).decode()}")
     return out
+
+
+def k_gguf_read(path, tensor=""):
+    """One tensor of a GGUF file / the array of an .npy file as f32, through the engine's own reader (host only).
+    Returns (array shaped like numpy would show it, ggml type)."""
+    lib = _abi.load_library()
+    n = C.c_int64(0); dims = (C.c_int64 * 4)(); ty = C.c_int32(0)
+    rc = lib.q3tts_k_gguf_read(os.fsencode(path), tensor.encode(), None, 0, C.byref(n), dims, C.byref(ty))
+    if rc != 0:
+        raise _abi.Q3Error(f"q3tts_k_gguf_read: {lib.q3tts_last_error(None).decode()} (status {rc})")
+    out = np.zeros(n.value, dtype=np.float32)
+    rc = lib.q3tts_k_gguf_read(os.fsencode(path), tensor.encode(), _ptr(out, f32p), n.value, C.byref(n), dims, C.byref(ty))
+    if rc != 0:
+        raise _abi.Q3Error(f"q3tts_k_gguf_read: {lib.q3tts_last_error(None).decode()} (status {rc})")
+    shape = [int(d) for d in dims if d]
+    if not str(path).endswith(".npy"):
+        shape = shape[::-1]  # ggml lists the contiguous dimension first
+    return out.reshape(shape), int(ty.value)
 
 
 def k_rng_f32(seed, n):

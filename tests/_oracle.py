@@ -42,6 +42,8 @@ def lib():
     L.q3o_synth.restype = C.c_float
     L.q3o_bf16.argtypes = [C.c_float]
     L.q3o_bf16.restype = C.c_uint16
+    L.q3o_synth_fill.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_float, C.c_float, C.c_int32, f32p]
+    L.q3o_synth_fill.restype = None
     L.q3o_gemm_exact.argtypes = [f32p, C.c_int32, C.c_int32, C.POINTER(C.c_uint16), C.c_int32, f32p, C.c_float, f32p,
                                  C.c_int32, f32p, C.POINTER(C.c_uint64)]
     L.q3o_gemm_exact.restype = None
@@ -129,3 +131,80 @@ class OracleModel:
         n = self.L.q3o_generate(self.h, ptr(embd, f32p), embd.shape[0], temperature, top_k, top_p, seed, max_steps,
                                 min_frames, force_eos_at, ptr(codes, i32p), C.byref(eos))
         return codes[:n].copy(), bool(eos.value)
+
+
+# ---- the synthetic model as files (loader parity): same tensor ids / scales as oracle/q3_oracle.c tfm_init, q3o_create
+_G_TALKER, _G_PRED, _G_ASSET = 1, 2, 3
+_W = dict(attn_norm=0, q=1, k=2, v=3, qnorm=4, knorm=5, o=6, ffn_norm=7, gate=8, up=9, down=10)
+_L_MODEL = 255
+
+
+def _tid(g, l, w):
+    return (g << 16) | (l << 8) | w
+
+
+def synth_tensor(seed, tid, shape, base, std, round_bf16):
+    out = np.zeros(int(np.prod(shape)), dtype=np.float32)
+    lib().q3o_synth_fill(seed, tid, out.size, base, std, 1 if round_bf16 else 0, ptr(out, f32p))
+    return out.reshape(shape)
+
+
+def synth_transformer_tensors(m, seed, talker):
+    """llama.cpp qwen3 tensor names -> f32 arrays of the synthetic Talker / Predictor (matrices are bf16-exact)."""
+    if talker:
+        g, L, d, Hq, Hkv, hd, F, head_n = _G_TALKER, m.t_n_layer, m.t_d_model, m.t_n_head, m.t_n_kv_head, m.t_head_dim, m.t_d_ffn, m.t_vocab
+    else:
+        g, L, d, Hq, Hkv, hd, F = _G_PRED, m.p_n_layer, m.p_d_model, m.p_n_head, m.p_n_kv_head, m.p_head_dim, m.p_d_ffn
+        head_n = (m.n_codebooks - 1) * m.codebook_size
+    nq, nkv = Hq * hd, Hkv * hd
+    t = {}
+    for l in range(L):
+        b = "blk.%d." % l
+        t[b + "attn_norm.weight"] = synth_tensor(seed, _tid(g, l, _W["attn_norm"]), (d,), 1.0, 0.05, False)
+        t[b + "ffn_norm.weight"] = synth_tensor(seed, _tid(g, l, _W["ffn_norm"]), (d,), 1.0, 0.05, False)
+        t[b + "attn_q_norm.weight"] = synth_tensor(seed, _tid(g, l, _W["qnorm"]), (hd,), 1.0, 0.05, False)
+        t[b + "attn_k_norm.weight"] = synth_tensor(seed, _tid(g, l, _W["knorm"]), (hd,), 1.0, 0.05, False)
+        t[b + "attn_q.weight"] = synth_tensor(seed, _tid(g, l, _W["q"]), (nq, d), 0.0, 0.02, True)
+        t[b + "attn_k.weight"] = synth_tensor(seed, _tid(g, l, _W["k"]), (nkv, d), 0.0, 0.02, True)
+        t[b + "attn_v.weight"] = synth_tensor(seed, _tid(g, l, _W["v"]), (nkv, d), 0.0, 0.02, True)
+        t[b + "attn_output.weight"] = synth_tensor(seed, _tid(g, l, _W["o"]), (d, nq), 0.0, 0.02, True)
+        t[b + "ffn_gate.weight"] = synth_tensor(seed, _tid(g, l, _W["gate"]), (F, d), 0.0, 0.02, True)
+        t[b + "ffn_up.weight"] = synth_tensor(seed, _tid(g, l, _W["up"]), (F, d), 0.0, 0.02, True)
+        t[b + "ffn_down.weight"] = synth_tensor(seed, _tid(g, l, _W["down"]), (d, F), 0.0, 0.02, True)
+    t["output_norm.weight"] = synth_tensor(seed, _tid(g, _L_MODEL, 0), (d,), 1.0, 0.05, False)
+    t["output.weight"] = synth_tensor(seed, _tid(g, _L_MODEL, 1), (head_n, d), 0.0, 0.02, True)
+    return t
+
+
+def synth_asset_tensors(m, seed, with_text=True):
+    """qwen3_assets.gguf tensor names (src/assets_manager.rs:212-241) -> f32 arrays of the synthetic assets."""
+    d = m.d_embed
+    t = {"proj.weight": synth_tensor(seed, _tid(_G_ASSET, 0, 1), (m.p_d_model, d), 0.0, 0.02, True),
+         "proj.bias": synth_tensor(seed, _tid(_G_ASSET, 0, 2), (m.p_d_model,), 0.0, 0.02, False)}
+    if with_text:
+        t["text_embd"] = synth_tensor(seed, _tid(_G_ASSET, 0, 0), (m.text_vocab, d), 0.0, 0.05, True)
+    for q in range(m.n_codebooks):
+        rows = m.codec0_rows if q == 0 else m.codecq_rows
+        t["codec_embd.%d" % q] = synth_tensor(seed, _tid(_G_ASSET, 1 + q, 0), (rows, d), 0.0, 0.05, True)
+    return t
+
+
+def write_model_dir(path, m, seed, matrix_type=30, assets="gguf", with_text=True):
+    """The synthetic model as the reference's quant directory: two llama.cpp-style GGUFs + qwen3_assets.gguf (or NPY)."""
+    import _gguf as G
+    os.makedirs(path, exist_ok=True)
+    for talker, fname in ((True, "qwen3_tts_talker.gguf"), (False, "qwen3_tts_predictor.gguf")):
+        tens = synth_transformer_tensors(m, seed, talker)
+        G.write(os.path.join(path, fname), [(k, v, matrix_type if v.ndim == 2 else G.F32) for k, v in tens.items()],
+                meta={"general.architecture": "qwen3", "general.alignment": 32, "qwen3.block_count": m.t_n_layer if talker else m.p_n_layer,
+                      "tokenizer.ggml.tokens": ["<a>", "<b>"], "tokenizer.ggml.token_type": [1, 1]})
+    at = synth_asset_tensors(m, seed, with_text)
+    if assets == "gguf":
+        G.write(os.path.join(path, "qwen3_assets.gguf"), [(k, v, G.F32) for k, v in at.items()], meta={"general.architecture": "qwen3-tts-assets"})
+    else:  # the legacy NPY layout (src/assets_manager.rs:267-300)
+        np.save(os.path.join(path, "proj_weight.npy"), at["proj.weight"])
+        np.save(os.path.join(path, "proj_bias.npy"), at["proj.bias"])
+        if with_text:
+            np.save(os.path.join(path, "text_embedding_projected.npy"), at["text_embd"])
+        for q in range(m.n_codebooks):
+            np.save(os.path.join(path, "codec_embedding_%d.npy" % q), at["codec_embd.%d" % q])

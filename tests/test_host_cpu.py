@@ -101,3 +101,66 @@ def test_pcm_gather_over_gloo_world2(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert out.read_text() == "ok 7"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# loader row: the engine's GGUF / NPY reader against the numpy restatement (tests/_gguf.py).
+# Host-only entry point of the C ABI: needs no GPU.
+# ---------------------------------------------------------------------------------------------------------------
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_gguf_reader_matches_numpy_restatement(tmp_path):
+    import _gguf as G
+    from q3tts import native
+    rng = np.random.default_rng(5)
+    a = (rng.standard_normal((48, 96)) * 0.05).astype(np.float32)
+    a[0, :4] = [0.0, -0.0, 6.1e-5, -65504.0]  # zero / f16 subnormal boundary / f16 max
+    v = rng.standard_normal(96).astype(np.float32)
+    path = str(tmp_path / "t.gguf")
+    G.write(path, [("blk.0.attn_q.weight", a, G.F32), ("m.f16", a, G.F16), ("m.bf16", a, G.BF16), ("m.q8", a, G.Q8_0), ("v", v, G.F32)],
+            meta={"general.architecture": "qwen3", "general.alignment": 32, "qwen3.block_count": 2, "tokenizer.ggml.tokens": ["a", "bc"],
+                  "tokenizer.ggml.token_type": [1, 2, 3], "some.float": 1.5, "some.flag": True, "big": 2 ** 40})
+    ref = G.read(path)
+    for name, (want, ty) in ref.items():
+        got, gty = native.k_gguf_read(path, name)
+        assert gty == ty and got.shape == want.shape and np.array_equal(_bits(got), _bits(want)), name
+    assert np.array_equal(_bits(ref["blk.0.attn_q.weight"][0]), _bits(a))                       # F32 is a byte copy
+    assert np.array_equal(G.f32_to_bf16_bits(ref["m.bf16"][0]), G.f32_to_bf16_bits(a))            # BF16 = RNE of the f32 value
+    assert np.abs(ref["m.q8"][0] - a).max() <= np.abs(a).max() / 127.0                          # Q8_0 block error bound
+    G.write(str(tmp_path / "v2.gguf"), [("v", v, G.F32)], version=2)                                # v2 has the same layout
+    assert np.array_equal(native.k_gguf_read(str(tmp_path / "v2.gguf"), "v")[0], v)
+    np.save(tmp_path / "x.npy", a)                                                                # NPY fallback reader
+    got, _ = native.k_gguf_read(str(tmp_path / "x.npy"))
+    assert got.shape == a.shape and np.array_equal(_bits(got), _bits(a))
+
+
+def test_gguf_reader_errors_are_loud(tmp_path):
+    import struct
+    import _gguf as G
+    from q3tts import _abi, native
+    v = np.arange(64, dtype=np.float32)
+    good = str(tmp_path / "g.gguf")
+    G.write(good, [("v", v, G.F32)])
+    with pytest.raises(_abi.Q3Error, match="missing"):
+        native.k_gguf_read(good, "nope")
+    with pytest.raises(_abi.Q3Error, match="cannot open"):
+        native.k_gguf_read(str(tmp_path / "absent.gguf"), "v")
+    raw = open(good, "rb").read()
+    (tmp_path / "magic.gguf").write_bytes(b"GGML" + raw[4:])
+    with pytest.raises(_abi.Q3Error, match="not a GGUF"):
+        native.k_gguf_read(str(tmp_path / "magic.gguf"), "v")
+    (tmp_path / "v1.gguf").write_bytes(raw[:4] + struct.pack("<I", 1) + raw[8:])
+    with pytest.raises(_abi.Q3Error, match="version"):
+        native.k_gguf_read(str(tmp_path / "v1.gguf"), "v")
+    (tmp_path / "cut.gguf").write_bytes(raw[:-100])
+    with pytest.raises(_abi.Q3Error, match="outside the file"):
+        native.k_gguf_read(str(tmp_path / "cut.gguf"), "v")
+    # a K-quant tensor (type 12 = Q4_K) is listed but refused when asked for
+    G.write(str(tmp_path / "kq.gguf"), [("v", v, G.F32)], raw_types={"v": 12})
+    with pytest.raises(_abi.Q3Error, match="unsupported ggml type 12"):
+        native.k_gguf_read(str(tmp_path / "kq.gguf"), "v")
+    np.save(tmp_path / "f64.npy", v.astype(np.float64))
+    with pytest.raises(_abi.Q3Error, match="f32"):
+        native.k_gguf_read(str(tmp_path / "f64.npy"))

@@ -392,3 +392,52 @@ def test_api_mirror_generate_with_voice(tiny_voc, tmp_path):
     assert te.get_speaker("nobody") is voice  # fallback chain: id -> name -> vivian (src/tts/engine.rs:211-231)
     with pytest.raises(Exception):
         te.generate_with_voice("plain text needs a tokenizer.json", voice)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# loader row: an engine built from model FILES equals the engine built from the generator
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("matrix_type,assets,with_text", [(30, "gguf", True), (0, "npy", True), (1, "gguf", False)])
+def test_engine_from_model_files(oracle, tmp_path, matrix_type, assets, with_text):
+    """weights_path = the reference's quant directory (llama.cpp-style talker / predictor GGUFs + qwen3_assets.gguf or
+    NPY). The files hold the synthetic model (bf16-exact matrices), so BF16, F32 and F16 containers must all reproduce
+    the oracle's ids bit for bit; without a text table every text id follows the out-of-range formula and tts_pad is 0."""
+    from q3tts import _abi, native
+    cfg = _abi.tiny_config(max_batch=2, n_ctx=128, with_vocoder=0)
+    oracle.write_model_dir(str(tmp_path), cfg.model, 0, matrix_type=matrix_type, assets=assets, with_text=with_text)
+    cfg.weights_path = str(tmp_path).encode()
+    eng = native.NativeEngine(cfg)
+    ocfg = _abi.tiny_config(max_batch=2, n_ctx=128, with_vocoder=0)
+    if not with_text:
+        ocfg.model.text_vocab = 0
+    om = oracle.OracleModel(ocfg.model, seed=0, n_ctx=128, n_threads=4)
+    try:
+        desc, keep = oracle.make_prompt_desc(np.arange(900, 912), spk_emb=_spk(cfg.model.d_embed))
+        pe = om.build_prompt(desc)
+        assert np.array_equal(_bits(eng.build_prompt(desc)), _bits(pe))
+        for kw in (dict(temperature=0.0, max_steps=6), dict(temperature=0.7, top_k=40, top_p=0.9, seed=11, max_steps=6)):
+            ref, _ = om.generate(pe, **kw)
+            assert np.array_equal(eng.generate(desc=desc, **kw).codes, ref)
+    finally:
+        eng.close()
+        om.close()
+
+
+def test_model_files_errors_are_loud(oracle, tmp_path):
+    import _gguf as G
+    from q3tts import _abi, native
+    cfg = _abi.tiny_config(max_batch=1, n_ctx=128, with_vocoder=0)
+    cfg.weights_path = str(tmp_path / "nowhere").encode()
+    with pytest.raises(_abi.Q3Error, match="cannot open"):
+        native.NativeEngine(cfg)
+    oracle.write_model_dir(str(tmp_path), cfg.model, 0, with_text=False)
+    t = oracle.synth_transformer_tensors(cfg.model, 0, True)
+    bad = dict(t); bad.pop("blk.1.ffn_up.weight")
+    G.write(str(tmp_path / "qwen3_tts_talker.gguf"), [(k, v, G.BF16 if v.ndim == 2 else G.F32) for k, v in bad.items()])
+    cfg.weights_path = str(tmp_path).encode()
+    with pytest.raises(_abi.Q3Error, match="blk.1.ffn_up.weight.*missing"):
+        native.NativeEngine(cfg)
+    bad = dict(t); bad["blk.0.attn_q.weight"] = bad["blk.0.attn_q.weight"][:, :-32]
+    G.write(str(tmp_path / "qwen3_tts_talker.gguf"), [(k, v, G.BF16 if v.ndim == 2 else G.F32) for k, v in bad.items()])
+    with pytest.raises(_abi.Q3Error, match="attn_q.weight.*shape"):
+        native.NativeEngine(cfg)
