@@ -190,6 +190,12 @@ typedef struct q3tts_timings {
 } q3tts_timings;
 int q3tts_get_timings(const q3tts_engine* e, q3tts_timings* out);
 
+/* Log-mel front-end of the voice-clone path (replaces SpeakerEncoder::compute_mel, src/models/onnx.rs:166-321): 24 kHz mono
+ * f32 in, [n_frames][128] log-mel out (n_fft 1024, hop 256, Slaney mels, the reference's padding rules). The encoders that
+ * consume it are ONNX-only in the reference and are not part of this library yet. */
+int32_t q3tts_mel_frames(int64_t n_samples);
+int q3tts_mel(q3tts_engine* e, const float* audio, int64_t n_samples, float* out, int32_t cap_frames, int32_t* n_frames);
+
 /* ---- kernel-level test hooks (host buffers in/out; used only by tests/ and bench.py) ----------- */
 /* y[B][N] = exact_gemm(norm?(x)[B][K], W[N][K] bf16 bits) (+bias) — canonical order of DESIGN.md §4.1 */
 int q3tts_k_gemm_exact(int32_t device, const float* x, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N,

@@ -115,6 +115,11 @@ int32_t q3o_generate(q3o_model* m, const float* prompt_embd, int32_t n_tok, floa
 int32_t q3o_chunk_plan(int32_t n_frames, int32_t* calls_frames, int32_t* calls_final, int32_t max_calls);
 
 /* vocoder (q3_oracle_vocoder.c) ------------------------------------------------------------- */
+/* log-mel front-end of the clone path (q3_oracle_mel.c; src/models/onnx.rs:166-321) */
+void q3o_mel_tables(float* hann1024, float* cos1024, float* sin1024, float* fb128x513);
+int32_t q3o_mel_frames(int64_t n_samples);
+int32_t q3o_mel(const float* audio, int64_t n_samples, float* out, float* pre_log);
+
 typedef struct q3o_vocoder q3o_vocoder;
 q3o_vocoder* q3o_vocoder_create(const q3o_vocoder_config* cfg, uint64_t seed, int32_t n_threads);
 void q3o_vocoder_destroy(q3o_vocoder* v);

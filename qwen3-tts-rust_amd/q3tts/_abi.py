@@ -100,7 +100,7 @@ SYMBOLS = [
     "q3tts_set_max_steps", "q3tts_build_prompt", "q3tts_free", "q3tts_generate", "q3tts_generate_batch",
     "q3tts_result_free", "q3tts_stream_begin", "q3tts_stream_poll", "q3tts_stream_end", "q3tts_write_weights",
     "q3tts_get_timings", "q3tts_k_gemm_exact", "q3tts_k_attention", "q3tts_k_sample", "q3tts_k_talker_prefill",
-    "q3tts_k_vocoder", "q3tts_k_rng_f32", "q3tts_k_probe", "q3tts_k_gguf_read",
+    "q3tts_k_vocoder", "q3tts_k_rng_f32", "q3tts_k_probe", "q3tts_k_gguf_read", "q3tts_mel_frames", "q3tts_mel",
 ]
 
 
@@ -155,6 +155,9 @@ def load_library(path=None):
     lib.q3tts_k_vocoder.argtypes = [vp, i32p, C.c_int32, C.c_int32, f32p, i32p]
     lib.q3tts_k_rng_f32.argtypes = [C.c_uint64, C.c_int32, f32p]
     lib.q3tts_k_probe.argtypes = [C.c_void_p, C.c_int32]
+    lib.q3tts_mel_frames.argtypes = [C.c_int64]
+    lib.q3tts_mel_frames.restype = C.c_int32
+    lib.q3tts_mel.argtypes = [C.c_void_p, f32p, C.c_int64, f32p, C.c_int32, C.POINTER(C.c_int32)]
     lib.q3tts_k_gguf_read.argtypes = [C.c_char_p, C.c_char_p, f32p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     if path is None:
         _lib = lib

@@ -142,6 +142,15 @@ class NativeEngine:
         self._check(self.lib.q3tts_get_timings(self.h, C.byref(t)), "q3tts_get_timings")
         return t
 
+    def mel(self, audio):
+        """24 kHz mono f32 -> [n_frames][128] log-mel (the clone path's front-end)."""
+        a = np.ascontiguousarray(audio, dtype=np.float32)
+        cap = int(self.lib.q3tts_mel_frames(a.size))
+        out = np.zeros((max(cap, 1), 128), dtype=np.float32)
+        n = C.c_int32(0)
+        self._check(self.lib.q3tts_mel(self.h, _ptr(a, f32p) if a.size else None, a.size, _ptr(out, f32p), cap, C.byref(n)), "q3tts_mel")
+        return out[:n.value].copy()
+
     def probe(self, enable):
         """Measurement mode (bench.py): eager frame steps with HIP events around the Predictor gate/up GEMM."""
         self._check(self.lib.q3tts_k_probe(self.h, int(bool(enable))), "q3tts_k_probe")

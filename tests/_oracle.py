@@ -75,6 +75,10 @@ def lib():
     L.q3o_generate.restype = C.c_int32
     L.q3o_chunk_plan.argtypes = [C.c_int32, i32p, i32p, C.c_int32]
     L.q3o_chunk_plan.restype = C.c_int32
+    L.q3o_mel_frames.argtypes = [C.c_int64]
+    L.q3o_mel_frames.restype = C.c_int32
+    L.q3o_mel.argtypes = [f32p, C.c_int64, f32p, f32p]
+    L.q3o_mel.restype = C.c_int32
     if hasattr(L, "q3o_vocoder_create"):
         L.q3o_vocoder_create.argtypes = [C.POINTER(_abi.VocoderConfig), C.c_uint64, C.c_int32]
         L.q3o_vocoder_create.restype = vp
@@ -208,3 +212,13 @@ def write_model_dir(path, m, seed, matrix_type=30, assets="gguf", with_text=True
             np.save(os.path.join(path, "text_embedding_projected.npy"), at["text_embd"])
         for q in range(m.n_codebooks):
             np.save(os.path.join(path, "codec_embedding_%d.npy" % q), at["codec_embd.%d" % q])
+
+
+def mel(audio, want_pre_log=False):
+    """Oracle log-mel (oracle/q3_oracle_mel.c): [n_frames][128]."""
+    a = np.ascontiguousarray(audio, dtype=np.float32)
+    cap = max(1, int(lib().q3o_mel_frames(a.size)))
+    out = np.zeros((cap, 128), dtype=np.float32)
+    pre = np.zeros((cap, 128), dtype=np.float32)
+    n = lib().q3o_mel(ptr(a, f32p) if a.size else None, a.size, ptr(out, f32p), ptr(pre, f32p))
+    return (out[:n].copy(), pre[:n].copy()) if want_pre_log else out[:n].copy()

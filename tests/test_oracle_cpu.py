@@ -238,3 +238,48 @@ def test_vocoder_oracle_properties(oracle):
     assert L.q3o_vocoder_decode(v, oracle.ptr(codes[:4].copy(), oracle.i32p), 4, 0, oracle.ptr(buf, oracle.f32p), buf.size) == 2 * 1920
     assert L.q3o_vocoder_decode(v, oracle.ptr(codes[4:].copy(), oracle.i32p), 2, 1, oracle.ptr(buf, oracle.f32p), buf.size) == 4 * 1920
     L.q3o_vocoder_destroy(v)
+
+
+def _mel_numpy_f64(audio):
+    """Independent restatement of the SPEC (src/models/onnx.rs:166-321) in float64 with numpy's rFFT: pins the padding rules,
+    window, Slaney filterbank and log floor of the oracle (the oracle's own DFT order is pinned by the GPU parity test)."""
+    x = np.asarray(audio, dtype=np.float64)
+    n, pad = x.size, 384
+    head = [x[i] if i < n else 0.0 for i in range(pad, 0, -1)]
+    tail = [x[max(n - 1 - i, 0)] if n > 0 else 0.0 for i in range(1, pad + 1)]
+    p = np.concatenate([head, x, tail])
+    if p.size < 1024:
+        return np.zeros((0, 128))
+    nf = (p.size - 1024) // 256 + 1
+    win = 0.5 * (1.0 - np.cos(2.0 * np.pi * np.arange(1024) / 1024.0))
+    fr = np.stack([p[f * 256:f * 256 + 1024] * win for f in range(nf)])
+    mag = np.sqrt(np.abs(np.fft.rfft(fr, axis=1)) ** 2 + 1e-9)
+
+    def hz_to_mel(f):
+        return np.where(f >= 1000.0, 15.0 + np.log(np.maximum(f, 1e-9) / 1000.0) / (np.log(6.4) / 27.0), f / (200.0 / 3.0))
+
+    def mel_to_hz(m):
+        return np.where(m >= 15.0, 1000.0 * np.exp((np.log(6.4) / 27.0) * (m - 15.0)), (200.0 / 3.0) * m)
+
+    edges = mel_to_hz(np.linspace(hz_to_mel(np.float64(0.0)), hz_to_mel(np.float64(12000.0)), 130))
+    freqs = np.arange(513) * 24000.0 / 1024.0
+    fb = np.zeros((128, 513))
+    for m in range(128):
+        fl, fc, frr = edges[m], edges[m + 1], edges[m + 2]
+        up = (freqs - fl) / (fc - fl)
+        dn = (frr - freqs) / (frr - fc)
+        w = np.where((freqs >= fl) & (freqs <= fc), up, np.where((freqs > fc) & (freqs <= frr), dn, 0.0))
+        fb[m] = w * (2.0 / (frr - fl))
+    return np.log(np.maximum(mag @ fb.T, 1e-5))
+
+
+@pytest.mark.parametrize("n", [0, 100, 255, 256, 1000, 24000])
+def test_mel_oracle_follows_the_spec(oracle, n):
+    rng = np.random.default_rng(n)
+    t = np.arange(n) / 24000.0
+    audio = (0.3 * np.sin(2 * np.pi * 220.0 * t) + 0.1 * np.sin(2 * np.pi * 3100.0 * t) + 0.01 * rng.standard_normal(n)).astype(np.float32)
+    got = oracle.mel(audio)
+    ref = _mel_numpy_f64(audio)
+    assert got.shape == ref.shape == ((0, 128) if n < 256 else ((n + 768 - 1024) // 256 + 1, 128))
+    if n >= 256:
+        assert np.abs(got - ref).max() <= 2e-3   # f32 DFT + f32 filterbank vs float64; log floor region included

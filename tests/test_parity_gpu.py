@@ -441,3 +441,20 @@ def test_model_files_errors_are_loud(oracle, tmp_path):
     G.write(str(tmp_path / "qwen3_tts_talker.gguf"), [(k, v, G.BF16 if v.ndim == 2 else G.F32) for k, v in bad.items()])
     with pytest.raises(_abi.Q3Error, match="attn_q.weight.*shape"):
         native.NativeEngine(cfg)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# clone-path front-end (the part pinned in-repo): log-mel on the device vs the oracle
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [0, 255, 256, 5000, 72000])
+def test_mel_matches_oracle(oracle, tiny, n):
+    cfg, eng, om = tiny
+    rng = np.random.default_rng(100 + n)
+    t = np.arange(n) / 24000.0
+    audio = (0.25 * np.sin(2 * np.pi * 180.0 * t) * (1 + 0.5 * np.sin(2 * np.pi * 3.0 * t)) + 0.02 * rng.standard_normal(n)).astype(np.float32)
+    ref = oracle.mel(audio)
+    got = eng.mel(audio)
+    assert got.shape == ref.shape
+    if n >= 256:
+        # same DFT / filterbank order on both sides: only the final logf (device vs libm) may differ in the last place
+        assert np.abs(got - ref).max() <= 4e-6, float(np.abs(got - ref).max())
