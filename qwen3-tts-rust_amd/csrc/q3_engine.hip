@@ -1107,6 +1107,18 @@ extern "C" int q3tts_k_gemm_exact(int32_t device, const float* x, int32_t B, int
     if (epi == Q3_EPI_ARGMAX) {
         if (keys) HK(hipMemcpy(keys, dk.p, (size_t)B * 8, hipMemcpyDeviceToHost));
     } else HK(hipMemcpy(y, dy.p, ny * 4, hipMemcpyDeviceToHost));
+#ifdef Q3_STAMPS
+    {  // experiment builds: phase stamps of workgroup 0 / wave 0 of one warm launch (shader-clock cycles from kernel entry)
+        DevBuf dd; dd.alloc(64 * 8);
+        g.dbg = nullptr; q3_launch_gemm(g, nullptr); q3_launch_gemm(g, nullptr);
+        g.dbg = (unsigned long long*)dd.p; hipMemset(dd.p, 0, 64 * 8);
+        q3_launch_gemm(g, nullptr); hipDeviceSynchronize();
+        unsigned long long st[8]; hipMemcpy(st, dd.p, 64, hipMemcpyDeviceToHost);
+        fprintf(stderr, "stamps B=%d K=%d N=%d norm=%d epi=%d: entry->loop %llu | first operands %llu | loop end %llu | barrier %llu | sums %llu | stores done %llu\n",
+                B, K, N, norm_w ? 1 : 0, epi, st[1] - st[0], st[2] - st[0], st[3] - st[0], st[4] - st[0], st[5] - st[0], st[6] - st[0]);
+        g.dbg = nullptr;
+    }
+#endif
     if (iters > 0 && mean_ms) {
         g.epi = epi == Q3_EPI_RESID ? Q3_EPI_STORE : epi;
         hipEvent_t a, b; HK(hipEventCreate(&a)); HK(hipEventCreate(&b));

@@ -52,6 +52,11 @@ __device__ __forceinline__ float sq4(const float4 v, float acc) {
 }
 
 #define XLDS_MAX_FLOATS 12288
+#ifdef Q3_STAMPS
+#define STAMP(i) do { if (g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 // shared epilogue: thread (row, col) already holds the canonical sum s of its output element
 template <int ROWS, int COLS>
@@ -201,6 +206,7 @@ __global__ __launch_bounds__(512, (RT <= 2 && NT == 1 && BPS > 0 && BPS <= 2) ? 
     constexpr int CP = NT * 16 + 1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nbt = blockIdx.x, row0 = blockIdx.y * (RT * 16);
+    STAMP(0);
     const int nrows = min(RT * 16, g.B - row0);
     const int K = g.K;
     const int bps = BPS > 0 ? BPS : (K >> 9);
@@ -260,6 +266,7 @@ __global__ __launch_bounds__(512, (RT <= 2 && NT == 1 && BPS > 0 && BPS <= 2) ? 
         __syncthreads();
     }
     const float* nwa = nwl + koff;
+    STAMP(1);
     for (int kb0 = 0; kb0 < nblk; kb0 += WPF) {
 #pragma unroll
         for (int j = 0; j < WPF; ++j) {
@@ -304,6 +311,9 @@ __global__ __launch_bounds__(512, (RT <= 2 && NT == 1 && BPS > 0 && BPS <= 2) ? 
                     for (int c = 0; c < NT; ++c) wq[j][c] = ntload16(wp + c * tile_stride + (size_t)(kb + WPF) * 64);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef Q3_STAMPS
+                if (kb == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(2); }
+#endif
                 // independent (row tile, column tile) chains interleave; each chain still sees t = 0..7 in order
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
@@ -314,6 +324,7 @@ __global__ __launch_bounds__(512, (RT <= 2 && NT == 1 && BPS > 0 && BPS <= 2) ? 
             }
         }
     }
+    STAMP(3);
     // q_w = p_2w + p_2w+1, then the eight q meet in LDS and are summed in order
 #pragma unroll
     for (int r = 0; r < RT; ++r)
@@ -330,6 +341,7 @@ __global__ __launch_bounds__(512, (RT <= 2 && NT == 1 && BPS > 0 && BPS <= 2) ? 
         }
     }
     __syncthreads();
+    STAMP(4);
     if (NORM) {
         if (tid < RT * 16) {
             float tot = ssred[tid];
@@ -351,7 +363,12 @@ __global__ __launch_bounds__(512, (RT <= 2 && NT == 1 && BPS > 0 && BPS <= 2) ? 
         if (g.epi == Q3_EPI_RESID) g.y[(size_t)(row0 + row) * g.ldy + nbt * NT * 16 + col] = yres[i] + s;
         else store_elem(g, sums, s, (size_t)(row0 + row), nbt * NT * 16 + col, row, col, NT * 16);
     }
+    STAMP(5);
     epilogue<RT * 16, NT * 16>(g, sums, tid, 512, row0, nrows, nbt * NT * 16);
+#ifdef Q3_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STAMP(6);
 }
 
 template <bool NORM>

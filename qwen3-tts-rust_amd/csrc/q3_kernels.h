@@ -15,6 +15,9 @@ struct Q3Gemm {
     float* y; int ldy;                // SWIGLU writes [B][N/2]
     unsigned long long* keys; int key_stride;  // ARGMAX: atomicMax(keys[row*key_stride])
     int epi;
+#ifdef Q3_STAMPS
+    unsigned long long* dbg;          // experiment builds only (tools/exp): s_memtime stamps of workgroup 0 / wave 0
+#endif
 };
 void q3_launch_gemm(const Q3Gemm& g, hipStream_t s);
 
