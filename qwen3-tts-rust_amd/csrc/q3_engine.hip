@@ -1116,6 +1116,9 @@ extern "C" int q3tts_k_gemm_exact(int32_t device, const float* x, int32_t B, int
         unsigned long long st[8]; hipMemcpy(st, dd.p, 64, hipMemcpyDeviceToHost);
         fprintf(stderr, "stamps B=%d K=%d N=%d norm=%d epi=%d: entry->loop %llu | first operands %llu | loop end %llu | barrier %llu | sums %llu | stores done %llu\n",
                 B, K, N, norm_w ? 1 : 0, epi, st[1] - st[0], st[2] - st[0], st[3] - st[0], st[4] - st[0], st[5] - st[0], st[6] - st[0]);
+        unsigned long long ws[64]; hipMemcpy(ws, dd.p, 64 * 8, hipMemcpyDeviceToHost);
+        for (int w = 0; w < 8; ++w)
+            fprintf(stderr, "   wave %d: first operands %llu, mid loop %llu, loop end %llu\n", w, ws[8 + w * 4] - st[0], ws[8 + w * 4 + 1] - st[0], ws[8 + w * 4 + 2] - st[0]);
         g.dbg = nullptr;
     }
 #endif
