@@ -202,7 +202,8 @@ __global__ __launch_bounds__(512, (RT <= 2 && NT == 1 && BPS > 0 && BPS <= 2) ? 
     __shared__ float ssred[NORM ? 8 * RT * 16 : 1];
     __shared__ float srow[NORM ? RT * 16 : 1];
     constexpr int WPF = NT == 1 ? 8 : 4;
-    constexpr int XPF = (RT == 4 || (NORM && RT * NT >= 6)) ? 2 : (RT == 2 ? 4 : 8);  // NORM keeps a[] apart from the ring: shallower ring for the widest tile
+    constexpr int XPF0 = (RT == 4 || (NORM && RT * NT >= 6)) ? 2 : (RT == 2 ? 4 : 8);  // NORM keeps a[] apart from the ring: shallower ring for the widest tile
+    constexpr int XPF = XPF0 < WPF ? XPF0 : WPF;  // the ring slot of block kb is kb % XPF == j % XPF only if XPF divides WPF
     constexpr int CP = NT * 16 + 1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nbt = blockIdx.x, row0 = blockIdx.y * (RT * 16);
@@ -421,6 +422,15 @@ void q3_launch_gemm(const Q3Gemm& g, hipStream_t s) {
         // gives every CU a workgroup (2 row chunks of 32 rows each)
         if (tiles >= 384 && tiles % 3 == 0) NT = 3;
         else if (tiles >= 256 && tiles % 2 == 0) NT = 2;
+    }
+    // Per-CU operand bytes per k are 64*RT (x, f32) + 32*NT (weights, bf16): with ~128 column tiles and 64 rows a 16 x 32
+    // workgroup tile (RT 1, NT 2: 128 B/k) still fills 256 CUs and moves 20 % less than 32 x 16 (160 B/k) — the launch is
+    // bound by what a CU's load path delivers, not by MFMA issue (profiles/README.md). Q3_RT1NT2=0 restores 32 x 16.
+    static const int rt1nt2 = getenv("Q3_RT1NT2") ? atoi(getenv("Q3_RT1NT2")) : 1;
+    if (rt1nt2 && NT == 1 && g.B > 32 && tiles % 2 == 0 && (long)(tiles / 2) * ((g.B + 15) / 16) >= 256) {
+        dim3 grid(tiles / 2, (g.B + 15) / 16);
+        launch_ring<1, 2>(g, grid, s);
+        return;
     }
     if (NT > 1) {
         dim3 grid(tiles / NT, (g.B + 31) / 32);

@@ -47,7 +47,8 @@ def _oracle_gemm(O, x, w, norm_w, eps, bias, epi, y_in=None):
 
 
 @pytest.mark.parametrize("B,K,N", [(1, 512, 16), (1, 2048, 256), (3, 512, 48), (6, 2048, 64), (7, 2048, 64), (16, 1024, 64), (17, 2048, 32), (33, 1536, 64),
-                                   (64, 2048, 128), (70, 512, 32), (2, 6144, 64), (3, 6144, 32), (40, 1024, 12288), (64, 3072, 8192), (31, 2048, 96)])
+                                   (64, 2048, 128), (70, 512, 32), (2, 6144, 64), (3, 6144, 32), (40, 1024, 12288), (64, 3072, 8192), (31, 2048, 96),
+                                   (64, 6144, 2048), (64, 2048, 2048), (50, 1024, 2048), (200, 2048, 2048)])
 def test_gemm_exact_store_bias(oracle, native, B, K, N):
     rng = np.random.default_rng(B * 1000 + K + N)
     x = _rand(rng, (B, K))
