@@ -53,6 +53,7 @@ static int validate(const q3tts_engine_config& c, std::string& why) {
     REQ(m.t_n_layer > 0 && m.p_n_layer > 0);
     REQ(m.t_head_dim == 128 && m.p_head_dim == 128);  // exact attention kernel: 16 lanes x 8 dims per key
     REQ(m.t_d_model % 512 == 0 && m.p_d_model % 512 == 0 && m.t_d_ffn % 512 == 0 && m.p_d_ffn % 512 == 0);
+    REQ(m.t_d_model <= 8192 && m.p_d_model <= 8192);  // fused RMSNorm: a wave's share of the norm weights is one LDS strip of <= 1024 floats
     REQ((m.t_n_head * m.t_head_dim) % 512 == 0 && (m.p_n_head * m.p_head_dim) % 512 == 0);
     REQ(m.t_n_head % m.t_n_kv_head == 0 && m.p_n_head % m.p_n_kv_head == 0);
     { int r = m.t_n_head / m.t_n_kv_head; REQ(r == 1 || r == 2 || r == 4); r = m.p_n_head / m.p_n_kv_head; REQ(r == 1 || r == 2 || r == 4); }
@@ -1081,7 +1082,7 @@ struct DevBuf {
 
 extern "C" int q3tts_k_gemm_exact(int32_t device, const float* x, int32_t B, int32_t K, const uint16_t* w, int32_t N, const float* norm_w,
                                   float eps, const float* bias, int32_t epi, float* y, uint64_t* keys, int32_t iters, float* mean_ms) {
-    if (!x || !w || !y || B <= 0 || K % 512 || N % 16) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "gemm hook: bad shape");
+    if (!x || !w || !y || B <= 0 || K % 512 || N % 16 || (norm_w && K > 8192)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "gemm hook: bad shape");
     if (epi == Q3_EPI_SWIGLU && (N % 32)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "swiglu needs N % 32 == 0");
     HK(hipSetDevice(device));
     const int F = N / 2;

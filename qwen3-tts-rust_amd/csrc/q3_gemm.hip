@@ -221,11 +221,15 @@ __global__ __launch_bounds__(512, (RT <= 2 && NT == 1 && BPS > 0 && BPS <= 2) ? 
     f32x4 acc[RT][NT], accA[RT][NT];
     float ss[RT], ssA[RT];  // NORM: (slice, kq) chains of the rows' sums of squares
     const float* xr[RT];
-    // NORM: the norm weights go to LDS once; their loads are the OLDEST in the queue
-    const int K4 = K >> 2;
-    const float4* nsrc = (const float4*)(NORM ? g.norm_w : g.x);
-    float4 nv0, nv1;
-    if (NORM) { nv0 = nsrc[min(tid, K4 - 1)]; nv1 = nsrc[min(tid + 512, K4 - 1)]; }
+    // NORM: every wave parks the norm weights of ITS OWN k range (K/8 floats) in a wave-private LDS strip: no workgroup
+    // barrier in the prologue (writer and reader are the same wave); these loads are the OLDEST in the queue
+    const int KW4 = K >> 5;  // float4 per wave
+    const float4* nsrc = (const float4*)(NORM ? g.norm_w + wave * (K >> 3) : g.x);
+    float4 nv0, nv1, nv2, nv3;
+    if (NORM) {
+        nv0 = nsrc[min(lane, KW4 - 1)]; nv1 = nsrc[min(lane + 64, KW4 - 1)];
+        nv2 = nsrc[min(lane + 128, KW4 - 1)]; nv3 = nsrc[min(lane + 192, KW4 - 1)];
+    }
     // RESID: the residual operand is fetched up front instead of at the very end
     constexpr int NOUT = (RT * 16 * NT * 16 + 511) / 512;
     float yres[NOUT];
@@ -260,13 +264,14 @@ __global__ __launch_bounds__(512, (RT <= 2 && NT == 1 && BPS > 0 && BPS <= 2) ? 
             for (int c = 0; c < NT; ++c) wq[j][c] = ntload16(wp + c * tile_stride + (size_t)j * 64);
         }
     __builtin_amdgcn_sched_barrier(0);
+    float* nww = nwl + wave * (K >> 3);
     if (NORM) {
-        if (tid < K4) ((float4*)nwl)[tid] = nv0;
-        if (tid + 512 < K4) ((float4*)nwl)[tid + 512] = nv1;
-        for (int i = tid + 1024; i < K4; i += 512) ((float4*)nwl)[i] = nsrc[i];
-        __syncthreads();
+        if (lane < KW4) ((float4*)nww)[lane] = nv0;
+        if (lane + 64 < KW4) ((float4*)nww)[lane + 64] = nv1;
+        if (lane + 128 < KW4) ((float4*)nww)[lane + 128] = nv2;
+        if (lane + 192 < KW4) ((float4*)nww)[lane + 192] = nv3;  // K <= 8192
     }
-    const float* nwa = nwl + koff;
+    const float* nwa = nww + kq * 4;
     STAMP(1);
     for (int kb0 = 0; kb0 < nblk; kb0 += WPF) {
 #pragma unroll

@@ -18,7 +18,7 @@ for (B, K, N, norm) in shapes:
     x = rng.standard_normal((B, K)).astype(np.float32)
     w = (rng.integers(0, 65536, size=(N, K)) & 0xBFFF).astype(np.uint16)  # finite bf16 bit patterns
     nw = np.ones(K, dtype=np.float32) if norm else None
-    _, _, ms = native.k_gemm_exact(x, w, norm_w=nw, epilogue=0, iters=50)
+    _, _, ms = native.k_gemm_exact(x, w, norm_w=nw, epilogue=0, iters=300)
     us = ms * 1e3
     print(f"B={B:3d} K={K:5d} N={N:6d} norm={norm}: {us:8.2f} us  {N * K * 2 / ms / 1e6:8.1f} GB/s  {2.0 * B * N * K / ms / 1e9:8.2f} TFLOP/s "
           f"(padded MFMA rate {2.0 * max(16, (B + 15) // 16 * 16) * N * K / ms / 1e9:7.2f})", flush=True)
