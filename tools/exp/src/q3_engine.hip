@@ -1,0 +1,1256 @@
+// q3_engine.hip — host side of libq3tts: weights, KV slabs, the replayable frame-step graph, the continuous
+// batching loop and the C ABI of include/q3tts.h. The loop restates run_inference_stream
+// (/root/reference/src/tts/engine.rs:445-656) with every per-frame decision on the device: one graph replay =
+// sample -> 15 predictor passes -> feedback -> Talker step, no host round trip (the reference crosses the
+// host<->backend boundary >= 33 times per frame).
+#include "q3_engine.h"
+#include "q3_gguf.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+static thread_local std::string g_err;
+
+int q3_set_err(q3tts_engine* e, int code, const std::string& msg) {
+    if (e) e->err = msg;
+    g_err = msg;
+    return code;
+}
+extern "C" const char* q3tts_last_error(const q3tts_engine* e) { return e ? e->err.c_str() : g_err.c_str(); }
+
+// ------------------------------------------------------------------------------------------------
+// configuration
+// ------------------------------------------------------------------------------------------------
+extern "C" void q3tts_default_config(q3tts_engine_config* c) {
+    memset(c, 0, sizeof(*c));
+    q3tts_model_config& m = c->model;
+    m.t_n_layer = 28; m.t_d_model = 2048; m.t_n_head = 16; m.t_n_kv_head = 8; m.t_head_dim = 128; m.t_d_ffn = 6144;
+    m.t_vocab = 3072; m.t_rope_theta = 1000000.0f;
+    m.t_mrope_sections[0] = 24; m.t_mrope_sections[1] = 20; m.t_mrope_sections[2] = 20; m.t_mrope_sections[3] = 0;
+    m.p_n_layer = 5; m.p_d_model = 1024; m.p_n_head = 16; m.p_n_kv_head = 8; m.p_head_dim = 128; m.p_d_ffn = 3072;
+    m.p_rope_theta = 1000000.0f;
+    m.n_codebooks = 16; m.codebook_size = 2048; m.rms_eps = 1e-6f;
+    m.d_embed = 2048; m.text_vocab = 151936; m.codec0_rows = 3072; m.codecq_rows = 2048;
+    m.sample_limit = 2160; m.eos_code = 2150; m.tts_pad_id = 151671;
+    q3tts_vocoder_config& v = c->vocoder;
+    v.n_codebooks = 16; v.codebook_size = 2048; v.codebook_dim = 512; v.latent_dim = 1024; v.pre_conv_kernel = 3;
+    v.n_layer = 8; v.n_head = 16; v.head_dim = 64; v.d_ffn = 3072; v.sliding_window = 72;
+    v.rope_theta = 10000.0f; v.rms_eps = 1e-5f; v.layer_scale_init = 0.01f;
+    v.n_upsample = 2; v.upsample_ratios[0] = 2; v.upsample_ratios[1] = 2;
+    v.decoder_dim = 1536; v.n_dec_blocks = 4;
+    v.dec_rates[0] = 8; v.dec_rates[1] = 5; v.dec_rates[2] = 4; v.dec_rates[3] = 3;
+    v.lookahead_frames = 0; v.sample_rate = 24000;
+    c->device = 0; c->max_batch = 1; c->n_ctx = 4096; c->max_steps_cap = 512; c->with_vocoder = 1;
+    c->synth_seed = 0; c->weights_path = nullptr;
+}
+
+static int validate(const q3tts_engine_config& c, std::string& why) {
+    const q3tts_model_config& m = c.model;
+#define REQ(cond) do { if (!(cond)) { why = "config check failed: " #cond; return Q3TTS_ERR_INVALID; } } while (0)
+    REQ(m.t_n_layer > 0 && m.p_n_layer > 0);
+    REQ(m.t_head_dim == 128 && m.p_head_dim == 128);  // exact attention kernel: 16 lanes x 8 dims per key
+    REQ(m.t_d_model % 512 == 0 && m.p_d_model % 512 == 0 && m.t_d_ffn % 512 == 0 && m.p_d_ffn % 512 == 0);
+    REQ(m.t_d_model <= 8192 && m.p_d_model <= 8192);  // fused RMSNorm: a wave's share of the norm weights is one LDS strip of <= 1024 floats
+    REQ((m.t_n_head * m.t_head_dim) % 512 == 0 && (m.p_n_head * m.p_head_dim) % 512 == 0);
+    REQ(m.t_n_head % m.t_n_kv_head == 0 && m.p_n_head % m.p_n_kv_head == 0);
+    { int r = m.t_n_head / m.t_n_kv_head; REQ(r == 1 || r == 2 || r == 4); r = m.p_n_head / m.p_n_kv_head; REQ(r == 1 || r == 2 || r == 4); }
+    REQ(m.t_vocab % 16 == 0 && m.codebook_size % 16 == 0 && m.t_d_ffn % 8 == 0);
+    REQ(m.d_embed == m.t_d_model);  // feedback row feeds the Talker directly (src/tts/engine.rs:631)
+    REQ(m.d_embed % 512 == 0);
+    REQ(m.n_codebooks >= 2 && m.n_codebooks <= 16);
+    REQ(m.sample_limit > 0 && m.sample_limit <= m.t_vocab && m.sample_limit <= 4096);
+    REQ(m.t_mrope_sections[0] + m.t_mrope_sections[1] + m.t_mrope_sections[2] + m.t_mrope_sections[3] == m.t_head_dim / 2);
+    REQ(m.tts_pad_id >= 0 && m.tts_pad_id < m.text_vocab);
+    REQ(c.max_batch >= 1 && c.max_batch <= 64);
+    REQ(c.n_ctx >= 64 && c.n_ctx % 64 == 0 && c.n_ctx <= 8192);
+    REQ(c.max_steps_cap >= 1 && c.max_steps_cap < c.n_ctx);
+    REQ(m.n_codebooks + 1 <= 64);
+#undef REQ
+    return Q3TTS_OK;
+}
+
+template <class T>
+static int dalloc(q3tts_engine* e, T** p, size_t n) {
+    void* q = nullptr;
+    hipError_t err = hipMalloc(&q, n * sizeof(T) + 64);
+    if (err != hipSuccess) return q3_set_err(e, Q3TTS_ERR_OOM, std::string("hipMalloc: ") + hipGetErrorString(err));
+    err = hipMemsetAsync(q, 0, n * sizeof(T) + 64, e->stream);
+    if (err != hipSuccess) return q3_set_err(e, Q3TTS_ERR_DEVICE, std::string("hipMemset: ") + hipGetErrorString(err));
+    *p = (T*)q;
+    return Q3TTS_OK;
+}
+#define TRY(x) do { int rc__ = (x); if (rc__ != Q3TTS_OK) return rc__; } while (0)
+
+// RoPE tables in double on the host (same formula the oracle restates)
+static void rope_tables(int n_pos, int hd, float theta, const int* sections, std::vector<float>& cs, std::vector<float>& sn) {
+    const int half = hd / 2;
+    int s3 = half;
+    if (sections) s3 = sections[0] + sections[1] + sections[2];
+    cs.resize((size_t)n_pos * half); sn.resize((size_t)n_pos * half);
+    for (int p = 0; p < n_pos; ++p)
+        for (int i = 0; i < half; ++i) {
+            const double inv = pow((double)theta, -2.0 * (double)i / (double)hd);
+            const double ang = (i < s3) ? (double)p * inv : 0.0;
+            cs[(size_t)p * half + i] = (float)cos(ang);
+            sn[(size_t)p * half + i] = (float)sin(ang);
+        }
+}
+
+// ---- real weights: llama.cpp's tensor names for the qwen3 architecture --------------------------
+struct GgSrc {
+    q3tts_engine* e; const Q3Gguf* g; const char* file;
+    std::vector<uint16_t> host; uint16_t* dev[2] = {nullptr, nullptr}; size_t dev_cap[2] = {0, 0};
+    ~GgSrc() { for (auto p : dev) if (p) hipFree(p); }
+    int fail(const std::string& msg) { return q3_set_err(e, Q3TTS_ERR_INVALID, std::string(file) + ": " + msg); }
+    const Q3GgufTensor* need(const std::string& name, uint64_t ne0, uint64_t ne1, int* rc) {
+        const Q3GgufTensor* t = g->find(name);
+        if (!t) { *rc = fail("tensor '" + name + "' is missing"); return nullptr; }
+        const uint64_t d1 = t->dims.size() > 1 ? t->dims[1] : 1;
+        if (t->dims[0] != ne0 || d1 != ne1 || t->dims.size() > 2) {
+            *rc = fail("tensor '" + name + "' has shape [" + std::to_string(d1) + "][" + std::to_string(t->dims[0]) + "], the configuration needs [" +
+                       std::to_string(ne1) + "][" + std::to_string(ne0) + "]");
+            return nullptr;
+        }
+        *rc = Q3TTS_OK;
+        return t;
+    }
+    // f32 vector -> device
+    int vec(const std::string& name, size_t n, float* dst) {
+        int rc; const Q3GgufTensor* t = need(name, n, 1, &rc);
+        if (!t) return rc;
+        std::vector<float> h(n); std::string err;
+        if (q3_gguf_to_f32(*t, h.data(), err)) return fail(err);
+        Q3_HIP(e, hipMemcpy(dst, h.data(), n * 4, hipMemcpyHostToDevice));
+        return Q3TTS_OK;
+    }
+    // [N][K] matrix -> bf16 row-major staging buffer `which` on the device
+    int mat(const std::string& name, size_t N, size_t K, int which) {
+        int rc; const Q3GgufTensor* t = need(name, K, N, &rc);
+        if (!t) return rc;
+        host.resize(N * K); std::string err;
+        if (q3_gguf_to_bf16(*t, host.data(), err)) return fail(err);
+        if (dev_cap[which] < N * K) {
+            if (dev[which]) hipFree(dev[which]);
+            dev[which] = nullptr; dev_cap[which] = 0;
+            void* p = nullptr;
+            if (hipMalloc(&p, N * K * 2) != hipSuccess) return q3_set_err(e, Q3TTS_ERR_OOM, "hipMalloc (weight staging)");
+            dev[which] = (uint16_t*)p; dev_cap[which] = N * K;
+        }
+        Q3_HIP(e, hipMemcpy(dev[which], host.data(), N * K * 2, hipMemcpyHostToDevice));
+        return Q3TTS_OK;
+    }
+};
+
+static int init_tfm(q3tts_engine* e, Q3Tfm& t, int grp, int L, int d, int Hq, int Hkv, int hd, int F, int head_n, float theta,
+                    const int* sections, int n_ctx, int n_slots, GgSrc* gg = nullptr) {
+    t.L = L; t.d = d; t.Hq = Hq; t.Hkv = Hkv; t.hd = hd; t.F = F; t.nq = Hq * hd; t.nkv = Hkv * hd; t.nqkv = t.nq + 2 * t.nkv;
+    t.head_n = head_n; t.n_ctx = n_ctx; t.n_slots = n_slots;
+    const uint64_t seed = e->cfg.synth_seed;
+    const float ms = 0.02f / Q3_IH4_STD, ns = 0.05f / Q3_IH4_STD;
+    hipStream_t s = e->stream;
+    t.attn_norm.resize(L); t.ffn_norm.resize(L); t.qn.resize(L); t.kn.resize(L);
+    t.wqkv.resize(L); t.wo.resize(L); t.wgu.resize(L); t.wd.resize(L);
+    for (int l = 0; l < L; ++l) {
+        TRY(dalloc(e, &t.attn_norm[l], (size_t)d)); TRY(dalloc(e, &t.ffn_norm[l], (size_t)d));
+        TRY(dalloc(e, &t.qn[l], (size_t)hd)); TRY(dalloc(e, &t.kn[l], (size_t)hd));
+        if (gg) {  // blk.N.* of a llama.cpp qwen3 GGUF (weights [out][in], NeoX RoPE: no q/k permutation)
+            const std::string b = "blk." + std::to_string(l) + ".";
+            Q3_HIP(e, hipStreamSynchronize(s));
+            TRY(gg->vec(b + "attn_norm.weight", d, t.attn_norm[l])); TRY(gg->vec(b + "ffn_norm.weight", d, t.ffn_norm[l]));
+            TRY(gg->vec(b + "attn_q_norm.weight", hd, t.qn[l])); TRY(gg->vec(b + "attn_k_norm.weight", hd, t.kn[l]));
+            TRY(dalloc(e, &t.wqkv[l], (size_t)t.nqkv * d / 8)); TRY(dalloc(e, &t.wo[l], (size_t)d * t.nq / 8));
+            TRY(dalloc(e, &t.wgu[l], (size_t)2 * F * d / 8)); TRY(dalloc(e, &t.wd[l], (size_t)d * F / 8));
+            Q3Fill f{}; f.mode = 0;
+            auto put = [&](const std::string& name, uint4* dst, int Ntot, int K, int row0, int rows) -> int {
+                TRY(gg->mat(name, rows, K, 0));
+                f.dst = dst; f.N = Ntot; f.K = K; f.mode = 0; f.row0 = row0; f.rows = rows; f.src_a = gg->dev[0]; f.src_b = nullptr;
+                q3_launch_fill_tiled(f, s);
+                Q3_HIP(e, hipStreamSynchronize(s));  // the staging buffer is reused by the next tensor
+                return Q3TTS_OK;
+            };
+            TRY(put(b + "attn_q.weight", t.wqkv[l], t.nqkv, d, 0, t.nq));
+            TRY(put(b + "attn_k.weight", t.wqkv[l], t.nqkv, d, t.nq, t.nkv));
+            TRY(put(b + "attn_v.weight", t.wqkv[l], t.nqkv, d, t.nq + t.nkv, t.nkv));
+            TRY(put(b + "attn_output.weight", t.wo[l], d, t.nq, 0, d));
+            TRY(gg->mat(b + "ffn_gate.weight", F, d, 0)); TRY(gg->mat(b + "ffn_up.weight", F, d, 1));
+            f.dst = t.wgu[l]; f.N = 2 * F; f.K = d; f.mode = 1; f.src_a = gg->dev[0]; f.src_b = gg->dev[1];
+            q3_launch_fill_tiled(f, s);
+            Q3_HIP(e, hipStreamSynchronize(s));
+            TRY(put(b + "ffn_down.weight", t.wd[l], d, F, 0, d));
+            t.weight_bytes += 2ull * ((size_t)t.nqkv * d + (size_t)d * t.nq + 3ull * F * d);
+            continue;
+        }
+        q3_launch_fill_f32(t.attn_norm[l], d, seed, Q3_TID(grp, l, Q3W_ATTN_NORM), 1.0f, ns, 0, s);
+        q3_launch_fill_f32(t.ffn_norm[l], d, seed, Q3_TID(grp, l, Q3W_FFN_NORM), 1.0f, ns, 0, s);
+        q3_launch_fill_f32(t.qn[l], hd, seed, Q3_TID(grp, l, Q3W_QNORM), 1.0f, ns, 0, s);
+        q3_launch_fill_f32(t.kn[l], hd, seed, Q3_TID(grp, l, Q3W_KNORM), 1.0f, ns, 0, s);
+        TRY(dalloc(e, &t.wqkv[l], (size_t)t.nqkv * d / 8)); TRY(dalloc(e, &t.wo[l], (size_t)d * t.nq / 8));
+        TRY(dalloc(e, &t.wgu[l], (size_t)2 * F * d / 8)); TRY(dalloc(e, &t.wd[l], (size_t)d * F / 8));
+        Q3Fill f{}; f.seed = seed; f.scale = ms;
+        f.dst = t.wqkv[l]; f.N = t.nqkv; f.K = d; f.mode = 0;
+        f.row0 = 0; f.rows = t.nq; f.tid_a = Q3_TID(grp, l, Q3W_Q); q3_launch_fill_tiled(f, s);
+        f.row0 = t.nq; f.rows = t.nkv; f.tid_a = Q3_TID(grp, l, Q3W_K); q3_launch_fill_tiled(f, s);
+        f.row0 = t.nq + t.nkv; f.rows = t.nkv; f.tid_a = Q3_TID(grp, l, Q3W_V); q3_launch_fill_tiled(f, s);
+        f.dst = t.wo[l]; f.N = d; f.K = t.nq; f.row0 = 0; f.rows = d; f.tid_a = Q3_TID(grp, l, Q3W_O); q3_launch_fill_tiled(f, s);
+        f.dst = t.wgu[l]; f.N = 2 * F; f.K = d; f.mode = 1; f.tid_a = Q3_TID(grp, l, Q3W_GATE); f.tid_b = Q3_TID(grp, l, Q3W_UP);
+        q3_launch_fill_tiled(f, s);
+        f.dst = t.wd[l]; f.N = d; f.K = F; f.mode = 0; f.row0 = 0; f.rows = d; f.tid_a = Q3_TID(grp, l, Q3W_DOWN); q3_launch_fill_tiled(f, s);
+        t.weight_bytes += 2ull * ((size_t)t.nqkv * d + (size_t)d * t.nq + 3ull * F * d);
+    }
+    TRY(dalloc(e, &t.out_norm, (size_t)d));
+    TRY(dalloc(e, &t.head, (size_t)head_n * d / 8));
+    t.weight_bytes += 2ull * (size_t)head_n * d;
+    if (gg) {
+        Q3_HIP(e, hipStreamSynchronize(s));
+        TRY(gg->vec("output_norm.weight", d, t.out_norm));
+        TRY(gg->mat("output.weight", head_n, d, 0));
+        Q3Fill f{}; f.dst = t.head; f.N = head_n; f.K = d; f.mode = 0; f.row0 = 0; f.rows = head_n; f.src_a = gg->dev[0];
+        q3_launch_fill_tiled(f, s);
+        Q3_HIP(e, hipStreamSynchronize(s));
+    } else {
+        q3_launch_fill_f32(t.out_norm, d, seed, Q3_TID(grp, Q3_L_MODEL, Q3WM_OUT_NORM), 1.0f, ns, 0, s);
+        Q3Fill f{}; f.seed = seed; f.scale = ms; f.dst = t.head; f.N = head_n; f.K = d; f.mode = 0; f.row0 = 0; f.rows = head_n;
+        f.tid_a = Q3_TID(grp, Q3_L_MODEL, Q3WM_HEAD); q3_launch_fill_tiled(f, s);
+    }
+    t.layer_stride = (size_t)n_slots * Hkv * n_ctx * hd;
+    TRY(dalloc(e, &t.kc, t.layer_stride * L)); TRY(dalloc(e, &t.vc, t.layer_stride * L));
+    std::vector<float> cs, sn;
+    rope_tables(n_ctx, hd, theta, sections, cs, sn);
+    TRY(dalloc(e, &t.cs, cs.size())); TRY(dalloc(e, &t.sn, sn.size()));
+    Q3_HIP(e, hipMemcpyAsync(t.cs, cs.data(), cs.size() * 4, hipMemcpyHostToDevice, s));
+    Q3_HIP(e, hipMemcpyAsync(t.sn, sn.data(), sn.size() * 4, hipMemcpyHostToDevice, s));
+    Q3_HIP(e, hipStreamSynchronize(s));
+    return Q3TTS_OK;
+}
+static void free_tfm(Q3Tfm& t) {
+    for (auto p : t.attn_norm) hipFree(p); for (auto p : t.ffn_norm) hipFree(p); for (auto p : t.qn) hipFree(p);
+    for (auto p : t.kn) hipFree(p); for (auto p : t.wqkv) hipFree(p); for (auto p : t.wo) hipFree(p);
+    for (auto p : t.wgu) hipFree(p); for (auto p : t.wd) hipFree(p);
+    hipFree(t.out_norm); hipFree(t.head); hipFree(t.kc); hipFree(t.vc); hipFree(t.cs); hipFree(t.sn);
+}
+
+static int alloc_scratch(q3tts_engine* e, Q3Scratch& sc, int rows, int nqkv, int nq, int F, int dmax) {
+    sc.rows = rows;
+    TRY(dalloc(e, &sc.qkv, (size_t)rows * nqkv)); TRY(dalloc(e, &sc.att, (size_t)rows * nq)); TRY(dalloc(e, &sc.h, (size_t)rows * F));
+    return Q3TTS_OK;
+}
+
+// K1-K8 of SURVEY.md §8a: one decoder block per iteration, 6 launches (norm+QKV, qk-prep, attention, O+residual,
+// norm+gate/up+SwiGLU, down+residual)
+static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, int rows, const int* row_pos, const int* row_slot, Q3Scratch& sc, hipStream_t s,
+                       bool one_row_per_slot = false, hipEvent_t* probe = nullptr) {
+    const float eps = e->cfg.model.rms_eps;
+    for (int l = 0; l < t.L; ++l) {
+        Q3Gemm g{};
+        g.x = x; g.ldx = t.d; g.B = rows; g.w = t.wqkv[l]; g.K = t.d; g.N = t.nqkv; g.norm_w = t.attn_norm[l]; g.eps = eps;
+        g.y = sc.qkv; g.ldy = t.nqkv; g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);
+        Q3QkPrep qp{}; qp.qkv = sc.qkv; qp.ld = t.nqkv; qp.rows = rows; qp.Hq = t.Hq; qp.Hkv = t.Hkv; qp.hd = t.hd;
+        qp.qnw = t.qn[l]; qp.knw = t.kn[l]; qp.eps = eps; qp.cs = t.cs; qp.sn = t.sn;
+        qp.kc = t.kc + l * t.layer_stride; qp.vc = t.vc + l * t.layer_stride; qp.n_ctx = t.n_ctx; qp.row_pos = row_pos; qp.row_slot = row_slot;
+        const bool fused = one_row_per_slot && t.Hq / t.Hkv >= 2;
+        if (!fused) q3_launch_qk_prep(qp, s);
+        Q3Attend at{}; at.qkv = sc.qkv; at.ld = t.nqkv; at.rows = rows; at.out = sc.att; at.ldo = t.nq; at.Hq = t.Hq; at.Hkv = t.Hkv; at.hd = t.hd;
+        at.kc = qp.kc; at.vc = qp.vc; at.n_ctx = t.n_ctx; at.row_pos = row_pos; at.row_slot = row_slot;
+        at.fused = fused; at.prep = qp;
+        {
+            static unsigned long long* abuf = nullptr;
+            static const char* which = getenv("Q3_ATT_STAMP");
+            if (!abuf) { hipMalloc((void**)&abuf, 256); hipMemset(abuf, 0, 256); }
+            at.dbg = nullptr;
+            if (which && fused && l == t.L - 1 && ((which[0] == 'P') == (&t == &e->P))) {
+                at.dbg = abuf;
+                unsigned long long st[16]; hipMemcpy(st, abuf, 128, hipMemcpyDeviceToHost);
+                fprintf(stderr, "attend stamps: pos/slot %lld | prep done %lld | barrier1 %lld | scores %lld | barrier2 %lld | barrier3 %lld | PV %lld | barrier4 %lld | end %lld\n",
+                        (long long)(st[1] - st[0]), (long long)(st[2] - st[0]), (long long)(st[3] - st[0]), (long long)(st[4] - st[0]), (long long)(st[5] - st[0]), (long long)(st[6] - st[0]), (long long)(st[7] - st[0]), (long long)(st[8] - st[0]), (long long)(st[9] - st[0]));
+            }
+        }
+        q3_launch_attend(at, s);
+        g = Q3Gemm{}; g.x = sc.att; g.ldx = t.nq; g.B = rows; g.w = t.wo[l]; g.K = t.nq; g.N = t.d; g.y = x; g.ldy = t.d; g.epi = Q3_EPI_RESID;
+        q3_launch_gemm(g, s);
+        g = Q3Gemm{}; g.x = x; g.ldx = t.d; g.B = rows; g.w = t.wgu[l]; g.K = t.d; g.N = 2 * t.F; g.norm_w = t.ffn_norm[l]; g.eps = eps;
+        g.y = sc.h; g.ldy = t.F; g.epi = Q3_EPI_SWIGLU;
+        if (probe && l == 0) hipEventRecord(probe[0], s);
+        q3_launch_gemm(g, s);
+        if (probe && l == 0) hipEventRecord(probe[1], s);
+        g = Q3Gemm{}; g.x = sc.h; g.ldx = t.F; g.B = rows; g.w = t.wd[l]; g.K = t.F; g.N = t.d; g.y = x; g.ldy = t.d; g.epi = Q3_EPI_RESID;
+        q3_launch_gemm(g, s);
+    }
+}
+
+// one frame: src/tts/engine.rs:545-642 for the slots [b0, b0 + nb) of one lane
+static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
+    const q3tts_model_config& m = e->cfg.model;
+    const int ncb = m.n_codebooks, cbs = m.codebook_size, dp = m.p_d_model, de = m.d_embed, cap = e->cfg.max_steps_cap;
+    const float eps = m.rms_eps;
+    Q3Slot* slots = e->slots;
+    int* codes = e->codes;
+    Q3Sample sa{}; sa.logits = L.logits; sa.ld = m.t_vocab; sa.limit = m.sample_limit; sa.eos = m.eos_code; sa.slots = slots; sa.B = B; sa.row_slot = L.slot_id;
+    sa.rng = e->rng; sa.codes = codes; sa.max_steps_cap = cap; sa.ncb = ncb; sa.keys = L.keys;
+    q3_launch_sample(sa, s);
+    Q3PredInput pi{}; pi.xT = L.xT; pi.out_norm = e->T.out_norm; pi.eps = eps; pi.d = de; pi.codec0 = e->codec[0]; pi.codec0_rows = m.codec0_rows;
+    pi.slots = slots; pi.row_slot = L.slot_id; pi.X = L.X; pi.fb = L.fb; pi.B = B;
+    q3_launch_pred_input(pi, s);
+    const size_t head_tile_stride = (size_t)(cbs / 16) * (dp / 32) * 64;  // uint4 per predictor head
+    auto pred_next = [&](int q) {
+        Q3PredNext pn{}; pn.keys = L.keys; pn.q = q; pn.ncb = ncb; pn.codec_q = e->codec[q]; pn.rows_q = m.codecq_rows; pn.d = de;
+        pn.slots = slots; pn.row_slot = L.slot_id; pn.B = B; pn.codes = codes; pn.max_steps_cap = cap; pn.fb = L.fb; pn.X = L.X;
+        pn.tts_pad = e->tts_pad; pn.xT = L.xT; pn.row_pos_t = L.row_pos_t;
+        q3_launch_pred_next(pn, s);
+    };
+    for (int q = 0; q < ncb - 1; ++q) {  // pass q produces code_{q+1}
+        const int rows = q == 0 ? 2 * B : B;
+        if (q > 0) pred_next(q);
+        Q3Gemm g{}; g.x = L.X; g.ldx = de; g.B = rows; g.w = e->proj_w; g.K = de; g.N = dp; g.bias = e->proj_b; g.y = L.px; g.ldy = dp;
+        g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);  // H6: src/assets_manager.rs:383-399
+        hipEvent_t* pe = nullptr;
+        if (e->probe && q == 1 && B == L.nb && e->probe_i + 2 <= 8) { pe = &e->probe_ev[e->probe_i]; e->probe_i += 2; }
+        run_layers(e, e->P, L.px, rows, q == 0 ? L.posA : L.pos_q + (size_t)q * L.nb, q == 0 ? L.slotA : L.slot_id, L.sc, s, q > 0, pe);
+        g = Q3Gemm{}; g.x = q == 0 ? L.px + dp : L.px; g.ldx = q == 0 ? 2 * dp : dp; g.B = B; g.w = e->P.head + head_tile_stride * q;
+        g.K = dp; g.N = cbs; g.norm_w = e->P.out_norm; g.eps = eps; g.keys = L.keys + (q + 1); g.key_stride = ncb; g.epi = Q3_EPI_ARGMAX;
+        q3_launch_gemm(g, s);
+    }
+    pred_next(ncb - 1);
+    run_layers(e, e->T, L.xT, B, L.row_pos_t, L.slot_id, L.sc, s, true);
+    Q3Gemm g{}; g.x = L.xT; g.ldx = m.t_d_model; g.B = B; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab; g.norm_w = e->T.out_norm; g.eps = eps;
+    g.y = L.logits; g.ldy = m.t_vocab; g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);
+}
+
+static bool file_exists(const std::string& p) { FILE* f = fopen(p.c_str(), "rb"); if (f) fclose(f); return f != nullptr; }
+static uint16_t host_bf16(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static int upload_table(q3tts_engine* e, float** dst, const float* host, size_t n) {
+    TRY(dalloc(e, dst, n));
+    Q3_HIP(e, hipMemcpy(*dst, host, n * 4, hipMemcpyHostToDevice));
+    return Q3TTS_OK;
+}
+static int upload_proj(q3tts_engine* e, const float* w, const float* b) {
+    const q3tts_model_config& m = e->cfg.model;
+    const size_t n = (size_t)m.p_d_model * m.d_embed;
+    std::vector<uint16_t> h(n);
+    for (size_t i = 0; i < n; ++i) h[i] = host_bf16(w[i]);  // the projection runs on the bf16 GEMM (documented deviation)
+    void* stage = nullptr;
+    if (hipMalloc(&stage, n * 2) != hipSuccess) return q3_set_err(e, Q3TTS_ERR_OOM, "hipMalloc (projection staging)");
+    hipError_t er = hipMemcpy(stage, h.data(), n * 2, hipMemcpyHostToDevice);
+    int rc = Q3TTS_OK;
+    if (er == hipSuccess) rc = dalloc(e, &e->proj_w, n / 8);
+    if (er == hipSuccess && rc == Q3TTS_OK) {
+        Q3Fill f{}; f.dst = e->proj_w; f.N = m.p_d_model; f.K = m.d_embed; f.mode = 0; f.row0 = 0; f.rows = m.p_d_model; f.src_a = (const uint16_t*)stage;
+        q3_launch_fill_tiled(f, e->stream);
+        er = hipStreamSynchronize(e->stream);
+    }
+    hipFree(stage);
+    if (er != hipSuccess) return q3_set_err(e, Q3TTS_ERR_DEVICE, hipGetErrorString(er));
+    TRY(rc);
+    return upload_table(e, &e->proj_b, b, (size_t)m.p_d_model);
+}
+// Assets::load (src/assets_manager.rs:14-26): qwen3_assets.gguf if present, else the NPY files. Table row counts come from
+// the files (they define the out-of-range rules, :419-460); a missing text table means "every id is out of range".
+static int load_assets_files(q3tts_engine* e, const std::string& dir) {
+    q3tts_model_config& m = e->cfg.model;
+    const size_t d = (size_t)m.d_embed;
+    std::vector<std::vector<float>> tabs(1 + m.n_codebooks);  // text, codec 0..
+    std::vector<size_t> rows(1 + m.n_codebooks, 0);
+    std::vector<float> pw, pb;
+    std::string err;
+    const std::string gpath = dir + "/qwen3_assets.gguf";
+    if (file_exists(gpath)) {
+        Q3Gguf g;
+        if (g.open(gpath, err)) return q3_set_err(e, Q3TTS_ERR_INVALID, err);
+        auto fetch = [&](const std::string& name, uint64_t ne0, bool required, std::vector<float>& out, size_t* nrows) -> int {
+            const Q3GgufTensor* t = g.find(name);
+            if (!t) return required ? q3_set_err(e, Q3TTS_ERR_INVALID, gpath + ": " + name + " (tensor) missing") : Q3TTS_OK;
+            if (t->dims[0] != ne0 || t->dims.size() > 2) return q3_set_err(e, Q3TTS_ERR_INVALID, gpath + ": tensor '" + name + "' has the wrong row length");
+            out.resize(t->nelem);
+            if (q3_gguf_to_f32(*t, out.data(), err)) return q3_set_err(e, Q3TTS_ERR_INVALID, gpath + ": " + err);
+            if (nrows) *nrows = t->dims.size() > 1 ? (size_t)t->dims[1] : 1;
+            return Q3TTS_OK;
+        };
+        size_t pr = 0;
+        TRY(fetch("proj.weight", d, true, pw, &pr));
+        if (pr != (size_t)m.p_d_model) return q3_set_err(e, Q3TTS_ERR_INVALID, gpath + ": proj.weight does not have p_d_model rows");
+        TRY(fetch("proj.bias", (uint64_t)m.p_d_model, true, pb, nullptr));
+        TRY(fetch("text_embd", d, false, tabs[0], &rows[0]));
+        for (int q = 0; q < m.n_codebooks; ++q) TRY(fetch("codec_embd." + std::to_string(q), d, true, tabs[1 + q], &rows[1 + q]));
+    } else {
+        auto fetch = [&](const std::string& file, bool required, std::vector<float>& out, size_t* nrows, size_t row_len) -> int {
+            const std::string path = dir + "/" + file;
+            if (!file_exists(path)) return required ? q3_set_err(e, Q3TTS_ERR_INVALID, "neither qwen3_assets.gguf nor " + file + " in " + dir) : Q3TTS_OK;
+            std::vector<size_t> shape;
+            if (q3_npy_load_f32(path, out, shape, err)) return q3_set_err(e, Q3TTS_ERR_INVALID, err);
+            if (out.size() % row_len) return q3_set_err(e, Q3TTS_ERR_INVALID, path + ": size is not a multiple of the row length");
+            if (nrows) *nrows = out.size() / row_len;
+            return Q3TTS_OK;
+        };
+        size_t pr = 0, br = 0;
+        TRY(fetch("proj_weight.npy", true, pw, &pr, d));
+        TRY(fetch("proj_bias.npy", true, pb, &br, 1));
+        if (pr != (size_t)m.p_d_model || br != (size_t)m.p_d_model) return q3_set_err(e, Q3TTS_ERR_INVALID, dir + ": projection shape does not match p_d_model");
+        TRY(fetch("text_embedding_projected.npy", false, tabs[0], &rows[0], d));
+        for (int q = 0; q < m.n_codebooks; ++q) TRY(fetch("codec_embedding_" + std::to_string(q) + ".npy", true, tabs[1 + q], &rows[1 + q], d));
+    }
+    for (int q = 2; q < m.n_codebooks; ++q)
+        if (rows[1 + q] != rows[2]) return q3_set_err(e, Q3TTS_ERR_INVALID, dir + ": codec tables 1.." + std::to_string(m.n_codebooks - 1) + " differ in size");
+    m.text_vocab = (int32_t)rows[0]; m.codec0_rows = (int32_t)rows[1];
+    if (m.n_codebooks > 1) m.codecq_rows = (int32_t)rows[2];
+    if (rows[0]) TRY(upload_table(e, &e->text, tabs[0].data(), tabs[0].size()));
+    e->codec.resize(m.n_codebooks);
+    for (int q = 0; q < m.n_codebooks; ++q) TRY(upload_table(e, &e->codec[q], tabs[1 + q].data(), tabs[1 + q].size()));
+    TRY(upload_proj(e, pw.data(), pb.data()));
+    // tts_pad = row 151671 of the text table when it is that large, else zeros (src/assets_manager.rs:244-249)
+    if ((size_t)m.tts_pad_id < rows[0]) e->tts_pad = e->text + (size_t)m.tts_pad_id * d;
+    else { TRY(dalloc(e, &e->tts_pad_own, d)); Q3_HIP(e, hipMemset(e->tts_pad_own, 0, d * 4)); e->tts_pad = e->tts_pad_own; }
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine** out) {
+    if (!cfg || !out) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "null argument");
+    std::string why;
+    if (validate(*cfg, why) != Q3TTS_OK) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, why);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return q3_set_err(nullptr, Q3TTS_ERR_DEVICE, "no HIP device: libq3tts has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "device ordinal out of range");
+    q3tts_engine* e = new q3tts_engine();
+    e->cfg = *cfg; e->cfg.weights_path = nullptr;
+    e->max_steps = cfg->max_steps_cap < 512 ? cfg->max_steps_cap : 512;
+    auto fail = [&](int rc) { std::string m = e->err; q3tts_engine_destroy(e); g_err = m; return rc; };
+#define TRYC(x) do { int rc__ = (x); if (rc__ != Q3TTS_OK) return fail(rc__); } while (0)
+#define HIPC(call) do { hipError_t er__ = (call); if (er__ != hipSuccess) { q3_set_err(e, Q3TTS_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(er__)); return fail(Q3TTS_ERR_DEVICE); } } while (0)
+    HIPC(hipSetDevice(cfg->device));
+    HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    // Q3TTS_VOC_SERIAL=1: the vocoder shares the decoder stream (no overlap): isolates its kernels in a profile
+    if (getenv("Q3TTS_VOC_SERIAL") && atoi(getenv("Q3TTS_VOC_SERIAL"))) e->vstream = e->stream;
+    else HIPC(hipStreamCreateWithFlags(&e->vstream, hipStreamNonBlocking));
+    HIPC(hipEventCreate(&e->ev0)); HIPC(hipEventCreate(&e->ev1)); HIPC(hipEventCreate(&e->ev2)); HIPC(hipEventCreate(&e->ev3));
+    e->fin_ev.resize(cfg->max_batch, nullptr);
+    for (auto& ev : e->fin_ev) HIPC(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    q3tts_model_config& m = e->cfg.model;  // (table row counts follow the files when weights_path is given)
+    const int B = cfg->max_batch;
+    e->B = B;
+    hipStream_t s = e->stream;
+    // weights_path = the reference's quant directory (src/tts/engine.rs:91-131): qwen3_tts_talker.gguf,
+    // qwen3_tts_predictor.gguf, qwen3_assets.gguf (or the NPY fallback). NULL: seeded synthetic weights.
+    const std::string wdir = cfg->weights_path ? cfg->weights_path : "";
+    Q3Gguf gt, gp;
+    GgSrc st{e, &gt, "qwen3_tts_talker.gguf"}, sp{e, &gp, "qwen3_tts_predictor.gguf"};
+    if (!wdir.empty()) {
+        std::string er;
+        if (gt.open(wdir + "/qwen3_tts_talker.gguf", er) || gp.open(wdir + "/qwen3_tts_predictor.gguf", er)) { q3_set_err(e, Q3TTS_ERR_INVALID, er); return fail(Q3TTS_ERR_INVALID); }
+    }
+    TRYC(init_tfm(e, e->T, Q3G_TALKER, m.t_n_layer, m.t_d_model, m.t_n_head, m.t_n_kv_head, m.t_head_dim, m.t_d_ffn, m.t_vocab,
+                  m.t_rope_theta, m.t_mrope_sections, cfg->n_ctx, B, wdir.empty() ? nullptr : &st));
+    TRYC(init_tfm(e, e->P, Q3G_PRED, m.p_n_layer, m.p_d_model, m.p_n_head, m.p_n_kv_head, m.p_head_dim, m.p_d_ffn,
+                  (m.n_codebooks - 1) * m.codebook_size, m.p_rope_theta, nullptr, 64, B, wdir.empty() ? nullptr : &sp));
+    // assets (F32 tables like qwen3_assets.gguf: src/assets_manager.rs:212-241; values bf16-representable)
+    const uint64_t seed = cfg->synth_seed;
+    const float es = 0.05f / Q3_IH4_STD;
+    if (!wdir.empty()) {
+        TRYC(load_assets_files(e, wdir));
+        { void* cd = nullptr; HIPC(hipMalloc(&cd, sizeof(float*) * 16)); e->codec_dev = (const float**)cd; }
+        HIPC(hipMemcpyAsync((void*)e->codec_dev, e->codec.data(), sizeof(float*) * m.n_codebooks, hipMemcpyHostToDevice, s));
+    } else {
+    TRYC(dalloc(e, &e->text, (size_t)m.text_vocab * m.d_embed));
+    q3_launch_fill_f32(e->text, (size_t)m.text_vocab * m.d_embed, seed, Q3_TID(Q3G_ASSET, 0, Q3WA_TEXT), 0.0f, es, 1, s);
+    e->codec.resize(m.n_codebooks);
+    for (int q = 0; q < m.n_codebooks; ++q) {
+        const size_t rows = q == 0 ? m.codec0_rows : m.codecq_rows;
+        TRYC(dalloc(e, &e->codec[q], rows * m.d_embed));
+        q3_launch_fill_f32(e->codec[q], rows * m.d_embed, seed, Q3_TID(Q3G_ASSET, 1 + q, 0), 0.0f, es, 1, s);
+    }
+    { void* cd = nullptr; HIPC(hipMalloc(&cd, sizeof(float*) * 16)); e->codec_dev = (const float**)cd; }
+    HIPC(hipMemcpyAsync((void*)e->codec_dev, e->codec.data(), sizeof(float*) * m.n_codebooks, hipMemcpyHostToDevice, s));
+    TRYC(dalloc(e, &e->proj_w, (size_t)m.p_d_model * m.d_embed / 8));
+    { Q3Fill f{}; f.seed = seed; f.scale = 0.02f / Q3_IH4_STD; f.dst = e->proj_w; f.N = m.p_d_model; f.K = m.d_embed; f.mode = 0; f.row0 = 0;
+      f.rows = m.p_d_model; f.tid_a = Q3_TID(Q3G_ASSET, 0, Q3WA_PROJ_W); q3_launch_fill_tiled(f, s); }
+    TRYC(dalloc(e, &e->proj_b, (size_t)m.p_d_model));
+    q3_launch_fill_f32(e->proj_b, m.p_d_model, seed, Q3_TID(Q3G_ASSET, 0, Q3WA_PROJ_B), 0.0f, 0.02f / Q3_IH4_STD, 0, s);
+    e->tts_pad = e->text + (size_t)m.tts_pad_id * m.d_embed;  // src/assets_manager.rs:244-249
+    }
+    // decode state
+    TRYC(dalloc(e, &e->slots, (size_t)B));
+    HIPC(hipHostMalloc((void**)&e->slots_host, sizeof(Q3Slot) * 2 * B, hipHostMallocDefault));
+    memset(e->slots_host, 0, sizeof(Q3Slot) * 2 * B);
+    TRYC(dalloc(e, &e->codes, (size_t)B * cfg->max_steps_cap * m.n_codebooks)); TRYC(dalloc(e, &e->rng, (size_t)B * cfg->max_steps_cap));
+    {
+        const int nb = B;
+        const int nqkv_max = std::max(e->T.nqkv, e->P.nqkv), nq_max = std::max(e->T.nq, e->P.nq), F_max = std::max(e->T.F, e->P.F);
+        e->lanes.resize(1);
+        Q3Lane& L = e->lanes[0];
+        L.nb = nb;
+        HIPC(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        HIPC(hipEventCreate(&L.ev_begin)); HIPC(hipEventCreate(&L.ev_end));
+        TRYC(dalloc(e, &L.xT, (size_t)nb * m.t_d_model)); TRYC(dalloc(e, &L.logits, (size_t)nb * m.t_vocab)); TRYC(dalloc(e, &L.logits_tmp, (size_t)nb * std::max(m.t_vocab, m.t_d_model)));
+        TRYC(dalloc(e, &L.X, (size_t)2 * nb * m.d_embed)); TRYC(dalloc(e, &L.fb, (size_t)nb * m.d_embed));
+        TRYC(dalloc(e, &L.px, (size_t)2 * nb * m.p_d_model)); TRYC(dalloc(e, &L.keys, (size_t)nb * m.n_codebooks));
+        TRYC(dalloc(e, &L.row_pos_t, (size_t)nb)); TRYC(dalloc(e, &L.slot_id, (size_t)nb)); TRYC(dalloc(e, &L.perm, (size_t)nb));
+        TRYC(dalloc(e, &L.posA, (size_t)2 * nb)); TRYC(dalloc(e, &L.slotA, (size_t)2 * nb)); TRYC(dalloc(e, &L.pos_q, (size_t)m.n_codebooks * nb));
+        std::vector<int> sid(nb), pa(2 * nb), sla(2 * nb), pq((size_t)m.n_codebooks * nb), rp(nb, -1);
+        for (int b = 0; b < nb; ++b) { sid[b] = b; pa[2 * b] = 0; pa[2 * b + 1] = 1; sla[2 * b] = sla[2 * b + 1] = b; }
+        for (int q = 0; q < m.n_codebooks; ++q) for (int b = 0; b < nb; ++b) pq[(size_t)q * nb + b] = q + 1;  // src/tts/engine.rs:604
+        HIPC(hipMemcpyAsync(L.slot_id, sid.data(), nb * 4, hipMemcpyHostToDevice, s));
+        HIPC(hipMemcpyAsync(L.posA, pa.data(), 2 * nb * 4, hipMemcpyHostToDevice, s));
+        HIPC(hipMemcpyAsync(L.slotA, sla.data(), 2 * nb * 4, hipMemcpyHostToDevice, s));
+        HIPC(hipMemcpyAsync(L.pos_q, pq.data(), pq.size() * 4, hipMemcpyHostToDevice, s));
+        HIPC(hipMemcpyAsync(L.row_pos_t, rp.data(), nb * 4, hipMemcpyHostToDevice, s));
+        HIPC(hipStreamSynchronize(s));
+        TRYC(alloc_scratch(e, L.sc, 2 * nb, nqkv_max, nq_max, F_max, std::max(m.t_d_model, m.p_d_model)));
+        for (int r = 1; r < nb; r *= 2) e->buckets.push_back(r);
+        e->buckets.push_back(nb);
+        e->cur_bucket = (int)e->buckets.size() - 1;
+        e->row_of_slot = sid; e->slot_of_row = sid;
+    }
+    TRYC(alloc_scratch(e, e->sc_pre, cfg->n_ctx, e->T.nqkv, e->T.nq, e->T.F, m.t_d_model));
+    TRYC(dalloc(e, &e->xp, (size_t)cfg->n_ctx * m.t_d_model));
+    TRYC(dalloc(e, &e->pf_pos, (size_t)cfg->n_ctx)); TRYC(dalloc(e, &e->pf_slot, (size_t)cfg->n_ctx));
+    { std::vector<int> pp(cfg->n_ctx); for (int i = 0; i < cfg->n_ctx; ++i) pp[i] = i;
+      HIPC(hipMemcpyAsync(e->pf_pos, pp.data(), pp.size() * 4, hipMemcpyHostToDevice, s)); HIPC(hipStreamSynchronize(s)); }
+    e->prow_cap = cfg->n_ctx;
+    TRYC(dalloc(e, &e->prow_dev, (size_t)e->prow_cap)); TRYC(dalloc(e, &e->spk_dev, (size_t)m.d_embed));
+    TRYC(dalloc(e, &e->refcodes_dev, (size_t)cfg->n_ctx * 16));
+    if (cfg->with_vocoder) {
+        TRYC(q3_voc_create(e));
+        HIPC(hipHostMalloc((void**)&e->first_chunk_host, sizeof(float) * 4 * (size_t)q3_voc_samples_per_frame(e), hipHostMallocDefault));
+    }
+    // capture the frame step once per row-count bucket; every later frame is a replay (Q3TTS_NO_GRAPH=1: eager launches,
+    // for profilers)
+    HIPC(hipStreamSynchronize(s));
+    if (!(getenv("Q3TTS_NO_GRAPH") && atoi(getenv("Q3TTS_NO_GRAPH")))) {
+        Q3Lane& L = e->lanes[0];
+        L.graphs.resize(e->buckets.size(), nullptr); L.execs.resize(e->buckets.size(), nullptr);
+        for (size_t bi = 0; bi < e->buckets.size(); ++bi) {
+            HIPC(hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal));
+            record_frame(e, L, L.stream, e->buckets[bi]);
+            HIPC(hipStreamEndCapture(L.stream, &L.graphs[bi]));
+            HIPC(hipGraphInstantiate(&L.execs[bi], L.graphs[bi], nullptr, nullptr, 0));
+            HIPC(hipStreamSynchronize(L.stream));
+        }
+    }
+    // algorithmic bytes of one frame step, context term added per run
+    e->tm.algo_bytes_per_step = 0;
+#undef TRYC
+#undef HIPC
+    *out = e;
+    return Q3TTS_OK;
+}
+
+extern "C" void q3tts_engine_destroy(q3tts_engine* e) {
+    if (!e) return;
+    hipSetDevice(e->cfg.device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->vstream) hipStreamSynchronize(e->vstream);
+    if (e->voc) q3_voc_destroy(e);
+    q3_mel_destroy(e);
+    if (e->first_chunk_host) hipHostFree(e->first_chunk_host);
+    for (auto& L : e->lanes) {
+        if (L.stream) hipStreamSynchronize(L.stream);
+        for (auto ge : L.execs) if (ge) hipGraphExecDestroy(ge);
+        for (auto gr : L.graphs) if (gr) hipGraphDestroy(gr);
+        hipFree(L.logits_tmp); hipFree(L.perm);
+        hipFree(L.xT); hipFree(L.logits); hipFree(L.X); hipFree(L.fb); hipFree(L.px); hipFree(L.keys);
+        hipFree(L.row_pos_t); hipFree(L.slot_id); hipFree(L.posA); hipFree(L.slotA); hipFree(L.pos_q);
+        hipFree(L.sc.qkv); hipFree(L.sc.att); hipFree(L.sc.h);
+        if (L.ev_begin) hipEventDestroy(L.ev_begin); if (L.ev_end) hipEventDestroy(L.ev_end);
+        if (L.stream) hipStreamDestroy(L.stream);
+    }
+    free_tfm(e->T); free_tfm(e->P);
+    hipFree(e->text); for (auto p : e->codec) hipFree(p); hipFree((void*)e->codec_dev); hipFree(e->proj_w); hipFree(e->proj_b);
+    hipFree(e->tts_pad_own);
+    hipFree(e->slots); if (e->slots_host) hipHostFree(e->slots_host);
+    hipFree(e->codes); hipFree(e->rng);
+    hipFree(e->sc_pre.qkv); hipFree(e->sc_pre.att); hipFree(e->sc_pre.h);
+    hipFree(e->xp); hipFree(e->pf_pos); hipFree(e->pf_slot); hipFree(e->prow_dev); hipFree(e->spk_dev); hipFree(e->refcodes_dev);
+    for (auto ev : e->fin_ev) if (ev) hipEventDestroy(ev);
+    for (auto ev : e->probe_ev) if (ev) hipEventDestroy(ev);
+    if (e->ev0) hipEventDestroy(e->ev0); if (e->ev1) hipEventDestroy(e->ev1); if (e->ev2) hipEventDestroy(e->ev2); if (e->ev3) hipEventDestroy(e->ev3);
+    if (e->stream) hipStreamDestroy(e->stream);
+    if (e->vstream && e->vstream != e->stream) hipStreamDestroy(e->vstream);
+    delete e;
+}
+
+extern "C" int q3tts_set_sampler(q3tts_engine* e, float temperature, int32_t top_k, float top_p, int32_t has_seed, uint64_t seed) {
+    if (!e) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "null engine");
+    e->temperature = temperature; e->top_k = top_k; e->top_p = top_p; e->has_seed = has_seed; e->seed = seed;
+    return Q3TTS_OK;
+}
+extern "C" int q3tts_set_max_steps(q3tts_engine* e, int32_t n) {
+    if (!e) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "null engine");
+    if (n < 0 || n > e->cfg.max_steps_cap) return q3_set_err(e, Q3TTS_ERR_INVALID, "max_steps exceeds max_steps_cap");
+    e->max_steps = n;
+    return Q3TTS_OK;
+}
+extern "C" void q3tts_free(void* p) { free(p); }
+
+// ------------------------------------------------------------------------------------------------
+// H1 prompt builder: row list on the host (src/tts/prompt.rs:141-277, :28-118), gathers on the device
+// ------------------------------------------------------------------------------------------------
+enum { PAD = 2148, BOS = 2149, THINK = 2154, NOTHINK = 2155, THINK_BOS = 2156, THINK_EOS = 2157, CODEC_BOS_ICL = 2160 };
+enum { BOS_TOKEN = 151672, EOS_TOKEN = 151673 };
+
+static int build_prompt_dev(q3tts_engine* e, const q3tts_prompt_desc* p, float* out, int max_rows, int* n_out) {
+    const q3tts_model_config& m = e->cfg.model;
+    if (!p || (p->n_text > 0 && !p->text_ids)) return q3_set_err(e, Q3TTS_ERR_INVALID, "prompt: text_ids missing");
+    const int marker = m.tts_pad_id;
+    std::vector<Q3PromptRow> rows;
+    int ref_row0 = -1;
+    auto T1 = [&](int id) { rows.push_back({1, id, 0, 0}); };
+    auto MC = [&](int cid) { rows.push_back({1, marker, 2, cid}); };       // marker + codec0[cid]
+    auto TP = [&](int tid) { rows.push_back({1, tid, 2, PAD}); };          // text[tid] + codec0[PAD]
+    if (p->instruct_ids) {  // :153-169
+        T1(151644); T1(872); T1(198);
+        for (int i = 0; i < p->n_instruct; ++i) T1((int)p->instruct_ids[i]);
+        T1(151645); T1(198);
+    }
+    T1(151644); T1(77091); T1(198);  // :171-175
+    if (p->lang_id >= 0) { MC(THINK); MC(THINK_BOS); MC(p->lang_id); MC(THINK_EOS); }  // :180-191
+    else { MC(NOTHINK); MC(THINK_BOS); MC(THINK_EOS); }                                // :192-204
+    if (p->spk_id >= 0) MC(p->spk_id);                                                 // :207-214
+    else if (p->spk_emb) rows.push_back({1, marker, -1, 0});                           // :215-222
+    if (p->ref_codes) {  // build_clone_prompt :38-106
+        TP(BOS_TOKEN);
+        for (int i = 0; i < p->n_ref_text; ++i) TP((int)p->ref_text_ids[i]);
+        TP(EOS_TOKEN);
+        MC(CODEC_BOS_ICL);
+        ref_row0 = (int)rows.size();
+        for (int i = 0; i < p->n_ref_frames; ++i) rows.push_back({-2, 0, 0, 0});  // filled by the frame kernel
+        MC(PAD);
+    }
+    TP(BOS_TOKEN);                                             // :229-239
+    for (int i = 0; i < p->n_text; ++i) TP((int)p->text_ids[i]);  // :241-245
+    TP(EOS_TOKEN);                                             // :247-254
+    MC(BOS);                                                   // :256-264
+    const int n = (int)rows.size();
+    if (n > max_rows || n > e->prow_cap) return q3_set_err(e, Q3TTS_ERR_INVALID, "prompt longer than n_ctx");
+    hipStream_t s = e->stream;
+    Q3_HIP(e, hipMemcpyAsync(e->prow_dev, rows.data(), sizeof(Q3PromptRow) * n, hipMemcpyHostToDevice, s));
+    if (p->spk_emb) Q3_HIP(e, hipMemcpyAsync(e->spk_dev, p->spk_emb, (size_t)m.d_embed * 4, hipMemcpyHostToDevice, s));
+    Q3_HIP(e, hipStreamSynchronize(s));  // rows is a stack vector
+    q3_launch_prompt_rows(e->prow_dev, n, e->text, m.text_vocab, e->codec_dev, m.codec0_rows, m.codecq_rows, m.n_codebooks, e->spk_dev,
+                          m.d_embed, out, s);
+    if (ref_row0 >= 0 && p->n_ref_frames > 0) {
+        Q3_HIP(e, hipMemcpyAsync(e->refcodes_dev, p->ref_codes, (size_t)p->n_ref_frames * 16 * 4, hipMemcpyHostToDevice, s));
+        Q3_HIP(e, hipStreamSynchronize(s));
+        q3_launch_prompt_ref_frames(e->refcodes_dev, p->n_ref_frames, e->text + (size_t)marker * m.d_embed, e->codec_dev, m.codec0_rows,
+                                    m.codecq_rows, m.n_codebooks, m.d_embed, out + (size_t)ref_row0 * m.d_embed, s);
+    }
+    *n_out = n;
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_build_prompt(q3tts_engine* e, const q3tts_prompt_desc* p, float** out_embd, int32_t* out_n) {
+    if (!e || !p || !out_embd || !out_n) return q3_set_err(e, Q3TTS_ERR_INVALID, "null argument");
+    Q3_HIP(e, hipSetDevice(e->cfg.device));
+    int n = 0;
+    TRY(build_prompt_dev(e, p, e->xp, e->cfg.n_ctx, &n));
+    const size_t bytes = (size_t)n * e->cfg.model.d_embed * 4;
+    float* h = (float*)malloc(bytes);
+    if (!h) return q3_set_err(e, Q3TTS_ERR_OOM, "malloc");
+    hipError_t er = hipMemcpyAsync(h, e->xp, bytes, hipMemcpyDeviceToHost, e->stream);
+    if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
+    if (er != hipSuccess) { free(h); return q3_set_err(e, Q3TTS_ERR_DEVICE, hipGetErrorString(er)); }
+    *out_embd = h; *out_n = n;
+    return Q3TTS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// generation
+// ------------------------------------------------------------------------------------------------
+// Map the live slots onto rows [0, n) of the smallest bucket that holds them (idle slots fill the rest: every row keeps
+// a distinct, valid slot). Row-indexed state that outlives a frame (the Talker logits) moves with its slot.
+static int plan_rows(q3tts_engine* e, const std::vector<int>& live_in) {
+    Q3Lane& L = e->lanes[0];
+    const int B = e->B;
+    std::vector<int> live(live_in);
+    std::sort(live.begin(), live.end());
+    int bi = 0;
+    while (bi + 1 < (int)e->buckets.size() && e->buckets[bi] < (int)live.size()) ++bi;
+    bool ok = bi == e->cur_bucket;
+    if (ok) for (int b : live) if (e->row_of_slot[b] >= e->buckets[bi]) { ok = false; break; }
+    if (ok) return Q3TTS_OK;
+    std::vector<int> slot_of_row(B, -1), perm(B), used(B, 0), sla(2 * (size_t)B);
+    int r = 0;
+    for (int b : live) { slot_of_row[r++] = b; used[b] = 1; }
+    for (int b = 0; b < B && r < B; ++b) if (!used[b]) slot_of_row[r++] = b;
+    for (r = 0; r < B; ++r) { perm[r] = e->row_of_slot[slot_of_row[r]]; sla[2 * r] = sla[2 * r + 1] = slot_of_row[r]; }
+    hipStream_t s = e->stream;
+    Q3_HIP(e, hipMemcpyAsync(L.perm, perm.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+    Q3_HIP(e, hipMemcpyAsync(L.slot_id, slot_of_row.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+    Q3_HIP(e, hipMemcpyAsync(L.slotA, sla.data(), (size_t)2 * B * 4, hipMemcpyHostToDevice, s));
+    // row state that outlives a frame: the Talker logits (sampled at the next frame) and its last hidden row (the
+    // Predictor's first input)
+    q3_launch_gather_rows(L.logits_tmp, L.logits, L.perm, B, e->cfg.model.t_vocab, s);
+    Q3_HIP(e, hipMemcpyAsync(L.logits, L.logits_tmp, (size_t)B * e->cfg.model.t_vocab * 4, hipMemcpyDeviceToDevice, s));
+    q3_launch_gather_rows(L.logits_tmp, L.xT, L.perm, B, e->cfg.model.t_d_model, s);
+    Q3_HIP(e, hipMemcpyAsync(L.xT, L.logits_tmp, (size_t)B * e->cfg.model.t_d_model * 4, hipMemcpyDeviceToDevice, s));
+    Q3_HIP(e, hipStreamSynchronize(s));  // the uploads read locals
+    for (r = 0; r < B; ++r) e->row_of_slot[slot_of_row[r]] = r;
+    e->slot_of_row = slot_of_row;
+    e->cur_bucket = bi;
+    return Q3TTS_OK;
+}
+
+// CH frame steps over the current row bucket; afterwards the slot mirror is on the host. Returns the device time (ms).
+static int run_chunk(q3tts_engine* e, int CH, float* dev_ms) {
+    hipStream_t s = e->stream;
+    Q3Lane& L = e->lanes[0];
+    Q3_HIP(e, hipEventRecord(e->ev1, s));  // admissions (prefill, state uploads) precede the frames
+    Q3_HIP(e, hipStreamWaitEvent(L.stream, e->ev1, 0));
+    Q3_HIP(e, hipEventRecord(L.ev_begin, L.stream));
+    e->probe_i = 0;
+    if (e->probe) { hipEventRecord(e->probe_ev[8], L.stream); hipEventRecord(e->probe_ev[9], L.stream); }  // empty bracket
+    for (int i = 0; i < CH; ++i) {
+        if (!L.execs.empty() && !e->probe) { Q3_HIP(e, hipGraphLaunch(L.execs[e->cur_bucket], L.stream)); }
+        else { record_frame(e, L, L.stream, e->buckets[e->cur_bucket]); Q3_HIP(e, hipGetLastError()); }
+    }
+    e->row_steps += (long long)CH * e->buckets[e->cur_bucket];
+    Q3_HIP(e, hipEventRecord(L.ev_end, L.stream));
+    Q3_HIP(e, hipStreamWaitEvent(s, L.ev_end, 0));
+    Q3_HIP(e, hipEventRecord(e->ev3, s));  // the vocoder stream waits on this
+    Q3_HIP(e, hipMemcpyAsync(e->slots_host, e->slots, sizeof(Q3Slot) * e->B, hipMemcpyDeviceToHost, s));
+    Q3_HIP(e, hipStreamSynchronize(s));
+    if (dev_ms) { *dev_ms = 0.0f; hipEventElapsedTime(dev_ms, L.ev_begin, L.ev_end); }
+    for (int i = 0; i + 1 < e->probe_i; i += 2) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, e->probe_ev[i], e->probe_ev[i + 1]) == hipSuccess) { e->probe_ms += ms; ++e->probe_cnt; }
+    }
+    if (e->probe) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, e->probe_ev[8], e->probe_ev[9]) == hipSuccess) { e->probe_empty_ms += ms; ++e->probe_empty_cnt; }
+    }
+    return Q3TTS_OK;
+}
+
+static uint64_t wall_seed() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+}
+
+// Talker prefill (src/tts/engine.rs:455-462) of several requests at once: their prompt rows are concatenated into one
+// batch (row -> (slot, position) maps), so the weights stream once for all of them; then per request the last row
+// seeds the slot (logits, state, sampler draws). rc[i] receives the per-request status.
+struct Adm { int b; const q3tts_request* r; int n, row0, max_steps; };
+
+static int admit_group(q3tts_engine* e, std::vector<Adm>& grp, int total) {
+    const q3tts_model_config& m = e->cfg.model;
+    hipStream_t s = e->stream;
+    if (grp.empty()) return Q3TTS_OK;
+    std::vector<int> pos(total), slot(total);
+    for (const Adm& a : grp) for (int i = 0; i < a.n; ++i) { pos[a.row0 + i] = i; slot[a.row0 + i] = a.b; }
+    Q3_HIP(e, hipMemcpyAsync(e->pf_pos, pos.data(), (size_t)total * 4, hipMemcpyHostToDevice, s));
+    Q3_HIP(e, hipMemcpyAsync(e->pf_slot, slot.data(), (size_t)total * 4, hipMemcpyHostToDevice, s));
+    Q3_HIP(e, hipStreamSynchronize(s));  // pos/slot are locals
+    run_layers(e, e->T, e->xp, total, e->pf_pos, e->pf_slot, e->sc_pre, s);
+    for (const Adm& a : grp) {
+        const q3tts_request* r = a.r;
+        const int b = a.b;
+        Q3Lane& L = e->lanes[0];
+        const int row = e->row_of_slot[b];
+        q3_launch_copy_rows(L.xT + (size_t)row * m.t_d_model, m.t_d_model, e->xp + (size_t)(a.row0 + a.n - 1) * m.t_d_model, m.t_d_model, 1, m.t_d_model, s);
+        Q3Gemm g{}; g.x = L.xT + (size_t)row * m.t_d_model; g.ldx = m.t_d_model; g.B = 1; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab;
+        g.norm_w = e->T.out_norm; g.eps = m.rms_eps; g.y = L.logits + (size_t)row * m.t_vocab; g.ldy = m.t_vocab; g.epi = Q3_EPI_STORE;
+        q3_launch_gemm(g, s);
+        // sampler stream (src/tts/engine.rs:473-485)
+        float temperature = e->temperature, top_p = e->top_p; int top_k = e->top_k, has_seed = e->has_seed; uint64_t seed = e->seed;
+        if (!r->use_engine_sampler) { temperature = r->temperature; top_k = r->top_k; top_p = r->top_p; has_seed = r->has_seed; seed = r->seed; }
+        if (!has_seed) seed = wall_seed();
+        if (temperature > 0.0f) {
+            std::vector<float> draws(a.max_steps);
+            q3_stdrng_f32(seed, a.max_steps, draws.data());
+            Q3_HIP(e, hipMemcpyAsync(e->rng + (size_t)b * e->cfg.max_steps_cap, draws.data(), (size_t)a.max_steps * 4, hipMemcpyHostToDevice, s));
+            Q3_HIP(e, hipStreamSynchronize(s));
+        }
+        Q3Slot* st = e->slots_host + e->B + b;  // pinned staging half
+        memset(st, 0, sizeof(*st));
+        st->active = 1; st->cur_pos = a.n; st->n_frames = 0; st->max_steps = a.max_steps; st->min_frames = r->min_frames;
+        st->force_eos_at = r->force_eos_at; st->top_k = top_k; st->temperature = temperature; st->top_p = top_p;
+        st->rng_base = b * e->cfg.max_steps_cap;
+        Q3_HIP(e, hipMemcpyAsync(e->slots + b, st, sizeof(Q3Slot), hipMemcpyHostToDevice, s));
+        if (e->voc) TRY(q3_voc_reset(e, b));
+    }
+    return Q3TTS_OK;
+}
+
+// slots[i] <- reqs[i]; rc[i] = status of request i (a failing request does not stop the others)
+static int admit_many(q3tts_engine* e, const int* slots, const q3tts_request* const* reqs, int count, int* rc) {
+    const q3tts_model_config& m = e->cfg.model;
+    hipStream_t s = e->stream;
+    std::vector<Adm> grp;
+    int total = 0;
+    for (int i = 0; i < count; ++i) {
+        const q3tts_request* r = reqs[i];
+        rc[i] = Q3TTS_OK;
+        const int max_steps = r->max_steps > 0 ? r->max_steps : e->max_steps;
+        if (max_steps > e->cfg.max_steps_cap) { rc[i] = q3_set_err(e, Q3TTS_ERR_INVALID, "max_steps exceeds max_steps_cap"); continue; }
+        int n = 0;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const int room = e->cfg.n_ctx - total;
+            if (r->prompt_embd) {
+                n = r->n_tok;
+                if (n <= 0 || n > e->cfg.n_ctx) { rc[i] = q3_set_err(e, Q3TTS_ERR_INVALID, "n_tok out of range"); break; }
+                if (n > room) { if (total == 0) { rc[i] = q3_set_err(e, Q3TTS_ERR_INVALID, "n_tok out of range"); break; } }
+                else { Q3_HIP(e, hipMemcpyAsync(e->xp + (size_t)total * m.d_embed, r->prompt_embd, (size_t)n * m.d_embed * 4, hipMemcpyHostToDevice, s)); break; }
+            } else if (r->prompt) {
+                const int brc = build_prompt_dev(e, r->prompt, e->xp + (size_t)total * m.d_embed, room, &n);
+                if (brc == Q3TTS_OK) break;
+                if (total == 0) { rc[i] = brc; break; }
+            } else { rc[i] = q3_set_err(e, Q3TTS_ERR_INVALID, "request has neither prompt_embd nor prompt"); break; }
+            TRY(admit_group(e, grp, total));  // batch full: flush, then retry this request in an empty batch
+            grp.clear(); total = 0;
+        }
+        if (rc[i] != Q3TTS_OK) continue;
+        if (n + max_steps > e->cfg.n_ctx) { rc[i] = q3_set_err(e, Q3TTS_ERR_INVALID, "prompt + max_steps exceeds n_ctx"); continue; }
+        grp.push_back(Adm{slots[i], r, n, total, max_steps});
+        total += n;
+    }
+    return admit_group(e, grp, total);
+}
+
+static int admit(q3tts_engine* e, int b, const q3tts_request* r) {
+    int rc = Q3TTS_OK;
+    int st = admit_many(e, &b, &r, 1, &rc);
+    return st != Q3TTS_OK ? st : rc;
+}
+
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct SlotRun { int req = -1; int voc_frames = 0; double t_first = 0; };
+
+// Results of a finished slot. The codes come back on the decoder stream at once; the PCM (pinned host buffer) is copied
+// on the vocoder stream. With `defer` the call does not wait for the vocoder: the copy is enqueued behind the slot's last
+// vocoder chunk, `fin_ev` is recorded after it and the caller completes the result later (complete_result), so the next
+// decode chunk is launched while the vocoder is still working.
+static int finalize(q3tts_engine* e, int b, const q3tts_request* r, q3tts_result* o, const SlotRun& sr, double t0, bool defer = false,
+                    hipEvent_t fin_ev = nullptr) {
+    const int ncb = e->cfg.model.n_codebooks;
+    const Q3Slot& st = e->slots_host[b];
+    o->n_frames = st.n_frames; o->hit_eos = st.hit_eos;
+    o->codes = (int32_t*)malloc(sizeof(int32_t) * (size_t)std::max(1, st.n_frames * ncb));
+    if (!o->codes) return q3_set_err(e, Q3TTS_ERR_OOM, "malloc");
+    if (st.n_frames > 0)
+        Q3_HIP(e, hipMemcpyAsync(o->codes, e->codes + (size_t)b * e->cfg.max_steps_cap * ncb, sizeof(int32_t) * (size_t)st.n_frames * ncb,
+                                 hipMemcpyDeviceToHost, e->stream));
+    o->sample_rate = e->cfg.vocoder.sample_rate;
+    if (r->want_pcm && e->voc) {
+        const int ns = q3_voc_samples(e, b);
+        o->n_samples = ns;
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, sizeof(float) * (size_t)std::max(1, ns), hipHostMallocDefault) != hipSuccess) return q3_set_err(e, Q3TTS_ERR_OOM, "hipHostMalloc");
+        o->pcm = (float*)hp;
+        if (ns > 0) Q3_HIP(e, hipMemcpyAsync(o->pcm, q3_voc_pcm(e, b), sizeof(float) * (size_t)ns, hipMemcpyDeviceToHost, e->vstream));
+        if (defer) Q3_HIP(e, hipEventRecord(fin_ev, e->vstream));
+        else Q3_HIP(e, hipStreamSynchronize(e->vstream));
+    } else if (defer) {
+        Q3_HIP(e, hipEventRecord(fin_ev, e->vstream));
+    }
+    Q3_HIP(e, hipStreamSynchronize(e->stream));
+    o->first_chunk_ms = sr.t_first > 0 ? (float)(sr.t_first - t0) : 0.0f;
+    o->total_ms = (float)(now_ms() - t0);
+    o->status = defer ? Q3TTS_ERR_STATE : Q3TTS_OK;  // a deferred result becomes OK in complete_result
+    return Q3TTS_OK;
+}
+
+static int complete_result(q3tts_engine* e, q3tts_result* o, hipEvent_t fin_ev, double t0) {
+    Q3_HIP(e, hipEventSynchronize(fin_ev));
+    o->total_ms = (float)(now_ms() - t0);
+    o->status = Q3TTS_OK;
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, int32_t n, q3tts_result* outs) {
+    if (!e || !reqs || !outs || n <= 0) return q3_set_err(e, Q3TTS_ERR_INVALID, "null/empty argument");
+    Q3_HIP(e, hipSetDevice(e->cfg.device));
+    for (int i = 0; i < n; ++i) { memset(&outs[i], 0, sizeof(outs[i])); outs[i].status = Q3TTS_ERR_STATE; }
+    for (int i = 0; i < n; ++i)
+        if (reqs[i].want_pcm && !e->voc) return q3_set_err(e, Q3TTS_ERR_STATE, "want_pcm on an engine created with with_vocoder = 0");
+    const int B = e->B, CH = 4;  // 4-frame chunks: src/tts/engine.rs:509-512
+    const int spf = e->voc ? q3_voc_samples_per_frame(e) : 0;
+    std::vector<SlotRun> run(B);
+    const double t0 = now_ms();
+    std::vector<int> pending(B, -1);  // request whose PCM copy is still in flight on the vocoder stream, per slot
+    auto drain = [&](int b) -> int {
+        if (pending[b] >= 0) { TRY(complete_result(e, &outs[pending[b]], e->fin_ev[b], t0)); pending[b] = -1; }
+        return Q3TTS_OK;
+    };
+    int next = 0, done = 0;
+    double dec_ms = 0, pre_ms = 0, voc_ms = 0;
+    long long steps = 0, ctx_tokens = 0, live_slot_steps = 0;
+    e->probe_ms = 0; e->probe_cnt = 0; e->row_steps = 0; e->probe_empty_ms = 0; e->probe_empty_cnt = 0;
+    hipStream_t s = e->stream;
+    while (done < n) {
+        bool admitted = false;
+        {
+            std::vector<int> as, ai; std::vector<const q3tts_request*> ar;
+            for (int b = 0; b < B && next < n; ++b)
+                if (run[b].req < 0) { TRY(drain(b)); as.push_back(b); ar.push_back(&reqs[next]); ai.push_back(next++); }
+            {
+                std::vector<int> live(as);
+                for (int b = 0; b < B; ++b) if (run[b].req >= 0) live.push_back(b);
+                TRY(plan_rows(e, live));
+            }
+            if (!as.empty()) {
+                Q3_HIP(e, hipEventRecord(e->ev0, s));
+                admitted = true;
+                std::vector<int> rcs(as.size());
+                TRY(admit_many(e, as.data(), ar.data(), (int)as.size(), rcs.data()));
+                for (size_t i = 0; i < as.size(); ++i) {
+                    if (rcs[i] != Q3TTS_OK) { outs[ai[i]].status = rcs[i]; ++done; }
+                    else { run[as[i]] = SlotRun{}; run[as[i]].req = ai[i]; }
+                }
+            }
+        }
+        if (admitted) { Q3_HIP(e, hipEventRecord(e->ev2, s)); }
+        bool any = false;
+        for (int b = 0; b < B; ++b) if (run[b].req >= 0) any = true;
+        if (!any) break;
+        float ms = 0;
+        TRY(run_chunk(e, CH, &ms));
+        dec_ms += ms; steps += CH;
+        if (admitted) { hipEventElapsedTime(&ms, e->ev0, e->ev2); pre_ms += ms; }
+        for (int b = 0; b < B; ++b) if (run[b].req >= 0) { ctx_tokens += (long long)e->slots_host[b].cur_pos * CH; live_slot_steps += CH; }
+        // H8: the vocoder consumes 4-frame chunks (src/tts/engine.rs:507-541). It runs on its own stream behind an
+        // event, batched over every slot that has a chunk ready, so chunk k's PCM overlaps the decoding of chunk k+1.
+        if (e->voc) {
+            const double tv0 = now_ms();
+            hipStream_t vs = e->vstream;
+            bool waited = false, first = false;
+            auto ensure_wait = [&]() -> int { if (!waited) { Q3_HIP(e, hipStreamWaitEvent(vs, e->ev3, 0)); waited = true; } return Q3TTS_OK; };
+            // ONE batched call per chunk: every slot with new frames runs nf = 4. A finished utterance whose tail is
+            // shorter is padded with throw-away frames: the vocoder is causal, so they cannot change the samples already
+            // due, their own samples are never reported, and the slot's vocoder state is reset at its next admission.
+            int list[64], real[64];
+            for (;;) {
+                int ns = 0;
+                for (int b = 0; b < B; ++b) {
+                    if (run[b].req < 0 || !reqs[run[b].req].want_pcm) continue;
+                    const int pend = e->slots_host[b].n_frames - run[b].voc_frames;
+                    if (pend >= 4 || (pend > 0 && !e->slots_host[b].active)) { real[ns] = std::min(pend, 4); list[ns++] = b; }
+                }
+                if (!ns) break;
+                TRY(ensure_wait());
+                TRY(q3_voc_decode_batch(e, list, real, ns, 4, vs));
+                for (int i = 0; i < ns; ++i) { if (run[list[i]].voc_frames == 0) first = true; run[list[i]].voc_frames += real[i]; }
+            }
+            if (first) {  // first-chunk latency: the first chunk's PCM resident on the host
+                for (int b = 0; b < B; ++b)
+                    if (run[b].req >= 0 && run[b].t_first == 0 && run[b].voc_frames > 0) {
+                        const int nsmp = std::min(run[b].voc_frames, 4) * spf;
+                        Q3_HIP(e, hipMemcpyAsync(e->first_chunk_host, q3_voc_pcm(e, b), sizeof(float) * (size_t)nsmp, hipMemcpyDeviceToHost, vs));
+                    }
+                Q3_HIP(e, hipStreamSynchronize(vs));
+                const double tn = now_ms();
+                for (int b = 0; b < B; ++b) if (run[b].req >= 0 && run[b].t_first == 0 && run[b].voc_frames > 0) run[b].t_first = tn;
+            }
+            voc_ms += now_ms() - tv0;
+        }
+        for (int b = 0; b < B; ++b) {
+            if (run[b].req < 0 || e->slots_host[b].active) continue;
+            if (e->voc) q3_voc_mark_last(e, b);
+            // hand the slot's results over without waiting for the vocoder (completed at slot reuse / at the end)
+            for (int j = 0; j < B; ++j)
+                if (pending[j] >= 0 && hipEventQuery(e->fin_ev[j]) == hipSuccess) TRY(drain(j));
+            TRY(finalize(e, b, &reqs[run[b].req], &outs[run[b].req], run[b], t0, true, e->fin_ev[b]));
+            pending[b] = run[b].req;
+            run[b].req = -1; ++done;
+        }
+    }
+    for (int b = 0; b < B; ++b) TRY(drain(b));
+    e->tm.prefill_ms = (float)pre_ms; e->tm.decode_ms = (float)dec_ms; e->tm.vocoder_ms = (float)voc_ms;
+    e->tm.total_ms = (float)(now_ms() - t0); e->tm.frame_steps = steps; e->tm.frame_step_ms = steps ? (float)(dec_ms / steps) : 0.0f;
+    // bytes = 2*W_T + 15*2*W_P(layers) + 15*2*h + 16*2*pj + KV bytes of the live context + gathers
+    {
+        const q3tts_model_config& m = e->cfg.model;
+        const long long wt = (long long)e->T.weight_bytes;  // includes lm_head
+        const long long wp_layers = (long long)e->P.weight_bytes - 2ll * e->P.head_n * m.p_d_model;
+        const long long head1 = 2ll * m.codebook_size * m.p_d_model, pj = 2ll * m.p_d_model * m.d_embed;
+        const long long kv_per_tok = 2ll * m.t_n_layer * 2 * m.t_n_kv_head * m.t_head_dim;
+        const long long fixed = wt + (m.n_codebooks - 1) * (wp_layers + head1) + m.n_codebooks * pj;
+        e->tm.algo_bytes_per_step = fixed + (steps ? kv_per_tok * (ctx_tokens / steps) : 0);
+        e->tm.mean_live_slots = steps ? (float)((double)live_slot_steps / (double)steps) : 0.0f;
+        e->tm.algo_flops_per_step = (long long)((double)fixed * (double)e->tm.mean_live_slots);  // 2 flop per bf16 weight (2 bytes) per live row
+        e->tm.mean_rows = steps ? (float)((double)e->row_steps / (double)steps) : 0.0f;
+        e->tm.probe_kernel_ms = e->probe_cnt ? (float)(e->probe_ms / (double)e->probe_cnt) : 0.0f;
+        e->tm.probe_count = e->probe_cnt;
+        e->tm.probe_empty_ms = e->probe_empty_cnt ? (float)(e->probe_empty_ms / (double)e->probe_empty_cnt) : 0.0f;
+    }
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_generate(q3tts_engine* e, const q3tts_request* req, q3tts_result* out) {
+    int rc = q3tts_generate_batch(e, req, 1, out);
+    if (rc != Q3TTS_OK) return rc;
+    return out->status;
+}
+
+extern "C" void q3tts_result_free(q3tts_result* r) {
+    if (!r) return;
+    free(r->codes);
+    if (r->pcm) hipHostFree(r->pcm);  // pinned: filled by an asynchronous device-to-host copy
+    r->codes = nullptr; r->pcm = nullptr;
+}
+
+extern "C" int q3tts_get_timings(const q3tts_engine* e, q3tts_timings* out) {
+    if (!e || !out) return Q3TTS_ERR_INVALID;
+    *out = e->tm;
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_write_weights(q3tts_engine* e, const char* path) {
+    (void)path;
+    return q3_set_err(e, Q3TTS_ERR_UNSUPPORTED, "Q3TW writer not built in this round");
+}
+
+// ------------------------------------------------------------------------------------------------
+// streaming (H8): 4-frame chunks
+// ------------------------------------------------------------------------------------------------
+struct q3tts_stream {
+    q3tts_engine* e; q3tts_request req; int voc_frames = 0; bool finished = false; bool final_sent = false;
+    std::vector<float> chunk; double t0 = 0, t_first = 0;
+};
+
+extern "C" int q3tts_stream_begin(q3tts_engine* e, const q3tts_request* req, q3tts_stream** out) {
+    if (!e || !req || !out) return q3_set_err(e, Q3TTS_ERR_INVALID, "null argument");
+    if (!e->voc) return q3_set_err(e, Q3TTS_ERR_STATE, "streaming needs with_vocoder = 1");
+    Q3_HIP(e, hipSetDevice(e->cfg.device));
+    q3tts_stream* st = new q3tts_stream();
+    st->e = e; st->req = *req; st->t0 = now_ms();
+    int rc = plan_rows(e, std::vector<int>{0});
+    if (rc == Q3TTS_OK) rc = admit(e, 0, req);
+    if (rc != Q3TTS_OK) { delete st; return rc; }
+    *out = st;
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_stream_poll(q3tts_stream* st, const float** chunk, int32_t* n_samples, int32_t* is_final) {
+    if (!st || !chunk || !n_samples || !is_final) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "null argument");
+    q3tts_engine* e = st->e;
+    *chunk = nullptr; *n_samples = 0; *is_final = 0;
+    if (st->final_sent) { *is_final = 1; return Q3TTS_OK; }
+    hipStream_t s = e->stream;
+    const int spf = q3_voc_samples_per_frame(e);
+    for (;;) {
+        const Q3Slot& sl = e->slots_host[0];
+        if (!st->finished) {
+            TRY(run_chunk(e, 4, nullptr));
+            if (!sl.active) st->finished = true;
+        }
+        int nf = 0, last = 0;
+        if (sl.n_frames - st->voc_frames >= 4) nf = 4;
+        else if (st->finished && sl.n_frames > st->voc_frames) { nf = sl.n_frames - st->voc_frames; last = 1; }
+        if (nf > 0) {
+            const int before = q3_voc_samples(e, 0);
+            TRY(q3_voc_decode(e, 0, st->voc_frames, nf, last, s));
+            st->voc_frames += nf;
+            const int after = q3_voc_samples(e, 0);
+            st->chunk.resize((size_t)std::max(1, after - before));
+            if (after > before)
+                Q3_HIP(e, hipMemcpyAsync(st->chunk.data(), q3_voc_pcm(e, 0) + before, sizeof(float) * (size_t)(after - before), hipMemcpyDeviceToHost, s));
+            Q3_HIP(e, hipStreamSynchronize(s));
+            if (st->t_first == 0) st->t_first = now_ms();
+            *chunk = st->chunk.data(); *n_samples = after - before;
+            if (st->finished && st->voc_frames >= sl.n_frames) { *is_final = 1; st->final_sent = true; }
+            (void)spf;
+            return Q3TTS_OK;
+        }
+        if (st->finished) { *is_final = 1; st->final_sent = true; return Q3TTS_OK; }
+    }
+}
+
+extern "C" int q3tts_stream_end(q3tts_stream* st, q3tts_result* out) {
+    if (!st) return Q3TTS_ERR_INVALID;
+    q3tts_engine* e = st->e;
+    int rc = Q3TTS_OK;
+    // make sure the slot is retired even if the caller stops early
+    Q3Slot* stage = e->slots_host + e->B;
+    memset(stage, 0, sizeof(Q3Slot));
+    hipMemcpyAsync(e->slots_host, e->slots, sizeof(Q3Slot), hipMemcpyDeviceToHost, e->stream);
+    hipStreamSynchronize(e->stream);
+    if (out) {
+        memset(out, 0, sizeof(*out));
+        SlotRun sr; sr.t_first = st->t_first;
+        q3tts_request r = st->req; r.want_pcm = 1;
+        rc = finalize(e, 0, &r, out, sr, st->t0);
+    }
+    hipMemcpyAsync(e->slots, stage, sizeof(Q3Slot), hipMemcpyHostToDevice, e->stream);
+    hipStreamSynchronize(e->stream);
+    delete st;
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel-level test hooks
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes + 64) == hipSuccess && hipMemset(p, 0, bytes + 64) == hipSuccess ? 0 : -1; }
+};
+#define HK(call) do { hipError_t er__ = (call); if (er__ != hipSuccess) return q3_set_err(nullptr, Q3TTS_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(er__)); } while (0)
+
+extern "C" int q3tts_k_gemm_exact(int32_t device, const float* x, int32_t B, int32_t K, const uint16_t* w, int32_t N, const float* norm_w,
+                                  float eps, const float* bias, int32_t epi, float* y, uint64_t* keys, int32_t iters, float* mean_ms) {
+    if (!x || !w || !y || B <= 0 || K % 512 || N % 16 || (norm_w && K > 8192)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "gemm hook: bad shape");
+    if (epi == Q3_EPI_SWIGLU && (N % 32)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "swiglu needs N % 32 == 0");
+    HK(hipSetDevice(device));
+    const int F = N / 2;
+    const size_t ny = epi == Q3_EPI_SWIGLU ? (size_t)B * F : (size_t)B * N;
+    DevBuf dx, dw, dwt, dn, db, dy, dk;
+    if (dx.alloc((size_t)B * K * 4) || dw.alloc((size_t)N * K * 2) || dwt.alloc((size_t)N * K * 2) || dn.alloc((size_t)K * 4) ||
+        db.alloc((size_t)N * 4) || dy.alloc(ny * 4) || dk.alloc((size_t)B * 8))
+        return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
+    HK(hipMemcpy(dx.p, x, (size_t)B * K * 4, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dw.p, w, (size_t)N * K * 2, hipMemcpyHostToDevice));
+    if (norm_w) HK(hipMemcpy(dn.p, norm_w, (size_t)K * 4, hipMemcpyHostToDevice));
+    if (bias) HK(hipMemcpy(db.p, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+    if (epi == Q3_EPI_RESID) HK(hipMemcpy(dy.p, y, ny * 4, hipMemcpyHostToDevice));
+    Q3Fill f{}; f.dst = (uint4*)dwt.p; f.N = N; f.K = K;
+    if (epi == Q3_EPI_SWIGLU) { f.mode = 1; f.src_a = (const uint16_t*)dw.p; f.src_b = (const uint16_t*)dw.p + (size_t)F * K; }
+    else { f.mode = 0; f.row0 = 0; f.rows = N; f.src_a = (const uint16_t*)dw.p; }
+    q3_launch_fill_tiled(f, nullptr);
+    Q3Gemm g{}; g.x = (const float*)dx.p; g.ldx = K; g.B = B; g.w = (const uint4*)dwt.p; g.K = K; g.N = N;
+    g.norm_w = norm_w ? (const float*)dn.p : nullptr; g.eps = eps; g.bias = bias ? (const float*)db.p : nullptr;
+    g.y = (float*)dy.p; g.ldy = epi == Q3_EPI_SWIGLU ? F : N; g.keys = (unsigned long long*)dk.p; g.key_stride = 1; g.epi = epi;
+    q3_launch_gemm(g, nullptr);
+    HK(hipDeviceSynchronize());
+    if (epi == Q3_EPI_ARGMAX) {
+        if (keys) HK(hipMemcpy(keys, dk.p, (size_t)B * 8, hipMemcpyDeviceToHost));
+    } else HK(hipMemcpy(y, dy.p, ny * 4, hipMemcpyDeviceToHost));
+#ifdef Q3_STAMPS
+    {  // experiment builds: phase stamps of workgroup 0 / wave 0 of one warm launch (shader-clock cycles from kernel entry)
+        DevBuf dd; dd.alloc(64 * 8);
+        g.dbg = nullptr; q3_launch_gemm(g, nullptr); q3_launch_gemm(g, nullptr);
+        g.dbg = (unsigned long long*)dd.p; hipMemset(dd.p, 0, 64 * 8);
+        q3_launch_gemm(g, nullptr); hipDeviceSynchronize();
+        unsigned long long st[8]; hipMemcpy(st, dd.p, 64, hipMemcpyDeviceToHost);
+        fprintf(stderr, "stamps B=%d K=%d N=%d norm=%d epi=%d: entry->loop %llu | first operands %llu | loop end %llu | barrier %llu | sums %llu | stores done %llu\n",
+                B, K, N, norm_w ? 1 : 0, epi, st[1] - st[0], st[2] - st[0], st[3] - st[0], st[4] - st[0], st[5] - st[0], st[6] - st[0]);
+        unsigned long long ws[64]; hipMemcpy(ws, dd.p, 64 * 8, hipMemcpyDeviceToHost);
+        for (int w = 0; w < 8; ++w)
+            fprintf(stderr, "   wave %d: first operands %llu, mid loop %llu, loop end %llu\n", w, ws[8 + w * 4] - st[0], ws[8 + w * 4 + 1] - st[0], ws[8 + w * 4 + 2] - st[0]);
+        g.dbg = nullptr;
+    }
+#endif
+    if (iters > 0 && mean_ms) {
+        g.epi = epi == Q3_EPI_RESID ? Q3_EPI_STORE : epi;
+        hipEvent_t a, b; HK(hipEventCreate(&a)); HK(hipEventCreate(&b));
+        q3_launch_gemm(g, nullptr);
+        HK(hipEventRecord(a, nullptr));
+        for (int i = 0; i < iters; ++i) q3_launch_gemm(g, nullptr);
+        HK(hipEventRecord(b, nullptr)); HK(hipEventSynchronize(b));
+        float ms = 0; hipEventElapsedTime(&ms, a, b); *mean_ms = ms / iters;
+        hipEventDestroy(a); hipEventDestroy(b);
+    }
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_k_attention(int32_t device, const float* qkv, int32_t n_rows, int32_t pos0, int32_t Hq, int32_t Hkv, int32_t hd,
+                                 const float* qnw, const float* knw, float eps, float theta, const int32_t* sections, float* out) {
+    if (!qkv || !out || hd != 128 || n_rows <= 0 || Hq % Hkv) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "attention hook: bad shape");
+    HK(hipSetDevice(device));
+    const int n_ctx = ((pos0 + n_rows + 63) / 64) * 64, ld = (Hq + 2 * Hkv) * hd;
+    std::vector<float> cs, sn;
+    rope_tables(n_ctx, hd, theta, sections, cs, sn);
+    std::vector<int> rp(n_rows), rs(n_rows, 0);
+    for (int i = 0; i < n_rows; ++i) rp[i] = pos0 + i;
+    DevBuf dq, dout, dqn, dkn, dcs, dsn, dkc, dvc, drp, drs;
+    if (dq.alloc((size_t)n_rows * ld * 4) || dout.alloc((size_t)n_rows * Hq * hd * 4) || dqn.alloc(hd * 4) || dkn.alloc(hd * 4) ||
+        dcs.alloc(cs.size() * 4) || dsn.alloc(sn.size() * 4) || dkc.alloc((size_t)Hkv * n_ctx * hd * 2) || dvc.alloc((size_t)Hkv * n_ctx * hd * 2) ||
+        drp.alloc(n_rows * 4) || drs.alloc(n_rows * 4))
+        return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
+    HK(hipMemcpy(dq.p, qkv, (size_t)n_rows * ld * 4, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dqn.p, qnw, hd * 4, hipMemcpyHostToDevice)); HK(hipMemcpy(dkn.p, knw, hd * 4, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dcs.p, cs.data(), cs.size() * 4, hipMemcpyHostToDevice)); HK(hipMemcpy(dsn.p, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+    HK(hipMemcpy(drp.p, rp.data(), n_rows * 4, hipMemcpyHostToDevice)); HK(hipMemcpy(drs.p, rs.data(), n_rows * 4, hipMemcpyHostToDevice));
+    Q3QkPrep qp{}; qp.qkv = (float*)dq.p; qp.ld = ld; qp.rows = n_rows; qp.Hq = Hq; qp.Hkv = Hkv; qp.hd = hd; qp.qnw = (const float*)dqn.p;
+    qp.knw = (const float*)dkn.p; qp.eps = eps; qp.cs = (const float*)dcs.p; qp.sn = (const float*)dsn.p; qp.kc = (uint16_t*)dkc.p;
+    qp.vc = (uint16_t*)dvc.p; qp.n_ctx = n_ctx; qp.row_pos = (const int*)drp.p; qp.row_slot = (const int*)drs.p;
+    q3_launch_qk_prep(qp, nullptr);
+    Q3Attend at{}; at.dbg = nullptr; at.qkv = (const float*)dq.p; at.ld = ld; at.rows = n_rows; at.out = (float*)dout.p; at.ldo = Hq * hd; at.Hq = Hq; at.Hkv = Hkv;
+    at.hd = hd; at.kc = (const uint16_t*)dkc.p; at.vc = (const uint16_t*)dvc.p; at.n_ctx = n_ctx; at.row_pos = qp.row_pos; at.row_slot = qp.row_slot;
+    q3_launch_attend(at, nullptr);
+    HK(hipDeviceSynchronize());
+    HK(hipMemcpy(out, dout.p, (size_t)n_rows * Hq * hd * 4, hipMemcpyDeviceToHost));
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_k_sample(int32_t device, const float* logits, int32_t n, int32_t ld, int32_t limit, float temperature, int32_t top_k,
+                              float top_p, const float* r, int32_t* out) {
+    if (!logits || !out || n <= 0 || limit <= 0 || limit > 4096 || limit > ld) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "sample hook: bad shape");
+    HK(hipSetDevice(device));
+    DevBuf dl, dr, dout;
+    if (dl.alloc((size_t)n * ld * 4) || dr.alloc((size_t)n * 4) || dout.alloc((size_t)n * 4)) return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
+    HK(hipMemcpy(dl.p, logits, (size_t)n * ld * 4, hipMemcpyHostToDevice));
+    if (r) HK(hipMemcpy(dr.p, r, (size_t)n * 4, hipMemcpyHostToDevice));
+    q3_launch_sample_rows((const float*)dl.p, n, ld, limit, temperature, top_k, top_p, r ? (const float*)dr.p : nullptr, (int*)dout.p, nullptr);
+    HK(hipDeviceSynchronize());
+    HK(hipMemcpy(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_k_talker_prefill(q3tts_engine* e, const float* embd, int32_t n_tok, float* hidden_out, float* logits_out) {
+    if (!e || !embd || n_tok <= 0) return q3_set_err(e, Q3TTS_ERR_INVALID, "null argument");
+    Q3_HIP(e, hipSetDevice(e->cfg.device));
+    q3tts_request r{}; r.prompt_embd = embd; r.n_tok = n_tok; r.use_engine_sampler = 0; r.temperature = 0; r.max_steps = 1;
+    TRY(plan_rows(e, std::vector<int>{0}));
+    TRY(admit(e, 0, &r));
+    const q3tts_model_config& m = e->cfg.model;
+    hipStream_t s = e->stream;
+    if (hidden_out) {
+        q3_launch_rmsnorm_rows(e->lanes[0].xT, m.t_d_model, e->T.out_norm, m.rms_eps, m.t_d_model, 1, e->lanes[0].X, m.t_d_model, s);
+        Q3_HIP(e, hipMemcpyAsync(hidden_out, e->lanes[0].X, (size_t)m.t_d_model * 4, hipMemcpyDeviceToHost, s));
+    }
+    if (logits_out) Q3_HIP(e, hipMemcpyAsync(logits_out, e->lanes[0].logits, (size_t)m.t_vocab * 4, hipMemcpyDeviceToHost, s));
+    Q3Slot* stage = e->slots_host + e->B; memset(stage, 0, sizeof(Q3Slot));
+    Q3_HIP(e, hipMemcpyAsync(e->slots, stage, sizeof(Q3Slot), hipMemcpyHostToDevice, s));  // retire the slot again
+    Q3_HIP(e, hipStreamSynchronize(s));
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_k_gguf_read(const char* path, const char* tensor, float* out, int64_t cap, int64_t* nelem, int64_t* dims4, int32_t* ggml_type) {
+    if (!path || !tensor || !nelem) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "null argument");
+    std::string err;
+    const std::string p = path;
+    if (p.size() > 4 && p.compare(p.size() - 4, 4, ".npy") == 0) {
+        std::vector<float> v; std::vector<size_t> shape;
+        if (q3_npy_load_f32(p, v, shape, err)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, err);
+        *nelem = (int64_t)v.size();
+        if (dims4) for (int i = 0; i < 4; ++i) dims4[i] = i < (int)shape.size() ? (int64_t)shape[i] : 0;
+        if (ggml_type) *ggml_type = Q3_GGML_F32;
+        if (out) { if (cap < *nelem) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "output buffer too small"); memcpy(out, v.data(), v.size() * 4); }
+        return Q3TTS_OK;
+    }
+    Q3Gguf g;
+    if (g.open(p, err)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, err);
+    const Q3GgufTensor* t = g.find(tensor);
+    if (!t) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, std::string("tensor '") + tensor + "' is missing");
+    *nelem = (int64_t)t->nelem;
+    if (dims4) for (int i = 0; i < 4; ++i) dims4[i] = i < (int)t->dims.size() ? (int64_t)t->dims[i] : 0;
+    if (ggml_type) *ggml_type = (int32_t)t->type;
+    if (out) {
+        if (cap < *nelem) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "output buffer too small");
+        if (q3_gguf_to_f32(*t, out, err)) return q3_set_err(nullptr, Q3TTS_ERR_UNSUPPORTED, err);
+    }
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_k_probe(q3tts_engine* e, int32_t enable) {
+    if (!e) return Q3TTS_ERR_INVALID;
+    Q3_HIP(e, hipSetDevice(e->cfg.device));
+    if (enable && e->probe_ev.empty()) {
+        e->probe_ev.resize(10, nullptr);  // 4 frames x 2 + one empty bracket per chunk (event overhead calibration)
+        for (auto& ev : e->probe_ev) Q3_HIP(e, hipEventCreate(&ev));
+    }
+    e->probe = enable ? 1 : 0;
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_k_rng_f32(uint64_t seed, int32_t n, float* out) {
+    if (!out || n < 0) return Q3TTS_ERR_INVALID;
+    q3_stdrng_f32(seed, n, out);
+    return Q3TTS_OK;
+}

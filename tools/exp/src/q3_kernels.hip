@@ -154,11 +154,14 @@ void q3_launch_qk_prep(const Q3QkPrep& a, hipStream_t s) {
 // its own row (k_qk_prep's work) and serves the newest key/value from LDS, saving one launch per layer.
 template <int R, bool FUSED>
 __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
+#define ASTAMP(i) do { if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int g = blockIdx.x, row = blockIdx.y;
+    ASTAMP(0);
     const int pos = a.row_pos[row];
     if (pos < 0) return;
     const int slot = a.row_slot[row];
+    ASTAMP(1);
     const int T = pos + 1, Tcap = a.n_ctx, hd = a.hd, nch = hd >> 3;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hh = wave >> 2, sw = wave & 3;
     float* p_all = smem;                      // [R][Tcap]
@@ -190,7 +193,9 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
     } else {
         for (int i = tid; i < R * hd; i += R * 256) qh[i] = a.qkv[(size_t)row * a.ld + (size_t)g * R * hd + i];
     }
+    ASTAMP(2);
     __syncthreads();
+    ASTAMP(3);
     const uint16_t* kb = a.kc + hb * hd;
     const uint16_t* vb = a.vc + hb * hd;
     const float scale = 1.0f / sqrtf((float)hd);
@@ -201,8 +206,7 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
         const int t = blk * 64 + lane;
         const uint4* kp = (const uint4*)(kb + (size_t)blk * 64 * hd) + lane;
         float s = 0.0f;
-        if (nch == 16) {  // hd = 128: all 16 key chunks in flight at once (a runtime-bound loop issues load, use, load, use ...:
-                          // measured 10 k of the kernel's 20 k cycles at T <= 17, tools/exp/stamp_attend.py)
+        if (nch == 16) {  // hd = 128: all 16 key chunks in flight at once (a runtime-bound loop issues load, use, load, use ...)
             uint4 kv[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) kv[c] = kp[c * 64];
@@ -233,9 +237,11 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
         s = s * scale;
         if (t < T) { p[t] = s; mloc = fmaxf(mloc, s); }
     }
+    ASTAMP(4);
     mloc = wave_max(mloc);
     if (lane == 0) mw[hh * 4 + sw] = mloc;
     __syncthreads();
+    ASTAMP(5);
     const float m = fmaxf(fmaxf(mw[hh * 4], mw[hh * 4 + 1]), fmaxf(mw[hh * 4 + 2], mw[hh * 4 + 3]));
     float lsum = 0.0f;
     for (int blk = sw; blk * 64 < T; blk += 4) {
@@ -245,6 +251,7 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
     lsum = wave_sum(lsum);
     if (lane == 0) lw[hh * 4 + sw] = lsum;
     __syncthreads();
+    ASTAMP(6);
     const int kg = lane >> 4, dl = lane & 15;
     float o[8];
 #pragma unroll
@@ -271,7 +278,9 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) ow[(hh * 4 + sw) * hd + dl * 8 + e] = o[e];
     }
+    ASTAMP(7);
     __syncthreads();
+    ASTAMP(8);
     for (int i = tid; i < R * hd; i += R * 256) {
         const int h2 = i / hd, d = i - h2 * hd;
         const float r0 = ow[(h2 * 4 + 0) * hd + d], r1 = ow[(h2 * 4 + 1) * hd + d], r2 = ow[(h2 * 4 + 2) * hd + d],
@@ -280,6 +289,7 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
         const float l = ((lw[h2 * 4] + lw[h2 * 4 + 1]) + lw[h2 * 4 + 2]) + lw[h2 * 4 + 3];
         a.out[(size_t)row * a.ldo + (size_t)(g * R + h2) * hd + d] = ov / l;
     }
+    ASTAMP(9);
 }
 void q3_launch_attend(const Q3Attend& a, hipStream_t s) {
     const int R = a.Hq / a.Hkv;

@@ -1,0 +1,972 @@
+// q3_vocoder.hip — streaming neural-codec vocoder (V1-V6 of SURVEY.md §8a) on gfx950.
+//
+// Replaces the onnxruntime session behind AudioDecoder::decode (/root/reference/src/models/onnx.rs:342-459): codes
+// [N][16] (+ is_last) -> 24 kHz PCM, with the streaming state (conv histories, sliding-window KV ring) resident on
+// the device per utterance slot instead of being deep-copied through the host on every call
+// (src/models/onnx.rs:369-384,410-455). Structure: restated in oracle/q3_oracle_vocoder.c (same model family as
+// transformers' qwen3_omni_moe Code2Wav); every dimension comes from q3tts_vocoder_config.
+//
+// Layout: activations are channels-last f32 [slot][hist + T][C]; every convolution (k taps, dilation d, transposed or
+// not) is a multi-tap GEMM  out[t][n] = bias[n] + sum_tap X[t - (ntap-1-tap)*d][:] . W[tap][n][:]  on
+// v_mfma_f32_16x16x32_bf16 (bf16 operands, f32 accumulate) with fused epilogues. All convolutions are causal, so
+// chunked streaming equals one-shot decoding; each conv input keeps its last (k-1)*d rows per slot.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "q3_engine.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define VOC_MAX_NS 64   // slots per batched call
+#define VOC_FCAP 4      // frames per slot per call (the reference's 4-frame chunk: src/tts/engine.rs:509-512)
+
+enum { VC_CODEBOOK = 0, VC_PRE = 32, VC_TFM = 40, VC_FINAL_NORM = 60, VC_UP = 64, VC_DEC_IN = 72, VC_BLK = 80, VC_OUT = 120 };
+enum { VW_W = 0, VW_B = 1, VW_IN_NORM = 2, VW_Q = 3, VW_K = 4, VW_V = 5, VW_O = 6, VW_LS_ATTN = 7, VW_POST_NORM = 8, VW_GATE = 9,
+       VW_UP = 10, VW_DOWN = 11, VW_LS_MLP = 12, VW_DW_W = 13, VW_DW_B = 14, VW_LN_W = 15, VW_LN_B = 16, VW_PW1 = 17, VW_PW1_B = 18,
+       VW_PW2 = 19, VW_PW2_B = 20, VW_GAMMA = 21, VW_ALPHA = 22, VW_BETA = 23, VW_W2 = 24, VW_B2 = 25, VW_ALPHA2 = 26, VW_BETA2 = 27 };
+#define VTID(l, w) Q3_TID(Q3G_VOC, l, w)
+
+struct VCall {  // passed by value to the kernels of one batched call
+    int ns, nf;
+    int slot[VOC_MAX_NS];
+    int pos[VOC_MAX_NS];      // frames already decoded for the slot
+};
+
+struct VConv { int ntap = 1, dil = 1, cin = 0, nout = 0, bias_n = 0; uint16_t* w = nullptr; float* b = nullptr; };
+// work buffer of a conv input: [VOC_MAX_NS][H + Tcap][C] (slot-major) + per-slot history [B][H][C]
+struct VBuf { float* p = nullptr; float* hist = nullptr; int H = 0, C = 0, Tcap = 0; size_t stride() const { return (size_t)(H + Tcap) * C; } };
+
+struct VLayer { float *in_norm, *post_norm, *ls_attn, *ls_mlp; VConv q, k, v, o, gate, up, down;
+                VConv qkv, gu; };  // fused launches: qkv = rows of q | k | v; gu = 16-row groups of gate and up alternating
+struct VUp { VConv ct, pw1, pw2; float *dw_w, *dw_b, *ln_w, *ln_b, *gamma; int r; VBuf dw_in; };
+struct VRes { float *ea, *ib, *ea2, *ib2; VConv c1, c2; VBuf c1_in; };
+struct VBlk { float *ea, *ib; VConv ct; VRes res[3]; int r, cin, cout; VBuf ct_in; };
+
+struct Q3Voc {
+    q3tts_vocoder_config c;
+    int spf = 1, B = 0, RW = 0;
+    std::vector<float*> cb; const float** cb_dev = nullptr;
+    VConv pre; VBuf pre_in;
+    std::vector<VLayer> L; float* final_norm = nullptr;
+    std::vector<VUp> U;
+    VConv dec_in; VBuf dec_in_in;
+    std::vector<VBlk> Bk;
+    float *oea = nullptr, *oib = nullptr, *out_w = nullptr, *out_b = nullptr; VBuf out_in; int out_c = 0;
+    float *kring = nullptr, *vring = nullptr;  // [n_layer][B][RW][HH]
+    float *x = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *g = nullptr;  // transformer scratch [M][.]
+    float *t1 = nullptr, *t2 = nullptr, *t3 = nullptr;  // generic scratch (largest stage)
+    float* pcm = nullptr; size_t pcm_stride = 0;         // [B][max_steps_cap * spf]
+    std::vector<int> frames_done, last_flag;
+    std::vector<void*> allocs;
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------------------------
+struct VGemm {
+    const float* x; size_t x_stride; int x_off;   // row (s, t) tap 0 shift 0 at x + s*x_stride + x_off + t*cin
+    int T, M;                                     // rows per slot, total rows = ns*T
+    VConv c;
+    float* y; size_t y_stride; int y_off;         // out row (s,t) at y + s*y_stride + y_off + t*nout (t*nout/2 for epi 4)
+    const float* scale;                           // epilogue 1: y += scale[n % scale_n] * (acc + bias)
+    int scale_n;
+    int epi;                                      // 0 store, 1 y += scale*(.), 2 y += (.), 3 gelu, 4 swiglu (16-column tiles alternate gate / up)
+    int store;                                    // 0: the primary output is not written (only y2 is wanted)
+    float* y2; size_t y2_stride; int y2_off;      // optional second output: SnakeBeta(v) with the NEXT layer's parameters,
+    const float *ea, *ib; int snake_n;            //   written straight into that layer's conv-input work buffer
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// shared epilogue of one output element (row (s, t), column n)
+__device__ __forceinline__ void vepi(const VGemm& g, float v, int s, int t, int n, float yold) {
+    const int nout = g.c.nout;
+    if (g.c.b) v += g.c.b[n % g.c.bias_n];
+    float* yp = g.y + (size_t)s * g.y_stride + g.y_off + (size_t)t * nout + n;
+    if (g.epi == 1) v = yold + g.scale[n % g.scale_n] * v;
+    else if (g.epi == 2) v = yold + v;
+    else if (g.epi == 3) v = gelu_erf(v);
+    if (g.store) *yp = v;
+    if (g.y2) {
+        const int c = n % g.snake_n;
+        const float sn = __sinf(v * g.ea[c]);
+        g.y2[(size_t)s * g.y2_stride + g.y2_off + (size_t)t * nout + n] = v + g.ib[c] * (sn * sn);
+    }
+}
+
+// Small-M GEMM (M <= 512 rows: the 12.5 Hz transformer, the first up-sampling stages, the drain phase of a batch):
+// workgroup tile 64 x 32, wave = 16 rows x 32 cols (2 MFMA tiles), no LDS and no barriers. The few rows cannot hide
+// memory latency with MFMA work, so fragments ride an 8-deep register ring (A: 32 B of f32 per lane -> bf16x8,
+// B: 16 B of bf16 per lane per column tile) and the grid is cut fine enough to put a workgroup on every CU.
+#define VS_PF 8
+__global__ __launch_bounds__(256) void k_vgemm_small(VGemm g) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m0 = blockIdx.y * 64 + wave * 16, n0 = blockIdx.x * 32;
+    if (m0 >= g.M) return;
+    const int lr = lane & 15, kq = lane >> 4;
+    const int cin = g.c.cin, nout = g.c.nout, kpt = cin >> 5, steps = g.c.ntap * kpt;
+    const float* xrow;
+    {
+        int m = m0 + lr; if (m >= g.M) m = g.M - 1;
+        const int s = m / g.T, t = m - s * g.T;
+        xrow = g.x + (size_t)s * g.x_stride + g.x_off + (size_t)t * cin + kq * 8;
+    }
+    const uint16_t* wrow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { int n = n0 + j * 16 + lr; if (n >= nout) n = nout - 1; wrow[j] = g.c.w + (size_t)n * cin + kq * 8; }
+    float4 ra[VS_PF][2]; uint4 rb[VS_PF][2];
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    // (no branch inside the ring: loads past the end re-read the last step and their A fragment is zeroed, so the
+    //  compiler can count outstanding loads exactly: vmcnt(28) at each consumption instead of vmcnt(0))
+#define VS_ISSUE(slot_, step_)                                                                        \
+    do {                                                                                              \
+        const int st__ = min((step_), steps - 1);                                                     \
+        const int tap__ = st__ / kpt, k0__ = (st__ - tap__ * kpt) << 5;                               \
+        const float* p__ = xrow - (long)(g.c.ntap - 1 - tap__) * g.c.dil * cin + k0__;                \
+        ra[slot_][0] = *(const float4*)p__; ra[slot_][1] = *(const float4*)(p__ + 4);                 \
+        const size_t wo__ = (size_t)tap__ * nout * cin + k0__;                                        \
+        rb[slot_][0] = *(const uint4*)(wrow[0] + wo__); rb[slot_][1] = *(const uint4*)(wrow[1] + wo__); \
+    } while (0)
+#pragma unroll
+    for (int j = 0; j < VS_PF; ++j) VS_ISSUE(j, j);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int s0 = 0; s0 < steps; s0 += VS_PF) {
+#pragma unroll
+        for (int j = 0; j < VS_PF; ++j) {
+            const int step = s0 + j;
+            const float live = step < steps ? 1.0f : 0.0f;
+            bf16x8 a;
+            const float4 v0 = ra[j][0], v1 = ra[j][1];
+            a[0] = (__bf16)(v0.x * live); a[1] = (__bf16)(v0.y * live); a[2] = (__bf16)(v0.z * live); a[3] = (__bf16)(v0.w * live);
+            a[4] = (__bf16)(v1.x * live); a[5] = (__bf16)(v1.y * live); a[6] = (__bf16)(v1.z * live); a[7] = (__bf16)(v1.w * live);
+            const uint4 u0 = rb[j][0], u1 = rb[j][1];
+            const bf16x8 b0 = *(const bf16x8*)&u0, b1 = *(const bf16x8*)&u1;
+            __builtin_amdgcn_sched_barrier(0);
+            VS_ISSUE(j, step + VS_PF);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[1], 0, 0, 0);
+        }
+    }
+#undef VS_ISSUE
+    // D layout: lane holds rows 4*(lane>>4)+e, column lane&15
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int m = m0 + 4 * kq + e;
+        if (m >= g.M) continue;
+        const int s = m / g.T, t = m - s * g.T;
+        if (g.epi == 4) {  // column tile 0 = gate, tile 1 = the matching up columns (interleaved weight rows)
+            const int n = blockIdx.x * 16 + lr;
+            if (n0 + 16 + lr < nout) {
+                const float gt = acc[0][e], up = acc[1][e];
+                g.y[(size_t)s * g.y_stride + g.y_off + (size_t)t * (nout >> 1) + n] = (gt / (1.0f + expf(-gt))) * up;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + j * 16 + lr;
+                if (n < nout) {
+                    const float yold = (g.epi == 1 || g.epi == 2) ? g.y[(size_t)s * g.y_stride + g.y_off + (size_t)t * nout + n] : 0.0f;
+                    vepi(g, acc[j][e], s, t, n, yold);
+                }
+            }
+        }
+    }
+}
+
+// LDS-tiled GEMM for the big-M convolutions (the decoder blocks: thousands of rows per slot): workgroup tile
+// 128 x (NJ*32), K step 32, 2 x 2 waves of 64 x (NJ*16) (4 x NJ MFMA tiles); NJ = 3 serves the 96- and 192-channel
+// blocks without padding waste. A (f32 -> bf16) and W tiles go through registers into double-buffered LDS; the
+// registers run two K steps ahead of the LDS copy (three ahead of the MFMAs), rows are padded to 40 bf16 (80 B) so
+// that the 16 lanes of a ds_read_b128 group hit 16 distinct 4-bank slots. Conv taps are just extra K steps with a
+// shifted row pointer.
+#define VT_LD 40
+struct VStage { float4 a0, a1, a2, a3; uint4 b0, b1; float live; };
+template <int NJ>
+__global__ __launch_bounds__(256) void k_vgemm_lds(VGemm g) {
+    constexpr int BN = NJ * 32;
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][128 * VT_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * VT_LD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * BN;
+    const int cin = g.c.cin, nout = g.c.nout, kpt = cin >> 5, steps = g.c.ntap * kpt;
+    const int ldr = tid >> 1, half = tid & 1;  // loader: row/col ldr, 16 k-elements at half*16
+    const bool bload = ldr < BN;
+    const float* xrow;
+    {
+        int m = m0 + ldr; if (m >= g.M) m = g.M - 1;
+        const int s = m / g.T, t = m - s * g.T;
+        xrow = g.x + (size_t)s * g.x_stride + g.x_off + (size_t)t * cin + half * 16;
+    }
+    const uint16_t* wrow;
+    { int n = n0 + ldr; if (n >= nout) n = nout - 1; wrow = g.c.w + (size_t)n * cin + half * 16; }
+    auto gload = [&](VStage& r, int step_) {  // steps past the end re-read the last tile; their A part is zeroed
+        const int step = min(step_, steps - 1);
+        const int tap = step / kpt, k0 = (step - tap * kpt) << 5;
+        const float* p = xrow - (long)(g.c.ntap - 1 - tap) * g.c.dil * cin + k0;
+        r.a0 = ((const float4*)p)[0]; r.a1 = ((const float4*)p)[1]; r.a2 = ((const float4*)p)[2]; r.a3 = ((const float4*)p)[3];
+        if (bload) { const uint16_t* q = wrow + (size_t)tap * nout * cin + k0; r.b0 = ((const uint4*)q)[0]; r.b1 = ((const uint4*)q)[1]; }
+        r.live = step_ < steps ? 1.0f : 0.0f;
+    };
+    auto sstore = [&](const VStage& r, int buf) {
+        bf16x8 lo, hi;
+        const float lv = r.live;
+        lo[0] = (__bf16)(r.a0.x * lv); lo[1] = (__bf16)(r.a0.y * lv); lo[2] = (__bf16)(r.a0.z * lv); lo[3] = (__bf16)(r.a0.w * lv);
+        lo[4] = (__bf16)(r.a1.x * lv); lo[5] = (__bf16)(r.a1.y * lv); lo[6] = (__bf16)(r.a1.z * lv); lo[7] = (__bf16)(r.a1.w * lv);
+        hi[0] = (__bf16)(r.a2.x * lv); hi[1] = (__bf16)(r.a2.y * lv); hi[2] = (__bf16)(r.a2.z * lv); hi[3] = (__bf16)(r.a2.w * lv);
+        hi[4] = (__bf16)(r.a3.x * lv); hi[5] = (__bf16)(r.a3.y * lv); hi[6] = (__bf16)(r.a3.z * lv); hi[7] = (__bf16)(r.a3.w * lv);
+        __bf16* ap = &As[buf][ldr * VT_LD + half * 16];
+        *(bf16x8*)ap = lo; *(bf16x8*)(ap + 8) = hi;
+        if (bload) { uint4* bp = (uint4*)&Bs[buf][ldr * VT_LD + half * 16]; bp[0] = r.b0; bp[1] = r.b1; }
+    };
+    f32x4 acc[4][NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define VT_COMPUTE(buf_)                                                                                              \
+    do {                                                                                                              \
+        bf16x8 a__[4], b__[NJ];                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) a__[i] = *(const bf16x8*)&As[buf_][(wm * 64 + i * 16 + lr) * VT_LD + kq * 8];     \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) b__[j] = *(const bf16x8*)&Bs[buf_][(wn * NJ * 16 + j * 16 + lr) * VT_LD + kq * 8]; \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+            _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                            \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a__[i], b__[j], acc[i][j], 0, 0, 0);              \
+    } while (0)
+    // at the top of step k: LDS[k & 1] holds tile k, R0/R1 (alternating) hold tiles k+1 and k+2
+    VStage R0, R1;
+    gload(R0, 0); sstore(R0, 0);
+    gload(R0, 1);
+    gload(R1, 2);
+    __syncthreads();
+    for (int step = 0; step < steps; step += 2) {  // an odd tail runs one zeroed tile: the loop body has no branch
+        sstore(R0, 1);       // tile step+1 -> LDS[1] (last read before the previous barrier)
+        gload(R0, step + 3);
+        VT_COMPUTE(0);
+        __syncthreads();
+        sstore(R1, 0);       // tile step+2 -> LDS[0]
+        gload(R1, step + 4);
+        VT_COMPUTE(1);
+        __syncthreads();
+    }
+    const bool rmw = g.epi == 1 || g.epi == 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float yv[4][NJ];  // residual operands of this row tile: one batch of loads, not a round trip per element
+        if (rmw) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = min(m0 + wm * 64 + i * 16 + 4 * kq + e, g.M - 1);
+                const int s = m / g.T, t = m - s * g.T;
+                const float* yp = g.y + (size_t)s * g.y_stride + g.y_off + (size_t)t * nout;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) yv[e][j] = yp[min(n0 + wn * NJ * 16 + j * 16 + lr, nout - 1)];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = m0 + wm * 64 + i * 16 + 4 * kq + e;
+            if (m >= g.M) continue;
+            const int s = m / g.T, t = m - s * g.T;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n0 + wn * NJ * 16 + j * 16 + lr;
+                if (n < nout) vepi(g, acc[i][j][e], s, t, n, rmw ? yv[e][j] : 0.0f);
+            }
+        }
+    }
+}
+
+// Fused residual unit of the narrow decoder blocks (C <= 192 channels, where everything is HBM-bound):
+//   o += conv1x1(snake2(conv7_dil(xin)))  and  next_in = snake_next(o)
+// in ONE pass: the workgroup stages its R + 6*dil input rows in LDS as bf16 once (the seven taps read LDS, not HBM),
+// streams the weight chunks through a double-buffered LDS ring, keeps the intermediate (snake2 output) as a bf16 tile
+// in LDS for the 1x1 convolution and finishes with the residual read-modify-write. HBM traffic per unit: read xin,
+// read/write o, write next_in: the un-fused chain moved the activations three more times. Arithmetic per output element
+// is the same as k_vgemm_lds + vepi (32-wide K steps in order, bf16 operands, f32 accumulate).
+struct VResUnit {
+    const float* xin; size_t xin_stride;  // work buffer [H + T][C] per slot, H = 6*dil history rows in front
+    int T, dil;
+    const uint16_t *w1, *w2; const float *b1, *b2;  // conv k7 [7][C][C], conv k1 [C][C]
+    const float *ea2, *ib2;               // snake between the convolutions
+    float* o; size_t o_stride; int store_o;
+    float* y2; size_t y2_stride; int y2_off; const float *ea3, *ib3;  // snake of the consumer, written into its work buffer
+};
+template <int NT, int MT>
+__global__ __launch_bounds__(256) void k_voc_resunit(VResUnit g) {
+    constexpr int C = NT * 16, KS = C / 32, R = 64 * MT, LDA = C + 8, S1 = 7 * KS, S = 8 * KS;
+    constexpr int BPASS = (C + 63) / 64;  // weight-chunk loader passes: 64 rows x 64 B per pass
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
+    const int halo = 6 * g.dil;
+    __bf16* At = lds;                                  // [R + halo][LDA]
+    __bf16* Zt = lds;                                  // [R][LDA]: reuses the input tile once conv1 has consumed it
+    __bf16* Bs = At + (size_t)(R + halo) * LDA;         // [2][C][VT_LD]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+    const int sidx = blockIdx.y, t0 = blockIdx.x * R, T = g.T;
+    // weight chunk pipeline: chunk c < S1 is (tap, ks) of conv1, chunk S1 + ks is conv2
+    const int bn = tid >> 2, bpart = tid & 3;
+    uint4 rb0, rb1, rb2;  // (named scalars: an indexed array lands in scratch here)
+    rb1 = rb2 = make_uint4(0, 0, 0, 0);
+#define VR_GLOADB(step_)                                                                                                 \
+    do {                                                                                                                \
+        const int st__ = min((step_), S - 1);                                                                           \
+        const uint16_t* base__ = (st__ < S1 ? g.w1 + (size_t)(st__ / KS) * C * C + (st__ % KS) * 32 : g.w2 + (st__ - S1) * 32) + bpart * 8; \
+        rb0 = *(const uint4*)(base__ + (size_t)min(bn, C - 1) * C);                                                      \
+        if (BPASS > 1) rb1 = *(const uint4*)(base__ + (size_t)min(bn + 64, C - 1) * C);                                  \
+        if (BPASS > 2) rb2 = *(const uint4*)(base__ + (size_t)min(bn + 128, C - 1) * C);                                 \
+    } while (0)
+#define VR_SSTOREB(buf_)                                                                                                \
+    do {                                                                                                                \
+        __bf16* d__ = &Bs[((size_t)(buf_) * C + bn) * VT_LD + bpart * 8];                                               \
+        if (bn < C) *(uint4*)d__ = rb0;                                                                                 \
+        if (BPASS > 1 && bn + 64 < C) *(uint4*)(d__ + 64 * VT_LD) = rb1;                                                \
+        if (BPASS > 2 && bn + 128 < C) *(uint4*)(d__ + 128 * VT_LD) = rb2;                                              \
+    } while (0)
+    VR_GLOADB(0);
+    // stage the input rows (f32 -> bf16), rows past T are zero
+    {
+        const float* xp = g.xin + (size_t)sidx * g.xin_stride + (size_t)t0 * C;  // buffer row t0 = output row t0 - halo
+        const int nrow = R + halo, c4 = C / 4, total = nrow * c4;
+        for (int base = tid; base < total; base += 8 * 256) {  // 8 loads in flight per thread, then convert + store
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(base + u * 256, total - 1), r = i / c4, c = (i - r * c4) * 4;
+                v[u] = *(const float4*)(xp + (size_t)min(r, T + halo - 1 - t0) * C + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256;
+                if (i < total) {
+                    const int r = i / c4, c = (i - r * c4) * 4;
+                    const bool live = t0 + r < T + halo;
+                    __bf16* d = At + (size_t)r * LDA + c;
+                    d[0] = (__bf16)(live ? v[u].x : 0.f); d[1] = (__bf16)(live ? v[u].y : 0.f);
+                    d[2] = (__bf16)(live ? v[u].z : 0.f); d[3] = (__bf16)(live ? v[u].w : 0.f);
+                }
+            }
+        }
+    }
+    VR_SSTOREB(0);
+    VR_GLOADB(1);
+    __syncthreads();
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wrow0 = wave * MT * 16;
+#define VR_STEP(step_, SRC_, ROWOFF_, KOFF_)                                                                             \
+    do {                                                                                                                \
+        const int buf__ = (step_) & 1;                                                                                  \
+        bf16x8 a__[MT], b__[NT];                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                  \
+            a__[i] = *(const bf16x8*)&SRC_[(size_t)(wrow0 + i * 16 + lr + (ROWOFF_)) * LDA + (KOFF_) + kq * 8];         \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                  \
+            b__[j] = *(const bf16x8*)&Bs[((size_t)buf__ * C + j * 16 + lr) * VT_LD + kq * 8];                           \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                  \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                              \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a__[i], b__[j], acc[i][j], 0, 0, 0);                \
+        VR_SSTOREB(buf__ ^ 1);                                                                                          \
+        VR_GLOADB((step_) + 2);                                                                                         \
+        __syncthreads();                                                                                                \
+    } while (0)
+    for (int step = 0; step < S1; ++step) {
+        const int tap = step / KS, ks = step - tap * KS;
+        VR_STEP(step, At, tap * g.dil, ks * 32);
+    }
+    // the residual operand is fetched now and consumed after the second convolution (one batch of loads in flight,
+    // not one round trip per element)
+    float ov[MT][4][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int t = min(t0 + wrow0 + i * 16 + 4 * kq + e, T - 1);
+            const float* op = g.o + (size_t)sidx * g.o_stride + (size_t)t * C;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) ov[i][e][j] = op[j * 16 + lr];
+        }
+    // snake2(conv1 + bias) -> bf16 tile (D layout: lane holds rows 4*kq+e, column lr of every tile)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = j * 16 + lr;
+            const float bb = g.b1[n], ea = g.ea2[n], ib = g.ib2[n];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = acc[i][j][e] + bb;
+                const float sn = __sinf(v * ea);
+                Zt[(size_t)(wrow0 + i * 16 + 4 * kq + e) * LDA + n] = (__bf16)(v + ib * (sn * sn));
+                acc[i][j][e] = 0.0f;
+            }
+        }
+    __syncthreads();
+    for (int step = S1; step < S; ++step) VR_STEP(step, Zt, 0, (step - S1) * 32);
+#undef VR_STEP
+#undef VR_GLOADB
+#undef VR_SSTOREB
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int t = t0 + wrow0 + i * 16 + 4 * kq + e;
+            if (t >= T) continue;
+            float* op = g.o + (size_t)sidx * g.o_stride + (size_t)t * C;
+            float* yp = g.y2 + (size_t)sidx * g.y2_stride + g.y2_off + (size_t)t * C;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = j * 16 + lr;
+                const float v = ov[i][e][j] + (acc[i][j][e] + g.b2[n]);
+                if (g.store_o) op[n] = v;
+                const float sn = __sinf(v * g.ea3[n]);
+                yp[n] = v + g.ib3[n] * (sn * sn);
+            }
+        }
+}
+
+__global__ void k_voc_embed(VCall cl, const int* codes, int max_steps_cap, int ncb_model, const float* const* cb, int ncb, int cbs, int cd,
+                            float* out, size_t out_stride, int out_off) {
+    const int s = blockIdx.y, t = blockIdx.x;
+    const int slot = cl.slot[s], frame = min(cl.pos[s] + t, max_steps_cap - 1);  // (padding frames may point past the last row)
+    const int* cp = codes + ((size_t)slot * max_steps_cap + frame) * ncb_model;
+    for (int i = threadIdx.x; i < cd; i += blockDim.x) {
+        float acc = 0.0f;
+        for (int q = 0; q < ncb; ++q) {
+            int code = cp[q];
+            code = code < 0 ? 0 : (code >= cbs ? cbs - 1 : code);  // clamp [0, 2047]: src/tts/engine.rs:515-519
+            acc += cb[q][(size_t)code * cd + i];
+        }
+        out[(size_t)s * out_stride + out_off + (size_t)t * cd + i] = acc;
+    }
+}
+
+// history rows: work[s][0:H] <- hist[slot]  (load)   /   hist[slot] <- work[s][T : T+H]  (save)
+__global__ void k_voc_hist(VCall cl, float* work, size_t stride, float* hist, int H, int C, int T, int save) {
+    const int s = blockIdx.y, slot = cl.slot[s];
+    const size_t n = (size_t)H * C;
+    float* w = work + (size_t)s * stride + (save ? (size_t)T * C : 0);
+    float* h = hist + (size_t)slot * n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (save) h[i] = w[i]; else w[i] = h[i];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_voc_rmsnorm(const float* x, const float* w, float eps, int d, float* y) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const float* xr = x + (size_t)r * d;
+    float ss = 0.0f;
+    for (int i = lane; i < d; i += 64) ss += xr[i] * xr[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
+    const float rinv = 1.0f / sqrtf(ss / (float)d + eps);
+    for (int i = lane; i < d; i += 64) y[(size_t)r * d + i] = (xr[i] * rinv) * w[i];
+}
+
+// RoPE + ring append + sliding-window attention; one workgroup (64 threads) per (slot, head), tokens in order
+__global__ __launch_bounds__(64) void k_voc_attn(VCall cl, const float* qkv, float* kring, float* vring,
+                                                 int H, int hd, int RW, int W, float theta, float* att) {
+    __shared__ float sc[512];
+    __shared__ float qs[128];
+    const int s = blockIdx.y, h = blockIdx.x, lane = threadIdx.x, HH = H * hd, half = hd >> 1;
+    const int slot = cl.slot[s], T = cl.nf;
+    float* kr = kring + (size_t)slot * RW * HH + h * hd;
+    float* vr = vring + (size_t)slot * RW * HH + h * hd;
+    const float scale = 1.0f / sqrtf((float)hd);
+    for (int t = 0; t < T; ++t) {
+        const int pos = cl.pos[s] + t;
+        const size_t row = ((size_t)s * T + t) * HH + h * hd;
+        const float* qp = qkv + ((size_t)s * T + t) * 3 * HH + h * hd;  // q | k | v of this row inside the fused [M][3*HH] buffer
+        const float* kp0 = qp + HH; const float* vp = qp + 2 * HH;
+        if (lane < half) {
+            const double inv = pow((double)theta, -2.0 * (double)lane / (double)hd), ang = (double)pos * inv;
+            const float cs = (float)cos(ang), sn = (float)sin(ang);
+            float a = qp[lane], b = qp[lane + half];
+            qs[lane] = a * cs - b * sn; qs[lane + half] = b * cs + a * sn;
+            a = kp0[lane]; b = kp0[lane + half];
+            float* kd = kr + (size_t)(pos % RW) * HH;
+            kd[lane] = a * cs - b * sn; kd[lane + half] = b * cs + a * sn;
+        }
+        for (int i = lane; i < hd; i += 64) vr[(size_t)(pos % RW) * HH + i] = vp[i];
+        __syncthreads();
+        const int j0 = pos - W + 1 > 0 ? pos - W + 1 : 0, nk = pos - j0 + 1;
+        for (int j = lane; j < nk; j += 64) {
+            const float* kp = kr + (size_t)((j0 + j) % RW) * HH;
+            float a = 0.0f;
+            for (int i = 0; i < hd; ++i) a += qs[i] * kp[i];
+            sc[j] = a * scale;
+        }
+        __syncthreads();
+        // softmax weights once per key (lane j), max and sum by wave reductions; then P.V with the weights from LDS
+        float m = -INFINITY;
+        for (int j = lane; j < nk; j += 64) m = fmaxf(m, sc[j]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float l = 0.0f;
+        for (int j = lane; j < nk; j += 64) { const float pj = expf(sc[j] - m); sc[j] = pj; l += pj; }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) l += __shfl_xor(l, o);
+        __syncthreads();
+        for (int i = lane; i < hd; i += 64) {
+            float o = 0.0f;
+            for (int j = 0; j < nk; ++j) o += sc[j] * vr[(size_t)((j0 + j) % RW) * HH + i];
+            att[row + i] = o / l;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_voc_swiglu(float* g, const float* u, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        g[i] = (g[i] / (1.0f + expf(-g[i]))) * u[i];
+}
+
+// ConvNeXt front: depthwise causal conv k7 + LayerNorm(eps 1e-6) per position; one wave per (slot, t)
+__global__ __launch_bounds__(64) void k_voc_dw_ln(const float* x, size_t x_stride, int H, int T, int C, const float* dw_w, const float* dw_b,
+                                                  const float* ln_w, const float* ln_b, float* y) {
+    extern __shared__ float row[];
+    const int s = blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
+    const float* xp = x + (size_t)s * x_stride + (size_t)(H + t) * C;
+    float sum = 0.0f;
+    for (int i = lane; i < C; i += 64) {
+        float a = dw_b[i];
+#pragma unroll
+        for (int tap = 0; tap < 7; ++tap) a += xp[(long)(tap - 6) * C + i] * dw_w[(size_t)tap * C + i];
+        row[i] = a; sum += a;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+    const float mean = sum / (float)C;
+    float var = 0.0f;
+    for (int i = lane; i < C; i += 64) { const float z = row[i] - mean; var += z * z; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) var += __shfl_xor(var, m);
+    const float rinv = 1.0f / sqrtf(var / (float)C + 1e-6f);
+    float* yp = y + ((size_t)s * T + t) * C;
+    for (int i = lane; i < C; i += 64) yp[i] = ((row[i] - mean) * rinv) * ln_w[i] + ln_b[i];
+}
+
+// V6: Conv k7 C -> 1 over the snaked input (with history) + clamp -> PCM of the slot. A block produces 64 samples:
+// the 70-row input window is staged in LDS with coalesced loads (rows padded to C+1 floats: the per-thread row
+// stride then walks all banks), weights in LDS too; same summation order as before (per tap, channels ascending).
+__global__ __launch_bounds__(256) void k_voc_out(VCall cl, const float* x, size_t x_stride, int H, int T, int C, const float* w, const float* b,
+                                                 float* pcm, size_t pcm_stride, int spf) {
+    extern __shared__ float sm[];  // win[70][C+1] | wl[7*C]
+    const int s = blockIdx.y, slot = cl.slot[s], t0 = blockIdx.x * 64, tid = threadIdx.x, CP = C + 1;
+    float* win = sm; float* wl = sm + 70 * CP;
+    const float* xp = x + (size_t)s * x_stride + (size_t)(H + t0 - 6) * C;  // window row 0 = t0 - 6
+    const int nrow = min(70, T - t0 + 6);
+    for (int i = tid; i < nrow * C; i += 256) { const int r = i / C, c = i - r * C; win[r * CP + c] = q3_round_bf16(xp[i]); }
+    for (int i = tid; i < 7 * C; i += 256) wl[i] = w[i];
+    __syncthreads();
+    // 4 threads per output sample split the channels; partial sums are combined in a fixed order
+    const int o = tid >> 2, part = tid & 3, t = t0 + o;
+    float acc[7];
+#pragma unroll
+    for (int tap = 0; tap < 7; ++tap) {
+        float a = 0.0f;
+        if (t < T) for (int i = part; i < C; i += 4) a += win[(o + tap) * CP + i] * wl[tap * C + i];
+        a += __shfl_xor(a, 1); a += __shfl_xor(a, 2);
+        acc[tap] = a;
+    }
+    if (t < T && part == 0) {
+        float r = 0.0f;
+#pragma unroll
+        for (int tap = 0; tap < 7; ++tap) r += acc[tap];
+        r += b[0];
+        pcm[(size_t)slot * pcm_stride + (size_t)cl.pos[s] * spf + t] = fminf(1.0f, fmaxf(-1.0f, r));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host
+// ------------------------------------------------------------------------------------------------------------------
+template <class T>
+static int valloc(q3tts_engine* e, Q3Voc* v, T** p, size_t n) {
+    void* q = nullptr;
+    if (hipMalloc(&q, n * sizeof(T) + 256) != hipSuccess) return q3_set_err(e, Q3TTS_ERR_OOM, "hipMalloc (vocoder)");
+    hipMemsetAsync(q, 0, n * sizeof(T) + 256, e->stream);
+    v->allocs.push_back(q);
+    *p = (T*)q;
+    return Q3TTS_OK;
+}
+#define VTRY(x) do { int rc__ = (x); if (rc__ != Q3TTS_OK) return rc__; } while (0)
+
+static int gen_vec(q3tts_engine* e, Q3Voc* v, float** p, uint32_t tid, size_t n, float base, float std) {
+    VTRY(valloc(e, v, p, n));
+    q3_launch_fill_f32(*p, n, e->cfg.synth_seed, tid, base, std / Q3_IH4_STD, 0, e->stream);
+    return Q3TTS_OK;
+}
+__global__ void k_fill_bf16(uint16_t* dst, size_t n, uint64_t seed, uint32_t tid, float scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = q3_bf16(q3_synth(seed, tid, i, scale));
+}
+static int gen_conv(q3tts_engine* e, Q3Voc* v, VConv* c, int comp, int ww, int wb, int ntap, int dil, int cin, int nout, int bias_n, float gain) {
+    c->ntap = ntap; c->dil = dil; c->cin = cin; c->nout = nout; c->bias_n = bias_n;
+    const size_t n = (size_t)ntap * nout * cin;
+    VTRY(valloc(e, v, &c->w, n));
+    const float scale = (gain / sqrtf((float)(ntap * cin))) / Q3_IH4_STD;
+    hipLaunchKernelGGL(k_fill_bf16, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65536)), dim3(256), 0, e->stream, c->w, n,
+                       e->cfg.synth_seed, VTID(comp, ww), scale);
+    c->b = nullptr;
+    if (bias_n) VTRY(gen_vec(e, v, &c->b, VTID(comp, wb), bias_n, 0.0f, 0.02f));
+    return Q3TTS_OK;
+}
+// SnakeBeta parameters: exp() evaluated in double on the host (same as the oracle)
+static int gen_snake(q3tts_engine* e, Q3Voc* v, uint32_t ta, uint32_t tb, int C, float** ea, float** ib) {
+    std::vector<float> a(C), b(C);
+    const float scale = 0.1f / Q3_IH4_STD;
+    for (int i = 0; i < C; ++i) {
+        const float al = 0.0f + q3_synth(e->cfg.synth_seed, ta, i, scale), be = 0.0f + q3_synth(e->cfg.synth_seed, tb, i, scale);
+        a[i] = (float)exp((double)al); b[i] = (float)(1.0 / (exp((double)be) + 1e-9));
+    }
+    VTRY(valloc(e, v, ea, (size_t)C)); VTRY(valloc(e, v, ib, (size_t)C));
+    // same stream as valloc's zero-fill (a null-stream copy could be overtaken by that memset), synced: a/b are locals
+    Q3_HIP(e, hipMemcpyAsync(*ea, a.data(), (size_t)C * 4, hipMemcpyHostToDevice, e->stream));
+    Q3_HIP(e, hipMemcpyAsync(*ib, b.data(), (size_t)C * 4, hipMemcpyHostToDevice, e->stream));
+    Q3_HIP(e, hipStreamSynchronize(e->stream));
+    return Q3TTS_OK;
+}
+static int mk_buf(q3tts_engine* e, Q3Voc* v, VBuf* b, int H, int C, int Tcap) {
+    b->H = H; b->C = C; b->Tcap = Tcap;
+    VTRY(valloc(e, v, &b->p, (size_t)VOC_MAX_NS * b->stride()));
+    VTRY(valloc(e, v, &b->hist, (size_t)v->B * std::max(1, H) * C));
+    return Q3TTS_OK;
+}
+
+int q3_voc_samples_per_frame(const q3tts_engine* e) { return e->voc ? e->voc->spf : 0; }
+
+int q3_voc_create(q3tts_engine* e) {
+    const q3tts_vocoder_config& c = e->cfg.vocoder;
+#define REQ(cond) do { if (!(cond)) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder config check failed: " #cond); } while (0)
+    REQ(c.n_codebooks >= 1 && c.n_codebooks <= 16 && c.n_codebooks <= e->cfg.model.n_codebooks);
+    REQ(c.codebook_dim % 32 == 0 && c.latent_dim % 32 == 0 && c.d_ffn % 32 == 0 && (c.n_head * c.head_dim) % 32 == 0);
+    REQ(c.d_ffn % 16 == 0);
+    REQ(c.head_dim <= 128 && c.head_dim % 2 == 0 && c.sliding_window >= 1 && c.sliding_window + VOC_FCAP <= 512);
+    REQ(c.n_upsample >= 0 && c.n_upsample <= Q3TTS_MAX_UPSAMPLE && c.n_dec_blocks >= 1 && c.n_dec_blocks <= Q3TTS_MAX_DEC_BLOCKS);
+    REQ(c.pre_conv_kernel >= 1 && c.lookahead_frames >= 0);
+    { int ch = c.decoder_dim; for (int b = 0; b < c.n_dec_blocks; ++b) { REQ(ch % 64 == 0); ch /= 2; } REQ(ch >= 1); }
+#undef REQ
+    Q3Voc* v = new Q3Voc();
+    e->voc = v;
+    v->c = c; v->B = e->B;
+    const int d = c.latent_dim, HH = c.n_head * c.head_dim;
+    v->RW = c.sliding_window + VOC_FCAP;
+    v->cb.resize(c.n_codebooks);
+    for (int q = 0; q < c.n_codebooks; ++q) {
+        VTRY(valloc(e, v, &v->cb[q], (size_t)c.codebook_size * c.codebook_dim));
+        q3_launch_fill_f32(v->cb[q], (size_t)c.codebook_size * c.codebook_dim, e->cfg.synth_seed, VTID(VC_CODEBOOK + q, VW_W), 0.0f,
+                           (1.0f / sqrtf(16.0f)) / Q3_IH4_STD, 1, e->stream);
+    }
+    { float** cd = nullptr; VTRY(valloc(e, v, &cd, (size_t)16)); v->cb_dev = (const float**)cd;
+      Q3_HIP(e, hipMemcpyAsync((void*)cd, v->cb.data(), sizeof(float*) * c.n_codebooks, hipMemcpyHostToDevice, e->stream));
+      Q3_HIP(e, hipStreamSynchronize(e->stream)); }
+    VTRY(gen_conv(e, v, &v->pre, VC_PRE, VW_W, VW_B, c.pre_conv_kernel, 1, c.codebook_dim, d, d, 1.0f));
+    VTRY(mk_buf(e, v, &v->pre_in, c.pre_conv_kernel - 1, c.codebook_dim, VOC_FCAP));
+    v->L.resize(c.n_layer);
+    for (int l = 0; l < c.n_layer; ++l) {
+        VLayer& y = v->L[l]; const int comp = VC_TFM + l;
+        VTRY(gen_vec(e, v, &y.in_norm, VTID(comp, VW_IN_NORM), d, 1.0f, 0.05f));
+        VTRY(gen_vec(e, v, &y.post_norm, VTID(comp, VW_POST_NORM), d, 1.0f, 0.05f));
+        VTRY(gen_vec(e, v, &y.ls_attn, VTID(comp, VW_LS_ATTN), d, c.layer_scale_init, 0.1f * c.layer_scale_init));
+        VTRY(gen_vec(e, v, &y.ls_mlp, VTID(comp, VW_LS_MLP), d, c.layer_scale_init, 0.1f * c.layer_scale_init));
+        VTRY(gen_conv(e, v, &y.q, comp, VW_Q, 0, 1, 1, d, HH, 0, 1.0f)); VTRY(gen_conv(e, v, &y.k, comp, VW_K, 0, 1, 1, d, HH, 0, 1.0f));
+        VTRY(gen_conv(e, v, &y.v, comp, VW_V, 0, 1, 1, d, HH, 0, 1.0f)); VTRY(gen_conv(e, v, &y.o, comp, VW_O, 0, 1, 1, HH, d, 0, 1.0f));
+        VTRY(gen_conv(e, v, &y.gate, comp, VW_GATE, 0, 1, 1, d, c.d_ffn, 0, 1.0f)); VTRY(gen_conv(e, v, &y.up, comp, VW_UP, 0, 1, 1, d, c.d_ffn, 0, 1.0f));
+        VTRY(gen_conv(e, v, &y.down, comp, VW_DOWN, 0, 1, 1, c.d_ffn, d, 0, 1.0f));
+        // fused copies (same bf16 values, rearranged rows)
+        y.qkv = y.q; y.qkv.nout = 3 * HH;
+        VTRY(valloc(e, v, &y.qkv.w, (size_t)3 * HH * d));
+        Q3_HIP(e, hipMemcpyAsync(y.qkv.w, y.q.w, (size_t)HH * d * 2, hipMemcpyDeviceToDevice, e->stream));
+        Q3_HIP(e, hipMemcpyAsync(y.qkv.w + (size_t)HH * d, y.k.w, (size_t)HH * d * 2, hipMemcpyDeviceToDevice, e->stream));
+        Q3_HIP(e, hipMemcpyAsync(y.qkv.w + (size_t)2 * HH * d, y.v.w, (size_t)HH * d * 2, hipMemcpyDeviceToDevice, e->stream));
+        y.gu = y.gate; y.gu.nout = 2 * c.d_ffn;
+        VTRY(valloc(e, v, &y.gu.w, (size_t)2 * c.d_ffn * d));
+        Q3_HIP(e, hipMemcpy2DAsync(y.gu.w, (size_t)32 * d * 2, y.gate.w, (size_t)16 * d * 2, (size_t)16 * d * 2, c.d_ffn / 16, hipMemcpyDeviceToDevice, e->stream));
+        Q3_HIP(e, hipMemcpy2DAsync(y.gu.w + (size_t)16 * d, (size_t)32 * d * 2, y.up.w, (size_t)16 * d * 2, (size_t)16 * d * 2, c.d_ffn / 16, hipMemcpyDeviceToDevice, e->stream));
+    }
+    VTRY(gen_vec(e, v, &v->final_norm, VTID(VC_FINAL_NORM, VW_W), d, 1.0f, 0.05f));
+    int rows = VOC_FCAP;  // rows per slot at the current stage
+    v->spf = 1;
+    v->U.resize(c.n_upsample);
+    for (int s = 0; s < c.n_upsample; ++s) {
+        VUp& p = v->U[s]; const int comp = VC_UP + s, r = c.upsample_ratios[s]; p.r = r; v->spf *= r;
+        VTRY(gen_conv(e, v, &p.ct, comp, VW_W, VW_B, 1, 1, d, r * d, d, 1.0f));
+        rows *= r;
+        VTRY(mk_buf(e, v, &p.dw_in, 6, d, rows));
+        VTRY(gen_vec(e, v, &p.dw_w, VTID(comp, VW_DW_W), (size_t)7 * d, 0.0f, 0.3f)); VTRY(gen_vec(e, v, &p.dw_b, VTID(comp, VW_DW_B), d, 0.0f, 0.02f));
+        VTRY(gen_vec(e, v, &p.ln_w, VTID(comp, VW_LN_W), d, 1.0f, 0.05f)); VTRY(gen_vec(e, v, &p.ln_b, VTID(comp, VW_LN_B), d, 0.0f, 0.02f));
+        VTRY(gen_conv(e, v, &p.pw1, comp, VW_PW1, VW_PW1_B, 1, 1, d, 4 * d, 4 * d, 1.0f));
+        VTRY(gen_conv(e, v, &p.pw2, comp, VW_PW2, VW_PW2_B, 1, 1, 4 * d, d, d, 1.0f));
+        VTRY(gen_vec(e, v, &p.gamma, VTID(comp, VW_GAMMA), d, 0.1f, 0.01f));
+    }
+    VTRY(gen_conv(e, v, &v->dec_in, VC_DEC_IN, VW_W, VW_B, 7, 1, d, c.decoder_dim, c.decoder_dim, 1.0f));
+    VTRY(mk_buf(e, v, &v->dec_in_in, 6, d, rows));
+    size_t scratch = (size_t)rows * std::max(4 * d, c.decoder_dim);
+    v->Bk.resize(c.n_dec_blocks);
+    int ch = c.decoder_dim;
+    for (int b = 0; b < c.n_dec_blocks; ++b) {
+        VBlk& k = v->Bk[b]; const int comp = VC_BLK + 4 * b, r = c.dec_rates[b]; k.r = r; k.cin = ch; k.cout = ch / 2; v->spf *= r;
+        VTRY(gen_snake(e, v, VTID(comp, VW_ALPHA), VTID(comp, VW_BETA), ch, &k.ea, &k.ib));
+        VTRY(gen_conv(e, v, &k.ct, comp, VW_W, VW_B, 2, 1, ch, r * k.cout, k.cout, 1.0f));
+        VTRY(mk_buf(e, v, &k.ct_in, 1, ch, rows));
+        rows *= r;
+        scratch = std::max(scratch, (size_t)rows * k.cout);
+        const int dil[3] = {1, 3, 9};
+        for (int u = 0; u < 3; ++u) {
+            VRes& s = k.res[u]; const int rc = comp + 1 + u;
+            VTRY(gen_snake(e, v, VTID(rc, VW_ALPHA), VTID(rc, VW_BETA), k.cout, &s.ea, &s.ib));
+            VTRY(gen_conv(e, v, &s.c1, rc, VW_W, VW_B, 7, dil[u], k.cout, k.cout, k.cout, 0.5f));
+            VTRY(mk_buf(e, v, &s.c1_in, 6 * dil[u], k.cout, rows));
+            VTRY(gen_snake(e, v, VTID(rc, VW_ALPHA2), VTID(rc, VW_BETA2), k.cout, &s.ea2, &s.ib2));
+            VTRY(gen_conv(e, v, &s.c2, rc, VW_W2, VW_B2, 1, 1, k.cout, k.cout, k.cout, 0.5f));
+        }
+        ch = k.cout;
+    }
+    v->out_c = ch;
+    VTRY(gen_snake(e, v, VTID(VC_OUT, VW_ALPHA), VTID(VC_OUT, VW_BETA), ch, &v->oea, &v->oib));
+    VTRY(valloc(e, v, &v->out_w, (size_t)7 * ch)); VTRY(gen_vec(e, v, &v->out_b, VTID(VC_OUT, VW_B), 1, 0.0f, 0.02f));
+    q3_launch_fill_f32(v->out_w, (size_t)7 * ch, e->cfg.synth_seed, VTID(VC_OUT, VW_W), 0.0f, (0.1f / sqrtf((float)(7 * ch))) / Q3_IH4_STD, 1, e->stream);
+    VTRY(mk_buf(e, v, &v->out_in, 6, ch, rows));
+    // transformer scratch [VOC_MAX_NS * VOC_FCAP][.]
+    const size_t M = (size_t)VOC_MAX_NS * VOC_FCAP;
+    VTRY(valloc(e, v, &v->x, M * d)); VTRY(valloc(e, v, &v->xn, M * d)); VTRY(valloc(e, v, &v->qkv, M * 3 * HH));
+    VTRY(valloc(e, v, &v->att, M * HH)); VTRY(valloc(e, v, &v->g, M * c.d_ffn));
+    VTRY(valloc(e, v, &v->kring, (size_t)c.n_layer * v->B * v->RW * HH)); VTRY(valloc(e, v, &v->vring, (size_t)c.n_layer * v->B * v->RW * HH));
+    VTRY(valloc(e, v, &v->t1, (size_t)VOC_MAX_NS * scratch)); VTRY(valloc(e, v, &v->t2, (size_t)VOC_MAX_NS * scratch)); VTRY(valloc(e, v, &v->t3, (size_t)VOC_MAX_NS * scratch));
+    v->pcm_stride = (size_t)(e->cfg.max_steps_cap + VOC_FCAP) * v->spf;  // + padding frames behind a finished utterance
+    VTRY(valloc(e, v, &v->pcm, (size_t)v->B * v->pcm_stride));
+    v->frames_done.assign(v->B, 0); v->last_flag.assign(v->B, 0);
+    Q3_HIP(e, hipStreamSynchronize(e->stream));
+    return Q3TTS_OK;
+}
+
+void q3_voc_destroy(q3tts_engine* e) {
+    Q3Voc* v = e->voc;
+    if (!v) return;
+    for (void* p : v->allocs) hipFree(p);
+    delete v;
+    e->voc = nullptr;
+}
+
+static void zero_hist(q3tts_engine* e, VBuf& b, int slot) {
+    if (b.H > 0) hipMemsetAsync(b.hist + (size_t)slot * b.H * b.C, 0, (size_t)b.H * b.C * 4, e->stream);
+}
+int q3_voc_reset(q3tts_engine* e, int slot) {
+    Q3Voc* v = e->voc;
+    if (!v) return Q3TTS_OK;
+    zero_hist(e, v->pre_in, slot);
+    for (auto& u : v->U) zero_hist(e, u.dw_in, slot);
+    zero_hist(e, v->dec_in_in, slot);
+    for (auto& b : v->Bk) { zero_hist(e, b.ct_in, slot); for (auto& r : b.res) zero_hist(e, r.c1_in, slot); }
+    zero_hist(e, v->out_in, slot);
+    v->frames_done[slot] = 0; v->last_flag[slot] = 0;
+    return Q3TTS_OK;
+}
+
+struct VSnake { float* y2 = nullptr; size_t stride = 0; int off = 0; const float* ea = nullptr; const float* ib = nullptr; int n = 1; };
+static VSnake snake_into(const VBuf& dst, const float* ea, const float* ib, int C) {
+    VSnake k; k.y2 = dst.p; k.stride = dst.stride(); k.off = dst.H * dst.C; k.ea = ea; k.ib = ib; k.n = C; return k;
+}
+static void vgemm(hipStream_t s, const VConv& c, const float* x, size_t x_stride, int x_off, int ns, int T, float* y, size_t y_stride, int y_off,
+                  int epi = 0, const float* scale = nullptr, int scale_n = 1, const VSnake* sk = nullptr, int store = 1) {
+    VGemm g; g.x = x; g.x_stride = x_stride; g.x_off = x_off; g.T = T; g.M = ns * T; g.c = c; g.y = y; g.y_stride = y_stride; g.y_off = y_off;
+    g.scale = scale; g.scale_n = scale_n; g.epi = epi; g.store = store;
+    g.y2 = nullptr; g.y2_stride = 0; g.y2_off = 0; g.ea = g.ib = nullptr; g.snake_n = 1;
+    if (sk) { g.y2 = sk->y2; g.y2_stride = sk->stride; g.y2_off = sk->off; g.ea = sk->ea; g.ib = sk->ib; g.snake_n = sk->n; }
+    // every kernel accumulates the same 32-wide K steps in the same order: the choice never changes a result
+    if (g.M <= 512 || epi == 4) {
+        dim3 grid((c.nout + 31) / 32, (g.M + 63) / 64);
+        hipLaunchKernelGGL(k_vgemm_small, grid, dim3(256), 0, s, g);
+    } else if (c.nout % 128 != 0 && c.nout % 96 == 0) {
+        dim3 grid(c.nout / 96, (g.M + 127) / 128);
+        hipLaunchKernelGGL((k_vgemm_lds<3>), grid, dim3(256), 0, s, g);
+    } else {
+        dim3 grid((c.nout + 127) / 128, (g.M + 127) / 128);
+        hipLaunchKernelGGL((k_vgemm_lds<4>), grid, dim3(256), 0, s, g);
+    }
+}
+static bool resunit_ok(int C) {
+    const char* ev = getenv("Q3TTS_VOC_NOFUSE");  // (read per call: the tests compare both paths in one process)
+    const int off = ev ? atoi(ev) : 0;
+    return !off && (C == 32 || C == 64 || C == 96 || C == 128 || C == 192);
+}
+template <int NT, int MT>
+static void launch_resunit_t(hipStream_t s, const VResUnit& g, int ns) {
+    constexpr int C = NT * 16, R = 64 * MT, LDA = C + 8;
+    const size_t lds = ((size_t)(R + 6 * g.dil) * LDA + (size_t)2 * C * VT_LD) * 2;
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute((const void*)k_voc_resunit<NT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr_set = true; }
+    hipLaunchKernelGGL((k_voc_resunit<NT, MT>), dim3((g.T + R - 1) / R, ns), dim3(256), lds, s, g);
+}
+static void launch_resunit(hipStream_t s, const VRes& r, int ns, int T, int C, float* o, int store_o, const VSnake& sk) {
+    VResUnit g;
+    g.xin = r.c1_in.p; g.xin_stride = r.c1_in.stride(); g.T = T; g.dil = r.c1.dil;
+    g.w1 = r.c1.w; g.w2 = r.c2.w; g.b1 = r.c1.b; g.b2 = r.c2.b; g.ea2 = r.ea2; g.ib2 = r.ib2;
+    g.o = o; g.o_stride = (size_t)T * C; g.store_o = store_o;
+    g.y2 = sk.y2; g.y2_stride = sk.stride; g.y2_off = sk.off; g.ea3 = sk.ea; g.ib3 = sk.ib;
+    switch (C) {
+        case 32: launch_resunit_t<2, 4>(s, g, ns); break;
+        case 64: launch_resunit_t<4, 3>(s, g, ns); break;
+        case 96: launch_resunit_t<6, 2>(s, g, ns); break;
+        case 128: launch_resunit_t<8, 1>(s, g, ns); break;
+        default: launch_resunit_t<12, 1>(s, g, ns); break;
+    }
+}
+static void hist(hipStream_t s, const VCall& cl, VBuf& b, int T, int save) {
+    if (b.H == 0) return;
+    const size_t n = (size_t)b.H * b.C;
+    hipLaunchKernelGGL(k_voc_hist, dim3((unsigned)std::min<size_t>((n + 255) / 256, 64), cl.ns), dim3(256), 0, s, cl, b.p, b.stride(), b.hist, b.H, b.C, T, save);
+}
+// one batched streaming call: ns slots x nf new frames each (uniform nf <= VOC_FCAP)
+static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
+    Q3Voc* v = e->voc;
+    const q3tts_vocoder_config& c = v->c;
+    const int ns = cl.ns, nf = cl.nf, d = c.latent_dim, HH = c.n_head * c.head_dim, M = ns * nf;
+    // V1 + V2
+    hist(s, cl, v->pre_in, nf, 0);
+    hipLaunchKernelGGL(k_voc_embed, dim3(nf, ns), dim3(128), 0, s, cl, e->codes, e->cfg.max_steps_cap, e->cfg.model.n_codebooks, v->cb_dev,
+                       c.n_codebooks, c.codebook_size, c.codebook_dim, v->pre_in.p, v->pre_in.stride(), v->pre_in.H * v->pre_in.C);
+    vgemm(s, v->pre, v->pre_in.p, v->pre_in.stride(), v->pre_in.H * v->pre_in.C, ns, nf, v->x, (size_t)nf * d, 0);
+    hist(s, cl, v->pre_in, nf, 1);
+    // V3 transformer (rows m = s*nf + t)
+    for (int l = 0; l < c.n_layer; ++l) {
+        VLayer& L = v->L[l];
+        hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, L.in_norm, c.rms_eps, d, v->xn);
+        vgemm(s, L.qkv, v->xn, 0, 0, 1, M, v->qkv, 0, 0);
+        hipLaunchKernelGGL(k_voc_attn, dim3(c.n_head, ns), dim3(64), 0, s, cl, v->qkv, v->kring + (size_t)l * v->B * v->RW * HH,
+                           v->vring + (size_t)l * v->B * v->RW * HH, c.n_head, c.head_dim, v->RW, c.sliding_window, c.rope_theta, v->att);
+        vgemm(s, L.o, v->att, 0, 0, 1, M, v->x, 0, 0, 1, L.ls_attn, d);
+        hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, L.post_norm, c.rms_eps, d, v->xn);
+        vgemm(s, L.gu, v->xn, 0, 0, 1, M, v->g, 0, 0, 4);  // gate | up in one launch, SwiGLU in the epilogue
+        vgemm(s, L.down, v->g, 0, 0, 1, M, v->x, 0, 0, 1, L.ls_mlp, d);
+    }
+    hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, v->final_norm, c.rms_eps, d, v->xn);
+    // V5a upsample stages; cur = [ns][T][d] contiguous per slot (stride T*d)
+    const float* cur = v->xn; int T = nf; size_t cur_stride = (size_t)nf * d; int cur_off = 0;
+    for (auto& p : v->U) {
+        hist(s, cl, p.dw_in, T * p.r, 0);
+        vgemm(s, p.ct, cur, cur_stride, cur_off, ns, T, p.dw_in.p, p.dw_in.stride(), p.dw_in.H * d);  // [T][r*d] == [T*r][d]
+        T *= p.r;
+        hipLaunchKernelGGL(k_voc_dw_ln, dim3(T, ns), dim3(64), (size_t)d * 4, s, p.dw_in.p, p.dw_in.stride(), p.dw_in.H, T, d, p.dw_w, p.dw_b, p.ln_w, p.ln_b, v->t1);
+        hist(s, cl, p.dw_in, T, 1);  // history = the raw ConvTranspose output, saved before the in-place residual below
+        vgemm(s, p.pw1, v->t1, (size_t)T * d, 0, ns, T, v->t2, (size_t)T * 4 * d, 0, 3);
+        vgemm(s, p.pw2, v->t2, (size_t)T * 4 * d, 0, ns, T, p.dw_in.p, p.dw_in.stride(), p.dw_in.H * d, 1, p.gamma, d);  // residual in place
+        cur = p.dw_in.p; cur_stride = p.dw_in.stride(); cur_off = p.dw_in.H * d;
+    }
+    // V5b decoder
+    hist(s, cl, v->dec_in_in, T, 0);
+    hipMemcpy2DAsync(v->dec_in_in.p + (size_t)v->dec_in_in.H * d, v->dec_in_in.stride() * 4, cur + cur_off, cur_stride * 4, (size_t)T * d * 4, ns,
+                     hipMemcpyDeviceToDevice, s);
+    int ch = c.decoder_dim;
+    // Every SnakeBeta runs in the epilogue of the convolution that produces its input and lands directly in the
+    // work buffer of the convolution that consumes it: dec_in -> blk0.ct_in; ct -> res0.c1_in; c1 -> (snake2) -> c2's
+    // input; c2 -> next unit's c1_in / next block's ct_in / the final conv's window.
+    hist(s, cl, v->Bk[0].ct_in, T, 0);
+    {
+        const VSnake sk = snake_into(v->Bk[0].ct_in, v->Bk[0].ea, v->Bk[0].ib, ch);
+        vgemm(s, v->dec_in, v->dec_in_in.p, v->dec_in_in.stride(), v->dec_in_in.H * d, ns, T, v->t1, (size_t)T * ch, 0, 0, nullptr, 1, &sk, 0);
+    }
+    hist(s, cl, v->dec_in_in, T, 1);
+    float* z = v->t1; float* o = v->t2;
+    for (size_t bi = 0; bi < v->Bk.size(); ++bi) {
+        VBlk& k = v->Bk[bi];
+        hist(s, cl, k.res[0].c1_in, T * k.r, 0);
+        {
+            const VSnake sk = snake_into(k.res[0].c1_in, k.res[0].ea, k.res[0].ib, k.cout);
+            vgemm(s, k.ct, k.ct_in.p, k.ct_in.stride(), k.ct_in.H * k.cin, ns, T, o, (size_t)T * k.r * k.cout, 0, 0, nullptr, 1, &sk, 1);
+        }
+        hist(s, cl, k.ct_in, T, 1);
+        T *= k.r; ch = k.cout;
+        for (int u = 0; u < 3; ++u) {
+            VRes& r = k.res[u];
+            if (resunit_ok(ch)) {  // narrow blocks: the whole residual unit in one pass over HBM
+                VSnake sk;
+                if (u < 2) { hist(s, cl, k.res[u + 1].c1_in, T, 0); sk = snake_into(k.res[u + 1].c1_in, k.res[u + 1].ea, k.res[u + 1].ib, ch); }
+                else if (bi + 1 < v->Bk.size()) { VBlk& nx = v->Bk[bi + 1]; hist(s, cl, nx.ct_in, T, 0); sk = snake_into(nx.ct_in, nx.ea, nx.ib, ch); }
+                else { hist(s, cl, v->out_in, T, 0); sk = snake_into(v->out_in, v->oea, v->oib, ch); }
+                launch_resunit(s, r, ns, T, ch, o, u < 2 ? 1 : 0, sk);
+                hist(s, cl, r.c1_in, T, 1);
+                continue;
+            }
+            {
+                VSnake sk; sk.y2 = z; sk.stride = (size_t)T * ch; sk.off = 0; sk.ea = r.ea2; sk.ib = r.ib2; sk.n = ch;  // snake2 -> z
+                vgemm(s, r.c1, r.c1_in.p, r.c1_in.stride(), r.c1_in.H * ch, ns, T, z, (size_t)T * ch, 0, 0, nullptr, 1, &sk, 0);
+            }
+            hist(s, cl, r.c1_in, T, 1);
+            VSnake sk;
+            if (u < 2) { hist(s, cl, k.res[u + 1].c1_in, T, 0); sk = snake_into(k.res[u + 1].c1_in, k.res[u + 1].ea, k.res[u + 1].ib, ch); }
+            else if (bi + 1 < v->Bk.size()) { VBlk& nx = v->Bk[bi + 1]; hist(s, cl, nx.ct_in, T, 0); sk = snake_into(nx.ct_in, nx.ea, nx.ib, ch); }
+            else { hist(s, cl, v->out_in, T, 0); sk = snake_into(v->out_in, v->oea, v->oib, ch); }
+            vgemm(s, r.c2, z, (size_t)T * ch, 0, ns, T, o, (size_t)T * ch, 0, 2, nullptr, 1, &sk, u < 2 ? 1 : 0);  // o += conv k1
+        }
+    }
+    // V6
+    hipLaunchKernelGGL(k_voc_out, dim3((T + 63) / 64, ns), dim3(256), (size_t)(70 * (ch + 1) + 7 * ch) * 4, s, cl, v->out_in.p, v->out_in.stride(), v->out_in.H, T, ch, v->out_w, v->out_b,
+                       v->pcm, v->pcm_stride, v->spf);
+    hist(s, cl, v->out_in, T, 1);
+    Q3_HIP(e, hipGetLastError());
+    return Q3TTS_OK;
+}
+
+// decode frames [f0, f0+nf) of ONE slot (codes already on the device); nf may exceed VOC_FCAP (split)
+int q3_voc_decode(q3tts_engine* e, int slot, int f0, int nf, int is_last, hipStream_t s) {
+    Q3Voc* v = e->voc;
+    if (!v) return q3_set_err(e, Q3TTS_ERR_STATE, "engine has no vocoder");
+    if (f0 != v->frames_done[slot]) return q3_set_err(e, Q3TTS_ERR_STATE, "vocoder frames must be consumed in order");
+    while (nf > 0) {
+        const int n = std::min(nf, VOC_FCAP);
+        VCall cl; memset(&cl, 0, sizeof(cl));
+        cl.ns = 1; cl.nf = n; cl.slot[0] = slot; cl.pos[0] = v->frames_done[slot];
+        VTRY(voc_call(e, cl, s));
+        v->frames_done[slot] += n; nf -= n;
+    }
+    if (is_last) v->last_flag[slot] = 1;
+    return Q3TTS_OK;
+}
+// batched variant: the same nf (<= VOC_FCAP) new frames for every listed slot
+int q3_voc_decode_batch(q3tts_engine* e, const int* slots, const int* real, int ns, int nf, hipStream_t s) {
+    Q3Voc* v = e->voc;
+    if (!v) return q3_set_err(e, Q3TTS_ERR_STATE, "engine has no vocoder");
+    if (ns <= 0 || ns > VOC_MAX_NS || nf <= 0 || nf > VOC_FCAP) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder batch shape");
+    VCall cl; memset(&cl, 0, sizeof(cl));
+    cl.ns = ns; cl.nf = nf;
+    for (int i = 0; i < ns; ++i) { cl.slot[i] = slots[i]; cl.pos[i] = v->frames_done[slots[i]]; }
+    VTRY(voc_call(e, cl, s));
+    for (int i = 0; i < ns; ++i) v->frames_done[slots[i]] += real ? real[i] : nf;
+    return Q3TTS_OK;
+}
+void q3_voc_mark_last(q3tts_engine* e, int slot) { if (e->voc) e->voc->last_flag[slot] = 1; }
+
+float* q3_voc_pcm(q3tts_engine* e, int slot) { return e->voc->pcm + (size_t)slot * e->voc->pcm_stride; }
+// V4: frames are withheld by lookahead_frames until more input arrives or the slot is flushed with is_last
+int q3_voc_samples(q3tts_engine* e, int slot) {
+    Q3Voc* v = e->voc;
+    int fr = v->frames_done[slot];
+    if (!v->last_flag[slot]) fr = std::max(0, fr - v->c.lookahead_frames);
+    return fr * v->spf;
+}
+
+extern "C" int q3tts_k_vocoder(q3tts_engine* e, const int32_t* codes, int32_t n_frames, int32_t chunk_frames, float* pcm_out, int32_t* n_samples_out) {
+    if (!e || !codes || !pcm_out || !n_samples_out || n_frames <= 0) return q3_set_err(e, Q3TTS_ERR_INVALID, "null argument");
+    if (!e->voc) return q3_set_err(e, Q3TTS_ERR_STATE, "engine created with with_vocoder = 0");
+    if (n_frames > e->cfg.max_steps_cap) return q3_set_err(e, Q3TTS_ERR_INVALID, "n_frames exceeds max_steps_cap");
+    Q3_HIP(e, hipSetDevice(e->cfg.device));
+    const int ncb = e->cfg.model.n_codebooks;
+    hipStream_t s = e->stream;
+    Q3_HIP(e, hipMemcpyAsync(e->codes, codes, sizeof(int32_t) * (size_t)n_frames * ncb, hipMemcpyHostToDevice, s));  // slot 0
+    VTRY(q3_voc_reset(e, 0));
+    const int step = chunk_frames > 0 ? chunk_frames : n_frames;
+    for (int f = 0; f < n_frames; f += step) {
+        const int n = std::min(step, n_frames - f);
+        VTRY(q3_voc_decode(e, 0, f, n, f + n >= n_frames, s));
+    }
+    const int ns = q3_voc_samples(e, 0);
+    Q3_HIP(e, hipMemcpyAsync(pcm_out, q3_voc_pcm(e, 0), sizeof(float) * (size_t)ns, hipMemcpyDeviceToHost, s));
+    Q3_HIP(e, hipStreamSynchronize(s));
+    *n_samples_out = ns;
+    return Q3TTS_OK;
+}
