@@ -249,18 +249,28 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.0f;
-    for (int t = 4 * sw + kg; t < T; t += 16) {
-        const uint4 vv = *(const uint4*)(vb + (size_t)t * hd + dl * 8);
-        const float pt = p[t];
-        if (FUSED && t == pos) {  // newest value: from LDS
+    // four value rows per trip, loaded together (a one-row loop issues load, use, load, use ... : one memory round trip per
+    // 16 cached tokens); the chain of a lane still sees its keys in ascending order
+    for (int t0 = 4 * sw + kg; t0 < T; t0 += 64) {
+        uint4 vv[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = fmaf(pt, vh[dl * 8 + e], o[e]);
-            continue;
+        for (int u = 0; u < 4; ++u) vv[u] = *(const uint4*)(vb + (size_t)min(t0 + 16 * u, T - 1) * hd + dl * 8);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + 16 * u;
+            if (t < T) {
+                const float pt = p[t];
+                if (FUSED && t == pos) {  // newest value: from LDS
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = fmaf(pt, vh[dl * 8 + e], o[e]);
+                } else {
+                    o[0] = fmaf(pt, q3_u2f(vv[u].x << 16), o[0]); o[1] = fmaf(pt, q3_u2f(vv[u].x & 0xffff0000u), o[1]);
+                    o[2] = fmaf(pt, q3_u2f(vv[u].y << 16), o[2]); o[3] = fmaf(pt, q3_u2f(vv[u].y & 0xffff0000u), o[3]);
+                    o[4] = fmaf(pt, q3_u2f(vv[u].z << 16), o[4]); o[5] = fmaf(pt, q3_u2f(vv[u].z & 0xffff0000u), o[5]);
+                    o[6] = fmaf(pt, q3_u2f(vv[u].w << 16), o[6]); o[7] = fmaf(pt, q3_u2f(vv[u].w & 0xffff0000u), o[7]);
+                }
+            }
         }
-        o[0] = fmaf(pt, q3_u2f(vv.x << 16), o[0]); o[1] = fmaf(pt, q3_u2f(vv.x & 0xffff0000u), o[1]);
-        o[2] = fmaf(pt, q3_u2f(vv.y << 16), o[2]); o[3] = fmaf(pt, q3_u2f(vv.y & 0xffff0000u), o[3]);
-        o[4] = fmaf(pt, q3_u2f(vv.z << 16), o[4]); o[5] = fmaf(pt, q3_u2f(vv.z & 0xffff0000u), o[5]);
-        o[6] = fmaf(pt, q3_u2f(vv.w << 16), o[6]); o[7] = fmaf(pt, q3_u2f(vv.w & 0xffff0000u), o[7]);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {

@@ -494,9 +494,19 @@ __global__ __launch_bounds__(64) void k_voc_attn(VCall cl, const float* qkv, flo
         __syncthreads();
         const int j0 = pos - W + 1 > 0 ? pos - W + 1 : 0, nk = pos - j0 + 1;
         for (int j = lane; j < nk; j += 64) {
-            const float* kp = kr + (size_t)((j0 + j) % RW) * HH;
+            const float4* kp = (const float4*)(kr + (size_t)((j0 + j) % RW) * HH);
             float a = 0.0f;
-            for (int i = 0; i < hd; ++i) a += qs[i] * kp[i];
+            for (int i0 = 0; i0 < hd; i0 += 32) {  // 8 x 16 B of the key row in flight per trip, same ascending chain
+                float4 kk[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) kk[u] = kp[min(i0 / 4 + u, hd / 4 - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i0 + 4 * u < hd) {
+                        const float* qp2 = qs + i0 + 4 * u;
+                        a += qp2[0] * kk[u].x; a += qp2[1] * kk[u].y; a += qp2[2] * kk[u].z; a += qp2[3] * kk[u].w;
+                    }
+            }
             sc[j] = a * scale;
         }
         __syncthreads();
@@ -512,7 +522,14 @@ __global__ __launch_bounds__(64) void k_voc_attn(VCall cl, const float* qkv, flo
         __syncthreads();
         for (int i = lane; i < hd; i += 64) {
             float o = 0.0f;
-            for (int j = 0; j < nk; ++j) o += sc[j] * vr[(size_t)((j0 + j) % RW) * HH + i];
+            for (int jb = 0; jb < nk; jb += 8) {  // 8 value rows in flight per trip, same ascending chain
+                float vv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) vv[u] = vr[(size_t)((j0 + min(jb + u, nk - 1)) % RW) * HH + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (jb + u < nk) o += sc[jb + u] * vv[u];
+            }
             att[row + i] = o / l;
         }
         __syncthreads();
@@ -645,7 +662,7 @@ int q3_voc_create(q3tts_engine* e) {
     REQ(c.n_codebooks >= 1 && c.n_codebooks <= 16 && c.n_codebooks <= e->cfg.model.n_codebooks);
     REQ(c.codebook_dim % 32 == 0 && c.latent_dim % 32 == 0 && c.d_ffn % 32 == 0 && (c.n_head * c.head_dim) % 32 == 0);
     REQ(c.d_ffn % 16 == 0);
-    REQ(c.head_dim <= 128 && c.head_dim % 2 == 0 && c.sliding_window >= 1 && c.sliding_window + VOC_FCAP <= 512);
+    REQ(c.head_dim <= 128 && c.head_dim % 4 == 0 && c.sliding_window >= 1 && c.sliding_window + VOC_FCAP <= 512);
     REQ(c.n_upsample >= 0 && c.n_upsample <= Q3TTS_MAX_UPSAMPLE && c.n_dec_blocks >= 1 && c.n_dec_blocks <= Q3TTS_MAX_DEC_BLOCKS);
     REQ(c.pre_conv_kernel >= 1 && c.lookahead_frames >= 0);
     { int ch = c.decoder_dim; for (int b = 0; b < c.n_dec_blocks; ++b) { REQ(ch % 64 == 0); ch /= 2; } REQ(ch >= 1); }
