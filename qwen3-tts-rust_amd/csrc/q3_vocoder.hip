@@ -459,11 +459,23 @@ __global__ __launch_bounds__(64) void k_voc_rmsnorm(const float* x, const float*
     const int r = blockIdx.x, lane = threadIdx.x;
     const float* xr = x + (size_t)r * d;
     float ss = 0.0f;
-    for (int i = lane; i < d; i += 64) ss += xr[i] * xr[i];
+    for (int i0 = lane; i0 < d; i0 += 8 * 64) {  // 8 loads in flight per trip, same ascending per-lane chain
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = xr[min(i0 + u * 64, d - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (i0 + u * 64 < d) ss += v[u] * v[u];
+    }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
     const float rinv = 1.0f / sqrtf(ss / (float)d + eps);
-    for (int i = lane; i < d; i += 64) y[(size_t)r * d + i] = (xr[i] * rinv) * w[i];
+    for (int i0 = lane; i0 < d; i0 += 8 * 64) {
+        float v[8], wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = min(i0 + u * 64, d - 1); v[u] = xr[i]; wv[u] = w[i]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (i0 + u * 64 < d) y[(size_t)r * d + i0 + u * 64] = (v[u] * rinv) * wv[u];
+    }
 }
 
 // RoPE + ring append + sliding-window attention; one workgroup (64 threads) per (slot, head), tokens in order
@@ -576,7 +588,16 @@ __global__ __launch_bounds__(256) void k_voc_out(VCall cl, const float* x, size_
     float* win = sm; float* wl = sm + 70 * CP;
     const float* xp = x + (size_t)s * x_stride + (size_t)(H + t0 - 6) * C;  // window row 0 = t0 - 6
     const int nrow = min(70, T - t0 + 6);
-    for (int i = tid; i < nrow * C; i += 256) { const int r = i / C, c = i - r * C; win[r * CP + c] = q3_round_bf16(xp[i]); }
+    for (int i0 = tid; i0 < nrow * C; i0 += 8 * 256) {  // 8 loads in flight per trip
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = xp[min(i0 + u * 256, nrow * C - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256;
+            if (i < nrow * C) { const int r = i / C, c = i - r * C; win[r * CP + c] = q3_round_bf16(v[u]); }
+        }
+    }
     for (int i = tid; i < 7 * C; i += 256) wl[i] = w[i];
     __syncthreads();
     // 4 threads per output sample split the channels; partial sums are combined in a fixed order
