@@ -377,6 +377,185 @@ __global__ __launch_bounds__(512, (RT <= 2 && NT == 1 && BPS > 0 && BPS <= 2) ? 
     STAMP(6);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// fat-wave kernel: 256 threads = 4 waves, ONE wave per SIMD with up to 512 VGPRs, wave w = the four adjacent K-slices
+// 4w .. 4w+3. The ring kernel's two waves per SIMD take turns rather than interleave and each is limited by what the
+// CU's load path delivers per MFMA (profiles/README.md); a wave that owns a 4-6x larger output tile (RT x NT up to 2 x 6 /
+// 4 x 4) does 3-4x the MFMA work per loaded byte and per ring slot, so the same rings now run ahead of the MFMA pipe.
+// Same canonical order: per slice one fmaf chain, q_2w = p_4w + p_4w+1, q_2w+1 = p_4w+2 + p_4w+3, y = q0 + ... + q7.
+// ---------------------------------------------------------------------------------------------------------------
+template <int RT, int NT, bool NORM>
+__global__ __launch_bounds__(256, 1) void k_gemm_fat(Q3Gemm g) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];  // red [8][RT*16][NT*16+1] | sums [RT*16][NT*16] | nwl [K]
+    __shared__ float ssred[NORM ? 8 * RT * 16 : 1];
+    __shared__ float srow[NORM ? RT * 16 : 1];
+    constexpr int WPF = 2;  // (register budget: the tile's accumulators and their parked copies come first)
+    constexpr int XPF = 2;
+    constexpr int CP = NT * 16 + 1;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nbt = blockIdx.x, row0 = blockIdx.y * (RT * 16);
+    const int nrows = min(RT * 16, g.B - row0);
+    const int K = g.K, bps = K >> 9, nblk = 4 * bps;
+    const int kq = lane >> 4, li = lane & 15;
+    const size_t tile_stride = (size_t)(K >> 5) * 64;
+    const uint4* wp = g.w + (size_t)nbt * NT * tile_stride + (size_t)wave * nblk * 64 + lane;
+    const int koff = wave * (K >> 2) + kq * 4;
+    float* red = dsm;
+    float* sums = red + 8 * RT * 16 * CP;
+    float* nwl = sums + RT * 16 * NT * 16;
+    uint4 wq[WPF][NT];
+    float4 xq[XPF][RT][2];
+    f32x4 acc[RT][NT], accA[RT][NT];
+    float ss[RT], ssA[RT], qs0[RT];
+    const float* xr[RT];
+    const int KW4 = K >> 4;  // float4 of norm weights per wave (K/4 floats)
+    const float4* nsrc = (const float4*)(NORM ? g.norm_w + wave * (K >> 2) : g.x);
+    float* nww = nwl + wave * (K >> 2);
+    if (NORM) {  // wave-private strip of the norm weights (K <= 8192: up to 8 float4 per lane)
+        for (int i = lane; i < KW4; i += 64) ((float4*)nww)[i] = nsrc[i];
+    }
+    constexpr int NOUT = (RT * 16 * NT * 16 + 255) / 256;
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        int lrw = r * 16 + li;
+        if (lrw >= nrows) lrw = nrows - 1;
+        xr[r] = g.x + (size_t)(row0 + lrw) * g.ldx + koff;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) { acc[r][c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; accA[r][c] = acc[r][c]; }
+        ss[r] = 0.0f; ssA[r] = 0.0f; qs0[r] = 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < XPF; ++j) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r) { xq[j][r][0] = *(const float4*)(xr[r] + j * 32); xq[j][r][1] = *(const float4*)(xr[r] + j * 32 + 16); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < WPF; ++j) {
+#pragma unroll
+        for (int c = 0; c < NT; ++c) wq[j][c] = ntload16(wp + c * tile_stride + (size_t)j * 64);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const float* nwa = nww + kq * 4;
+    for (int kb0 = 0; kb0 < nblk; kb0 += WPF) {  // nblk = 4*bps is a multiple of WPF
+#pragma unroll
+        for (int j = 0; j < WPF; ++j) {
+            const int kb = kb0 + j;
+            if (kb == bps || kb == 3 * bps) {  // slice 4w (4w+2) done: park its partial
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) { accA[r][c] = acc[r][c]; acc[r][c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
+                    ssA[r] = ss[r]; ss[r] = 0.0f;
+                }
+            } else if (kb == 2 * bps) {  // first pair done: q_2w = p_4w + p_4w+1
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) {  // straight to the reduction buffer: no register copy of q_2w is kept
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) red[(((2 * wave) * RT + r) * 16 + 4 * kq + jj) * CP + c * 16 + li] = accA[r][c][jj] + acc[r][c][jj];
+                        acc[r][c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                    }
+                    if (NORM) {
+                        float sa = ssA[r] + __shfl_xor(ssA[r], 16), sb = ss[r] + __shfl_xor(ss[r], 16);
+                        sa = sa + __shfl_xor(sa, 32); sb = sb + __shfl_xor(sb, 32);
+                        qs0[r] = sa + sb;
+                    }
+                    ss[r] = 0.0f;
+                }
+            }
+            float b[NT][8];
+#pragma unroll
+            for (int c = 0; c < NT; ++c) unpack8(wq[j][c], b[c]);
+            float a[RT][8];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const float4 x0 = xq[j % XPF][r][0], x1 = xq[j % XPF][r][1];
+                a[r][0] = x0.x; a[r][1] = x0.y; a[r][2] = x0.z; a[r][3] = x0.w; a[r][4] = x1.x; a[r][5] = x1.y; a[r][6] = x1.z; a[r][7] = x1.w;
+                if (NORM) { ss[r] = sq4(x0, ss[r]); ss[r] = sq4(x1, ss[r]); }
+            }
+            if (NORM) {
+                const float4 n0 = *(const float4*)(nwa + kb * 32), n1 = *(const float4*)(nwa + kb * 32 + 16);
+                const float nw[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) a[r][t] = a[r][t] * nw[t];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {   // refills are unconditional (clamped past the end): activations first, they must stay OLDER than the weights
+                const int kx = min(kb + XPF, nblk - 1), kw = min(kb + WPF, nblk - 1);
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    xq[j % XPF][r][0] = *(const float4*)(xr[r] + kx * 32);
+                    xq[j % XPF][r][1] = *(const float4*)(xr[r] + kx * 32 + 16);
+                }
+#pragma unroll
+                for (int c = 0; c < NT; ++c) wq[j][c] = ntload16(wp + c * tile_stride + (size_t)kw * 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], b[c][t], acc[r][c], 0, 0, 0);
+        }
+    }
+    // q_2w (already in LDS) and q_2w+1 = p_4w+2 + p_4w+3 meet the other waves' and are summed in order
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[(((2 * wave + 1) * RT + r) * 16 + 4 * kq + j) * CP + c * 16 + li] = accA[r][c][j] + acc[r][c][j];
+    if (NORM) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            float sa = ssA[r] + __shfl_xor(ssA[r], 16), sb = ss[r] + __shfl_xor(ss[r], 16);
+            sa = sa + __shfl_xor(sa, 32); sb = sb + __shfl_xor(sb, 32);
+            if (kq == 0) { ssred[((2 * wave) * RT + r) * 16 + li] = qs0[r]; ssred[((2 * wave + 1) * RT + r) * 16 + li] = sa + sb; }
+        }
+    }
+    __syncthreads();
+    if (NORM) {
+        if (tid < RT * 16) {
+            float tot = ssred[tid];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) tot = tot + ssred[w * RT * 16 + tid];
+            srow[tid] = 1.0f / sqrtf(tot / (float)K + g.eps);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) {
+        const int o = tid + i * 256;
+        const int row = o / (NT * 16), col = o - row * (NT * 16);
+        if (o >= RT * 16 * NT * 16 || row >= nrows) continue;
+        float s = red[row * CP + col];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) s = s + red[(w * RT * 16 + row) * CP + col];
+        if (NORM) s = s * srow[row];
+        store_elem(g, sums, s, (size_t)(row0 + row), nbt * NT * 16 + col, row, col, NT * 16);
+    }
+    epilogue<RT * 16, NT * 16>(g, sums, tid, 256, row0, nrows, nbt * NT * 16);
+}
+
+template <int RT, int NT>
+static void launch_fat(const Q3Gemm& g, dim3 grid, hipStream_t s) {
+    const bool norm = g.norm_w != nullptr;
+    const size_t lds = ((size_t)8 * RT * 16 * (NT * 16 + 1) + (size_t)RT * 16 * NT * 16 + (norm ? (size_t)g.K : 0)) * 4;
+    static size_t attr = 0;  // dynamic LDS above 64 KiB has to be allowed per kernel (K <= 8192 bounds it)
+    if (lds > attr) {
+        hipFuncSetAttribute((const void*)k_gemm_fat<RT, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)k_gemm_fat<RT, NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = lds;
+    }
+    if (norm) hipLaunchKernelGGL((k_gemm_fat<RT, NT, true>), grid, dim3(256), lds, s, g);
+    else hipLaunchKernelGGL((k_gemm_fat<RT, NT, false>), grid, dim3(256), lds, s, g);
+}
+
 template <bool NORM>
 static void launch_small(const Q3Gemm& g, dim3 grid, size_t lds, hipStream_t s) {
 #define L(BPS_) hipLaunchKernelGGL((k_gemm_small<NORM, BPS_>), grid, dim3(1024), lds, s, g)
@@ -421,6 +600,16 @@ void q3_launch_gemm(const Q3Gemm& g, hipStream_t s) {
         return;
     }
     const int tiles = g.N / 16;
+    // bit 1 (64 x 64 tiles for many rows, i.e. prefill: 78 -> 72.5 ms for 1 984 prompt rows) is on by default; bit 0
+    // (32 x 96 tiles for the 12 288-column gate/up GEMM at decode batch) measured slower than the ring kernel
+    // (7.78 vs 7.52 ms per frame step) and stays off
+    static const int fat = getenv("Q3_GEMM_FAT") ? atoi(getenv("Q3_GEMM_FAT")) : 2;
+    if (fat && g.B > 32 && g.K % 512 == 0 && g.K <= 8192) {
+        // very wide N at decode batch: 32 x 96 tiles still give every CU a workgroup
+        if ((fat & 1) && g.B <= 64 && tiles % 6 == 0 && (long)(tiles / 6) * ((g.B + 31) / 32) >= 256) { launch_fat<2, 6>(g, dim3(tiles / 6, (g.B + 31) / 32), s); return; }
+        // many rows (prefill): 64 x 64 tiles
+        if ((fat & 2) && g.B > 64 && tiles % 4 == 0 && (long)(tiles / 4) * ((g.B + 63) / 64) >= 256) { launch_fat<4, 4>(g, dim3(tiles / 4, (g.B + 63) / 64), s); return; }
+    }
     int NT = 1;
     if (g.B > 16) {
         // x-fragment traffic from L2 scales with 1/NT and is the co-bottleneck at B = 64: widest NT that still

@@ -48,7 +48,7 @@ def _oracle_gemm(O, x, w, norm_w, eps, bias, epi, y_in=None):
 
 @pytest.mark.parametrize("B,K,N", [(1, 512, 16), (1, 2048, 256), (3, 512, 48), (6, 2048, 64), (7, 2048, 64), (16, 1024, 64), (17, 2048, 32), (33, 1536, 64),
                                    (64, 2048, 128), (70, 512, 32), (2, 6144, 64), (3, 6144, 32), (40, 1024, 12288), (64, 3072, 8192), (31, 2048, 96),
-                                   (64, 6144, 2048), (64, 2048, 2048), (50, 1024, 2048), (200, 2048, 2048)])
+                                   (64, 6144, 2048), (64, 2048, 2048), (50, 1024, 2048), (200, 2048, 2048), (300, 2048, 4096), (257, 1024, 6144)])
 def test_gemm_exact_store_bias(oracle, native, B, K, N):
     rng = np.random.default_rng(B * 1000 + K + N)
     x = _rand(rng, (B, K))
@@ -63,7 +63,7 @@ def test_gemm_exact_store_bias(oracle, native, B, K, N):
 # runtime-K instances (K = 512/1024/2048 vs 1536/3072), ragged last row tile, SwiGLU / argmax epilogues below
 @pytest.mark.parametrize("B,K,N", [(1, 2048, 64), (5, 1024, 32), (12, 1024, 32), (13, 1024, 32), (40, 512, 64), (64, 2048, 12288),
                                    (64, 1024, 6144), (64, 1024, 4096), (64, 2048, 4096), (64, 2048, 3072), (32, 1024, 6144), (17, 1024, 96),
-                                   (128, 1024, 6144), (100, 2048, 4096), (37, 1536, 4096), (64, 3072, 6144), (200, 512, 48), (64, 1024, 2048)])
+                                   (128, 1024, 6144), (100, 2048, 4096), (37, 1536, 4096), (64, 3072, 6144), (200, 512, 48), (64, 1024, 2048), (320, 2048, 4096), (1000, 1024, 4096)])
 def test_gemm_exact_norm_prologue(oracle, native, B, K, N):
     rng = np.random.default_rng(7 + B)
     x = _rand(rng, (B, K), 3.0)
