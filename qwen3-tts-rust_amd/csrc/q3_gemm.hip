@@ -394,6 +394,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(Q3Gemm g) {
     constexpr int CP = NT * 16 + 1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nbt = blockIdx.x, row0 = blockIdx.y * (RT * 16);
+    STAMP(0);
     const int nrows = min(RT * 16, g.B - row0);
     const int K = g.K, bps = K >> 9, nblk = 4 * bps;
     const int kq = lane >> 4, li = lane & 15;
@@ -437,6 +438,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(Q3Gemm g) {
     }
     __builtin_amdgcn_sched_barrier(0);
     const float* nwa = nww + kq * 4;
+    STAMP(1);
     for (int kb0 = 0; kb0 < nblk; kb0 += WPF) {  // nblk = 4*bps is a multiple of WPF
 #pragma unroll
         for (int j = 0; j < WPF; ++j) {
@@ -503,6 +505,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(Q3Gemm g) {
                     for (int c = 0; c < NT; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][t], b[c][t], acc[r][c], 0, 0, 0);
         }
     }
+    STAMP(3);
     // q_2w (already in LDS) and q_2w+1 = p_4w+2 + p_4w+3 meet the other waves' and are summed in order
 #pragma unroll
     for (int r = 0; r < RT; ++r)
@@ -519,6 +522,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(Q3Gemm g) {
         }
     }
     __syncthreads();
+    STAMP(4);
     if (NORM) {
         if (tid < RT * 16) {
             float tot = ssred[tid];
@@ -539,7 +543,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_fat(Q3Gemm g) {
         if (NORM) s = s * srow[row];
         store_elem(g, sums, s, (size_t)(row0 + row), nbt * NT * 16 + col, row, col, NT * 16);
     }
+    STAMP(5);
     epilogue<RT * 16, NT * 16>(g, sums, tid, 256, row0, nrows, nbt * NT * 16);
+    STAMP(6);
 }
 
 template <int RT, int NT>
