@@ -132,7 +132,7 @@ def main():
         import torch
         from q3tts import dist as qd
         qd.gather_pcm(dist, [o.pcm if o.pcm is not None else np.zeros(0, dtype=np.float32) for o in outs], rank, world,
-                      device="cuda", dtype=torch.float16)
+                      device="cuda", dtype=torch.float16, to_numpy=False)
 
     def probe_leg():
         """Dominant kernel, in situ: the same batch of 64 utterances for 24 forced frames (codes only, so nothing else
