@@ -101,11 +101,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # rehearsal switches for a 1-GPU box: Q3TTS_DIST_BACKEND=gloo keeps the collectives on the host, Q3TTS_ONE_GPU=1 puts
+    # every rank's engine on GPU 0 (the driver's multi-GPU runs use neither: RCCL, one GPU per rank)
+    backend = os.environ.get("Q3TTS_DIST_BACKEND", "nccl")
+    if os.environ.get("Q3TTS_ONE_GPU", "0") not in ("", "0"):
+        local_rank = 0
+    tdev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from q3tts import _abi, native
     cfg = _abi.full_config_py()
@@ -122,7 +131,8 @@ def main():
     def sync_all():
         if dist is not None:
             import torch
-            torch.cuda.synchronize()
+            if tdev == "cuda":
+                torch.cuda.synchronize()
             dist.barrier()
 
     def gather_pcm(outs):
@@ -132,7 +142,7 @@ def main():
         import torch
         from q3tts import dist as qd
         qd.gather_pcm(dist, [o.pcm if o.pcm is not None else np.zeros(0, dtype=np.float32) for o in outs], rank, world,
-                      device="cuda", dtype=torch.float16, to_numpy=False)
+                      device=tdev, dtype=torch.float16, to_numpy=False)
 
     def probe_leg():
         """Dominant kernel, in situ: the same batch of 64 utterances for 24 forced frames (codes only, so nothing else
@@ -179,7 +189,7 @@ def main():
     assert [o.n_frames for o in outs] == frames, "forced lengths not honoured"
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed, float(step_frames)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, float(step_frames)], dtype=torch.float64, device=tdev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
