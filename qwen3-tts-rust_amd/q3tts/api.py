@@ -149,6 +149,11 @@ class TtsEngine:
     def set_max_steps(self, steps: int):
         self.max_steps = steps
 
+    def set_language(self, lang_id):
+        """the reference hard-codes lang_id = 2055 (Chinese) at src/tts/engine.rs:267,407,425; None selects the
+        no-language control block (NOTHINK variant, src/tts/prompt.rs:180-204)."""
+        self.lang_id = lang_id
+
     def set_sampler_config(self, config: SamplerConfig):
         self.sampler_config = config
 
@@ -182,6 +187,9 @@ class TtsEngine:
             return np.asarray(self.tokenizer.encode(text, add_special_tokens=False).ids, dtype=np.uint32)  # src/utils/tokenizer.rs:17-25
         return np.asarray(text, dtype=np.uint32)
 
+    def _lang(self):
+        return getattr(self, "lang_id", LANG_ID_CHINESE)
+
     def _desc(self, text, voice: VoiceFile, instruct):
         ids = self._encode(text)
         ins = None if instruct is None else self._encode(instruct)
@@ -189,9 +197,9 @@ class TtsEngine:
         if emb.size != self.cfg.model.d_embed:
             raise _abi.Q3Error(f"speaker_embedding has {emb.size} values, expected {self.cfg.model.d_embed}")
         if len(voice.audio_codes) == 0:  # src/tts/engine.rs:398-412: x-vector-only prompt
-            return native.make_prompt_desc(ids, spk_emb=emb, lang_id=LANG_ID_CHINESE, instruct_ids=ins)
+            return native.make_prompt_desc(ids, spk_emb=emb, lang_id=self._lang(), instruct_ids=ins)
         ref_ids = self._encode(voice.ref_text)  # :414-427: ICL clone prompt
-        return native.make_prompt_desc(ids, spk_emb=emb, lang_id=LANG_ID_CHINESE, instruct_ids=ins,
+        return native.make_prompt_desc(ids, spk_emb=emb, lang_id=self._lang(), instruct_ids=ins,
                                        ref_codes=np.asarray(voice.audio_codes, dtype=np.int32), ref_text_ids=ref_ids)
 
     def generate_with_voice(self, text, voice: VoiceFile, instruct=None) -> AudioSample:

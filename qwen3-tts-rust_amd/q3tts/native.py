@@ -25,7 +25,7 @@ def make_prompt_desc(text_ids, spk_emb=None, lang_id=2055, spk_id=-1, instruct_i
         ins = np.ascontiguousarray(instruct_ids, dtype=np.uint32)
         keep.append(ins)
         d.instruct_ids, d.n_instruct = _ptr(ins, u32p), len(ins)
-    d.lang_id, d.spk_id = lang_id, spk_id
+    d.lang_id, d.spk_id = (-1 if lang_id is None else lang_id), spk_id
     if spk_emb is not None:
         s = np.ascontiguousarray(spk_emb, dtype=np.float32)
         keep.append(s)

@@ -387,6 +387,11 @@ def test_api_mirror_generate_with_voice(tiny_voc, tmp_path):
     voice = api.VoiceFile.new("", [], _spk(cfg.model.d_embed).tolist())
     a = te.generate_with_voice(list(range(100, 110)), voice)
     assert a.sample_rate == 24000 and a.channels == 1 and len(a.samples) == 6 * 1920
+    te.set_language(None)  # no-language control block (NOTHINK variant): a different prompt, hence different audio
+    b = te.generate_with_voice(list(range(100, 110)), voice)
+    assert len(b.samples) == 6 * 1920 and not np.array_equal(np.asarray(a.samples), np.asarray(b.samples))
+    te.set_language(2055)
+    assert np.array_equal(np.asarray(te.generate_with_voice(list(range(100, 110)), voice).samples), np.asarray(a.samples))
     a.save_wav(tmp_path / "o.wav")
     assert api.AudioSample.load_wav(tmp_path / "o.wav").samples.size == 6 * 1920
     te.speakers = {"vivian": voice}
