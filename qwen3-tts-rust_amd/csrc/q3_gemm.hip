@@ -107,6 +107,7 @@ __global__ __launch_bounds__(1024) void k_gemm_small(Q3Gemm g) {
     constexpr int WPF = 8;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nb = blockIdx.x, nrows = g.B;
+    STAMP(0);
     const int K = g.K, K4 = K >> 2;
     const int bps = BPS > 0 ? BPS : (K >> 9);
     const int kq = lane >> 4, li = lane & 15;
@@ -134,7 +135,9 @@ __global__ __launch_bounds__(1024) void k_gemm_small(Q3Gemm g) {
         if (tid < K4) ((float4*)nwl)[tid] = nv0;
         if (tid + 1024 < K4) ((float4*)nwl)[tid + 1024] = nv1;
     }
+    STAMP(1);
     __syncthreads();
+    STAMP(2);
     const int lr = li < nrows ? li : nrows - 1;  // padding rows replicate the last row; their results are dropped
     const float* xa = dsm + (size_t)lr * K + koff;
     const float* nwa = nwl + koff;
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(1024) void k_gemm_small(Q3Gemm g) {
             }
         }
     }
+    STAMP(3);
     // D layout: lane holds rows 4*(lane>>4)+j, column lane&15
 #pragma unroll
     for (int j = 0; j < 4; ++j) red[(wave * 16 + 4 * kq + j) * 17 + li] = acc[j];
@@ -172,6 +176,7 @@ __global__ __launch_bounds__(1024) void k_gemm_small(Q3Gemm g) {
         if (kq == 0) ssred[wave * 16 + li] = ss;
     }
     __syncthreads();
+    STAMP(4);
     if (tid < 256) {
         const int row = tid >> 4, col = tid & 15;
         if (row < nrows) {
@@ -187,7 +192,9 @@ __global__ __launch_bounds__(1024) void k_gemm_small(Q3Gemm g) {
             store_elem(g, sums, s, (size_t)row, nb * 16 + col, row, col, 16);
         }
     }
+    STAMP(5);
     epilogue<16, 16>(g, sums, tid, 1024, 0, nrows, nb * 16);
+    STAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
