@@ -55,7 +55,7 @@ struct Q3Voc {
     float *oea = nullptr, *oib = nullptr, *out_w = nullptr, *out_b = nullptr; VBuf out_in; int out_c = 0;
     float *kring = nullptr, *vring = nullptr;  // [n_layer][B][RW][HH]
     float *x = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *g = nullptr;  // transformer scratch [M][.]
-    float *t1 = nullptr, *t2 = nullptr, *t3 = nullptr;  // generic scratch (largest stage)
+    float *t1 = nullptr, *t2 = nullptr;  // generic scratch (largest stage)
     float* pcm = nullptr; size_t pcm_stride = 0;         // [B][max_steps_cap * spf]
     std::vector<int> frames_done, last_flag;
     std::vector<void*> allocs;
@@ -548,11 +548,6 @@ __global__ __launch_bounds__(64) void k_voc_attn(VCall cl, const float* qkv, flo
     }
 }
 
-__global__ void k_voc_swiglu(float* g, const float* u, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        g[i] = (g[i] / (1.0f + expf(-g[i]))) * u[i];
-}
-
 // ConvNeXt front: depthwise causal conv k7 + LayerNorm(eps 1e-6) per position; one wave per (slot, t)
 __global__ __launch_bounds__(64) void k_voc_dw_ln(const float* x, size_t x_stride, int H, int T, int C, const float* dw_w, const float* dw_b,
                                                   const float* ln_w, const float* ln_b, float* y) {
@@ -774,7 +769,7 @@ int q3_voc_create(q3tts_engine* e) {
     VTRY(valloc(e, v, &v->x, M * d)); VTRY(valloc(e, v, &v->xn, M * d)); VTRY(valloc(e, v, &v->qkv, M * 3 * HH));
     VTRY(valloc(e, v, &v->att, M * HH)); VTRY(valloc(e, v, &v->g, M * c.d_ffn));
     VTRY(valloc(e, v, &v->kring, (size_t)c.n_layer * v->B * v->RW * HH)); VTRY(valloc(e, v, &v->vring, (size_t)c.n_layer * v->B * v->RW * HH));
-    VTRY(valloc(e, v, &v->t1, (size_t)VOC_MAX_NS * scratch)); VTRY(valloc(e, v, &v->t2, (size_t)VOC_MAX_NS * scratch)); VTRY(valloc(e, v, &v->t3, (size_t)VOC_MAX_NS * scratch));
+    VTRY(valloc(e, v, &v->t1, (size_t)VOC_MAX_NS * scratch)); VTRY(valloc(e, v, &v->t2, (size_t)VOC_MAX_NS * scratch));
     v->pcm_stride = (size_t)(e->cfg.max_steps_cap + VOC_FCAP) * v->spf;  // + padding frames behind a finished utterance
     VTRY(valloc(e, v, &v->pcm, (size_t)v->B * v->pcm_stride));
     v->frames_done.assign(v->B, 0); v->last_flag.assign(v->B, 0);
