@@ -182,7 +182,7 @@ typedef struct q3tts_timings {
     float probe_kernel_ms;    /* q3tts_k_probe: mean in-situ device time of the probed kernel (Predictor gate/up GEMM, full batch) */
     int64_t frame_steps;      /* graph replays timed */
     int64_t algo_bytes_per_step; /* SURVEY.md §8(d) algorithmic bytes of one frame step at the batch run */
-    int64_t algo_flops_per_step; /* 2 * (W_T + 15 W_P + 15 h + 16 pj) * mean live utterances per step (decoder GEMMs) */
+    int64_t algo_flops_per_step; /* 2 * (W_T + 15 W_P + 15 h + pj) * mean live utterances per step (decoder GEMMs) */
     float mean_live_slots;       /* utterances generating, averaged over the timed frame steps */
     float mean_rows;             /* decode rows per frame step (row bucket), averaged over the timed frame steps */
     int64_t probe_count;         /* launches behind probe_kernel_ms */

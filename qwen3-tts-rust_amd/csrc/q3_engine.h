@@ -50,6 +50,7 @@ struct q3tts_engine {
     float* text = nullptr;
     std::vector<float*> codec;            // host array of device pointers
     const float** codec_dev = nullptr;    // device array of the same pointers
+    std::vector<float*> pproj;            // proj(codec table q) [rows_q][p_d_model] f32: the Predictor's inputs are gathers
     uint4* proj_w = nullptr;
     float* proj_b = nullptr;
     float* tts_pad = nullptr;             // = text[tts_pad_id] (or tts_pad_own: zeros, when the loaded text table is too small)

@@ -279,20 +279,23 @@ static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
     sa.rng = e->rng; sa.codes = codes; sa.max_steps_cap = cap; sa.ncb = ncb; sa.keys = L.keys;
     q3_launch_sample(sa, s);
     Q3PredInput pi{}; pi.xT = L.xT; pi.out_norm = e->T.out_norm; pi.eps = eps; pi.d = de; pi.codec0 = e->codec[0]; pi.codec0_rows = m.codec0_rows;
-    pi.slots = slots; pi.row_slot = L.slot_id; pi.X = L.X; pi.fb = L.fb; pi.B = B;
+    pi.slots = slots; pi.row_slot = L.slot_id; pi.X = L.X; pi.fb = L.fb; pi.B = B; pi.pproj0 = e->pproj[0]; pi.proj_b = e->proj_b; pi.dp = dp; pi.px = L.px;
     q3_launch_pred_input(pi, s);
     const size_t head_tile_stride = (size_t)(cbs / 16) * (dp / 32) * 64;  // uint4 per predictor head
     auto pred_next = [&](int q) {
         Q3PredNext pn{}; pn.keys = L.keys; pn.q = q; pn.ncb = ncb; pn.codec_q = e->codec[q]; pn.rows_q = m.codecq_rows; pn.d = de;
-        pn.slots = slots; pn.row_slot = L.slot_id; pn.B = B; pn.codes = codes; pn.max_steps_cap = cap; pn.fb = L.fb; pn.X = L.X;
-        pn.tts_pad = e->tts_pad; pn.xT = L.xT; pn.row_pos_t = L.row_pos_t;
+        pn.slots = slots; pn.row_slot = L.slot_id; pn.B = B; pn.codes = codes; pn.max_steps_cap = cap; pn.fb = L.fb;
+        pn.tts_pad = e->tts_pad; pn.xT = L.xT; pn.row_pos_t = L.row_pos_t; pn.pproj_q = e->pproj[q]; pn.proj_b = e->proj_b; pn.dp = dp; pn.px = L.px;
         q3_launch_pred_next(pn, s);
     };
     for (int q = 0; q < ncb - 1; ++q) {  // pass q produces code_{q+1}
         const int rows = q == 0 ? 2 * B : B;
         if (q > 0) pred_next(q);
-        Q3Gemm g{}; g.x = L.X; g.ldx = de; g.B = rows; g.w = e->proj_w; g.K = de; g.N = dp; g.bias = e->proj_b; g.y = L.px; g.ldy = dp;
-        g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);  // H6: src/assets_manager.rs:383-399
+        Q3Gemm g{};
+        if (q == 0) {  // H6 (src/assets_manager.rs:383-399) for the hidden rows only; every code embedding arrives pre-projected
+            g.x = L.X; g.ldx = de; g.B = B; g.w = e->proj_w; g.K = de; g.N = dp; g.bias = e->proj_b; g.y = L.px; g.ldy = 2 * dp;
+            g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);
+        }
         hipEvent_t* pe = nullptr;
         if (e->probe && q == 1 && B == L.nb && e->probe_i + 2 <= 8) { pe = &e->probe_ev[e->probe_i]; e->probe_i += 2; }
         run_layers(e, e->P, L.px, rows, q == 0 ? L.posA : L.pos_q + (size_t)q * L.nb, q == 0 ? L.slotA : L.slot_id, L.sc, s, q > 0, pe);
@@ -460,6 +463,18 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
     q3_launch_fill_f32(e->proj_b, m.p_d_model, seed, Q3_TID(Q3G_ASSET, 0, Q3WA_PROJ_B), 0.0f, 0.02f / Q3_IH4_STD, 0, s);
     e->tts_pad = e->text + (size_t)m.tts_pad_id * m.d_embed;  // src/assets_manager.rs:244-249
     }
+    // pre-projected codec tables: proj(codec_q[code]) for every code, computed once with the exact GEMM (a row's result does
+    // not depend on the other rows, so a table row equals the on-the-fly projection bit for bit): the 15 Predictor passes
+    // after the first read their input with a gather instead of a GEMM launch each
+    e->pproj.assign(m.n_codebooks, nullptr);
+    for (int q = 0; q < m.n_codebooks; ++q) {
+        const int rows = q == 0 ? m.codec0_rows : m.codecq_rows;
+        TRYC(dalloc(e, &e->pproj[q], (size_t)rows * m.p_d_model));
+        Q3Gemm g{}; g.x = e->codec[q]; g.ldx = m.d_embed; g.B = rows; g.w = e->proj_w; g.K = m.d_embed; g.N = m.p_d_model; g.bias = e->proj_b;
+        g.y = e->pproj[q]; g.ldy = m.p_d_model; g.epi = Q3_EPI_STORE;
+        q3_launch_gemm(g, s);
+    }
+    HIPC(hipStreamSynchronize(s));
     // decode state
     TRYC(dalloc(e, &e->slots, (size_t)B));
     HIPC(hipHostMalloc((void**)&e->slots_host, sizeof(Q3Slot) * 2 * B, hipHostMallocDefault));
@@ -547,7 +562,7 @@ extern "C" void q3tts_engine_destroy(q3tts_engine* e) {
         if (L.stream) hipStreamDestroy(L.stream);
     }
     free_tfm(e->T); free_tfm(e->P);
-    hipFree(e->text); for (auto p : e->codec) hipFree(p); hipFree((void*)e->codec_dev); hipFree(e->proj_w); hipFree(e->proj_b);
+    hipFree(e->text); for (auto p : e->codec) hipFree(p); for (auto p : e->pproj) hipFree(p); hipFree((void*)e->codec_dev); hipFree(e->proj_w); hipFree(e->proj_b);
     hipFree(e->tts_pad_own);
     hipFree(e->slots); if (e->slots_host) hipHostFree(e->slots_host);
     hipFree(e->codes); hipFree(e->rng);
@@ -957,7 +972,7 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
         const long long wp_layers = (long long)e->P.weight_bytes - 2ll * e->P.head_n * m.p_d_model;
         const long long head1 = 2ll * m.codebook_size * m.p_d_model, pj = 2ll * m.p_d_model * m.d_embed;
         const long long kv_per_tok = 2ll * m.t_n_layer * 2 * m.t_n_kv_head * m.t_head_dim;
-        const long long fixed = wt + (m.n_codebooks - 1) * (wp_layers + head1) + m.n_codebooks * pj;
+        const long long fixed = wt + (m.n_codebooks - 1) * (wp_layers + head1) + pj;  // one projection GEMM per frame (hidden rows); codes come pre-projected
         e->tm.algo_bytes_per_step = fixed + (steps ? kv_per_tok * (ctx_tokens / steps) : 0);
         e->tm.mean_live_slots = steps ? (float)((double)live_slot_steps / (double)steps) : 0.0f;
         e->tm.algo_flops_per_step = (long long)((double)fixed * (double)e->tm.mean_live_slots);  // 2 flop per bf16 weight (2 bytes) per live row

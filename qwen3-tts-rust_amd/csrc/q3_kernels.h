@@ -70,22 +70,26 @@ void q3_launch_sample(const Q3Sample& a, hipStream_t s);
 void q3_launch_sample_rows(const float* logits, int n, int ld, int limit, float temperature, int top_k, float top_p,
                            const float* r, int* out, hipStream_t s);
 
-// predictor input of pass A: X[2b] = rmsnorm(xT[b]) ; X[2b+1] = codec0[code0] ; fb[b] = 0 + codec0[code0]
+// predictor input of pass A: X[b] = rmsnorm(xT[b]) (projected by a GEMM into px[2b]); px[2b+1] = proj(codec0[code0]) taken
+// from the pre-projected table (row-independent exact GEMM: the table row IS what projecting on the fly gives);
+// fb[b] = 0 + codec0[code0]
 struct Q3PredInput {
     const float* xT; const float* out_norm; float eps; int d;
     const float* codec0; int codec0_rows;
-    const Q3Slot* slots; const int* row_slot; float* X; float* fb; int B;
+    const float* pproj0; const float* proj_b; int dp;  // proj(codec0) table [codec0_rows][dp]; bias = proj(0)
+    const Q3Slot* slots; const int* row_slot; float* X; float* px; float* fb; int B;
 };
 void q3_launch_pred_input(const Q3PredInput& a, hipStream_t s);
 
-// after pass q-1: code_q from the argmax key, record it, fb += codec_q[code_q]; q<ncb-1: X[b] = emb;
+// after pass q-1: code_q from the argmax key, record it, fb += codec_q[code_q]; q<ncb-1: px[b] = projected emb;
 // last: fb += tts_pad -> xT[b], row_pos_t[b] = cur_pos++, n_frames++
 struct Q3PredNext {
     const unsigned long long* keys; int q; int ncb;
     const float* codec_q; int rows_q; int d;
     Q3Slot* slots; const int* row_slot; int B;
     int* codes; int max_steps_cap;
-    float* fb; float* X; const float* tts_pad; float* xT; int* row_pos_t;
+    float* fb; const float* tts_pad; float* xT; int* row_pos_t;
+    const float* pproj_q; const float* proj_b; int dp; float* px;  // q < ncb-1: px[b] = proj(codec_q[code]) from the table
 };
 void q3_launch_pred_next(const Q3PredNext& a, hipStream_t s);
 

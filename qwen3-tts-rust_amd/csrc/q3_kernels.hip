@@ -465,11 +465,12 @@ __global__ __launch_bounds__(256) void k_pred_input(Q3PredInput a) {
     const bool ok = code0 >= 0 && code0 < a.codec0_rows;  // OOB rows embed as zeros: src/assets_manager.rs:419-437
     const float* e = a.codec0 + (size_t)(ok ? code0 : 0) * d;
     for (int i = tid; i < d; i += 256) {
-        a.X[(size_t)(2 * b) * d + i] = (x[i] * rinv) * a.out_norm[i];
+        a.X[(size_t)b * d + i] = (x[i] * rinv) * a.out_norm[i];
         const float ev = ok ? e[i] : 0.0f;
-        a.X[(size_t)(2 * b + 1) * d + i] = ev;
         a.fb[(size_t)b * d + i] = 0.0f + ev;
     }
+    const float* pr = ok ? a.pproj0 + (size_t)code0 * a.dp : a.proj_b;  // proj(0) = bias
+    for (int i = tid; i < a.dp; i += 256) a.px[(size_t)(2 * b + 1) * a.dp + i] = pr[i];
 }
 void q3_launch_pred_input(const Q3PredInput& a, hipStream_t s) { hipLaunchKernelGGL(k_pred_input, dim3(a.B), dim3(256), 0, s, a); }
 
@@ -489,8 +490,12 @@ __global__ __launch_bounds__(256) void k_pred_next(Q3PredNext a) {
     for (int i = tid; i < d; i += 256) {
         const float ev = ok ? e[i] : 0.0f;
         float f = a.fb[(size_t)b * d + i] + ev;
-        if (!last) { a.X[(size_t)b * d + i] = ev; a.fb[(size_t)b * d + i] = f; }
+        if (!last) a.fb[(size_t)b * d + i] = f;
         else { f = f + a.tts_pad[i]; a.xT[(size_t)b * d + i] = f; }
+    }
+    if (!last) {
+        const float* pr = ok ? a.pproj_q + (size_t)code * a.dp : a.proj_b;
+        for (int i = tid; i < a.dp; i += 256) a.px[(size_t)b * a.dp + i] = pr[i];
     }
     if (last) {
         __syncthreads();
