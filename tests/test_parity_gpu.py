@@ -464,3 +464,21 @@ def test_mel_matches_oracle(oracle, tiny, n):
     if n >= 256:
         # same DFT / filterbank order on both sides: only the final logf (device vs libm) may differ in the last place
         assert np.abs(got - ref).max() <= 4e-6, float(np.abs(got - ref).max())
+
+
+def test_probe_mode_is_transparent(oracle, tiny):
+    """q3tts_k_probe (bench.py's in-situ kernel timer): eager frame steps with event brackets give the same ids as graph
+    replay and report a positive mean duration for the probed launches."""
+    cfg, eng, om = tiny
+    desc, keep = oracle.make_prompt_desc(np.arange(70, 80), spk_emb=_spk(cfg.model.d_embed))
+    reqs = [dict(desc=desc, temperature=0.7, seed=40 + i, max_steps=12, min_frames=8, force_eos_at=8) for i in range(4)]
+    ref = [o.codes for o in eng.generate_batch(reqs)]
+    eng.probe(True)
+    try:
+        outs = eng.generate_batch(reqs)
+        tm = eng.timings()
+    finally:
+        eng.probe(False)
+    assert all(np.array_equal(o.codes, r) for o, r in zip(outs, ref))
+    assert tm.probe_count > 0 and tm.probe_kernel_ms > 0 and tm.probe_empty_ms > 0
+    assert all(np.array_equal(o.codes, r) for o, r in zip(eng.generate_batch(reqs), ref))
