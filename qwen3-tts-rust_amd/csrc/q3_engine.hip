@@ -824,6 +824,40 @@ static double now_ms() {
 
 struct SlotRun { int req = -1; int voc_frames = 0; double t_first = 0; };
 
+// Pinned result buffers are recycled through a small process-wide pool: hipHostMalloc / hipHostFree cost ~0.3 ms each, and a
+// batch hands out one PCM buffer per utterance. A 64-byte header in front of the payload remembers the capacity.
+#include <mutex>
+namespace {
+struct PinHdr { size_t cap; size_t magic; };
+std::mutex g_pin_mu;
+std::vector<PinHdr*> g_pin_pool;
+size_t g_pin_bytes = 0;
+float* pin_alloc(size_t bytes) {
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        for (size_t i = 0; i < g_pin_pool.size(); ++i)
+            if (g_pin_pool[i]->cap >= bytes && g_pin_pool[i]->cap <= 2 * bytes + 4096) {
+                PinHdr* h = g_pin_pool[i];
+                g_pin_pool[i] = g_pin_pool.back(); g_pin_pool.pop_back(); g_pin_bytes -= h->cap;
+                return (float*)((char*)h + 64);
+            }
+    }
+    void* p = nullptr;
+    const size_t cap = (bytes + 65535) & ~(size_t)65535;
+    if (hipHostMalloc(&p, cap + 64, hipHostMallocDefault) != hipSuccess) return nullptr;
+    PinHdr* h = (PinHdr*)p; h->cap = cap; h->magic = 0x5133505043ull;
+    return (float*)((char*)p + 64);
+}
+void pin_free(float* q) {
+    if (!q) return;
+    PinHdr* h = (PinHdr*)((char*)q - 64);
+    if (h->magic != 0x5133505043ull) return;  // not ours: leave it alone
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    if (g_pin_pool.size() < 256 && g_pin_bytes + h->cap <= ((size_t)1 << 30)) { g_pin_pool.push_back(h); g_pin_bytes += h->cap; return; }
+    hipHostFree(h);
+}
+}  // namespace
+
 // Results of a finished slot. The codes come back on the decoder stream at once; the PCM (pinned host buffer) is copied
 // on the vocoder stream. With `defer` the call does not wait for the vocoder: the copy is enqueued behind the slot's last
 // vocoder chunk, `fin_ev` is recorded after it and the caller completes the result later (complete_result), so the next
@@ -842,9 +876,8 @@ static int finalize(q3tts_engine* e, int b, const q3tts_request* r, q3tts_result
     if (r->want_pcm && e->voc) {
         const int ns = q3_voc_samples(e, b);
         o->n_samples = ns;
-        void* hp = nullptr;
-        if (hipHostMalloc(&hp, sizeof(float) * (size_t)std::max(1, ns), hipHostMallocDefault) != hipSuccess) return q3_set_err(e, Q3TTS_ERR_OOM, "hipHostMalloc");
-        o->pcm = (float*)hp;
+        o->pcm = pin_alloc(sizeof(float) * (size_t)std::max(1, ns));
+        if (!o->pcm) return q3_set_err(e, Q3TTS_ERR_OOM, "hipHostMalloc");
         if (ns > 0) Q3_HIP(e, hipMemcpyAsync(o->pcm, q3_voc_pcm(e, b), sizeof(float) * (size_t)ns, hipMemcpyDeviceToHost, e->vstream));
         if (defer) Q3_HIP(e, hipEventRecord(fin_ev, e->vstream));
         else Q3_HIP(e, hipStreamSynchronize(e->vstream));
@@ -993,7 +1026,7 @@ extern "C" int q3tts_generate(q3tts_engine* e, const q3tts_request* req, q3tts_r
 extern "C" void q3tts_result_free(q3tts_result* r) {
     if (!r) return;
     free(r->codes);
-    if (r->pcm) hipHostFree(r->pcm);  // pinned: filled by an asynchronous device-to-host copy
+    pin_free(r->pcm);  // pinned (filled by an asynchronous device-to-host copy); goes back to the pool
     r->codes = nullptr; r->pcm = nullptr;
 }
 
