@@ -100,9 +100,10 @@ __device__ __forceinline__ void vepi(const VGemm& g, float v, int s, int t, int 
 // memory latency with MFMA work, so fragments ride an 8-deep register ring (A: 32 B of f32 per lane -> bf16x8,
 // B: 16 B of bf16 per lane per column tile) and the grid is cut fine enough to put a workgroup on every CU.
 #define VS_PF 8
+template <int NJ>  // column tiles per wave: 2 (64 x 32 workgroup tile) or 1 (64 x 16: twice the workgroups for narrow N)
 __global__ __launch_bounds__(256) void k_vgemm_small(VGemm g) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int m0 = blockIdx.y * 64 + wave * 16, n0 = blockIdx.x * 32;
+    const int m0 = blockIdx.y * 64 + wave * 16, n0 = blockIdx.x * (NJ * 16);
     if (m0 >= g.M) return;
     const int lr = lane & 15, kq = lane >> 4;
     const int cin = g.c.cin, nout = g.c.nout, kpt = cin >> 5, steps = g.c.ntap * kpt;
@@ -112,11 +113,13 @@ __global__ __launch_bounds__(256) void k_vgemm_small(VGemm g) {
         const int s = m / g.T, t = m - s * g.T;
         xrow = g.x + (size_t)s * g.x_stride + g.x_off + (size_t)t * cin + kq * 8;
     }
-    const uint16_t* wrow[2];
+    const uint16_t* wrow[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { int n = n0 + j * 16 + lr; if (n >= nout) n = nout - 1; wrow[j] = g.c.w + (size_t)n * cin + kq * 8; }
-    float4 ra[VS_PF][2]; uint4 rb[VS_PF][2];
-    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    for (int j = 0; j < NJ; ++j) { int n = n0 + j * 16 + lr; if (n >= nout) n = nout - 1; wrow[j] = g.c.w + (size_t)n * cin + kq * 8; }
+    float4 ra[VS_PF][2]; uint4 rb[VS_PF][NJ];
+    f32x4 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // (no branch inside the ring: loads past the end re-read the last step and their A fragment is zeroed, so the
     //  compiler can count outstanding loads exactly: vmcnt(28) at each consumption instead of vmcnt(0))
 #define VS_ISSUE(slot_, step_)                                                                        \
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256) void k_vgemm_small(VGemm g) {
         const float* p__ = xrow - (long)(g.c.ntap - 1 - tap__) * g.c.dil * cin + k0__;                \
         ra[slot_][0] = *(const float4*)p__; ra[slot_][1] = *(const float4*)(p__ + 4);                 \
         const size_t wo__ = (size_t)tap__ * nout * cin + k0__;                                        \
-        rb[slot_][0] = *(const uint4*)(wrow[0] + wo__); rb[slot_][1] = *(const uint4*)(wrow[1] + wo__); \
+        _Pragma("unroll") for (int jj__ = 0; jj__ < NJ; ++jj__) rb[slot_][jj__] = *(const uint4*)(wrow[jj__] + wo__); \
     } while (0)
 #pragma unroll
     for (int j = 0; j < VS_PF; ++j) VS_ISSUE(j, j);
@@ -140,13 +143,14 @@ __global__ __launch_bounds__(256) void k_vgemm_small(VGemm g) {
             const float4 v0 = ra[j][0], v1 = ra[j][1];
             a[0] = (__bf16)(v0.x * live); a[1] = (__bf16)(v0.y * live); a[2] = (__bf16)(v0.z * live); a[3] = (__bf16)(v0.w * live);
             a[4] = (__bf16)(v1.x * live); a[5] = (__bf16)(v1.y * live); a[6] = (__bf16)(v1.z * live); a[7] = (__bf16)(v1.w * live);
-            const uint4 u0 = rb[j][0], u1 = rb[j][1];
-            const bf16x8 b0 = *(const bf16x8*)&u0, b1 = *(const bf16x8*)&u1;
+            bf16x8 bfr[NJ];
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) { const uint4 u = rb[j][jj]; bfr[jj] = *(const bf16x8*)&u; }
             __builtin_amdgcn_sched_barrier(0);
             VS_ISSUE(j, step + VS_PF);
             __builtin_amdgcn_sched_barrier(0);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[1], 0, 0, 0);
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[jj], acc[jj], 0, 0, 0);
         }
     }
 #undef VS_ISSUE
@@ -156,15 +160,15 @@ __global__ __launch_bounds__(256) void k_vgemm_small(VGemm g) {
         const int m = m0 + 4 * kq + e;
         if (m >= g.M) continue;
         const int s = m / g.T, t = m - s * g.T;
-        if (g.epi == 4) {  // column tile 0 = gate, tile 1 = the matching up columns (interleaved weight rows)
+        if (NJ == 2 && g.epi == 4) {  // column tile 0 = gate, tile 1 = the matching up columns (interleaved weight rows)
             const int n = blockIdx.x * 16 + lr;
             if (n0 + 16 + lr < nout) {
-                const float gt = acc[0][e], up = acc[1][e];
+                const float gt = acc[0][e], up = acc[NJ - 1][e];
                 g.y[(size_t)s * g.y_stride + g.y_off + (size_t)t * (nout >> 1) + n] = (gt / (1.0f + expf(-gt))) * up;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int n = n0 + j * 16 + lr;
                 if (n < nout) {
                     const float yold = (g.epi == 1 || g.epi == 2) ? g.y[(size_t)s * g.y_stride + g.y_off + (size_t)t * nout + n] : 0.0f;
@@ -812,8 +816,16 @@ static void vgemm(hipStream_t s, const VConv& c, const float* x, size_t x_stride
     if (sk) { g.y2 = sk->y2; g.y2_stride = sk->stride; g.y2_off = sk->off; g.ea = sk->ea; g.ib = sk->ib; g.snake_n = sk->n; }
     // every kernel accumulates the same 32-wide K steps in the same order: the choice never changes a result
     if (g.M <= 512 || epi == 4) {
-        dim3 grid((c.nout + 31) / 32, (g.M + 63) / 64);
-        hipLaunchKernelGGL(k_vgemm_small, grid, dim3(256), 0, s, g);
+        // the kernel is bound by what one CU's load path delivers: a narrow N runs 64 x 16 tiles to put a workgroup on
+        // every CU instead of on half of them
+        const long wg32 = (long)((c.nout + 31) / 32) * ((g.M + 63) / 64);
+        if (epi != 4 && wg32 < 256) {
+            dim3 grid((c.nout + 15) / 16, (g.M + 63) / 64);
+            hipLaunchKernelGGL((k_vgemm_small<1>), grid, dim3(256), 0, s, g);
+        } else {
+            dim3 grid((c.nout + 31) / 32, (g.M + 63) / 64);
+            hipLaunchKernelGGL((k_vgemm_small<2>), grid, dim3(256), 0, s, g);
+        }
     } else if (c.nout % 128 != 0 && c.nout % 96 == 0) {
         dim3 grid(c.nout / 96, (g.M + 127) / 128);
         hipLaunchKernelGGL((k_vgemm_lds<3>), grid, dim3(256), 0, s, g);
