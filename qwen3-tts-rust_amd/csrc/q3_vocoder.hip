@@ -54,7 +54,7 @@ struct Q3Voc {
     std::vector<VBlk> Bk;
     float *oea = nullptr, *oib = nullptr, *out_w = nullptr, *out_b = nullptr; VBuf out_in; int out_c = 0;
     float *kring = nullptr, *vring = nullptr;  // [n_layer][B][RW][HH]
-    float *x = nullptr, *xn = nullptr, *qkv = nullptr, *att = nullptr, *g = nullptr;  // transformer scratch [M][.]
+    float *x = nullptr, *xn = nullptr, *xnb = nullptr, *qkv = nullptr, *att = nullptr, *g = nullptr;  // transformer scratch [M][.] (xnb, att, g: bf16)
     float *t1 = nullptr, *t2 = nullptr;  // generic scratch (largest stage)
     float* pcm = nullptr; size_t pcm_stride = 0;         // [B][max_steps_cap * spf]
     std::vector<int> frames_done, last_flag;
@@ -73,6 +73,8 @@ struct VGemm {
     int scale_n;
     int epi;                                      // 0 store, 1 y += scale*(.), 2 y += (.), 3 gelu, 4 swiglu (16-column tiles alternate gate / up)
     int store;                                    // 0: the primary output is not written (only y2 is wanted)
+    int a_bf16;                                   // x holds bf16 (the value a f32 source would be rounded to anyway); strides in elements
+    int y_bf16;                                   // epi 4 only: write the SwiGLU result as bf16 (it only ever feeds a GEMM)
     float* y2; size_t y2_stride; int y2_off;      // optional second output: SnakeBeta(v) with the NEXT layer's parameters,
     const float *ea, *ib; int snake_n;            //   written straight into that layer's conv-input work buffer
 };
@@ -100,23 +102,25 @@ __device__ __forceinline__ void vepi(const VGemm& g, float v, int s, int t, int 
 // memory latency with MFMA work, so fragments ride an 8-deep register ring (A: 32 B of f32 per lane -> bf16x8,
 // B: 16 B of bf16 per lane per column tile) and the grid is cut fine enough to put a workgroup on every CU.
 #define VS_PF 8
-template <int NJ>  // column tiles per wave: 2 (64 x 32 workgroup tile) or 1 (64 x 16: twice the workgroups for narrow N)
+template <int NJ, bool ABF>  // NJ column tiles per wave: 2 (64 x 32 workgroup tile) or 1 (64 x 16: twice the workgroups for
+                              // narrow N); ABF: the A operand is stored as bf16 (half the bytes, no conversion)
 __global__ __launch_bounds__(256) void k_vgemm_small(VGemm g) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int m0 = blockIdx.y * 64 + wave * 16, n0 = blockIdx.x * (NJ * 16);
     if (m0 >= g.M) return;
     const int lr = lane & 15, kq = lane >> 4;
     const int cin = g.c.cin, nout = g.c.nout, kpt = cin >> 5, steps = g.c.ntap * kpt;
-    const float* xrow;
+    const float* xrow; const uint16_t* xrow16;
     {
         int m = m0 + lr; if (m >= g.M) m = g.M - 1;
         const int s = m / g.T, t = m - s * g.T;
-        xrow = g.x + (size_t)s * g.x_stride + g.x_off + (size_t)t * cin + kq * 8;
+        const size_t eo = (size_t)s * g.x_stride + g.x_off + (size_t)t * cin + kq * 8;
+        xrow = g.x + eo; xrow16 = (const uint16_t*)g.x + eo;
     }
     const uint16_t* wrow[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) { int n = n0 + j * 16 + lr; if (n >= nout) n = nout - 1; wrow[j] = g.c.w + (size_t)n * cin + kq * 8; }
-    float4 ra[VS_PF][2]; uint4 rb[VS_PF][NJ];
+    float4 ra[VS_PF][ABF ? 1 : 2]; uint4 rb[VS_PF][NJ];
     f32x4 acc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -126,8 +130,9 @@ __global__ __launch_bounds__(256) void k_vgemm_small(VGemm g) {
     do {                                                                                              \
         const int st__ = min((step_), steps - 1);                                                     \
         const int tap__ = st__ / kpt, k0__ = (st__ - tap__ * kpt) << 5;                               \
-        const float* p__ = xrow - (long)(g.c.ntap - 1 - tap__) * g.c.dil * cin + k0__;                \
-        ra[slot_][0] = *(const float4*)p__; ra[slot_][1] = *(const float4*)(p__ + 4);                 \
+        const long sh__ = (long)(g.c.ntap - 1 - tap__) * g.c.dil * cin - k0__;                          \
+        if (ABF) ra[slot_][0] = *(const float4*)(xrow16 - sh__);                                      \
+        else { ra[slot_][0] = *(const float4*)(xrow - sh__); ra[slot_][ABF ? 0 : 1] = *(const float4*)(xrow - sh__ + 4); } \
         const size_t wo__ = (size_t)tap__ * nout * cin + k0__;                                        \
         _Pragma("unroll") for (int jj__ = 0; jj__ < NJ; ++jj__) rb[slot_][jj__] = *(const uint4*)(wrow[jj__] + wo__); \
     } while (0)
@@ -140,9 +145,15 @@ __global__ __launch_bounds__(256) void k_vgemm_small(VGemm g) {
             const int step = s0 + j;
             const float live = step < steps ? 1.0f : 0.0f;
             bf16x8 a;
-            const float4 v0 = ra[j][0], v1 = ra[j][1];
-            a[0] = (__bf16)(v0.x * live); a[1] = (__bf16)(v0.y * live); a[2] = (__bf16)(v0.z * live); a[3] = (__bf16)(v0.w * live);
-            a[4] = (__bf16)(v1.x * live); a[5] = (__bf16)(v1.y * live); a[6] = (__bf16)(v1.z * live); a[7] = (__bf16)(v1.w * live);
+            if (ABF) {  // 8 bf16 as they are; a step past the end contributes zeros
+                float4 v0 = ra[j][0];
+                if (step >= steps) v0 = make_float4(0.f, 0.f, 0.f, 0.f);
+                a = *(const bf16x8*)&v0;
+            } else {
+                const float4 v0 = ra[j][0], v1 = ra[j][ABF ? 0 : 1];
+                a[0] = (__bf16)(v0.x * live); a[1] = (__bf16)(v0.y * live); a[2] = (__bf16)(v0.z * live); a[3] = (__bf16)(v0.w * live);
+                a[4] = (__bf16)(v1.x * live); a[5] = (__bf16)(v1.y * live); a[6] = (__bf16)(v1.z * live); a[7] = (__bf16)(v1.w * live);
+            }
             bf16x8 bfr[NJ];
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj) { const uint4 u = rb[j][jj]; bfr[jj] = *(const bf16x8*)&u; }
@@ -164,7 +175,9 @@ __global__ __launch_bounds__(256) void k_vgemm_small(VGemm g) {
             const int n = blockIdx.x * 16 + lr;
             if (n0 + 16 + lr < nout) {
                 const float gt = acc[0][e], up = acc[NJ - 1][e];
-                g.y[(size_t)s * g.y_stride + g.y_off + (size_t)t * (nout >> 1) + n] = (gt / (1.0f + expf(-gt))) * up;
+                const float sv = (gt / (1.0f + expf(-gt))) * up;
+                const size_t yo = (size_t)s * g.y_stride + g.y_off + (size_t)t * (nout >> 1) + n;
+                if (g.y_bf16) ((__bf16*)g.y)[yo] = (__bf16)sv; else g.y[yo] = sv;
             }
         } else {
 #pragma unroll
@@ -459,7 +472,7 @@ __global__ void k_voc_hist(VCall cl, float* work, size_t stride, float* hist, in
     }
 }
 
-__global__ __launch_bounds__(64) void k_voc_rmsnorm(const float* x, const float* w, float eps, int d, float* y) {
+__global__ __launch_bounds__(64) void k_voc_rmsnorm(const float* x, const float* w, float eps, int d, float* y, int out_bf16) {
     const int r = blockIdx.x, lane = threadIdx.x;
     const float* xr = x + (size_t)r * d;
     float ss = 0.0f;
@@ -478,7 +491,11 @@ __global__ __launch_bounds__(64) void k_voc_rmsnorm(const float* x, const float*
 #pragma unroll
         for (int u = 0; u < 8; ++u) { const int i = min(i0 + u * 64, d - 1); v[u] = xr[i]; wv[u] = w[i]; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) if (i0 + u * 64 < d) y[(size_t)r * d + i0 + u * 64] = (v[u] * rinv) * wv[u];
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * 64 < d) {
+                const float o = (v[u] * rinv) * wv[u];
+                if (out_bf16) ((__bf16*)y)[(size_t)r * d + i0 + u * 64] = (__bf16)o; else y[(size_t)r * d + i0 + u * 64] = o;
+            }
     }
 }
 
@@ -546,7 +563,7 @@ __global__ __launch_bounds__(64) void k_voc_attn(VCall cl, const float* qkv, flo
                 for (int u = 0; u < 8; ++u)
                     if (jb + u < nk) o += sc[jb + u] * vv[u];
             }
-            att[row + i] = o / l;
+            ((__bf16*)att)[row + i] = (__bf16)(o / l);  // only ever the A operand of the output projection
         }
         __syncthreads();
     }
@@ -770,7 +787,7 @@ int q3_voc_create(q3tts_engine* e) {
     VTRY(mk_buf(e, v, &v->out_in, 6, ch, rows));
     // transformer scratch [VOC_MAX_NS * VOC_FCAP][.]
     const size_t M = (size_t)VOC_MAX_NS * VOC_FCAP;
-    VTRY(valloc(e, v, &v->x, M * d)); VTRY(valloc(e, v, &v->xn, M * d)); VTRY(valloc(e, v, &v->qkv, M * 3 * HH));
+    VTRY(valloc(e, v, &v->x, M * d)); VTRY(valloc(e, v, &v->xn, M * d)); VTRY(valloc(e, v, &v->xnb, M * d)); VTRY(valloc(e, v, &v->qkv, M * 3 * HH));
     VTRY(valloc(e, v, &v->att, M * HH)); VTRY(valloc(e, v, &v->g, M * c.d_ffn));
     VTRY(valloc(e, v, &v->kring, (size_t)c.n_layer * v->B * v->RW * HH)); VTRY(valloc(e, v, &v->vring, (size_t)c.n_layer * v->B * v->RW * HH));
     VTRY(valloc(e, v, &v->t1, (size_t)VOC_MAX_NS * scratch)); VTRY(valloc(e, v, &v->t2, (size_t)VOC_MAX_NS * scratch));
@@ -809,9 +826,9 @@ static VSnake snake_into(const VBuf& dst, const float* ea, const float* ib, int 
     VSnake k; k.y2 = dst.p; k.stride = dst.stride(); k.off = dst.H * dst.C; k.ea = ea; k.ib = ib; k.n = C; return k;
 }
 static void vgemm(hipStream_t s, const VConv& c, const float* x, size_t x_stride, int x_off, int ns, int T, float* y, size_t y_stride, int y_off,
-                  int epi = 0, const float* scale = nullptr, int scale_n = 1, const VSnake* sk = nullptr, int store = 1) {
+                  int epi = 0, const float* scale = nullptr, int scale_n = 1, const VSnake* sk = nullptr, int store = 1, int a_bf16 = 0, int y_bf16 = 0) {
     VGemm g; g.x = x; g.x_stride = x_stride; g.x_off = x_off; g.T = T; g.M = ns * T; g.c = c; g.y = y; g.y_stride = y_stride; g.y_off = y_off;
-    g.scale = scale; g.scale_n = scale_n; g.epi = epi; g.store = store;
+    g.scale = scale; g.scale_n = scale_n; g.epi = epi; g.store = store; g.a_bf16 = a_bf16; g.y_bf16 = y_bf16;
     g.y2 = nullptr; g.y2_stride = 0; g.y2_off = 0; g.ea = g.ib = nullptr; g.snake_n = 1;
     if (sk) { g.y2 = sk->y2; g.y2_stride = sk->stride; g.y2_off = sk->off; g.ea = sk->ea; g.ib = sk->ib; g.snake_n = sk->n; }
     // every kernel accumulates the same 32-wide K steps in the same order: the choice never changes a result
@@ -821,10 +838,12 @@ static void vgemm(hipStream_t s, const VConv& c, const float* x, size_t x_stride
         const long wg32 = (long)((c.nout + 31) / 32) * ((g.M + 63) / 64);
         if (epi != 4 && wg32 < 256) {
             dim3 grid((c.nout + 15) / 16, (g.M + 63) / 64);
-            hipLaunchKernelGGL((k_vgemm_small<1>), grid, dim3(256), 0, s, g);
+            if (a_bf16) hipLaunchKernelGGL((k_vgemm_small<1, true>), grid, dim3(256), 0, s, g);
+            else hipLaunchKernelGGL((k_vgemm_small<1, false>), grid, dim3(256), 0, s, g);
         } else {
             dim3 grid((c.nout + 31) / 32, (g.M + 63) / 64);
-            hipLaunchKernelGGL((k_vgemm_small<2>), grid, dim3(256), 0, s, g);
+            if (a_bf16) hipLaunchKernelGGL((k_vgemm_small<2, true>), grid, dim3(256), 0, s, g);
+            else hipLaunchKernelGGL((k_vgemm_small<2, false>), grid, dim3(256), 0, s, g);
         }
     } else if (c.nout % 128 != 0 && c.nout % 96 == 0) {
         dim3 grid(c.nout / 96, (g.M + 127) / 128);
@@ -880,16 +899,17 @@ static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
     // V3 transformer (rows m = s*nf + t)
     for (int l = 0; l < c.n_layer; ++l) {
         VLayer& L = v->L[l];
-        hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, L.in_norm, c.rms_eps, d, v->xn);
-        vgemm(s, L.qkv, v->xn, 0, 0, 1, M, v->qkv, 0, 0);
+        // GEMM-only activations (normed input, attention output, SwiGLU output) are stored as the bf16 they would be rounded to
+        hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, L.in_norm, c.rms_eps, d, v->xnb, 1);
+        vgemm(s, L.qkv, v->xnb, 0, 0, 1, M, v->qkv, 0, 0, 0, nullptr, 1, nullptr, 1, 1);
         hipLaunchKernelGGL(k_voc_attn, dim3(c.n_head, ns), dim3(64), 0, s, cl, v->qkv, v->kring + (size_t)l * v->B * v->RW * HH,
                            v->vring + (size_t)l * v->B * v->RW * HH, c.n_head, c.head_dim, v->RW, c.sliding_window, c.rope_theta, v->att);
-        vgemm(s, L.o, v->att, 0, 0, 1, M, v->x, 0, 0, 1, L.ls_attn, d);
-        hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, L.post_norm, c.rms_eps, d, v->xn);
-        vgemm(s, L.gu, v->xn, 0, 0, 1, M, v->g, 0, 0, 4);  // gate | up in one launch, SwiGLU in the epilogue
-        vgemm(s, L.down, v->g, 0, 0, 1, M, v->x, 0, 0, 1, L.ls_mlp, d);
+        vgemm(s, L.o, v->att, 0, 0, 1, M, v->x, 0, 0, 1, L.ls_attn, d, nullptr, 1, 1);
+        hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, L.post_norm, c.rms_eps, d, v->xnb, 1);
+        vgemm(s, L.gu, v->xnb, 0, 0, 1, M, v->g, 0, 0, 4, nullptr, 1, nullptr, 1, 1, 1);  // gate | up in one launch, SwiGLU in the epilogue
+        vgemm(s, L.down, v->g, 0, 0, 1, M, v->x, 0, 0, 1, L.ls_mlp, d, nullptr, 1, 1);
     }
-    hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, v->final_norm, c.rms_eps, d, v->xn);
+    hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, v->final_norm, c.rms_eps, d, v->xn, 0);
     // V5a upsample stages; cur = [ns][T][d] contiguous per slot (stride T*d)
     const float* cur = v->xn; int T = nf; size_t cur_stride = (size_t)nf * d; int cur_off = 0;
     for (auto& p : v->U) {
