@@ -35,7 +35,8 @@ struct VCall {  // passed by value to the kernels of one batched call
 
 struct VConv { int ntap = 1, dil = 1, cin = 0, nout = 0, bias_n = 0; uint16_t* w = nullptr; float* b = nullptr; };
 // work buffer of a conv input: [VOC_MAX_NS][H + Tcap][C] (slot-major) + per-slot history [B][H][C]
-struct VBuf { float* p = nullptr; float* hist = nullptr; int H = 0, C = 0, Tcap = 0; size_t stride() const { return (size_t)(H + Tcap) * C; } };
+struct VBuf { float* p = nullptr; float* hist = nullptr; int H = 0, C = 0, Tcap = 0; int bf16 = 0;  // bf16: elements are bf16 (GEMM-only inputs)
+              size_t stride() const { return (size_t)(H + Tcap) * C; } };  // in elements
 
 struct VLayer { float *in_norm, *post_norm, *ls_attn, *ls_mlp; VConv q, k, v, o, gate, up, down;
                 VConv qkv, gu; };  // fused launches: qkv = rows of q | k | v; gu = 16-row groups of gate and up alternating
@@ -77,6 +78,7 @@ struct VGemm {
     int y_bf16;                                   // epi 4 only: write the SwiGLU result as bf16 (it only ever feeds a GEMM)
     float* y2; size_t y2_stride; int y2_off;      // optional second output: SnakeBeta(v) with the NEXT layer's parameters,
     const float *ea, *ib; int snake_n;            //   written straight into that layer's conv-input work buffer
+    int y2_bf16;                                  //   ... which holds bf16 when it only ever feeds GEMMs
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -93,7 +95,9 @@ __device__ __forceinline__ void vepi(const VGemm& g, float v, int s, int t, int 
     if (g.y2) {
         const int c = n % g.snake_n;
         const float sn = __sinf(v * g.ea[c]);
-        g.y2[(size_t)s * g.y2_stride + g.y2_off + (size_t)t * nout + n] = v + g.ib[c] * (sn * sn);
+        const float sv = v + g.ib[c] * (sn * sn);
+        const size_t o2 = (size_t)s * g.y2_stride + g.y2_off + (size_t)t * nout + n;
+        if (g.y2_bf16) ((__bf16*)g.y2)[o2] = (__bf16)sv; else g.y2[o2] = sv;
     }
 }
 
@@ -199,8 +203,10 @@ __global__ __launch_bounds__(256) void k_vgemm_small(VGemm g) {
 // that the 16 lanes of a ds_read_b128 group hit 16 distinct 4-bank slots. Conv taps are just extra K steps with a
 // shifted row pointer.
 #define VT_LD 40
-struct VStage { float4 a0, a1, a2, a3; uint4 b0, b1; float live; };
-template <int NJ>
+template <bool ABF> struct VStage;  // one K step of staging registers (only the fields a variant uses: a union-style struct spills)
+template <> struct VStage<false> { float4 a0, a1, a2, a3; uint4 b0, b1; float live; };
+template <> struct VStage<true> { uint4 ab0, ab1; uint4 b0, b1; float live; };
+template <int NJ, bool ABF>
 __global__ __launch_bounds__(256) void k_vgemm_lds(VGemm g) {
     constexpr int BN = NJ * 32;
     __shared__ __attribute__((aligned(16))) __bf16 As[2][128 * VT_LD];
@@ -211,31 +217,39 @@ __global__ __launch_bounds__(256) void k_vgemm_lds(VGemm g) {
     const int cin = g.c.cin, nout = g.c.nout, kpt = cin >> 5, steps = g.c.ntap * kpt;
     const int ldr = tid >> 1, half = tid & 1;  // loader: row/col ldr, 16 k-elements at half*16
     const bool bload = ldr < BN;
-    const float* xrow;
+    const float* xrow; const uint16_t* xrow16;
     {
         int m = m0 + ldr; if (m >= g.M) m = g.M - 1;
         const int s = m / g.T, t = m - s * g.T;
-        xrow = g.x + (size_t)s * g.x_stride + g.x_off + (size_t)t * cin + half * 16;
+        const size_t eo = (size_t)s * g.x_stride + g.x_off + (size_t)t * cin + half * 16;
+        xrow = g.x + eo; xrow16 = (const uint16_t*)g.x + eo;
     }
     const uint16_t* wrow;
     { int n = n0 + ldr; if (n >= nout) n = nout - 1; wrow = g.c.w + (size_t)n * cin + half * 16; }
-    auto gload = [&](VStage& r, int step_) {  // steps past the end re-read the last tile; their A part is zeroed
+    auto gload = [&](VStage<ABF>& r, int step_) {  // steps past the end re-read the last tile; their A part is zeroed
         const int step = min(step_, steps - 1);
         const int tap = step / kpt, k0 = (step - tap * kpt) << 5;
-        const float* p = xrow - (long)(g.c.ntap - 1 - tap) * g.c.dil * cin + k0;
-        r.a0 = ((const float4*)p)[0]; r.a1 = ((const float4*)p)[1]; r.a2 = ((const float4*)p)[2]; r.a3 = ((const float4*)p)[3];
+        const long sh = (long)(g.c.ntap - 1 - tap) * g.c.dil * cin - k0;
+        if constexpr (ABF) { const uint4* p = (const uint4*)(xrow16 - sh); r.ab0 = p[0]; r.ab1 = p[1]; }
+        else { const float* p = xrow - sh; r.a0 = ((const float4*)p)[0]; r.a1 = ((const float4*)p)[1]; r.a2 = ((const float4*)p)[2]; r.a3 = ((const float4*)p)[3]; }
         if (bload) { const uint16_t* q = wrow + (size_t)tap * nout * cin + k0; r.b0 = ((const uint4*)q)[0]; r.b1 = ((const uint4*)q)[1]; }
         r.live = step_ < steps ? 1.0f : 0.0f;
     };
-    auto sstore = [&](const VStage& r, int buf) {
-        bf16x8 lo, hi;
+    auto sstore = [&](const VStage<ABF>& r, int buf) {
         const float lv = r.live;
-        lo[0] = (__bf16)(r.a0.x * lv); lo[1] = (__bf16)(r.a0.y * lv); lo[2] = (__bf16)(r.a0.z * lv); lo[3] = (__bf16)(r.a0.w * lv);
-        lo[4] = (__bf16)(r.a1.x * lv); lo[5] = (__bf16)(r.a1.y * lv); lo[6] = (__bf16)(r.a1.z * lv); lo[7] = (__bf16)(r.a1.w * lv);
-        hi[0] = (__bf16)(r.a2.x * lv); hi[1] = (__bf16)(r.a2.y * lv); hi[2] = (__bf16)(r.a2.z * lv); hi[3] = (__bf16)(r.a2.w * lv);
-        hi[4] = (__bf16)(r.a3.x * lv); hi[5] = (__bf16)(r.a3.y * lv); hi[6] = (__bf16)(r.a3.z * lv); hi[7] = (__bf16)(r.a3.w * lv);
         __bf16* ap = &As[buf][ldr * VT_LD + half * 16];
-        *(bf16x8*)ap = lo; *(bf16x8*)(ap + 8) = hi;
+        if constexpr (ABF) {
+            uint4 z0 = r.ab0, z1 = r.ab1;
+            if (lv == 0.0f) { z0 = make_uint4(0, 0, 0, 0); z1 = z0; }
+            *(uint4*)ap = z0; *(uint4*)(ap + 8) = z1;
+        } else {
+            bf16x8 lo, hi;
+            lo[0] = (__bf16)(r.a0.x * lv); lo[1] = (__bf16)(r.a0.y * lv); lo[2] = (__bf16)(r.a0.z * lv); lo[3] = (__bf16)(r.a0.w * lv);
+            lo[4] = (__bf16)(r.a1.x * lv); lo[5] = (__bf16)(r.a1.y * lv); lo[6] = (__bf16)(r.a1.z * lv); lo[7] = (__bf16)(r.a1.w * lv);
+            hi[0] = (__bf16)(r.a2.x * lv); hi[1] = (__bf16)(r.a2.y * lv); hi[2] = (__bf16)(r.a2.z * lv); hi[3] = (__bf16)(r.a2.w * lv);
+            hi[4] = (__bf16)(r.a3.x * lv); hi[5] = (__bf16)(r.a3.y * lv); hi[6] = (__bf16)(r.a3.z * lv); hi[7] = (__bf16)(r.a3.w * lv);
+            *(bf16x8*)ap = lo; *(bf16x8*)(ap + 8) = hi;
+        }
         if (bload) { uint4* bp = (uint4*)&Bs[buf][ldr * VT_LD + half * 16]; bp[0] = r.b0; bp[1] = r.b1; }
     };
     f32x4 acc[4][NJ];
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(256) void k_vgemm_lds(VGemm g) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a__[i], b__[j], acc[i][j], 0, 0, 0);              \
     } while (0)
     // at the top of step k: LDS[k & 1] holds tile k, R0/R1 (alternating) hold tiles k+1 and k+2
-    VStage R0, R1;
+    VStage<ABF> R0, R1;
     gload(R0, 0); sstore(R0, 0);
     gload(R0, 1);
     gload(R1, 2);
@@ -304,12 +318,12 @@ __global__ __launch_bounds__(256) void k_vgemm_lds(VGemm g) {
 // read/write o, write next_in: the un-fused chain moved the activations three more times. Arithmetic per output element
 // is the same as k_vgemm_lds + vepi (32-wide K steps in order, bf16 operands, f32 accumulate).
 struct VResUnit {
-    const float* xin; size_t xin_stride;  // work buffer [H + T][C] per slot, H = 6*dil history rows in front
+    const float* xin; size_t xin_stride;  // bf16 work buffer [H + T][C] per slot (stride in elements), H = 6*dil history rows in front
     int T, dil;
     const uint16_t *w1, *w2; const float *b1, *b2;  // conv k7 [7][C][C], conv k1 [C][C]
     const float *ea2, *ib2;               // snake between the convolutions
     float* o; size_t o_stride; int store_o;
-    float* y2; size_t y2_stride; int y2_off; const float *ea3, *ib3;  // snake of the consumer, written into its work buffer
+    float* y2; size_t y2_stride; int y2_off; const float *ea3, *ib3;  // snake of the consumer, written (bf16) into its work buffer
 };
 template <int NT, int MT>
 __global__ __launch_bounds__(256) void k_voc_resunit(VResUnit g) {
@@ -344,14 +358,14 @@ __global__ __launch_bounds__(256) void k_voc_resunit(VResUnit g) {
     VR_GLOADB(0);
     // stage the input rows (f32 -> bf16), rows past T are zero
     {
-        const float* xp = g.xin + (size_t)sidx * g.xin_stride + (size_t)t0 * C;  // buffer row t0 = output row t0 - halo
+        const uint16_t* xp = (const uint16_t*)g.xin + (size_t)sidx * g.xin_stride + (size_t)t0 * C;  // buffer row t0 = output row t0 - halo
         const int nrow = R + halo, c4 = C / 4, total = nrow * c4;
-        for (int base = tid; base < total; base += 8 * 256) {  // 8 loads in flight per thread, then convert + store
-            float4 v[8];
+        for (int base = tid; base < total; base += 8 * 256) {  // 8 loads (4 bf16 channels each) in flight per thread
+            uint2 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = min(base + u * 256, total - 1), r = i / c4, c = (i - r * c4) * 4;
-                v[u] = *(const float4*)(xp + (size_t)min(r, T + halo - 1 - t0) * C + c);
+                v[u] = *(const uint2*)(xp + (size_t)min(r, T + halo - 1 - t0) * C + c);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -359,9 +373,7 @@ __global__ __launch_bounds__(256) void k_voc_resunit(VResUnit g) {
                 if (i < total) {
                     const int r = i / c4, c = (i - r * c4) * 4;
                     const bool live = t0 + r < T + halo;
-                    __bf16* d = At + (size_t)r * LDA + c;
-                    d[0] = (__bf16)(live ? v[u].x : 0.f); d[1] = (__bf16)(live ? v[u].y : 0.f);
-                    d[2] = (__bf16)(live ? v[u].z : 0.f); d[3] = (__bf16)(live ? v[u].w : 0.f);
+                    *(uint2*)(At + (size_t)r * LDA + c) = live ? v[u] : make_uint2(0, 0);
                 }
             }
         }
@@ -433,14 +445,14 @@ __global__ __launch_bounds__(256) void k_voc_resunit(VResUnit g) {
             const int t = t0 + wrow0 + i * 16 + 4 * kq + e;
             if (t >= T) continue;
             float* op = g.o + (size_t)sidx * g.o_stride + (size_t)t * C;
-            float* yp = g.y2 + (size_t)sidx * g.y2_stride + g.y2_off + (size_t)t * C;
+            __bf16* yp = (__bf16*)g.y2 + (size_t)sidx * g.y2_stride + g.y2_off + (size_t)t * C;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int n = j * 16 + lr;
                 const float v = ov[i][e][j] + (acc[i][j][e] + g.b2[n]);
                 if (g.store_o) op[n] = v;
                 const float sn = __sinf(v * g.ea3[n]);
-                yp[n] = v + g.ib3[n] * (sn * sn);
+                yp[n] = (__bf16)(v + g.ib3[n] * (sn * sn));
             }
         }
 }
@@ -462,11 +474,12 @@ __global__ void k_voc_embed(VCall cl, const int* codes, int max_steps_cap, int n
 }
 
 // history rows: work[s][0:H] <- hist[slot]  (load)   /   hist[slot] <- work[s][T : T+H]  (save)
-__global__ void k_voc_hist(VCall cl, float* work, size_t stride, float* hist, int H, int C, int T, int save) {
+template <class E>
+__global__ void k_voc_hist(VCall cl, E* work, size_t stride, E* hist, int H, int C, int T, int save) {
     const int s = blockIdx.y, slot = cl.slot[s];
     const size_t n = (size_t)H * C;
-    float* w = work + (size_t)s * stride + (save ? (size_t)T * C : 0);
-    float* h = hist + (size_t)slot * n;
+    E* w = work + (size_t)s * stride + (save ? (size_t)T * C : 0);
+    E* h = hist + (size_t)slot * n;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         if (save) h[i] = w[i]; else w[i] = h[i];
     }
@@ -602,16 +615,16 @@ __global__ __launch_bounds__(256) void k_voc_out(VCall cl, const float* x, size_
     extern __shared__ float sm[];  // win[70][C+1] | wl[7*C]
     const int s = blockIdx.y, slot = cl.slot[s], t0 = blockIdx.x * 64, tid = threadIdx.x, CP = C + 1;
     float* win = sm; float* wl = sm + 70 * CP;
-    const float* xp = x + (size_t)s * x_stride + (size_t)(H + t0 - 6) * C;  // window row 0 = t0 - 6
+    const uint16_t* xp = (const uint16_t*)x + (size_t)s * x_stride + (size_t)(H + t0 - 6) * C;  // window row 0 = t0 - 6 (bf16 buffer)
     const int nrow = min(70, T - t0 + 6);
     for (int i0 = tid; i0 < nrow * C; i0 += 8 * 256) {  // 8 loads in flight per trip
-        float v[8];
+        uint16_t v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = xp[min(i0 + u * 256, nrow * C - 1)];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = i0 + u * 256;
-            if (i < nrow * C) { const int r = i / C, c = i - r * C; win[r * CP + c] = q3_round_bf16(v[u]); }
+            if (i < nrow * C) { const int r = i / C, c = i - r * C; win[r * CP + c] = q3_u2f((uint32_t)v[u] << 16); }
         }
     }
     for (int i = tid; i < 7 * C; i += 256) wl[i] = w[i];
@@ -684,8 +697,8 @@ static int gen_snake(q3tts_engine* e, Q3Voc* v, uint32_t ta, uint32_t tb, int C,
     Q3_HIP(e, hipStreamSynchronize(e->stream));
     return Q3TTS_OK;
 }
-static int mk_buf(q3tts_engine* e, Q3Voc* v, VBuf* b, int H, int C, int Tcap) {
-    b->H = H; b->C = C; b->Tcap = Tcap;
+static int mk_buf(q3tts_engine* e, Q3Voc* v, VBuf* b, int H, int C, int Tcap, int bf16 = 0) {
+    b->H = H; b->C = C; b->Tcap = Tcap; b->bf16 = bf16;
     VTRY(valloc(e, v, &b->p, (size_t)VOC_MAX_NS * b->stride()));
     VTRY(valloc(e, v, &b->hist, (size_t)v->B * std::max(1, H) * C));
     return Q3TTS_OK;
@@ -766,7 +779,7 @@ int q3_voc_create(q3tts_engine* e) {
         VBlk& k = v->Bk[b]; const int comp = VC_BLK + 4 * b, r = c.dec_rates[b]; k.r = r; k.cin = ch; k.cout = ch / 2; v->spf *= r;
         VTRY(gen_snake(e, v, VTID(comp, VW_ALPHA), VTID(comp, VW_BETA), ch, &k.ea, &k.ib));
         VTRY(gen_conv(e, v, &k.ct, comp, VW_W, VW_B, 2, 1, ch, r * k.cout, k.cout, 1.0f));
-        VTRY(mk_buf(e, v, &k.ct_in, 1, ch, rows));
+        VTRY(mk_buf(e, v, &k.ct_in, 1, ch, rows, 1));
         rows *= r;
         scratch = std::max(scratch, (size_t)rows * k.cout);
         const int dil[3] = {1, 3, 9};
@@ -774,7 +787,7 @@ int q3_voc_create(q3tts_engine* e) {
             VRes& s = k.res[u]; const int rc = comp + 1 + u;
             VTRY(gen_snake(e, v, VTID(rc, VW_ALPHA), VTID(rc, VW_BETA), k.cout, &s.ea, &s.ib));
             VTRY(gen_conv(e, v, &s.c1, rc, VW_W, VW_B, 7, dil[u], k.cout, k.cout, k.cout, 0.5f));
-            VTRY(mk_buf(e, v, &s.c1_in, 6 * dil[u], k.cout, rows));
+            VTRY(mk_buf(e, v, &s.c1_in, 6 * dil[u], k.cout, rows, 1));
             VTRY(gen_snake(e, v, VTID(rc, VW_ALPHA2), VTID(rc, VW_BETA2), k.cout, &s.ea2, &s.ib2));
             VTRY(gen_conv(e, v, &s.c2, rc, VW_W2, VW_B2, 1, 1, k.cout, k.cout, k.cout, 0.5f));
         }
@@ -784,7 +797,7 @@ int q3_voc_create(q3tts_engine* e) {
     VTRY(gen_snake(e, v, VTID(VC_OUT, VW_ALPHA), VTID(VC_OUT, VW_BETA), ch, &v->oea, &v->oib));
     VTRY(valloc(e, v, &v->out_w, (size_t)7 * ch)); VTRY(gen_vec(e, v, &v->out_b, VTID(VC_OUT, VW_B), 1, 0.0f, 0.02f));
     q3_launch_fill_f32(v->out_w, (size_t)7 * ch, e->cfg.synth_seed, VTID(VC_OUT, VW_W), 0.0f, (0.1f / sqrtf((float)(7 * ch))) / Q3_IH4_STD, 1, e->stream);
-    VTRY(mk_buf(e, v, &v->out_in, 6, ch, rows));
+    VTRY(mk_buf(e, v, &v->out_in, 6, ch, rows, 1));
     // transformer scratch [VOC_MAX_NS * VOC_FCAP][.]
     const size_t M = (size_t)VOC_MAX_NS * VOC_FCAP;
     VTRY(valloc(e, v, &v->x, M * d)); VTRY(valloc(e, v, &v->xn, M * d)); VTRY(valloc(e, v, &v->xnb, M * d)); VTRY(valloc(e, v, &v->qkv, M * 3 * HH));
@@ -807,7 +820,8 @@ void q3_voc_destroy(q3tts_engine* e) {
 }
 
 static void zero_hist(q3tts_engine* e, VBuf& b, int slot) {
-    if (b.H > 0) hipMemsetAsync(b.hist + (size_t)slot * b.H * b.C, 0, (size_t)b.H * b.C * 4, e->stream);
+    const size_t es = b.bf16 ? 2 : 4;
+    if (b.H > 0) hipMemsetAsync((char*)b.hist + (size_t)slot * b.H * b.C * es, 0, (size_t)b.H * b.C * es, e->stream);
 }
 int q3_voc_reset(q3tts_engine* e, int slot) {
     Q3Voc* v = e->voc;
@@ -821,16 +835,16 @@ int q3_voc_reset(q3tts_engine* e, int slot) {
     return Q3TTS_OK;
 }
 
-struct VSnake { float* y2 = nullptr; size_t stride = 0; int off = 0; const float* ea = nullptr; const float* ib = nullptr; int n = 1; };
+struct VSnake { float* y2 = nullptr; size_t stride = 0; int off = 0; const float* ea = nullptr; const float* ib = nullptr; int n = 1; int bf16 = 0; };
 static VSnake snake_into(const VBuf& dst, const float* ea, const float* ib, int C) {
-    VSnake k; k.y2 = dst.p; k.stride = dst.stride(); k.off = dst.H * dst.C; k.ea = ea; k.ib = ib; k.n = C; return k;
+    VSnake k; k.y2 = dst.p; k.stride = dst.stride(); k.off = dst.H * dst.C; k.ea = ea; k.ib = ib; k.n = C; k.bf16 = dst.bf16; return k;
 }
 static void vgemm(hipStream_t s, const VConv& c, const float* x, size_t x_stride, int x_off, int ns, int T, float* y, size_t y_stride, int y_off,
                   int epi = 0, const float* scale = nullptr, int scale_n = 1, const VSnake* sk = nullptr, int store = 1, int a_bf16 = 0, int y_bf16 = 0) {
     VGemm g; g.x = x; g.x_stride = x_stride; g.x_off = x_off; g.T = T; g.M = ns * T; g.c = c; g.y = y; g.y_stride = y_stride; g.y_off = y_off;
     g.scale = scale; g.scale_n = scale_n; g.epi = epi; g.store = store; g.a_bf16 = a_bf16; g.y_bf16 = y_bf16;
-    g.y2 = nullptr; g.y2_stride = 0; g.y2_off = 0; g.ea = g.ib = nullptr; g.snake_n = 1;
-    if (sk) { g.y2 = sk->y2; g.y2_stride = sk->stride; g.y2_off = sk->off; g.ea = sk->ea; g.ib = sk->ib; g.snake_n = sk->n; }
+    g.y2 = nullptr; g.y2_stride = 0; g.y2_off = 0; g.ea = g.ib = nullptr; g.snake_n = 1; g.y2_bf16 = 0;
+    if (sk) { g.y2 = sk->y2; g.y2_stride = sk->stride; g.y2_off = sk->off; g.ea = sk->ea; g.ib = sk->ib; g.snake_n = sk->n; g.y2_bf16 = sk->bf16; }
     // every kernel accumulates the same 32-wide K steps in the same order: the choice never changes a result
     if (g.M <= 512 || epi == 4) {
         // the kernel is bound by what one CU's load path delivers: a narrow N runs 64 x 16 tiles to put a workgroup on
@@ -847,10 +861,12 @@ static void vgemm(hipStream_t s, const VConv& c, const float* x, size_t x_stride
         }
     } else if (c.nout % 128 != 0 && c.nout % 96 == 0) {
         dim3 grid(c.nout / 96, (g.M + 127) / 128);
-        hipLaunchKernelGGL((k_vgemm_lds<3>), grid, dim3(256), 0, s, g);
+        if (a_bf16) hipLaunchKernelGGL((k_vgemm_lds<3, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((k_vgemm_lds<3, false>), grid, dim3(256), 0, s, g);
     } else {
         dim3 grid((c.nout + 127) / 128, (g.M + 127) / 128);
-        hipLaunchKernelGGL((k_vgemm_lds<4>), grid, dim3(256), 0, s, g);
+        if (a_bf16) hipLaunchKernelGGL((k_vgemm_lds<4, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((k_vgemm_lds<4, false>), grid, dim3(256), 0, s, g);
     }
 }
 static bool resunit_ok(int C) {
@@ -883,7 +899,9 @@ static void launch_resunit(hipStream_t s, const VRes& r, int ns, int T, int C, f
 static void hist(hipStream_t s, const VCall& cl, VBuf& b, int T, int save) {
     if (b.H == 0) return;
     const size_t n = (size_t)b.H * b.C;
-    hipLaunchKernelGGL(k_voc_hist, dim3((unsigned)std::min<size_t>((n + 255) / 256, 64), cl.ns), dim3(256), 0, s, cl, b.p, b.stride(), b.hist, b.H, b.C, T, save);
+    const dim3 grid((unsigned)std::min<size_t>((n + 255) / 256, 64), cl.ns);
+    if (b.bf16) hipLaunchKernelGGL((k_voc_hist<uint16_t>), grid, dim3(256), 0, s, cl, (uint16_t*)b.p, b.stride(), (uint16_t*)b.hist, b.H, b.C, T, save);
+    else hipLaunchKernelGGL((k_voc_hist<float>), grid, dim3(256), 0, s, cl, b.p, b.stride(), b.hist, b.H, b.C, T, save);
 }
 // one batched streaming call: ns slots x nf new frames each (uniform nf <= VOC_FCAP)
 static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
@@ -942,7 +960,7 @@ static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
         hist(s, cl, k.res[0].c1_in, T * k.r, 0);
         {
             const VSnake sk = snake_into(k.res[0].c1_in, k.res[0].ea, k.res[0].ib, k.cout);
-            vgemm(s, k.ct, k.ct_in.p, k.ct_in.stride(), k.ct_in.H * k.cin, ns, T, o, (size_t)T * k.r * k.cout, 0, 0, nullptr, 1, &sk, 1);
+            vgemm(s, k.ct, k.ct_in.p, k.ct_in.stride(), k.ct_in.H * k.cin, ns, T, o, (size_t)T * k.r * k.cout, 0, 0, nullptr, 1, &sk, 1, 1);
         }
         hist(s, cl, k.ct_in, T, 1);
         T *= k.r; ch = k.cout;
@@ -958,15 +976,15 @@ static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
                 continue;
             }
             {
-                VSnake sk; sk.y2 = z; sk.stride = (size_t)T * ch; sk.off = 0; sk.ea = r.ea2; sk.ib = r.ib2; sk.n = ch;  // snake2 -> z
-                vgemm(s, r.c1, r.c1_in.p, r.c1_in.stride(), r.c1_in.H * ch, ns, T, z, (size_t)T * ch, 0, 0, nullptr, 1, &sk, 0);
+                VSnake sk; sk.y2 = z; sk.stride = (size_t)T * ch; sk.off = 0; sk.ea = r.ea2; sk.ib = r.ib2; sk.n = ch; sk.bf16 = 1;  // snake2 -> z (bf16)
+                vgemm(s, r.c1, r.c1_in.p, r.c1_in.stride(), r.c1_in.H * ch, ns, T, z, (size_t)T * ch, 0, 0, nullptr, 1, &sk, 0, 1);
             }
             hist(s, cl, r.c1_in, T, 1);
             VSnake sk;
             if (u < 2) { hist(s, cl, k.res[u + 1].c1_in, T, 0); sk = snake_into(k.res[u + 1].c1_in, k.res[u + 1].ea, k.res[u + 1].ib, ch); }
             else if (bi + 1 < v->Bk.size()) { VBlk& nx = v->Bk[bi + 1]; hist(s, cl, nx.ct_in, T, 0); sk = snake_into(nx.ct_in, nx.ea, nx.ib, ch); }
             else { hist(s, cl, v->out_in, T, 0); sk = snake_into(v->out_in, v->oea, v->oib, ch); }
-            vgemm(s, r.c2, z, (size_t)T * ch, 0, ns, T, o, (size_t)T * ch, 0, 2, nullptr, 1, &sk, u < 2 ? 1 : 0);  // o += conv k1
+            vgemm(s, r.c2, z, (size_t)T * ch, 0, ns, T, o, (size_t)T * ch, 0, 2, nullptr, 1, &sk, u < 2 ? 1 : 0, 1);  // o += conv k1
         }
     }
     // V6
