@@ -191,10 +191,51 @@ typedef struct q3tts_timings {
 int q3tts_get_timings(const q3tts_engine* e, q3tts_timings* out);
 
 /* Log-mel front-end of the voice-clone path (replaces SpeakerEncoder::compute_mel, src/models/onnx.rs:166-321): 24 kHz mono
- * f32 in, [n_frames][128] log-mel out (n_fft 1024, hop 256, Slaney mels, the reference's padding rules). The encoders that
- * consume it are ONNX-only in the reference and are not part of this library yet. */
+ * f32 in, [n_frames][128] log-mel out (n_fft 1024, hop 256, Slaney mels, the reference's padding rules). */
 int32_t q3tts_mel_frames(int64_t n_samples);
 int q3tts_mel(q3tts_engine* e, const float* audio, int64_t n_samples, float* out, int32_t cap_frames, int32_t* n_frames);
+
+/* ---- voice-clone encoders (replace AudioEncoder / SpeakerEncoder, src/models/onnx.rs:82-165, and the encoder half of
+ * TtsEngine::create_voice_file, src/tts/engine.rs:324-387). The reference runs two ONNX graphs that are not in its
+ * repository; the structure here is the model family's (ECAPA-TDNN speaker encoder; SEANet + transformer + split residual
+ * VQ codec encoder), every dimension a field, weights seeded-synthetic. ------------------------------- */
+typedef struct q3tts_clone_config {
+    /* speaker encoder: log-mel [T][mel_dim] -> [se_dim] */
+    int32_t mel_dim;                 /* 128 (fixed by q3tts_mel) */
+    int32_t se_channels[5];          /* 512,512,512,512,1536: TDNN, 3 SE-Res2Net blocks, aggregation (= 3 x block width) */
+    int32_t se_kernels[5];           /* 5,3,3,3,1 */
+    int32_t se_dilations[5];         /* 1,2,3,4,1 */
+    int32_t se_attn_channels;        /* 128 */
+    int32_t se_res2net_scale;        /* 8 */
+    int32_t se_se_channels;          /* 128 */
+    int32_t se_dim;                  /* 2048 = model.d_embed ("spk_emb" [1,2048], src/models/onnx.rs:149) */
+    /* audio encoder: 24 kHz PCM -> [frames][ae_n_codebooks] */
+    int32_t ae_filters;              /* 64 */
+    int32_t ae_kernel, ae_res_kernel, ae_last_kernel;   /* 7, 3, 3 */
+    int32_t ae_n_ratios; int32_t ae_ratios[4];          /* 4: 4,5,6,8 (x960) */
+    int32_t ae_hidden;               /* 512 */
+    int32_t ae_n_layer, ae_n_head, ae_head_dim, ae_d_ffn, ae_window;  /* 8, 8, 64, 2048, 250 */
+    float ae_rope_theta, ae_ln_eps, ae_layer_scale;     /* 10000, 1e-5, 0.01 */
+    int32_t ae_down_stride;          /* 2 (x1920 = one 12.5 Hz frame) */
+    int32_t ae_vq_dim;               /* 256 */
+    int32_t ae_n_codebooks, ae_codebook_size;           /* 16, 2048 ("audio_codes" [1,frames,16], src/models/onnx.rs:107) */
+} q3tts_clone_config;
+void q3tts_clone_default_config(q3tts_clone_config* cfg);
+/* "load" both encoders into the engine (the reference does so when the two ONNX files exist, src/tts/engine.rs:139-160);
+ * weights are generated from cfg.synth_seed of the engine. Calling it again replaces them. */
+int q3tts_clone_init(q3tts_engine* e, const q3tts_clone_config* cfg);
+/* frames the audio encoder produces for n_samples (ceil division through every stride) */
+int32_t q3tts_clone_audio_frames(const q3tts_engine* e, int64_t n_samples);
+/* AudioEncoder::encode (src/models/onnx.rs:96-121): codes [n_frames][ae_n_codebooks] i64, row-major like "audio_codes".
+ * Q3TTS_ERR_STATE with "AudioEncoder not loaded" before q3tts_clone_init (src/tts/engine.rs:330-332). */
+int q3tts_clone_audio_encode(q3tts_engine* e, const float* audio, int64_t n_samples, int64_t* codes, int32_t cap_frames,
+                             int32_t* n_frames);
+/* SpeakerEncoder::encode (src/models/onnx.rs:135-160): log-mel on the device, then the encoder; out [se_dim] */
+int q3tts_clone_speaker_encode(q3tts_engine* e, const float* audio, int64_t n_samples, float* spk_emb);
+/* test hooks: the speaker encoder on a given log-mel; the audio encoder's pre-quantiser rows [n_frames][ae_hidden] */
+int q3tts_k_speaker_from_mel(q3tts_engine* e, const float* mel, int32_t n_frames, float* spk_emb);
+int q3tts_k_audio_latent(q3tts_engine* e, const float* audio, int64_t n_samples, float* latent, int32_t cap_frames,
+                         int32_t* n_frames);
 
 /* ---- kernel-level test hooks (host buffers in/out; used only by tests/ and bench.py) ----------- */
 /* y[B][N] = exact_gemm(norm?(x)[B][K], W[N][K] bf16 bits) (+bias) — canonical order of DESIGN.md §4.1 */

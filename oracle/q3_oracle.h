@@ -120,6 +120,26 @@ void q3o_mel_tables(float* hann1024, float* cos1024, float* sin1024, float* fb12
 int32_t q3o_mel_frames(int64_t n_samples);
 int32_t q3o_mel(const float* audio, int64_t n_samples, float* out, float* pre_log);
 
+/* voice-clone encoders (q3_oracle_clone.c; I/O contract src/models/onnx.rs:82-165, caller src/tts/engine.rs:324-387) */
+typedef struct q3o_clone_config {
+    /* speaker encoder: ECAPA-TDNN family, log-mel [T][mel_dim] -> [se_dim] */
+    int32_t mel_dim;
+    int32_t se_channels[5], se_kernels[5], se_dilations[5];
+    int32_t se_attn_channels, se_res2net_scale, se_se_channels, se_dim;
+    /* audio encoder: SEANet conv stack + transformer + stride-2 conv + split residual VQ, 24 kHz PCM -> [frames][ncb] */
+    int32_t ae_filters, ae_kernel, ae_res_kernel, ae_last_kernel;
+    int32_t ae_n_ratios, ae_ratios[4];
+    int32_t ae_hidden, ae_n_layer, ae_n_head, ae_head_dim, ae_d_ffn, ae_window;
+    float ae_rope_theta, ae_ln_eps, ae_layer_scale;
+    int32_t ae_down_stride, ae_vq_dim, ae_n_codebooks, ae_codebook_size;
+} q3o_clone_config;
+int32_t q3o_audio_frames(const q3o_clone_config* c, int64_t n_samples);
+/* returns 0 / <0; out[se_dim] */
+int32_t q3o_speaker_encode(const q3o_clone_config* c, uint64_t seed, const float* mel, int32_t n_frames, float* out);
+/* returns n_frames; codes [n_frames][ae_n_codebooks]; latent_out (optional) [n_frames][ae_hidden] = the rows fed to the VQ */
+int32_t q3o_audio_encode(const q3o_clone_config* c, uint64_t seed, const float* pcm, int64_t n_samples, int32_t* codes,
+                         int32_t cap_frames, float* latent_out);
+
 typedef struct q3o_vocoder q3o_vocoder;
 q3o_vocoder* q3o_vocoder_create(const q3o_vocoder_config* cfg, uint64_t seed, int32_t n_threads);
 void q3o_vocoder_destroy(q3o_vocoder* v);

@@ -9,6 +9,7 @@
 
 struct Q3Voc;  // vocoder (q3_vocoder.hip)
 struct Q3Mel;  // log-mel front-end (q3_mel.hip)
+struct Q3Clone;  // voice-clone encoders (q3_clone.hip)
 
 struct Q3Tfm {
     int L = 0, d = 0, Hq = 0, Hkv = 0, hd = 0, F = 0, nq = 0, nkv = 0, nqkv = 0, head_n = 0;
@@ -81,6 +82,7 @@ struct q3tts_engine {
     q3tts_timings tm{};
     Q3Voc* voc = nullptr;
     Q3Mel* mel = nullptr;               // created on first use
+    Q3Clone* clone = nullptr;           // q3tts_clone_init
     // q3tts_k_probe: eager frame steps, events around the Predictor gate/up GEMM (pass 1, layer 0) of every frame
     int probe = 0;
     std::vector<hipEvent_t> probe_ev;   // 2 per frame of a chunk
@@ -102,6 +104,8 @@ int q3_set_err(q3tts_engine* e, int code, const std::string& msg);
 void q3_stdrng_f32(uint64_t seed, int n, float* out);
 
 void q3_mel_destroy(q3tts_engine* e);
+int q3_mel_run(q3tts_engine* e, const float* audio, int64_t n_samples, int32_t* n_frames, float** out_dev);
+void q3_clone_destroy(q3tts_engine* e);
 // vocoder interface (q3_vocoder.hip)
 int q3_voc_create(q3tts_engine* e);
 void q3_voc_destroy(q3tts_engine* e);

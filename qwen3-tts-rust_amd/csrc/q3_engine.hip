@@ -549,6 +549,7 @@ extern "C" void q3tts_engine_destroy(q3tts_engine* e) {
     if (e->vstream) hipStreamSynchronize(e->vstream);
     if (e->voc) q3_voc_destroy(e);
     q3_mel_destroy(e);
+    q3_clone_destroy(e);
     if (e->first_chunk_host) hipHostFree(e->first_chunk_host);
     for (auto& L : e->lanes) {
         if (L.stream) hipStreamSynchronize(L.stream);

@@ -118,15 +118,14 @@ extern "C" int32_t q3tts_mel_frames(int64_t n_samples) {  // :248-262
     return (int32_t)((padded >= MEL_NFFT ? padded - MEL_NFFT : 0) / MEL_HOP + 1);
 }
 
-extern "C" int q3tts_mel(q3tts_engine* e, const float* audio, int64_t n_samples, float* out, int32_t cap_frames, int32_t* n_frames) {
-    if (!e || !out || !n_frames || n_samples < 0 || (n_samples > 0 && !audio)) return q3_set_err(e, Q3TTS_ERR_INVALID, "null argument");
-    Q3_HIP(e, hipSetDevice(e->cfg.device));
+// log-mel of a host clip, left on the device (m->out, [nf][128]); no synchronisation — the caller's work on e->stream follows it
+int q3_mel_run(q3tts_engine* e, const float* audio, int64_t n_samples, int32_t* n_frames, float** out_dev) {
     const int64_t padded = n_samples + 2 * MEL_PAD;
     int32_t nf = q3tts_mel_frames(n_samples);
     if ((int64_t)(nf - 1) * MEL_HOP + MEL_NFFT > padded) nf -= 1;  // the `break` of :266-269 (only for inputs shorter than one window)
     *n_frames = nf;
+    *out_dev = nullptr;
     if (nf <= 0) return Q3TTS_OK;
-    if (nf > cap_frames) return q3_set_err(e, Q3TTS_ERR_INVALID, "mel output buffer too small");
     int rc = mel_init(e);
     if (rc != Q3TTS_OK) return rc;
     Q3Mel* m = e->mel;
@@ -137,7 +136,22 @@ extern "C" int q3tts_mel(q3tts_engine* e, const float* audio, int64_t n_samples,
     if (n_samples > 0) Q3_HIP(e, hipMemcpyAsync(m->audio, audio, (size_t)n_samples * 4, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_mel, dim3(nf), dim3(256), 0, s, m->audio, (long long)n_samples, m->hann, m->cs, m->sn, m->fb, m->out);
     Q3_HIP(e, hipGetLastError());
-    Q3_HIP(e, hipMemcpyAsync(out, m->out, no * 4, hipMemcpyDeviceToHost, s));
-    Q3_HIP(e, hipStreamSynchronize(s));
+    *out_dev = m->out;
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_mel(q3tts_engine* e, const float* audio, int64_t n_samples, float* out, int32_t cap_frames, int32_t* n_frames) {
+    if (!e || !out || !n_frames || n_samples < 0 || (n_samples > 0 && !audio)) return q3_set_err(e, Q3TTS_ERR_INVALID, "null argument");
+    Q3_HIP(e, hipSetDevice(e->cfg.device));
+    int32_t nf = q3tts_mel_frames(n_samples);
+    if ((int64_t)(nf - 1) * MEL_HOP + MEL_NFFT > n_samples + 2 * MEL_PAD) nf -= 1;
+    *n_frames = nf;
+    if (nf <= 0) return Q3TTS_OK;
+    if (nf > cap_frames) return q3_set_err(e, Q3TTS_ERR_INVALID, "mel output buffer too small");
+    float* dev = nullptr;
+    int rc = q3_mel_run(e, audio, n_samples, &nf, &dev);
+    if (rc != Q3TTS_OK) return rc;
+    Q3_HIP(e, hipMemcpyAsync(out, dev, (size_t)nf * MEL_NMELS * 4, hipMemcpyDeviceToHost, e->stream));
+    Q3_HIP(e, hipStreamSynchronize(e->stream));
     return Q3TTS_OK;
 }

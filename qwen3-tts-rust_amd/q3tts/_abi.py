@@ -94,6 +94,21 @@ class Timings(C.Structure):
     ]
 
 
+class CloneConfig(C.Structure):
+    """q3tts_clone_config: the two encoders of the voice-clone front-end (include/q3tts.h)."""
+    _fields_ = [
+        ("mel_dim", C.c_int32),
+        ("se_channels", C.c_int32 * 5), ("se_kernels", C.c_int32 * 5), ("se_dilations", C.c_int32 * 5),
+        ("se_attn_channels", C.c_int32), ("se_res2net_scale", C.c_int32), ("se_se_channels", C.c_int32), ("se_dim", C.c_int32),
+        ("ae_filters", C.c_int32), ("ae_kernel", C.c_int32), ("ae_res_kernel", C.c_int32), ("ae_last_kernel", C.c_int32),
+        ("ae_n_ratios", C.c_int32), ("ae_ratios", C.c_int32 * 4),
+        ("ae_hidden", C.c_int32), ("ae_n_layer", C.c_int32), ("ae_n_head", C.c_int32), ("ae_head_dim", C.c_int32),
+        ("ae_d_ffn", C.c_int32), ("ae_window", C.c_int32),
+        ("ae_rope_theta", C.c_float), ("ae_ln_eps", C.c_float), ("ae_layer_scale", C.c_float),
+        ("ae_down_stride", C.c_int32), ("ae_vq_dim", C.c_int32), ("ae_n_codebooks", C.c_int32), ("ae_codebook_size", C.c_int32),
+    ]
+
+
 # every symbol include/q3tts.h declares (tests check the export list against the header text)
 SYMBOLS = [
     "q3tts_default_config", "q3tts_engine_create", "q3tts_engine_destroy", "q3tts_last_error", "q3tts_set_sampler",
@@ -101,6 +116,8 @@ SYMBOLS = [
     "q3tts_result_free", "q3tts_stream_begin", "q3tts_stream_poll", "q3tts_stream_end", "q3tts_write_weights",
     "q3tts_get_timings", "q3tts_k_gemm_exact", "q3tts_k_attention", "q3tts_k_sample", "q3tts_k_talker_prefill",
     "q3tts_k_vocoder", "q3tts_k_rng_f32", "q3tts_k_probe", "q3tts_k_gguf_read", "q3tts_mel_frames", "q3tts_mel",
+    "q3tts_clone_default_config", "q3tts_clone_init", "q3tts_clone_audio_frames", "q3tts_clone_audio_encode",
+    "q3tts_clone_speaker_encode", "q3tts_k_speaker_from_mel", "q3tts_k_audio_latent",
 ]
 
 
@@ -159,6 +176,15 @@ def load_library(path=None):
     lib.q3tts_mel_frames.restype = C.c_int32
     lib.q3tts_mel.argtypes = [C.c_void_p, f32p, C.c_int64, f32p, C.c_int32, C.POINTER(C.c_int32)]
     lib.q3tts_k_gguf_read.argtypes = [C.c_char_p, C.c_char_p, f32p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    lib.q3tts_clone_default_config.argtypes = [C.POINTER(CloneConfig)]
+    lib.q3tts_clone_default_config.restype = None
+    lib.q3tts_clone_init.argtypes = [vp, C.POINTER(CloneConfig)]
+    lib.q3tts_clone_audio_frames.argtypes = [vp, C.c_int64]
+    lib.q3tts_clone_audio_frames.restype = C.c_int32
+    lib.q3tts_clone_audio_encode.argtypes = [vp, f32p, C.c_int64, C.POINTER(C.c_int64), C.c_int32, i32p]
+    lib.q3tts_clone_speaker_encode.argtypes = [vp, f32p, C.c_int64, f32p]
+    lib.q3tts_k_speaker_from_mel.argtypes = [vp, f32p, C.c_int32, f32p]
+    lib.q3tts_k_audio_latent.argtypes = [vp, f32p, C.c_int64, f32p, C.c_int32, i32p]
     if path is None:
         _lib = lib
     return lib
@@ -226,3 +252,37 @@ def full_config_py():
     cfg.synth_seed = 0
     cfg.weights_path = None
     return cfg
+
+
+def tiny_clone_config(d_embed=512):
+    """Small encoder shapes for the parity tests (every structural feature of the full shape, narrower)."""
+    c = CloneConfig()
+    c.mel_dim = 128
+    c.se_channels[:] = [64, 64, 64, 64, 192]
+    c.se_kernels[:] = [5, 3, 3, 3, 1]
+    c.se_dilations[:] = [1, 2, 3, 4, 1]
+    c.se_attn_channels, c.se_res2net_scale, c.se_se_channels, c.se_dim = 32, 4, 32, d_embed
+    c.ae_filters, c.ae_kernel, c.ae_res_kernel, c.ae_last_kernel = 32, 7, 3, 3
+    c.ae_n_ratios = 4
+    c.ae_ratios[:] = [4, 5, 6, 8]
+    c.ae_hidden, c.ae_n_layer, c.ae_n_head, c.ae_head_dim, c.ae_d_ffn, c.ae_window = 128, 2, 4, 32, 256, 6
+    c.ae_rope_theta, c.ae_ln_eps, c.ae_layer_scale = 10000.0, 1e-5, 0.5
+    c.ae_down_stride, c.ae_vq_dim, c.ae_n_codebooks, c.ae_codebook_size = 2, 32, 16, 64
+    return c
+
+
+def full_clone_config_py():
+    """The family's full encoder shapes (what q3tts_clone_default_config fills), without touching the library."""
+    c = CloneConfig()
+    c.mel_dim = 128
+    c.se_channels[:] = [512, 512, 512, 512, 1536]
+    c.se_kernels[:] = [5, 3, 3, 3, 1]
+    c.se_dilations[:] = [1, 2, 3, 4, 1]
+    c.se_attn_channels, c.se_res2net_scale, c.se_se_channels, c.se_dim = 128, 8, 128, 2048
+    c.ae_filters, c.ae_kernel, c.ae_res_kernel, c.ae_last_kernel = 64, 7, 3, 3
+    c.ae_n_ratios = 4
+    c.ae_ratios[:] = [4, 5, 6, 8]
+    c.ae_hidden, c.ae_n_layer, c.ae_n_head, c.ae_head_dim, c.ae_d_ffn, c.ae_window = 512, 8, 8, 64, 2048, 250
+    c.ae_rope_theta, c.ae_ln_eps, c.ae_layer_scale = 10000.0, 1e-5, 0.01
+    c.ae_down_stride, c.ae_vq_dim, c.ae_n_codebooks, c.ae_codebook_size = 2, 256, 16, 2048
+    return c

@@ -222,11 +222,80 @@ class TtsEngine:
         sr = self.cfg.vocoder.sample_rate
         return [AudioSample(o.pcm, sr, 1) for o in outs]
 
+    def load_clone_encoders(self, clone_config=None):
+        """The reference loads onnx/qwen3_tts_codec_encoder.onnx and onnx/qwen3_tts_speaker_encoder.onnx when they exist
+        (src/tts/engine.rs:139-160). Those graphs are not available; this loads the family-structure encoders with seeded
+        synthetic weights (q3tts_clone_init)."""
+        if clone_config is None:
+            clone_config = _abi.CloneConfig()
+            self._native.lib.q3tts_clone_default_config(clone_config)
+            clone_config.se_dim = self.cfg.model.d_embed
+            clone_config.ae_n_codebooks = self.cfg.model.n_codebooks
+            clone_config.ae_codebook_size = self.cfg.model.codebook_size
+        self._native.clone_init(clone_config)
+
+    @staticmethod
+    def _read_wav_any(path):
+        """create_voice_file's own WAV decoding (src/tts/engine.rs:339-373): f32 / i16 / i32, first channel, 24 kHz only."""
+        with open(path, "rb") as f:
+            raw = f.read()
+        if raw[:4] != b"RIFF" or raw[8:12] != b"WAVE":
+            raise _abi.Q3Error("WAV error: not a RIFF/WAVE file")
+        pos, fmt, data = 12, None, None
+        while pos + 8 <= len(raw):
+            cid, size = raw[pos:pos + 4], struct.unpack("<I", raw[pos + 4:pos + 8])[0]
+            body = raw[pos + 8:pos + 8 + size]
+            if cid == b"fmt ":
+                fmt = struct.unpack("<HHIIHH", body[:16])
+                if fmt[0] == 0xFFFE and len(body) >= 26:  # WAVE_FORMAT_EXTENSIBLE: sub-format tag
+                    fmt = (struct.unpack("<H", body[24:26])[0],) + fmt[1:]
+            elif cid == b"data":
+                data = body
+            pos += 8 + size + (size & 1)
+        if fmt is None or data is None:
+            raise _abi.Q3Error("WAV error: missing fmt or data chunk")
+        tag, channels, rate, _, _, bits = fmt
+        if rate != 24000:
+            raise _abi.Q3Error(f"Expected 24000Hz audio, found {rate}Hz")
+        if tag == 3 and bits == 32:
+            a = np.frombuffer(data[:len(data) // 4 * 4], dtype="<f4").astype(np.float32)
+        elif tag == 1 and bits == 16:
+            a = np.frombuffer(data[:len(data) // 2 * 2], dtype="<i2").astype(np.float32) / np.float32(32768.0)
+        elif tag == 1 and bits == 32:
+            a = (np.frombuffer(data[:len(data) // 4 * 4], dtype="<i4").astype(np.float32) / np.float32(2147483648.0)).astype(np.float32)
+        else:
+            raise _abi.Q3Error(f"Unsupported WAV format: {'Float' if tag == 3 else 'Int'} {bits} bits")
+        return a[::channels].copy() if channels > 1 else a
+
     def create_voice_file(self, audio_path, ref_text):  # src/tts/engine.rs:324-387
-        raise _abi.Q3Error("AudioEncoder not loaded: the codec/speaker encoders are SURVEY.md §8(f) 'next' rows")
+        if not hasattr(self._native, "clone_cfg"):
+            raise _abi.Q3Error("AudioEncoder not loaded. Please ensure models/onnx/qwen3_tts_codec_encoder.onnx exists.")
+        audio = self._read_wav_any(audio_path)
+        codes = self._native.audio_encode(audio)            # "Extracting audio codes..."
+        emb = self._native.speaker_encode(audio)            # "Extracting speaker embedding..."
+        return VoiceFile.new(ref_text, codes.reshape(-1).tolist(), emb.tolist())
+
+    def _process_reference(self, audio_path):  # src/tts/engine.rs:275-302 (TTSC cache beside the audio file)
+        cache_path = os.path.splitext(str(audio_path))[0] + ".cache"
+        if os.path.exists(cache_path):
+            try:
+                return load_cache(cache_path)
+            except (ValueError, struct.error, OSError):
+                pass
+        audio = AudioSample.load_wav(audio_path)
+        if not hasattr(self._native, "clone_cfg"):
+            raise _abi.Q3Error("AudioEncoder not loaded (required for processing raw audio)")
+        codes = self._native.audio_encode(audio.samples).reshape(-1).tolist()
+        emb = self._native.speaker_encode(audio.samples).tolist()
+        try:
+            save_cache(cache_path, codes, emb)
+        except OSError:
+            pass
+        return codes, emb
 
     def generate(self, text, ref_audio_path, ref_text, instruct=None):  # src/tts/engine.rs:243-272
-        raise _abi.Q3Error("AudioEncoder not loaded (required for processing raw audio)")
+        codes, emb = self._process_reference(ref_audio_path)
+        return self.generate_with_voice(text, VoiceFile.new(ref_text, codes, emb), instruct)
 
 
 def cleanup():

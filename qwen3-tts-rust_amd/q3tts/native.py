@@ -151,6 +151,53 @@ class NativeEngine:
         self._check(self.lib.q3tts_mel(self.h, _ptr(a, f32p) if a.size else None, a.size, _ptr(out, f32p), cap, C.byref(n)), "q3tts_mel")
         return out[:n.value].copy()
 
+    # voice-clone encoders (q3_clone.hip) ----------------------------------------------------------
+    def clone_init(self, ccfg):
+        self._check(self.lib.q3tts_clone_init(self.h, C.byref(ccfg)), "q3tts_clone_init")
+        self.clone_cfg = ccfg
+
+    def clone_audio_frames(self, n_samples):
+        return int(self.lib.q3tts_clone_audio_frames(self.h, int(n_samples)))
+
+    def _clone_codebooks(self):
+        c = getattr(self, "clone_cfg", None)
+        return c.ae_n_codebooks if c is not None else 16
+
+    def audio_encode(self, audio):
+        """AudioEncoder::encode: 24 kHz mono f32 -> i64 codes [n_frames][n_codebooks]."""
+        a = np.ascontiguousarray(audio, dtype=np.float32)
+        cap = max(self.clone_audio_frames(a.size), 1)
+        ncb = self._clone_codebooks()
+        out = np.zeros((cap, ncb), dtype=np.int64)
+        n = C.c_int32(0)
+        self._check(self.lib.q3tts_clone_audio_encode(self.h, _ptr(a, f32p) if a.size else None, a.size,
+                                                      out.ctypes.data_as(C.POINTER(C.c_int64)), cap, C.byref(n)), "q3tts_clone_audio_encode")
+        return out[:n.value].copy()
+
+    def audio_latent(self, audio):
+        a = np.ascontiguousarray(audio, dtype=np.float32)
+        cap = max(self.clone_audio_frames(a.size), 1)
+        out = np.zeros((cap, self.clone_cfg.ae_hidden), dtype=np.float32)
+        n = C.c_int32(0)
+        self._check(self.lib.q3tts_k_audio_latent(self.h, _ptr(a, f32p) if a.size else None, a.size, _ptr(out, f32p), cap, C.byref(n)),
+                    "q3tts_k_audio_latent")
+        return out[:n.value].copy()
+
+    def speaker_encode(self, audio):
+        """SpeakerEncoder::encode: 24 kHz mono f32 -> [se_dim] (log-mel on the device, then the encoder)."""
+        a = np.ascontiguousarray(audio, dtype=np.float32)
+        c = getattr(self, "clone_cfg", None)
+        out = np.zeros(c.se_dim if c is not None else self.cfg.model.d_embed, dtype=np.float32)
+        self._check(self.lib.q3tts_clone_speaker_encode(self.h, _ptr(a, f32p) if a.size else None, a.size, _ptr(out, f32p)),
+                    "q3tts_clone_speaker_encode")
+        return out
+
+    def speaker_from_mel(self, mel):
+        m = np.ascontiguousarray(mel, dtype=np.float32)
+        out = np.zeros(self.clone_cfg.se_dim, dtype=np.float32)
+        self._check(self.lib.q3tts_k_speaker_from_mel(self.h, _ptr(m, f32p), m.shape[0], _ptr(out, f32p)), "q3tts_k_speaker_from_mel")
+        return out
+
     def probe(self, enable):
         """Measurement mode (bench.py): eager frame steps with HIP events around the Predictor gate/up GEMM."""
         self._check(self.lib.q3tts_k_probe(self.h, int(bool(enable))), "q3tts_k_probe")

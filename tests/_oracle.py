@@ -79,6 +79,12 @@ def lib():
     L.q3o_mel_frames.restype = C.c_int32
     L.q3o_mel.argtypes = [f32p, C.c_int64, f32p, f32p]
     L.q3o_mel.restype = C.c_int32
+    L.q3o_audio_frames.argtypes = [C.POINTER(_abi.CloneConfig), C.c_int64]
+    L.q3o_audio_frames.restype = C.c_int32
+    L.q3o_speaker_encode.argtypes = [C.POINTER(_abi.CloneConfig), C.c_uint64, f32p, C.c_int32, f32p]
+    L.q3o_speaker_encode.restype = C.c_int32
+    L.q3o_audio_encode.argtypes = [C.POINTER(_abi.CloneConfig), C.c_uint64, f32p, C.c_int64, i32p, C.c_int32, f32p]
+    L.q3o_audio_encode.restype = C.c_int32
     if hasattr(L, "q3o_vocoder_create"):
         L.q3o_vocoder_create.argtypes = [C.POINTER(_abi.VocoderConfig), C.c_uint64, C.c_int32]
         L.q3o_vocoder_create.restype = vp
@@ -222,3 +228,23 @@ def mel(audio, want_pre_log=False):
     pre = np.zeros((cap, 128), dtype=np.float32)
     n = lib().q3o_mel(ptr(a, f32p) if a.size else None, a.size, ptr(out, f32p), ptr(pre, f32p))
     return (out[:n].copy(), pre[:n].copy()) if want_pre_log else out[:n].copy()
+
+
+def speaker_encode(ccfg, seed, mel_rows):
+    """Oracle speaker encoder (oracle/q3_oracle_clone.c) on a log-mel [T][128] -> [se_dim]."""
+    m = np.ascontiguousarray(mel_rows, dtype=np.float32)
+    out = np.zeros(ccfg.se_dim, dtype=np.float32)
+    rc = lib().q3o_speaker_encode(C.byref(ccfg), seed, ptr(m, f32p), m.shape[0], ptr(out, f32p))
+    assert rc == 0
+    return out
+
+
+def audio_encode(ccfg, seed, audio):
+    """Oracle audio encoder: (codes [frames][ncb] int32, pre-quantiser rows [frames][ae_hidden])."""
+    a = np.ascontiguousarray(audio, dtype=np.float32)
+    cap = max(1, int(lib().q3o_audio_frames(C.byref(ccfg), a.size)))
+    codes = np.zeros((cap, ccfg.ae_n_codebooks), dtype=np.int32)
+    lat = np.zeros((cap, ccfg.ae_hidden), dtype=np.float32)
+    n = lib().q3o_audio_encode(C.byref(ccfg), seed, ptr(a, f32p) if a.size else None, a.size, ptr(codes, i32p), cap, ptr(lat, f32p))
+    assert n >= 0
+    return codes[:n].copy(), lat[:n].copy()
