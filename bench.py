@@ -280,6 +280,30 @@ def main():
                                     "rtf_p50": round(float(np.median(rtfs)), 5), "first_chunk_ms_p50": round(float(np.median(firsts)), 2),
                                     "frame_step_ms": round(t1m.frame_step_ms, 4),
                                     "hbm_GBs": round(t1m.algo_bytes_per_step / (t1m.frame_step_ms * 1e-3) / 1e9, 1) if t1m.frame_step_ms else 0}
+        # BASELINE configs[4], clone variant: a 3 s (72 000-sample) synthetic reference clip goes through the device
+        # front-end (log-mel + speaker encoder + audio encoder, q3_clone.hip), then the ICL clone prompt is generated
+        ccfg = _abi.CloneConfig()
+        e1.lib.q3tts_clone_default_config(ccfg)
+        e1.clone_init(ccfg)
+        tt = np.arange(72000) / 24000.0
+        clip = (0.2 * np.sin(2 * np.pi * 140.0 * tt) + 0.02 * np.random.default_rng(5).standard_normal(72000)).astype(np.float32)
+        fe, cf = [], []
+        for it in range(12):
+            t1 = time.perf_counter()
+            ref_codes = e1.audio_encode(clip)
+            ref_emb = e1.speaker_encode(clip)
+            fe_ms = (time.perf_counter() - t1) * 1e3
+            dsc, keep2 = native.make_prompt_desc(ids, spk_emb=ref_emb, ref_codes=ref_codes.reshape(-1).astype(np.int32),
+                                                 ref_text_ids=np.arange(1000, 1012))
+            o = e1.generate(desc=dsc, temperature=0.0, max_steps=16, min_frames=16, want_pcm=cfg.with_vocoder)
+            if it >= 2:
+                fe.append(fe_ms)
+                cf.append(o.first_chunk_ms)
+        line["single_utterance"]["clone_variant"] = {
+            "workload": "BASELINE.json configs[4] clone variant: 3 s reference clip -> mel + speaker encoder + audio encoder "
+                        "(family-structure encoders, synthetic weights) -> ICL clone prompt (38 ref frames, 12 ref-text ids) -> first 4-frame chunk",
+            "front_end_ms_p50": round(float(np.median(fe)), 2), "first_chunk_ms_p50": round(float(np.median(cf)), 2),
+            "first_chunk_incl_front_end_ms_p50": round(float(np.median(np.asarray(fe) + np.asarray(cf))), 2)}
         e1.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = min(16, os.cpu_count() or 1)

@@ -221,7 +221,7 @@ typedef struct q3tts_clone_config {
     int32_t ae_n_codebooks, ae_codebook_size;           /* 16, 2048 ("audio_codes" [1,frames,16], src/models/onnx.rs:107) */
 } q3tts_clone_config;
 void q3tts_clone_default_config(q3tts_clone_config* cfg);
-/* "load" both encoders into the engine (the reference does so when the two ONNX files exist, src/tts/engine.rs:139-160);
+/* "load" both encoders into the engine (the reference does so when the two ONNX files exist, src/tts/engine.rs:105-119);
  * weights are generated from cfg.synth_seed of the engine. Calling it again replaces them. */
 int q3tts_clone_init(q3tts_engine* e, const q3tts_clone_config* cfg);
 /* frames the audio encoder produces for n_samples (ceil division through every stride) */

@@ -224,7 +224,7 @@ class TtsEngine:
 
     def load_clone_encoders(self, clone_config=None):
         """The reference loads onnx/qwen3_tts_codec_encoder.onnx and onnx/qwen3_tts_speaker_encoder.onnx when they exist
-        (src/tts/engine.rs:139-160). Those graphs are not available; this loads the family-structure encoders with seeded
+        (src/tts/engine.rs:105-119). Those graphs are not available; this loads the family-structure encoders with seeded
         synthetic weights (q3tts_clone_init)."""
         if clone_config is None:
             clone_config = _abi.CloneConfig()

@@ -58,6 +58,26 @@ extern "C" {
     pub fn q3tts_generate(e: *mut q3tts_engine, req: *const q3tts_request, out: *mut q3tts_result) -> c_int;
     pub fn q3tts_generate_batch(e: *mut q3tts_engine, reqs: *const q3tts_request, n: i32, outs: *mut q3tts_result) -> c_int;
     pub fn q3tts_result_free(r: *mut q3tts_result);
+    // voice-clone encoders (replace AudioEncoder / SpeakerEncoder, src/models/onnx.rs:82-160)
+    pub fn q3tts_clone_default_config(cfg: *mut q3tts_clone_config);
+    pub fn q3tts_clone_init(e: *mut q3tts_engine, cfg: *const q3tts_clone_config) -> c_int;
+    pub fn q3tts_clone_audio_frames(e: *const q3tts_engine, n_samples: i64) -> i32;
+    pub fn q3tts_clone_audio_encode(e: *mut q3tts_engine, audio: *const c_float, n_samples: i64, codes: *mut i64, cap_frames: i32, n_frames: *mut i32) -> c_int;
+    pub fn q3tts_clone_speaker_encode(e: *mut q3tts_engine, audio: *const c_float, n_samples: i64, spk_emb: *mut c_float) -> c_int;
+}
+
+/// q3tts_clone_config (include/q3tts.h), field for field
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct q3tts_clone_config {
+    pub mel_dim: i32,
+    pub se_channels: [i32; 5], pub se_kernels: [i32; 5], pub se_dilations: [i32; 5],
+    pub se_attn_channels: i32, pub se_res2net_scale: i32, pub se_se_channels: i32, pub se_dim: i32,
+    pub ae_filters: i32, pub ae_kernel: i32, pub ae_res_kernel: i32, pub ae_last_kernel: i32,
+    pub ae_n_ratios: i32, pub ae_ratios: [i32; 4],
+    pub ae_hidden: i32, pub ae_n_layer: i32, pub ae_n_head: i32, pub ae_head_dim: i32, pub ae_d_ffn: i32, pub ae_window: i32,
+    pub ae_rope_theta: c_float, pub ae_ln_eps: c_float, pub ae_layer_scale: c_float,
+    pub ae_down_stride: i32, pub ae_vq_dim: i32, pub ae_n_codebooks: i32, pub ae_codebook_size: i32,
 }
 
 // ---- the reference crate's public names on top of the C ABI (src/lib.rs:11-20) ------------------------------------
@@ -109,6 +129,23 @@ impl TtsEngine {
             let samples = std::slice::from_raw_parts(out.pcm, out.n_samples as usize).to_vec();
             q3tts_result_free(&mut out);
             Ok(AudioSample { samples, sample_rate: 24000, channels: 1 })
+        }
+    }
+}
+impl TtsEngine {
+    /// The encoder half of create_voice_file (src/tts/engine.rs:375-386): 24 kHz mono samples -> VoiceFile. WAV decoding
+    /// (hound, :339-373) stays in the crate.
+    pub fn create_voice_from_samples(&mut self, audio: &[f32], ref_text: String) -> Result<VoiceFile, String> {
+        unsafe {
+            let cap = q3tts_clone_audio_frames(self.raw, audio.len() as i64).max(1);
+            let mut codes = vec![0i64; cap as usize * 16];
+            let mut nf = 0i32;
+            let err = |e: *mut q3tts_engine| CStr::from_ptr(q3tts_last_error(e)).to_string_lossy().into_owned();
+            if q3tts_clone_audio_encode(self.raw, audio.as_ptr(), audio.len() as i64, codes.as_mut_ptr(), cap, &mut nf) != 0 { return Err(err(self.raw)); }
+            codes.truncate(nf as usize * 16);
+            let mut emb = vec![0f32; 2048];
+            if q3tts_clone_speaker_encode(self.raw, audio.as_ptr(), audio.len() as i64, emb.as_mut_ptr()) != 0 { return Err(err(self.raw)); }
+            Ok(VoiceFile { ref_text, audio_codes: codes, speaker_embedding: emb })
         }
     }
 }
