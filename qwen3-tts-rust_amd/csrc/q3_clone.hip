@@ -104,26 +104,27 @@ __global__ void k_combine(float* dst, int ldd, const float* a, int lda, const fl
     else r = av + s[i] * bv;
     dst[t * ldd + i] = r;
 }
+#define CS_B 16  // rows loaded per batch: the loads of a batch are in flight together, the chain consumes them in order
 // per channel: mean = sum_t w_t x_t (w_t = 1/T when w == nullptr), std = sqrt(max(sum_t w_t (x_t - mean)^2, 1e-12)); ascending t
 __global__ void k_colstats(const float* __restrict__ x, int ld, int T, int C, const float* __restrict__ w, int ldw, float* mean, float* sd) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const float u = 1.0f / (float)T;
     float m = 0.0f;
-    for (int t0 = 0; t0 < T; t0 += 8) {
-        float xv[8], wv[8];
+    for (int t0 = 0; t0 < T; t0 += CS_B) {
+        float xv[CS_B], wv[CS_B];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const int t = min(t0 + e, T - 1); xv[e] = x[(size_t)t * ld + c]; wv[e] = w ? w[(size_t)t * ldw + c] : u; }
+        for (int e = 0; e < CS_B; ++e) { const int t = min(t0 + e, T - 1); xv[e] = x[(size_t)t * ld + c]; wv[e] = w ? w[(size_t)t * ldw + c] : u; }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) if (t0 + e < T) m = fmaf(wv[e], xv[e], m);
+        for (int e = 0; e < CS_B; ++e) if (t0 + e < T) m = fmaf(wv[e], xv[e], m);
     }
     float v = 0.0f;
-    for (int t0 = 0; t0 < T; t0 += 8) {
-        float xv[8], wv[8];
+    for (int t0 = 0; t0 < T; t0 += CS_B) {
+        float xv[CS_B], wv[CS_B];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const int t = min(t0 + e, T - 1); xv[e] = x[(size_t)t * ld + c]; wv[e] = w ? w[(size_t)t * ldw + c] : u; }
+        for (int e = 0; e < CS_B; ++e) { const int t = min(t0 + e, T - 1); xv[e] = x[(size_t)t * ld + c]; wv[e] = w ? w[(size_t)t * ldw + c] : u; }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) if (t0 + e < T) { const float d = xv[e] - m; v = fmaf(wv[e], d * d, v); }
+        for (int e = 0; e < CS_B; ++e) if (t0 + e < T) { const float d = xv[e] - m; v = fmaf(wv[e], d * d, v); }
     }
     mean[c] = m; sd[c] = sqrtf(fmaxf(v, 1e-12f));
 }
@@ -132,16 +133,28 @@ __global__ void k_softmax_time(float* e, int ld, int T, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float mx = e[c];
-    for (int t = 1; t < T; ++t) mx = fmaxf(mx, e[(size_t)t * ld + c]);
-    float l = 0.0f;
-    for (int t0 = 0; t0 < T; t0 += 8) {
-        float p[8];
+    for (int t0 = 0; t0 < T; t0 += CS_B) {
+        float v[CS_B];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const int t = min(t0 + k, T - 1); p[k] = q3_expf(e[(size_t)t * ld + c] - mx); }
+        for (int k = 0; k < CS_B; ++k) v[k] = e[(size_t)min(t0 + k, T - 1) * ld + c];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) if (t0 + k < T) { e[(size_t)(t0 + k) * ld + c] = p[k]; l += p[k]; }
+        for (int k = 0; k < CS_B; ++k) mx = fmaxf(mx, v[k]);
     }
-    for (int t = 0; t < T; ++t) e[(size_t)t * ld + c] = e[(size_t)t * ld + c] / l;
+    float l = 0.0f;
+    for (int t0 = 0; t0 < T; t0 += CS_B) {
+        float p[CS_B];
+#pragma unroll
+        for (int k = 0; k < CS_B; ++k) p[k] = q3_expf(e[(size_t)min(t0 + k, T - 1) * ld + c] - mx);
+#pragma unroll
+        for (int k = 0; k < CS_B; ++k) if (t0 + k < T) { e[(size_t)(t0 + k) * ld + c] = p[k]; l += p[k]; }
+    }
+    for (int t0 = 0; t0 < T; t0 += CS_B) {
+        float p[CS_B];
+#pragma unroll
+        for (int k = 0; k < CS_B; ++k) p[k] = e[(size_t)min(t0 + k, T - 1) * ld + c];
+#pragma unroll
+        for (int k = 0; k < CS_B; ++k) if (t0 + k < T) e[(size_t)(t0 + k) * ld + c] = p[k] / l;
+    }
 }
 // att_in[t] = [x[t] | mean | std]
 __global__ void k_att_in(const float* x, const float* mean, const float* sd, float* out, int T, int C) {
@@ -161,10 +174,22 @@ __global__ void k_layernorm(const float* __restrict__ x, int d, const float* __r
     __syncthreads();
     if (threadIdx.x == 0) {
         float s = 0.0f;
-        for (int i = 0; i < d; ++i) s += row[i];
+        for (int i = 0; i < d; i += 16) {  // d % 16 == 0; the 16 LDS reads are issued together, the chain consumes them in order
+            float rv[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) rv[k] = row[i + k];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += rv[k];
+        }
         const float mean = s / (float)d;
         float v = 0.0f;
-        for (int i = 0; i < d; ++i) { const float dx = row[i] - mean; v = fmaf(dx, dx, v); }
+        for (int i = 0; i < d; i += 16) {
+            float rv[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) rv[k] = row[i + k];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { const float dx = rv[k] - mean; v = fmaf(dx, dx, v); }
+        }
         st[0] = mean; st[1] = 1.0f / sqrtf(v / (float)d + eps);
     }
     __syncthreads();
@@ -218,33 +243,58 @@ __global__ void __launch_bounds__(64) k_enc_attn(const float* __restrict__ qkv, 
         att[(size_t)t * dq + hh * hd + i] = acc / lsum;
     }
 }
-// split residual VQ of one frame per workgroup (256 threads): nearest codeword in squared Euclidean distance (ascending-d
-// fmaf chain per codeword; ties -> smaller index), codebook 0 on the semantic projection, 1.. on the acoustic residual
-__global__ void __launch_bounds__(256) k_rvq(const float* __restrict__ ps, const float* __restrict__ pa, int D,
-                                             const float* const* __restrict__ cb, int ncb, int CS, long long* __restrict__ codes) {
+// codebook [CS][D] -> [D/4][CS][4]: the codewords of neighbouring lanes are neighbours in memory
+__global__ void k_cb_transpose(const float* __restrict__ cb, float* __restrict__ out, int CS, int D) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)CS * D) return;
+    const int j = (int)(gid / D), i = (int)(gid % D);
+    out[((size_t)(i >> 2) * CS + j) * 4 + (i & 3)] = cb[gid];
+}
+// split residual VQ of one frame per workgroup: nearest codeword in squared Euclidean distance (ascending-d fmaf chain per
+// codeword; ties -> smaller index), codebook 0 on the semantic projection, 1.. on the acoustic residual. 1024 lanes, two
+// codewords per lane at a time, 16 dims of both loaded per batch from the transposed codebook (coalesced, 8 loads in flight
+// per lane, 16 waves per CU): the launch is bound by load latency, not by the chains.
+#define RVQ_T 1024
+#define RVQ_CW 2
+__global__ void __launch_bounds__(RVQ_T) k_rvq(const float* __restrict__ ps, const float* __restrict__ pa, int D,
+                                               const float* const* __restrict__ cbT, int ncb, int CS, long long* __restrict__ codes) {
     extern __shared__ float r[];  // [D]
-    __shared__ float rd[256]; __shared__ int ri[256];
+    __shared__ float rd[RVQ_T]; __shared__ int ri[RVQ_T];
     const int t = blockIdx.x, tid = threadIdx.x;
     for (int q = 0; q < ncb; ++q) {
-        if (q < 2) { const float* p = (q == 0 ? ps : pa) + (size_t)t * D; for (int i = tid; i < D; i += 256) r[i] = p[i]; }
+        if (q < 2) { const float* p = (q == 0 ? ps : pa) + (size_t)t * D; for (int i = tid; i < D; i += RVQ_T) r[i] = p[i]; }
         __syncthreads();
-        const float* book = cb[q];
+        const float4* book = (const float4*)cbT[q];
         float bd = 3.0e38f; int bi = 0x7fffffff;
-        for (int j = tid; j < CS; j += 256) {
-            const float* cw = book + (size_t)j * D;
-            float dist = 0.0f;
-            for (int i = 0; i < D; i += 4) {
-                const float4 c4 = *(const float4*)(cw + i);
-                float e = r[i] - c4.x; dist = fmaf(e, e, dist);
-                e = r[i + 1] - c4.y; dist = fmaf(e, e, dist);
-                e = r[i + 2] - c4.z; dist = fmaf(e, e, dist);
-                e = r[i + 3] - c4.w; dist = fmaf(e, e, dist);
+        for (int j0 = tid; j0 < CS; j0 += RVQ_T * RVQ_CW) {
+            float dist[RVQ_CW]; int jj[RVQ_CW];
+#pragma unroll
+            for (int u = 0; u < RVQ_CW; ++u) { dist[u] = 0.0f; jj[u] = min(j0 + u * RVQ_T, CS - 1); }
+            for (int i4 = 0; i4 < (D >> 2); i4 += 4) {  // D % 16 == 0
+                float4 c4[4][RVQ_CW];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int u = 0; u < RVQ_CW; ++u) c4[g][u] = book[(size_t)(i4 + g) * CS + jj[u]];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 rv = *(const float4*)(r + 4 * (i4 + g));
+#pragma unroll
+                    for (int u = 0; u < RVQ_CW; ++u) {
+                        float e = rv.x - c4[g][u].x; dist[u] = fmaf(e, e, dist[u]);
+                        e = rv.y - c4[g][u].y; dist[u] = fmaf(e, e, dist[u]);
+                        e = rv.z - c4[g][u].z; dist[u] = fmaf(e, e, dist[u]);
+                        e = rv.w - c4[g][u].w; dist[u] = fmaf(e, e, dist[u]);
+                    }
+                }
             }
-            if (dist < bd) { bd = dist; bi = j; }
+#pragma unroll
+            for (int u = 0; u < RVQ_CW; ++u)
+                if (j0 + u * RVQ_T < CS && dist[u] < bd) { bd = dist[u]; bi = j0 + u * RVQ_T; }
         }
         rd[tid] = bd; ri[tid] = bi;
         __syncthreads();
-        for (int m = 128; m >= 1; m >>= 1) {
+        for (int m = RVQ_T / 2; m >= 1; m >>= 1) {
             if (tid < m) {
                 const float od = rd[tid + m]; const int oi = ri[tid + m];
                 if (od < rd[tid] || (od == rd[tid] && oi < ri[tid])) { rd[tid] = od; ri[tid] = oi; }
@@ -253,7 +303,7 @@ __global__ void __launch_bounds__(256) k_rvq(const float* __restrict__ ps, const
         }
         const int best = ri[0] == 0x7fffffff ? 0 : ri[0];
         if (tid == 0) codes[(size_t)t * ncb + q] = best;
-        if (q > 0) for (int i = tid; i < D; i += 256) r[i] = r[i] - book[(size_t)best * D + i];
+        if (q > 0) for (int i = tid; i < D; i += RVQ_T) r[i] = r[i] - cbT[q][((size_t)(i >> 2) * CS + best) * 4 + (i & 3)];
         __syncthreads();
     }
 }
@@ -450,7 +500,7 @@ void audio_forward(Ctx& X, const float* pcm, int64_t n, float* lat_dev, long lon
     conv_run(X, X.c->semp, lat_dev, H, Tf, ACT_NONE, ps, D, Tf);
     conv_run(X, X.c->acp, lat_dev, H, Tf, ACT_NONE, pa, D, Tf);
     if (!A.dry)
-        hipLaunchKernelGGL(k_rvq, dim3(Tf), dim3(256), (size_t)D * 4, X.s, ps, pa, D, X.c->cb_dev, c.ae_n_codebooks, c.ae_codebook_size, codes_dev);
+        hipLaunchKernelGGL(k_rvq, dim3(Tf), dim3(RVQ_T), (size_t)D * 4, X.s, ps, pa, D, X.c->cb_dev, c.ae_n_codebooks, c.ae_codebook_size, codes_dev);
 }
 
 int validate(q3tts_engine* e, const q3tts_clone_config& c) {
@@ -578,8 +628,17 @@ extern "C" int q3tts_clone_init(q3tts_engine* e, const q3tts_clone_config* cfg) 
     CK(mk_conv(e, c, c->semp, AC_SEM_PROJ, 0, -1, H, g.ae_vq_dim, 1, 1, 1, 0, PAD_ZERO));
     CK(mk_conv(e, c, c->acp, AC_AC_PROJ, 0, -1, H, g.ae_vq_dim, 1, 1, 1, 0, PAD_ZERO));
     c->cb.resize(g.ae_n_codebooks);
-    for (int q = 0; q < g.ae_n_codebooks; ++q)
-        CK(mk_vec(e, c, &c->cb[q], AC_CODEBOOK + q, 0, (size_t)g.ae_codebook_size * g.ae_vq_dim, 0.0f, 1.0f / sqrtf((float)g.ae_vq_dim)));
+    for (int q = 0; q < g.ae_n_codebooks; ++q) {  // generated row-major [CS][D] (the logical tensor), kept transposed for k_rvq
+        const size_t ne = (size_t)g.ae_codebook_size * g.ae_vq_dim;
+        float* rowmajor = nullptr;
+        Q3_HIP(e, hipMalloc((void**)&rowmajor, ne * 4));
+        q3_launch_fill_f32(rowmajor, ne, e->cfg.synth_seed, Q3_TID(Q3G_CLONE, AC_CODEBOOK + q, 0), 0.0f, (1.0f / sqrtf((float)g.ae_vq_dim)) / Q3_IH4_STD, 0, e->stream);
+        rc = dev_alloc(e, c, (void**)&c->cb[q], ne * 4);
+        if (!rc) hipLaunchKernelGGL(k_cb_transpose, dim3(nblk(ne)), dim3(256), 0, e->stream, rowmajor, c->cb[q], g.ae_codebook_size, g.ae_vq_dim);
+        hipStreamSynchronize(e->stream);
+        hipFree(rowmajor);
+        CK(rc);
+    }
     CK(dev_alloc(e, c, (void**)&c->cb_dev, sizeof(float*) * g.ae_n_codebooks));
     Q3_HIP(e, hipMemcpyAsync((void*)c->cb_dev, c->cb.data(), sizeof(float*) * g.ae_n_codebooks, hipMemcpyHostToDevice, e->stream));
     // RoPE tables (evaluated in double on the host, like the decoder's)
