@@ -237,6 +237,23 @@ int q3tts_k_speaker_from_mel(q3tts_engine* e, const float* mel, int32_t n_frames
 int q3tts_k_audio_latent(q3tts_engine* e, const float* audio, int64_t n_samples, float* latent, int32_t cap_frames,
                          int32_t* n_frames);
 
+/* ---- tokenizer (host only; replaces the `tokenizers`-crate wrapper src/utils/tokenizer.rs:1-37 for non-Rust hosts) ----
+ * Reads model_dir/tokenizer/tokenizer.json of the Qwen2 family: added tokens, NFC, Split(Qwen2 regex) + ByteLevel, BPE.
+ * Any other pipeline is refused at load (Q3TTS_ERR_UNSUPPORTED), input that is not already NFC is refused by encode.
+ * No engine and no GPU needed; errors go to the caller's buffer. A handle is not thread-safe (it caches words). */
+typedef struct q3tts_tokenizer q3tts_tokenizer;
+int q3tts_tokenizer_load(const char* tokenizer_json_path, q3tts_tokenizer** out, char* err, int32_t err_cap);
+void q3tts_tokenizer_free(q3tts_tokenizer* t);
+int32_t q3tts_tokenizer_vocab_size(const q3tts_tokenizer* t);
+/* Tokenizer::encode(text) = inner.encode(text, add_special_tokens = false).get_ids() (src/utils/tokenizer.rs:17-25).
+ * *n_ids receives the count even when cap is too small (then Q3TTS_ERR_INVALID). */
+int q3tts_tokenizer_encode(const q3tts_tokenizer* t, const char* utf8, int64_t n_bytes, uint32_t* ids, int32_t cap,
+                           int32_t* n_ids, char* err, int32_t err_cap);
+/* Tokenizer::decode(ids) = inner.decode(ids, skip_special_tokens = false) (:27-35), as raw bytes (the crate applies
+ * from_utf8_lossy on top) */
+int q3tts_tokenizer_decode(const q3tts_tokenizer* t, const uint32_t* ids, int32_t n, char* out, int64_t cap, int64_t* n_bytes,
+                           char* err, int32_t err_cap);
+
 /* ---- kernel-level test hooks (host buffers in/out; used only by tests/ and bench.py) ----------- */
 /* y[B][N] = exact_gemm(norm?(x)[B][K], W[N][K] bf16 bits) (+bias) — canonical order of DESIGN.md §4.1 */
 int q3tts_k_gemm_exact(int32_t device, const float* x, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N,

@@ -113,6 +113,13 @@ def load_cache(path):
     return codes, emb
 
 
+def load_tokenizer(model_dir):
+    """Tokenizer::load(model_dir) (src/utils/tokenizer.rs:9-15): model_dir/tokenizer/tokenizer.json through the C++ byte-level
+    BPE reader of the library (q3tts_tokenizer_*); None when the file does not exist (token ids are then the input)."""
+    tj = os.path.join(model_dir, "tokenizer", "tokenizer.json")
+    return native.NativeTokenizer(tj) if os.path.exists(tj) else None
+
+
 class TtsEngine:
     """src/tts/engine.rs:53-72 — the engine owns weights, contexts and speakers; one utterance at a time per call
     (`&mut self`), or a list through `generate_batch_with_voice` (continuous batching, an extension)."""
@@ -130,12 +137,7 @@ class TtsEngine:
         """TtsEngine::new(model_dir, quant) (src/tts/engine.rs:84-169). There is no network here: with no weight
         container under model_dir the engine uses seeded synthetic weights of the configured shape."""
         cfg = config or _abi.default_config()
-        tok = None
-        if model_dir:
-            tj = os.path.join(model_dir, "tokenizer", "tokenizer.json")  # src/utils/tokenizer.rs:12
-            if os.path.exists(tj):
-                from tokenizers import Tokenizer as HfTokenizer
-                tok = HfTokenizer.from_file(tj)
+        tok = load_tokenizer(model_dir) if model_dir else None
         eng = cls(cfg, tok)
         for d in ([os.path.join(model_dir, "preset_speakers")] if model_dir else []) + ["speakers"]:  # :156-166
             if os.path.isdir(d):
@@ -184,7 +186,7 @@ class TtsEngine:
         if isinstance(text, str):
             if self.tokenizer is None:
                 raise _abi.Q3Error("no tokenizer.json available: pass token ids instead of text")
-            return np.asarray(self.tokenizer.encode(text, add_special_tokens=False).ids, dtype=np.uint32)  # src/utils/tokenizer.rs:17-25
+            return np.asarray(self.tokenizer.encode(text), dtype=np.uint32)  # src/utils/tokenizer.rs:17-25 (add_special_tokens = false)
         return np.asarray(text, dtype=np.uint32)
 
     def _lang(self):

@@ -318,3 +318,53 @@ def stream_chunks(engine: "NativeEngine", **kw):
         res = _abi.Result()
         engine._check(engine.lib.q3tts_stream_end(h, C.byref(res)), "q3tts_stream_end")
         engine.last_stream_result = engine._unpack(res)
+
+
+class NativeTokenizer:
+    """The C++ byte-level BPE reader (csrc/q3_tokenizer.cpp) behind Tokenizer::load / encode / decode of the reference
+    (src/utils/tokenizer.rs). Host only."""
+
+    def __init__(self, tokenizer_json_path):
+        self.lib = _abi.load_library()
+        self.h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = self.lib.q3tts_tokenizer_load(os.fsencode(str(tokenizer_json_path)), C.byref(self.h), err, len(err))
+        if rc != 0:
+            raise _abi.Q3Error(f"q3tts_tokenizer_load failed ({rc}): {err.value.decode('utf-8', 'replace')}")
+
+    def close(self):
+        if self.h:
+            self.lib.q3tts_tokenizer_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def vocab_size(self):
+        return int(self.lib.q3tts_tokenizer_vocab_size(self.h))
+
+    def encode(self, text):
+        raw = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+        cap = max(16, len(raw) + 8)
+        ids = np.zeros(cap, dtype=np.uint32)
+        n = C.c_int32(0)
+        err = C.create_string_buffer(512)
+        rc = self.lib.q3tts_tokenizer_encode(self.h, raw, len(raw), _ptr(ids, u32p), cap, C.byref(n), err, len(err))
+        if rc != 0:
+            raise _abi.Q3Error(f"q3tts_tokenizer_encode failed ({rc}): {err.value.decode('utf-8', 'replace')}")
+        return ids[:n.value].copy()
+
+    def decode(self, ids):
+        a = np.ascontiguousarray(ids, dtype=np.uint32)
+        cap = 64 + 64 * a.size
+        out = C.create_string_buffer(cap)
+        n = C.c_int64(0)
+        err = C.create_string_buffer(512)
+        rc = self.lib.q3tts_tokenizer_decode(self.h, _ptr(a, u32p), a.size, out, cap, C.byref(n), err, len(err))
+        if rc != 0:
+            raise _abi.Q3Error(f"q3tts_tokenizer_decode failed ({rc}): {err.value.decode('utf-8', 'replace')}")
+        return out.raw[:n.value].decode("utf-8", "replace")
