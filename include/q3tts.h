@@ -172,9 +172,6 @@ int q3tts_stream_begin(q3tts_engine* e, const q3tts_request* req, q3tts_stream**
 int q3tts_stream_poll(q3tts_stream* s, const float** chunk, int32_t* n_samples, int32_t* is_final);
 int q3tts_stream_end(q3tts_stream* s, q3tts_result* out_codes_optional);
 
-/* Synthetic weight container: lets tests exercise the file path with the same tensors. */
-int q3tts_write_weights(q3tts_engine* e, const char* path);
-
 /* Per-stage device timings of the last generate call (hipEvent), ms. */
 typedef struct q3tts_timings {
     float prefill_ms, decode_ms, vocoder_ms, total_ms;

@@ -1037,11 +1037,6 @@ extern "C" int q3tts_get_timings(const q3tts_engine* e, q3tts_timings* out) {
     return Q3TTS_OK;
 }
 
-extern "C" int q3tts_write_weights(q3tts_engine* e, const char* path) {
-    (void)path;
-    return q3_set_err(e, Q3TTS_ERR_UNSUPPORTED, "Q3TW writer not built in this round");
-}
-
 // ------------------------------------------------------------------------------------------------
 // streaming (H8): 4-frame chunks
 // ------------------------------------------------------------------------------------------------

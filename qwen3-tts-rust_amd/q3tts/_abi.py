@@ -113,7 +113,7 @@ class CloneConfig(C.Structure):
 SYMBOLS = [
     "q3tts_default_config", "q3tts_engine_create", "q3tts_engine_destroy", "q3tts_last_error", "q3tts_set_sampler",
     "q3tts_set_max_steps", "q3tts_build_prompt", "q3tts_free", "q3tts_generate", "q3tts_generate_batch",
-    "q3tts_result_free", "q3tts_stream_begin", "q3tts_stream_poll", "q3tts_stream_end", "q3tts_write_weights",
+    "q3tts_result_free", "q3tts_stream_begin", "q3tts_stream_poll", "q3tts_stream_end",
     "q3tts_get_timings", "q3tts_k_gemm_exact", "q3tts_k_attention", "q3tts_k_sample", "q3tts_k_talker_prefill",
     "q3tts_k_vocoder", "q3tts_k_rng_f32", "q3tts_k_probe", "q3tts_k_gguf_read", "q3tts_mel_frames", "q3tts_mel",
     "q3tts_clone_default_config", "q3tts_clone_init", "q3tts_clone_audio_frames", "q3tts_clone_audio_encode",
@@ -161,7 +161,6 @@ def load_library(path=None):
     lib.q3tts_stream_begin.argtypes = [vp, C.POINTER(Request), C.POINTER(vp)]
     lib.q3tts_stream_poll.argtypes = [vp, C.POINTER(f32p), i32p, i32p]
     lib.q3tts_stream_end.argtypes = [vp, C.POINTER(Result)]
-    lib.q3tts_write_weights.argtypes = [vp, C.c_char_p]
     lib.q3tts_get_timings.argtypes = [vp, C.POINTER(Timings)]
     lib.q3tts_k_gemm_exact.argtypes = [C.c_int32, f32p, C.c_int32, C.c_int32, C.POINTER(C.c_uint16), C.c_int32, f32p,
                                        C.c_float, f32p, C.c_int32, f32p, C.POINTER(C.c_uint64), C.c_int32, f32p]

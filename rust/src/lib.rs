@@ -91,14 +91,18 @@ pub struct AudioSample { pub samples: Vec<f32>, pub sample_rate: u32, pub channe
 pub struct TtsEngine { raw: *mut q3tts_engine, sampler: SamplerConfig, max_steps: usize }
 
 impl TtsEngine {
-    /// TtsEngine::new(model_dir, quant) — src/tts/engine.rs:84. `model_dir` would carry a Q3TW weight container.
-    pub fn new(_model_dir: &str, _quant: &str) -> Result<Self, String> {
+    /// TtsEngine::new(model_dir, quant) — src/tts/engine.rs:84-169. `model_dir/<quant dir>` (src/tts/engine.rs:91-95) holds
+    /// qwen3_tts_talker.gguf, qwen3_tts_predictor.gguf and qwen3_assets.gguf (or the NPY assets): passed as `weights_path`.
+    pub fn new(model_dir: &str, quant: &str) -> Result<Self, String> {
+        let quant_dir = match quant { "q5_k_m" => "gguf_q5_k_m", "q8_0" => "gguf_q8_0", _ => "gguf" };
+        let dir = std::ffi::CString::new(format!("{}/{}", model_dir, quant_dir)).map_err(|e| e.to_string())?;
         unsafe {
             let mut cfg: q3tts_engine_config = std::mem::zeroed();
             q3tts_default_config(&mut cfg);
+            cfg.weights_path = dir.as_ptr();   // borrowed for the call only
             let mut raw = std::ptr::null_mut();
             let rc = q3tts_engine_create(&cfg, &mut raw);
-            if rc != 0 { return Err(CStr::from_ptr(q3tts_last_error(std::ptr::null())).to_string_lossy().into_owned()); }
+            if rc != 0 { return Err(format!("q3tts_engine_create failed: {}", rc)); }
             Ok(Self { raw, sampler: SamplerConfig::default(), max_steps: 512 })
         }
     }
