@@ -137,6 +137,11 @@ class TtsEngine:
         """TtsEngine::new(model_dir, quant) (src/tts/engine.rs:84-169). There is no network here: with no weight
         container under model_dir the engine uses seeded synthetic weights of the configured shape."""
         cfg = config or _abi.default_config()
+        if model_dir:
+            quant_dir = {"q5_k_m": "gguf_q5_k_m", "q8_0": "gguf_q8_0"}.get(quant, "gguf")  # src/tts/engine.rs:91-95
+            wdir = os.path.join(model_dir, quant_dir)
+            if os.path.exists(os.path.join(wdir, "qwen3_tts_talker.gguf")):  # :121-122; absent -> synthetic weights (no downloader here)
+                cfg.weights_path = wdir.encode()
         tok = load_tokenizer(model_dir) if model_dir else None
         eng = cls(cfg, tok)
         for d in ([os.path.join(model_dir, "preset_speakers")] if model_dir else []) + ["speakers"]:  # :156-166

@@ -212,3 +212,40 @@ def test_full_shape_three_second_clip(oracle):
         assert np.array_equal(_bits(emb), _bits(oracle.speaker_encode(ccfg, 0, eng.mel(a))))
     finally:
         eng.close()
+
+
+def test_text_in_wav_out_from_a_model_directory(oracle, tmp_path):
+    """TtsEngine::new(model_dir, quant) + generate_with_voice(text, speaker) as a reference user writes it
+    (README.md:117-169): model_dir/gguf_q8_0/{talker,predictor,assets}.gguf, model_dir/tokenizer/tokenizer.json,
+    model_dir/preset_speakers/*.json -> text in, WAV out. Ids equal the oracle's on the crate's token ids."""
+    from test_tokenizer_cpu import _train
+    from q3tts import _abi, api
+    cfg = _abi.tiny_config(max_batch=2, n_ctx=128, with_vocoder=1)
+    root = tmp_path / "models"
+    (root / "gguf_q8_0").mkdir(parents=True)
+    (root / "tokenizer").mkdir()
+    (root / "preset_speakers").mkdir()
+    oracle.write_model_dir(str(root / "gguf_q8_0"), cfg.model, 0, matrix_type=30, assets="gguf", with_text=True)
+    hf, _ = _train(420, False, root / "tokenizer")
+    spk = ((np.arange(cfg.model.d_embed) % 11 - 5) * 0.0625).astype(np.float32)
+    api.VoiceFile.new("", [], spk.tolist()).with_metadata(name="Vivian").save(root / "preset_speakers" / "vivian.json")
+    te = api.TtsEngine.new(str(root), "q8_0", config=cfg)
+    try:
+        assert te.cfg.weights_path == str(root / "gguf_q8_0").encode() and te.tokenizer is not None
+        te.set_sampler_config(api.SamplerConfig(0.0, 40, 0.9, 1))
+        te.set_max_steps(5)
+        text = "你好，world! it's 2024."
+        audio = te.generate_with_voice(text, te.get_speaker("vivian"))
+        assert len(audio.samples) == 5 * 1920
+        audio.save_wav(tmp_path / "out.wav")
+        ids = hf.encode(text, add_special_tokens=False).ids
+        om = oracle.OracleModel(cfg.model, seed=0, n_ctx=128, n_threads=4)
+        try:
+            desc, keep = oracle.make_prompt_desc(ids, spk_emb=spk)
+            ref, _ = om.generate(om.build_prompt(desc), temperature=0.0, max_steps=5)
+        finally:
+            om.close()
+        d2, keep2 = te._desc(text, te.get_speaker("vivian"), None)
+        assert np.array_equal(te._native.generate(desc=d2, temperature=0.0, max_steps=5).codes, ref)
+    finally:
+        te.close()
