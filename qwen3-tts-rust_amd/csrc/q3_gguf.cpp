@@ -228,3 +228,35 @@ int q3_npy_load_f32(const std::string& path, std::vector<float>& out, std::vecto
     fclose(f);
     return 0;
 }
+
+// ---- C ABI test hook (host only) -------------------------------------------------------------------------------
+#include "../../include/q3tts.h"
+struct q3tts_engine;
+int q3_set_err(q3tts_engine* e, int code, const std::string& msg);  // q3_engine.hip (engine == nullptr: the global error slot)
+
+extern "C" int q3tts_k_gguf_read(const char* path, const char* tensor, float* out, int64_t cap, int64_t* nelem, int64_t* dims4, int32_t* ggml_type) {
+    if (!path || !tensor || !nelem) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "null argument");
+    std::string err;
+    const std::string p = path;
+    if (p.size() > 4 && p.compare(p.size() - 4, 4, ".npy") == 0) {
+        std::vector<float> v; std::vector<size_t> shape;
+        if (q3_npy_load_f32(p, v, shape, err)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, err);
+        *nelem = (int64_t)v.size();
+        if (dims4) for (int i = 0; i < 4; ++i) dims4[i] = i < (int)shape.size() ? (int64_t)shape[i] : 0;
+        if (ggml_type) *ggml_type = Q3_GGML_F32;
+        if (out) { if (cap < *nelem) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "output buffer too small"); memcpy(out, v.data(), v.size() * 4); }
+        return Q3TTS_OK;
+    }
+    Q3Gguf g;
+    if (g.open(p, err)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, err);
+    const Q3GgufTensor* t = g.find(tensor);
+    if (!t) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, std::string("tensor '") + tensor + "' is missing");
+    *nelem = (int64_t)t->nelem;
+    if (dims4) for (int i = 0; i < 4; ++i) dims4[i] = i < (int)t->dims.size() ? (int64_t)t->dims[i] : 0;
+    if (ggml_type) *ggml_type = (int32_t)t->type;
+    if (out) {
+        if (cap < *nelem) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "output buffer too small");
+        if (q3_gguf_to_f32(*t, out, err)) return q3_set_err(nullptr, Q3TTS_ERR_UNSUPPORTED, err);
+    }
+    return Q3TTS_OK;
+}
