@@ -277,6 +277,9 @@ int q3tts_k_gguf_read(const char* path, const char* tensor, float* out, int64_t 
  * pass 1 / layer 0 is bracketed by HIP events on its own stream; q3tts_timings.probe_kernel_ms / probe_count report it
  * for the frame steps that ran at the full row count. enable = 0 restores graph replay. */
 int q3tts_k_probe(q3tts_engine* e, int32_t enable);
+/* n_cases independent chains of `chain` v_mfma_f32_16x16x32_bf16 into one accumulator tile: a [n][chain][16][32] bf16 bits,
+ * b [n][chain][32][16], c / d [n][16][16] f32. Pins the instruction's accumulation arithmetic. */
+int q3tts_k_mfma_bf16(int32_t device, const uint16_t* a, const uint16_t* b, const float* c, float* d, int32_t n_cases, int32_t chain);
 /* rand 0.8 StdRng (ChaCha12) stream: seed_from_u64(seed) then n x gen::<f32>() */
 int q3tts_k_rng_f32(uint64_t seed, int32_t n, float* out);
 

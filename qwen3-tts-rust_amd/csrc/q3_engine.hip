@@ -1224,6 +1224,38 @@ extern "C" int q3tts_k_sample(int32_t device, const float* logits, int32_t n, in
     return Q3TTS_OK;
 }
 
+// one v_mfma_f32_16x16x32_bf16 chain per case (test hook: pins the instruction's accumulation arithmetic against the
+// oracle's integer restatement, oracle/q3_oracle.c q3o_mfma_bf16_dot32)
+typedef float q3_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 q3_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ void k_mfma_bf16_cases(const uint16_t* A, const uint16_t* B, const float* C, float* D, int chain) {
+    const int l = threadIdx.x, cs = blockIdx.x;
+    const uint16_t* a = A + (size_t)cs * chain * 512; const uint16_t* b = B + (size_t)cs * chain * 512;
+    q3_f32x4 acc;
+    for (int j = 0; j < 4; ++j) acc[j] = C[(size_t)cs * 256 + (4 * (l >> 4) + j) * 16 + (l & 15)];
+    for (int st = 0; st < chain; ++st) {
+        union { q3_bf16x8 v; uint16_t u[8]; } af, bf;
+        for (int j = 0; j < 8; ++j) {  // lane l holds A[row l & 15][k = 8 (l >> 4) + j] and B[k = 8 (l >> 4) + j][col l & 15]
+            af.u[j] = a[(size_t)st * 512 + (l & 15) * 32 + 8 * (l >> 4) + j];
+            bf.u[j] = b[(size_t)st * 512 + (8 * (l >> 4) + j) * 16 + (l & 15)];
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf.v, acc, 0, 0, 0);
+    }
+    for (int j = 0; j < 4; ++j) D[(size_t)cs * 256 + (4 * (l >> 4) + j) * 16 + (l & 15)] = acc[j];
+}
+extern "C" int q3tts_k_mfma_bf16(int32_t device, const uint16_t* a, const uint16_t* b, const float* c, float* d, int32_t n_cases, int32_t chain) {
+    if (!a || !b || !c || !d || n_cases <= 0 || chain <= 0) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "mfma hook: bad shape");
+    HK(hipSetDevice(device));
+    const size_t nab = (size_t)n_cases * chain * 512 * 2, ncd = (size_t)n_cases * 256 * 4;
+    DevBuf da, db, dc, dd;
+    if (da.alloc(nab) || db.alloc(nab) || dc.alloc(ncd) || dd.alloc(ncd)) return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
+    HK(hipMemcpy(da.p, a, nab, hipMemcpyHostToDevice)); HK(hipMemcpy(db.p, b, nab, hipMemcpyHostToDevice)); HK(hipMemcpy(dc.p, c, ncd, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_mfma_bf16_cases, dim3(n_cases), dim3(64), 0, nullptr, (const uint16_t*)da.p, (const uint16_t*)db.p, (const float*)dc.p, (float*)dd.p, chain);
+    HK(hipDeviceSynchronize());
+    HK(hipMemcpy(d, dd.p, ncd, hipMemcpyDeviceToHost));
+    return Q3TTS_OK;
+}
+
 extern "C" int q3tts_k_talker_prefill(q3tts_engine* e, const float* embd, int32_t n_tok, float* hidden_out, float* logits_out) {
     if (!e || !embd || n_tok <= 0) return q3_set_err(e, Q3TTS_ERR_INVALID, "null argument");
     Q3_HIP(e, hipSetDevice(e->cfg.device));
