@@ -280,6 +280,10 @@ int q3tts_k_probe(q3tts_engine* e, int32_t enable);
 /* n_cases independent chains of `chain` v_mfma_f32_16x16x32_bf16 into one accumulator tile: a [n][chain][16][32] bf16 bits,
  * b [n][chain][32][16], c / d [n][16][16] f32. Pins the instruction's accumulation arithmetic. */
 int q3tts_k_mfma_bf16(int32_t device, const uint16_t* a, const uint16_t* b, const float* c, float* d, int32_t n_cases, int32_t chain);
+/* PROTOTYPE (not used by the engine): canonical bf16-MFMA GEMM of DESIGN.md §16; x / w are bf16 bit patterns, K in {1024, 2048},
+ * N % 48 == 0; y[B][N] f32 equals oracle q3o_gemm_bf16 bit for bit */
+int q3tts_k_gemm_bf16(int32_t device, const uint16_t* x, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, float* y, int32_t iters,
+                      float* mean_kernel_ms);
 /* rand 0.8 StdRng (ChaCha12) stream: seed_from_u64(seed) then n x gen::<f32>() */
 int q3tts_k_rng_f32(uint64_t seed, int32_t n, float* out);
 

@@ -816,3 +816,29 @@ float q3o_mfma_bf16_dot32(const uint16_t* a, const uint16_t* b, float c) {
     }
     return acc;
 }
+
+/* canonical bf16-MFMA GEMM (prototype): x, w bf16 bits; 8 contiguous K-slices, each a chain of MFMA steps over
+ * ascending 32-blocks whose lane group g holds k = 4g..4g+3 and 16+4g..16+4g+3; slice results added in slice order */
+void q3o_gemm_bf16(const uint16_t* x, int32_t B, int32_t K, const uint16_t* w, int32_t N, float* y) {
+    const int per = K / 256;  /* 32-blocks per slice */
+#pragma omp parallel for schedule(static) collapse(2)
+    for (int b = 0; b < B; ++b)
+        for (int n = 0; n < N; ++n) {
+            float tot = 0.0f;
+            for (int sl = 0; sl < 8; ++sl) {
+                float acc = 0.0f;
+                for (int st = 0; st < per; ++st) {
+                    const int k0 = (sl * per + st) * 32;
+                    uint16_t av[32], bv[32];
+                    for (int g = 0; g < 4; ++g)
+                        for (int e = 0; e < 8; ++e) {
+                            const int k = k0 + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4));
+                            av[8 * g + e] = x[(size_t)b * K + k]; bv[8 * g + e] = w[(size_t)n * K + k];
+                        }
+                    acc = q3o_mfma_bf16_dot32(av, bv, acc);
+                }
+                tot = sl == 0 ? acc : tot + acc;
+            }
+            y[(size_t)b * N + n] = tot;
+        }
+}

@@ -1224,6 +1224,33 @@ extern "C" int q3tts_k_sample(int32_t device, const float* logits, int32_t n, in
     return Q3TTS_OK;
 }
 
+// prototype bf16-MFMA GEMM (q3_gemm_bf16.hip): x bf16 bits [B][K], w bf16 bits row-major [N][K] -> y [B][N]
+int q3_launch_gemm_bf16(const uint16_t* x, int ldx, int B, const uint4* w, int K, int N, float* y, int ldy, hipStream_t s);
+extern "C" int q3tts_k_gemm_bf16(int32_t device, const uint16_t* x, int32_t B, int32_t K, const uint16_t* w, int32_t N, float* y, int32_t iters,
+                                 float* mean_ms) {
+    if (!x || !w || !y || B <= 0 || (K != 1024 && K != 2048) || N % 48) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bf16 gemm hook: K in {1024, 2048}, N % 48 == 0");
+    HK(hipSetDevice(device));
+    DevBuf dx, dw, dwt, dy;
+    if (dx.alloc((size_t)B * K * 2) || dw.alloc((size_t)N * K * 2) || dwt.alloc((size_t)N * K * 2) || dy.alloc((size_t)B * N * 4)) return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
+    HK(hipMemcpy(dx.p, x, (size_t)B * K * 2, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dw.p, w, (size_t)N * K * 2, hipMemcpyHostToDevice));
+    Q3Fill f{}; f.dst = (uint4*)dwt.p; f.N = N; f.K = K; f.mode = 0; f.row0 = 0; f.rows = N; f.src_a = (const uint16_t*)dw.p;
+    q3_launch_fill_tiled(f, nullptr);
+    if (q3_launch_gemm_bf16((const uint16_t*)dx.p, K, B, (const uint4*)dwt.p, K, N, (float*)dy.p, N, nullptr)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bf16 gemm: shape");
+    HK(hipDeviceSynchronize());
+    HK(hipMemcpy(y, dy.p, (size_t)B * N * 4, hipMemcpyDeviceToHost));
+    if (iters > 0 && mean_ms) {
+        hipEvent_t a, b; HK(hipEventCreate(&a)); HK(hipEventCreate(&b));
+        q3_launch_gemm_bf16((const uint16_t*)dx.p, K, B, (const uint4*)dwt.p, K, N, (float*)dy.p, N, nullptr);
+        HK(hipEventRecord(a, nullptr));
+        for (int i = 0; i < iters; ++i) q3_launch_gemm_bf16((const uint16_t*)dx.p, K, B, (const uint4*)dwt.p, K, N, (float*)dy.p, N, nullptr);
+        HK(hipEventRecord(b, nullptr)); HK(hipEventSynchronize(b));
+        float ms = 0; hipEventElapsedTime(&ms, a, b); *mean_ms = ms / iters;
+        hipEventDestroy(a); hipEventDestroy(b);
+    }
+    return Q3TTS_OK;
+}
+
 // one v_mfma_f32_16x16x32_bf16 chain per case (test hook: pins the instruction's accumulation arithmetic against the
 // oracle's integer restatement, oracle/q3_oracle.c q3o_mfma_bf16_dot32)
 typedef float q3_f32x4 __attribute__((ext_vector_type(4)));

@@ -1,0 +1,77 @@
+// q3_gemm_bf16.hip — PROTOTYPE of the canonical bf16-MFMA GEMM. Not used by the engine yet: it exists to
+// show, measured and bit-exact against the oracle, what the decoder's GEMMs gain from v_mfma_f32_16x16x32_bf16 now that
+// the instruction's accumulation arithmetic is restated (oracle/q3_oracle.c::q3o_mfma_bf16_dot32).
+//
+// Canonical order: y[b][n] = ((((s_0 + s_1) + s_2) + ...) + s_7), s_w = the chain of MFMA steps over K-slice w (K/8
+// contiguous columns, 32 per instruction, ascending), each instruction consuming its 32 products lane group by lane group:
+// group g holds k = 4g..4g+3 and 16+4g..16+4g+3 of the 32-block — exactly what the tiled weight layout of DESIGN.md §2.1
+// puts into one lane, so weights are shared with the exact path. Activations arrive already rounded to bf16.
+// Workgroup = 8 waves = 8 K-slices of one 32 x 48 output tile (160 B of operands per k); a wave issues every
+// load of its slice before its first MFMA, so all of a CU's operand bytes are in flight at once.
+#include "q3_kernels.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int RT, int NT, int PER>
+__global__ __launch_bounds__(512) void k_gemm_bf16(const uint16_t* __restrict__ x, int ldx, int B, const uint4* __restrict__ w, int K, int N,
+                                                   float* __restrict__ y, int ldy) {
+    extern __shared__ float part[];  // [8 waves][RT*NT*4 regs][64 lanes]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kq = lane >> 4, r = lane & 15;
+    const int nb0 = blockIdx.x * NT, row0 = blockIdx.y * RT * 16, kblocks = K >> 5, kb0 = wave * PER;
+    uint2 alo[PER][RT], ahi[PER][RT]; uint4 bq[PER][NT];
+#pragma unroll
+    for (int s = 0; s < PER; ++s) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int row = min(row0 + 16 * i + r, B - 1);
+            const uint16_t* p = x + (size_t)row * ldx + (size_t)(kb0 + s) * 32 + 4 * kq;
+            alo[s][i] = *(const uint2*)p; ahi[s][i] = *(const uint2*)(p + 16);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bq[s][j] = w[((size_t)(nb0 + j) * kblocks + kb0 + s) * 64 + lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);  // every load of the slice is issued before the first MFMA (the scheduler would otherwise sink them)
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < PER; ++s) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            union { uint4 u; bf16x8 v; } a; a.u = make_uint4(alo[s][i].x, alo[s][i].y, ahi[s][i].x, ahi[s][i].y);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                union { uint4 u; bf16x8 v; } b; b.u = bq[s][j];
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[((size_t)wave * (RT * NT * 4) + (i * NT + j) * 4 + e) * 64 + lane] = acc[i][j][e];
+    __syncthreads();
+    // slice partials combined in slice order; element (tile t, reg e, lane l) -> row 16 i + 4 (l >> 4) + e, col 16 j + (l & 15)
+    for (int o = threadIdx.x; o < RT * NT * 4 * 64; o += 512) {
+        float v = part[o];
+#pragma unroll
+        for (int wv = 1; wv < 8; ++wv) v = v + part[(size_t)wv * (RT * NT * 4 * 64) + o];
+        const int l = o & 63, e = (o >> 6) & 3, t = o >> 8, i = t / NT, j = t - i * NT;
+        const int row = row0 + 16 * i + 4 * (l >> 4) + e;
+        if (row < B) y[(size_t)row * ldy + (size_t)(nb0 + j) * 16 + (l & 15)] = v;
+    }
+}
+
+// x: bf16 bits [B][ldx]; w: tiled bf16; K % 256 == 0 and K / 256 in {4, 8} (K = 1024, 2048), N % 48 == 0
+int q3_launch_gemm_bf16(const uint16_t* x, int ldx, int B, const uint4* w, int K, int N, float* y, int ldy, hipStream_t s) {
+    if (B < 1 || N % 48 || (K != 1024 && K != 2048)) return -1;
+    const dim3 grid(N / 48, (B + 31) / 32);
+    const size_t lds = (size_t)8 * 2 * 3 * 4 * 64 * 4;
+    if (K == 1024) hipLaunchKernelGGL((k_gemm_bf16<2, 3, 4>), grid, dim3(512), lds, s, x, ldx, B, w, K, N, y, ldy);
+    else hipLaunchKernelGGL((k_gemm_bf16<2, 3, 8>), grid, dim3(512), lds, s, x, ldx, B, w, K, N, y, ldy);
+    return 0;
+}

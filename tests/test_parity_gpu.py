@@ -524,3 +524,29 @@ def test_bf16_mfma_arithmetic_model(oracle):
                     assert _bits(np.float32(acc)) == _bits(D[c, i, j]), (s, cs, chain, cancel, c, i, j, acc, float(D[c, i, j]))
                     total += 1
     assert total == 10 * n * 6 * 4
+
+
+@pytest.mark.parametrize("B,K,N", [(64, 1024, 6144), (64, 1024, 4128), (50, 1024, 96), (33, 2048, 1008), (1, 1024, 48), (64, 2048, 4080)])
+def test_bf16_gemm_prototype_matches_oracle(oracle, B, K, N):
+    """The prototype canonical bf16-MFMA GEMM (csrc/q3_gemm_bf16.hip; not used by the engine yet): bit-exact
+    against the oracle's restatement of the instruction, ragged row counts included, and timed next to the exact kernel."""
+    from q3tts import _abi, native
+    lib = _abi.load_library()
+    L = oracle.lib()
+    L.q3o_gemm_bf16.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+    L.q3o_gemm_bf16.restype = None
+    rng = np.random.default_rng(B + K + N)
+    x = _rand(rng, (B, K), 1.5); x[:, :7] *= 300.0; x[:, 100:140] *= 1e-3   # outlier and tiny channels, as activations have
+    w = _rand(rng, (N, K), 0.02)
+    xb, wb = _bf16_bits(x), _bf16_bits(w)
+    ref = np.zeros((B, N), dtype=np.float32)
+    L.q3o_gemm_bf16(xb.ctypes.data, B, K, wb.ctypes.data, N, ref.ctypes.data)
+    y = np.zeros((B, N), dtype=np.float32)
+    ms = C.c_float(0)
+    assert lib.q3tts_k_gemm_bf16(0, xb.ctypes.data, B, K, wb.ctypes.data, N, y.ctypes.data, 200, C.byref(ms)) == 0
+    assert np.array_equal(_bits(y), _bits(ref))
+    xf = (xb.astype(np.uint32) << 16).view(np.float32).astype(np.float64); wf = (wb.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    assert np.abs(y - xf @ wf.T).max() <= 2e-5 * np.abs(xf @ wf.T).max()   # and it is a GEMM
+    if (B, K, N) == (64, 1024, 6144):
+        _, _, ms_exact = native.k_gemm_exact(((xb.astype(np.uint32) << 16).view(np.float32)), wb, epilogue=0, iters=200)
+        print(f"M=64 K=1024 N=6144 back-to-back launches: bf16-MFMA prototype {ms.value * 1e3:.2f} us, exact f32-MFMA kernel {ms_exact * 1e3:.2f} us")
