@@ -123,7 +123,8 @@ struct GgSrc {
         if (!t) return rc;
         std::vector<float> h(n); std::string err;
         if (q3_gguf_to_f32(*t, h.data(), err)) return fail(err);
-        Q3_HIP(e, hipMemcpy(dst, h.data(), n * 4, hipMemcpyHostToDevice));
+        Q3_HIP(e, hipMemcpyAsync(dst, h.data(), n * 4, hipMemcpyHostToDevice, e->stream));  // ordered after dalloc's zero fill
+        Q3_HIP(e, hipStreamSynchronize(e->stream));
         return Q3TTS_OK;
     }
     // [N][K] matrix -> bf16 row-major staging buffer `which` on the device
@@ -317,7 +318,10 @@ static uint16_t host_bf16(float f) {
 }
 static int upload_table(q3tts_engine* e, float** dst, const float* host, size_t n) {
     TRY(dalloc(e, dst, n));
-    Q3_HIP(e, hipMemcpy(*dst, host, n * 4, hipMemcpyHostToDevice));
+    // dalloc zero-fills asynchronously on e->stream, a non-blocking stream: the copy has to be ordered on that stream too
+    // (a plain hipMemcpy runs on the null stream and could be overtaken by the fill, zeroing rows of the table)
+    Q3_HIP(e, hipMemcpyAsync(*dst, host, n * 4, hipMemcpyHostToDevice, e->stream));
+    Q3_HIP(e, hipStreamSynchronize(e->stream));  // `host` may be a temporary of the caller
     return Q3TTS_OK;
 }
 static int upload_proj(q3tts_engine* e, const float* w, const float* b) {
