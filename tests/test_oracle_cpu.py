@@ -283,3 +283,21 @@ def test_mel_oracle_follows_the_spec(oracle, n):
     assert got.shape == ref.shape == ((0, 128) if n < 256 else ((n + 768 - 1024) // 256 + 1, 128))
     if n >= 256:
         assert np.abs(got - ref).max() <= 2e-3   # f32 DFT + f32 filterbank vs float64; log floor region included
+
+
+def test_bf16_mfma_restatement_against_hardware_vectors(oracle):
+    """tests/golden/bf16_mfma_mi355x.npz holds inputs and results of v_mfma_f32_16x16x32_bf16 measured on an MI355X
+    (tests/golden/make_bf16_mfma_golden.py): ~1 000 vectors from random exponent spreads, cancelling +-2^E pairs, one and
+    two active lane groups. The integer restatement in the oracle has to reproduce every one of them bit for bit."""
+    import ctypes as C
+    import os
+    Z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_mfma_mi355x.npz"))
+    L = oracle.lib()
+    L.q3o_mfma_bf16_dot32.argtypes = [C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.c_float]
+    L.q3o_mfma_bf16_dot32.restype = C.c_float
+    a, b, c, d = Z["a"], Z["b"], Z["c"], Z["d"]
+    assert a.shape[0] >= 900 and len(set(Z["set"].tolist())) >= 20
+    for i in range(a.shape[0]):
+        ai, bi = np.ascontiguousarray(a[i]), np.ascontiguousarray(b[i])
+        r = np.float32(L.q3o_mfma_bf16_dot32(ai.ctypes.data_as(C.POINTER(C.c_uint16)), bi.ctypes.data_as(C.POINTER(C.c_uint16)), float(c[i])))
+        assert r.view(np.uint32) == d[i].view(np.uint32), (str(Z["set"][i]), i, float(r), float(d[i]))
