@@ -236,7 +236,7 @@ int q3tts_k_audio_latent(q3tts_engine* e, const float* audio, int64_t n_samples,
 
 /* ---- tokenizer (host only; replaces the `tokenizers`-crate wrapper src/utils/tokenizer.rs:1-37 for non-Rust hosts) ----
  * Reads model_dir/tokenizer/tokenizer.json of the Qwen2 family: added tokens, NFC, Split(Qwen2 regex) + ByteLevel, BPE.
- * Any other pipeline is refused at load (Q3TTS_ERR_UNSUPPORTED), input that is not already NFC is refused by encode.
+ * Any other pipeline is refused at load (Q3TTS_ERR_UNSUPPORTED); input must be valid UTF-8.
  * No engine and no GPU needed; errors go to the caller's buffer. A handle is not thread-safe (it caches words). */
 typedef struct q3tts_tokenizer q3tts_tokenizer;
 int q3tts_tokenizer_load(const char* tokenizer_json_path, q3tts_tokenizer** out, char* err, int32_t err_cap);

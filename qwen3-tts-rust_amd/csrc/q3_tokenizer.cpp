@@ -7,8 +7,9 @@
 //   added tokens (leftmost-longest, matched on the raw text) -> NFC normaliser -> Split(the Qwen2 regex, Isolated) ->
 //   ByteLevel(add_prefix_space = false, use_regex = false) -> BPE(merges by rank) -> no post-processing.
 // Anything else in the file (another normaliser / pre-tokeniser / model type, added tokens with lstrip / rstrip /
-// single_word / normalized) is refused at load time with a message, not approximated. NFC: text that is already in NFC
-// passes (quick check over q3_unicode_tables.h); text that would need composing is refused by encode().
+// single_word / normalized) is refused at load time with a message, not approximated. NFC is implemented in full (UAX #15:
+// generated decomposition / combining-class / composition tables in q3_unicode_tables.h, algorithmic Hangul), behind a quick
+// check that lets already-normalised text through untouched.
 // Parity is pinned: the Python `tokenizers` package in this image (0.22.2) is the same crate, and tests/test_tokenizer_cpu.py
 // compares ids on tokenizers trained in the test (no tokenizer.json of the real model exists offline).
 #include <algorithm>
@@ -167,6 +168,77 @@ bool decode_utf8(const char* s, size_t n, std::vector<uint32_t>& cps, std::vecto
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// NFC (UAX #15): canonical decomposition (generated table + algorithmic Hangul), canonical ordering, canonical composition
+// ---------------------------------------------------------------------------------------------------------------
+uint8_t ccc_of(uint32_t cp) {
+    int lo = 0, hi = Q3U_CCC_N - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cp < Q3U_CCC[mid].cp) hi = mid - 1; else if (cp > Q3U_CCC[mid].cp) lo = mid + 1; else return Q3U_CCC[mid].cls;
+    }
+    return 0;
+}
+void decompose(uint32_t cp, std::vector<uint32_t>& out) {
+    if (cp >= 0xAC00 && cp <= 0xD7A3) {  // Hangul syllable -> L V (T)
+        const uint32_t si = cp - 0xAC00;
+        out.push_back(0x1100 + si / 588); out.push_back(0x1161 + (si % 588) / 28);
+        if (si % 28) out.push_back(0x11A7 + si % 28);
+        return;
+    }
+    int lo = 0, hi = Q3U_DECOMP_N - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cp < Q3U_DECOMP[mid].cp) hi = mid - 1;
+        else if (cp > Q3U_DECOMP[mid].cp) lo = mid + 1;
+        else { for (int i = 0; i < Q3U_DECOMP[mid].len; ++i) out.push_back(Q3U_DECOMP_POOL[Q3U_DECOMP[mid].off + i]); return; }
+    }
+    out.push_back(cp);
+}
+uint32_t compose_pair(uint32_t a, uint32_t b) {  // 0: no primary composite
+    if (a >= 0x1100 && a <= 0x1112 && b >= 0x1161 && b <= 0x1175) return 0xAC00 + ((a - 0x1100) * 21 + (b - 0x1161)) * 28;
+    if (a >= 0xAC00 && a <= 0xD7A3 && (a - 0xAC00) % 28 == 0 && b >= 0x11A8 && b <= 0x11C2) return a + (b - 0x11A7);
+    int lo = 0, hi = Q3U_COMP_N - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const Q3UComp& c = Q3U_COMP[mid];
+        if (a < c.a || (a == c.a && b < c.b)) hi = mid - 1; else if (a > c.a || (a == c.a && b > c.b)) lo = mid + 1; else return c.c;
+    }
+    return 0;
+}
+void nfc(std::vector<uint32_t>& cps) {
+    bool clean = true;
+    for (uint32_t c : cps) if (in_ranges(Q3U_NFC_UNSAFE, Q3U_NFC_UNSAFE_N, c)) { clean = false; break; }
+    if (clean) return;  // quick check: nothing that could decompose, reorder or compose
+    std::vector<uint32_t> d;
+    d.reserve(cps.size() + 8);
+    for (uint32_t c : cps) decompose(c, d);
+    for (size_t i = 1; i < d.size(); ++i) {  // canonical ordering: stable insertion sort of the non-starters by combining class
+        const uint8_t ci = ccc_of(d[i]);
+        if (!ci) continue;
+        size_t j = i;
+        while (j > 0) { const uint8_t cj = ccc_of(d[j - 1]); if (cj == 0 || cj <= ci) break; std::swap(d[j], d[j - 1]); --j; }
+    }
+    if (d.empty()) { cps.clear(); return; }
+    size_t starter_pos = 0, comp_pos = 1;
+    uint32_t starter = d[0];
+    int last_class = ccc_of(starter);
+    if (last_class != 0) last_class = 256;  // a leading non-starter never composes
+    for (size_t i = 1; i < d.size(); ++i) {
+        const uint32_t ch = d[i];
+        const int cls = ccc_of(ch);
+        const uint32_t composite = compose_pair(starter, ch);
+        if (composite && (last_class < cls || last_class == 0)) { d[starter_pos] = composite; starter = composite; }
+        else {
+            if (cls == 0) { starter_pos = comp_pos; starter = ch; }
+            last_class = cls;
+            d[comp_pos++] = ch;
+        }
+    }
+    d.resize(comp_pos);
+    cps.swap(d);
+}
+
 const char* QWEN2_SPLIT =
     "(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\\r\\n\\p{L}\\p{N}]?\\p{L}+|\\p{N}| ?[^\\s\\p{L}\\p{N}]+[\\r\\n]*|\\s*[\\r\\n]+|\\s+(?!\\S)|\\s+";
 
@@ -231,6 +303,7 @@ struct q3tts_tokenizer {
     uint32_t byte_id[256];                        // vocab id of each single-byte token
     std::unordered_map<uint32_t, uint8_t> cp_to_byte;
     mutable std::unordered_map<std::string, std::vector<uint32_t>> cache;
+    bool nfc = false;                             // "normalizer": {"type": "NFC"}
 };
 
 namespace {
@@ -297,6 +370,7 @@ extern "C" int q3tts_tokenizer_load(const char* path, q3tts_tokenizer** out, cha
     if (post && post->kind != JVal::Null && !(post->get("type") && post->get("type")->str == "ByteLevel")) return unsupported("post_processor must be ByteLevel or null");
 
     q3tts_tokenizer* t = new q3tts_tokenizer();
+    t->nfc = norm && norm->kind != JVal::Null;
     auto bail = [&](int code, const std::string& m) { delete t; return set_err(err, err_cap, code, m); };
     const JVal* vocab = model->get("vocab");
     if (!vocab || vocab->kind != JVal::Obj) return bail(Q3TTS_ERR_IO, "tokenizer.json: model.vocab missing");
@@ -366,14 +440,13 @@ extern "C" int q3tts_tokenizer_encode(const q3tts_tokenizer* t, const char* utf8
         if (b >= e) return Q3TTS_OK;
         std::vector<uint32_t> cps, offs;
         if (!decode_utf8(text.data() + b, e - b, cps, offs)) return set_err(err, err_cap, Q3TTS_ERR_INVALID, "input is not valid UTF-8");
-        for (uint32_t c : cps)
-            if (in_ranges(Q3U_NFC_UNSAFE, Q3U_NFC_UNSAFE_N, c))
-                return set_err(err, err_cap, Q3TTS_ERR_UNSUPPORTED, "input is not in Unicode NFC (combining or decomposed characters): normalise it first");
+        if (t->nfc) nfc(cps);
         size_t i = 0;
+        std::string piece;
         while (i < cps.size()) {
             const size_t len = split_match(cps, i);
-            std::string piece;
-            for (size_t k = offs[i]; k < offs[i + len]; ++k) piece += (char)text[b + k];
+            piece.clear();
+            for (size_t k = i; k < i + len; ++k) put_utf8(piece, cps[k]);
             bpe_word(*t, piece, out);
             i += len;
         }

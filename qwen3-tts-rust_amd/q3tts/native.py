@@ -354,6 +354,10 @@ class NativeTokenizer:
         n = C.c_int32(0)
         err = C.create_string_buffer(512)
         rc = self.lib.q3tts_tokenizer_encode(self.h, raw, len(raw), _ptr(ids, u32p), cap, C.byref(n), err, len(err))
+        if rc != 0 and n.value > cap:  # NFC can lengthen the text (composition exclusions): *n_ids carries the size needed
+            cap = n.value
+            ids = np.zeros(cap, dtype=np.uint32)
+            rc = self.lib.q3tts_tokenizer_encode(self.h, raw, len(raw), _ptr(ids, u32p), cap, C.byref(n), err, len(err))
         if rc != 0:
             raise _abi.Q3Error(f"q3tts_tokenizer_encode failed ({rc}): {err.value.decode('utf-8', 'replace')}")
         return ids[:n.value].copy()

@@ -83,12 +83,38 @@ def test_ids_equal_the_tokenizers_crate(tmp_path, vocab_size, strings):
         tk.close()
 
 
+def test_nfc_normaliser_matches_unicodedata_and_the_crate(tmp_path):
+    """The file's normaliser is NFC (UAX #15). ByteLevel BPE is lossless, so decode(encode(x)) is the normalised text: it must
+    equal unicodedata.normalize("NFC", x) (the tables are generated from the same data), and the ids must equal the crate's
+    on combining sequences, reordering of marks, Hangul jamo, singletons and composition exclusions."""
+    import unicodedata as ud
+    from q3tts import native
+    hf, path = _train(420, False, tmp_path)
+    tk = native.NativeTokenizer(path)
+    try:
+        samples = ["e\u0301", "A\u030a ngstro\u0308m", "a\u0323\u0301 vs a\u0301\u0323", "\u1100\u1161\u11a8 \u1112\u1161\u11ab\u1100\u1173\u11af", "\u212b \u2126 \u00c5",
+                   "\u0958 \u0915\u093c", "\u1e9b\u0323", "q\u0307\u0323", "\u0301leading mark", "\u0041\u0300\u0301\u0302\u0303", "cafe\u0301 nai\u0308ve re\u0301sume\u0301",
+                   "\ud55c\uae00 plain \u4f60\u597d", "\u0f73\u0f75\u0f81", "\u0b47\u0b56 \u0b47\u0b3e \u0b47\u0b57", "D\u0307\u0323 d\u0323\u0307"]
+        for x in samples:
+            want = ud.normalize("NFC", x)
+            ids = tk.encode(x).tolist()
+            assert tk.decode(ids) == want, (x.encode("unicode_escape"), tk.decode(ids).encode("unicode_escape"), want.encode("unicode_escape"))
+            assert ids == hf.encode(x, add_special_tokens=False).ids, x.encode("unicode_escape")
+        # seeded random strings over starters, marks of several combining classes, jamo and precomposed letters
+        pool = [chr(c) for c in [0x61, 0x65, 0x6F, 0x41, 0xE9, 0xC5, 0x1E9B, 0x300, 0x301, 0x302, 0x308, 0x30A, 0x323, 0x327, 0x328, 0x334, 0x345, 0x1100, 0x1161, 0x11A8,
+                                 0xAC00, 0xAC01, 0x915, 0x93C, 0x20, 0x4F60, 0x212B, 0x3099, 0x304B, 0x5B0, 0x5B4]]
+        rng = np.random.default_rng(7)
+        for _ in range(500):
+            x = "".join(rng.choice(pool, size=int(rng.integers(1, 12))))
+            assert tk.decode(tk.encode(x).tolist()) == ud.normalize("NFC", x), x.encode("unicode_escape")
+    finally:
+        tk.close()
+
+
 def test_tokenizer_refuses_what_it_does_not_implement(tmp_path):
     from q3tts import _abi, native
     hf, path = _train(420, False, tmp_path)
     tk = native.NativeTokenizer(path)
-    with pytest.raises(_abi.Q3Error, match="NFC"):
-        tk.encode("é")  # e + combining acute: NFC would compose it; refused, not approximated
     with pytest.raises(_abi.Q3Error, match="UTF-8"):
         tk.encode(b"\xff\xfe")
     tk.close()
