@@ -55,7 +55,7 @@ def cpu_baseline(cfg, spk, with_voc, threads):
     """The oracle (CPU restatement, kind "port") on a bounded sample of config 1: one utterance, n_text = 20, greedy."""
     import ctypes as C
     import _oracle as O
-    n_frames = 6
+    n_frames = 16  # ~10 s of CPU work on the box's host cores (bounded sample)
     t0 = time.time()
     om = O.OracleModel(cfg.model, seed=cfg.synth_seed, n_ctx=256, n_threads=threads)
     t_load = time.time() - t0
