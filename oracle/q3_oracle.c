@@ -842,3 +842,36 @@ void q3o_gemm_bf16(const uint16_t* x, int32_t B, int32_t K, const uint16_t* w, i
             y[(size_t)b * N + n] = tot;
         }
 }
+
+/* fused RMSNorm + canonical bf16 GEMM + SwiGLU (prototype of the Predictor's gate/up; q3_gemm_bf16.hip):
+ * ss: per slice w (8) and lane group kq (4) an fmaf chain over k = 32 kb + {4kq..4kq+3, 16+4kq..16+4kq+3}, kb ascending in the
+ * slice; S_w = (c0 + c1) + (c2 + c3); ss = S_0 + ... + S_7; s = 1/sqrtf(ss/K + eps); xn = bf16(x * nw); y = s * raw */
+void q3o_gemm_bf16_norm_swiglu(const float* x, int32_t B, int32_t K, const uint16_t* w, int32_t N, const float* nw, float eps, float* y) {
+    const int F = N / 2, per = K / 256;
+    uint16_t* xn = (uint16_t*)malloc((size_t)B * K * 2);
+    float* sc = (float*)malloc((size_t)B * 4);
+    for (int b = 0; b < B; ++b) {
+        const float* xr = x + (size_t)b * K;
+        float tot = 0.0f;
+        for (int sl = 0; sl < 8; ++sl) {
+            float c[4];
+            for (int kq = 0; kq < 4; ++kq) {
+                float a = 0.0f;
+                for (int st = 0; st < per; ++st) {
+                    const int k0 = (sl * per + st) * 32;
+                    for (int e = 0; e < 8; ++e) { const float v = xr[k0 + (e < 4 ? 4 * kq + e : 16 + 4 * kq + (e - 4))]; a = fmaf(v, v, a); }
+                }
+                c[kq] = a;
+            }
+            const float S = (c[0] + c[1]) + (c[2] + c[3]);
+            tot = sl == 0 ? S : tot + S;
+        }
+        sc[b] = 1.0f / sqrtf(tot / (float)K + eps);
+        for (int k = 0; k < K; ++k) xn[(size_t)b * K + k] = q3o_bf16(xr[k] * nw[k]);
+    }
+    float* raw = (float*)malloc((size_t)B * N * 4);
+    q3o_gemm_bf16(xn, B, K, w, N, raw);
+    for (int b = 0; b < B; ++b)
+        for (int j = 0; j < F; ++j) y[(size_t)b * F + j] = swiglu(sc[b] * raw[(size_t)b * N + j], sc[b] * raw[(size_t)b * N + F + j]);
+    free(raw); free(sc); free(xn);
+}

@@ -1255,6 +1255,38 @@ extern "C" int q3tts_k_gemm_bf16(int32_t device, const uint16_t* x, int32_t B, i
     return Q3TTS_OK;
 }
 
+int q3_launch_gemm_bf16_norm_swiglu(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy,
+                                    hipStream_t s);
+// prototype: fused RMSNorm + bf16-MFMA GEMM + SwiGLU (the Predictor's gate/up, K = 1024); w: logical [2F][K], gate rows then up rows
+extern "C" int q3tts_k_gemm_bf16_norm_swiglu(int32_t device, const float* x, int32_t B, int32_t K, const uint16_t* w, int32_t N, const float* norm_w,
+                                             float eps, float* y, int32_t iters, float* mean_ms) {
+    if (!x || !w || !y || !norm_w || B <= 0 || K != 1024 || N % 96) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bf16 norm/swiglu hook: K = 1024, N % 96 == 0");
+    HK(hipSetDevice(device));
+    const int F = N / 2;
+    DevBuf dx, dw, dwt, dn, dy;
+    if (dx.alloc((size_t)B * K * 4) || dw.alloc((size_t)N * K * 2) || dwt.alloc((size_t)N * K * 2) || dn.alloc((size_t)K * 4) || dy.alloc((size_t)B * F * 4))
+        return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
+    HK(hipMemcpy(dx.p, x, (size_t)B * K * 4, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dw.p, w, (size_t)N * K * 2, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dn.p, norm_w, (size_t)K * 4, hipMemcpyHostToDevice));
+    Q3Fill f{}; f.dst = (uint4*)dwt.p; f.N = N; f.K = K; f.mode = 1; f.src_a = (const uint16_t*)dw.p; f.src_b = (const uint16_t*)dw.p + (size_t)F * K;
+    q3_launch_fill_tiled(f, nullptr);
+    auto go = [&]() { return q3_launch_gemm_bf16_norm_swiglu((const float*)dx.p, K, B, (const uint4*)dwt.p, K, N, (const float*)dn.p, eps, (float*)dy.p, F, nullptr); };
+    if (go()) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bf16 norm/swiglu gemm: shape");
+    HK(hipDeviceSynchronize());
+    HK(hipMemcpy(y, dy.p, (size_t)B * F * 4, hipMemcpyDeviceToHost));
+    if (iters > 0 && mean_ms) {
+        hipEvent_t a, b; HK(hipEventCreate(&a)); HK(hipEventCreate(&b));
+        go();
+        HK(hipEventRecord(a, nullptr));
+        for (int i = 0; i < iters; ++i) go();
+        HK(hipEventRecord(b, nullptr)); HK(hipEventSynchronize(b));
+        float ms = 0; hipEventElapsedTime(&ms, a, b); *mean_ms = ms / iters;
+        hipEventDestroy(a); hipEventDestroy(b);
+    }
+    return Q3TTS_OK;
+}
+
 // one v_mfma_f32_16x16x32_bf16 chain per case (test hook: pins the instruction's accumulation arithmetic against the
 // oracle's integer restatement, oracle/q3_oracle.c q3o_mfma_bf16_dot32)
 typedef float q3_f32x4 __attribute__((ext_vector_type(4)));

@@ -11,6 +11,7 @@
 #include "q3_kernels.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <int RT, int NT, int PER>
 __global__ __launch_bounds__(512) void k_gemm_bf16(const uint16_t* __restrict__ x, int ldx, int B, const uint4* __restrict__ w, int K, int N,
@@ -73,5 +74,113 @@ int q3_launch_gemm_bf16(const uint16_t* x, int ldx, int B, const uint4* w, int K
     const size_t lds = (size_t)8 * 2 * 3 * 4 * 64 * 4;
     if (K == 1024) hipLaunchKernelGGL((k_gemm_bf16<2, 3, 4>), grid, dim3(512), lds, s, x, ldx, B, w, K, N, y, ldy);
     else hipLaunchKernelGGL((k_gemm_bf16<2, 3, 8>), grid, dim3(512), lds, s, x, ldx, B, w, K, N, y, ldy);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same order with the fused RMSNorm prologue and the SwiGLU epilogue of the Predictor's gate/up GEMM (K = 1024):
+//   xn[k] = bf16(x[k] * nw[k]);  raw[n] = canonical bf16 GEMM of xn;  y[n] = s_r * raw[n];  out = swiglu(y_gate, y_up)
+//   ss_r: per (slice w, lane group kq) an fmaf chain over the lane's own k (ascending), S_w = (c0 + c1) + (c2 + c3),
+//   ss = S_0 + ... + S_7, s_r = 1 / sqrtf(ss / K + eps)                                  
+// The A operand is still the f32 residual stream (the first integration step of §16): converted in the kernel.
+// ---------------------------------------------------------------------------------------------------------------
+template <int RT, int NT, int PER>
+__global__ __launch_bounds__(512) void k_gemm_bf16_norm_swiglu(const float* __restrict__ x, int ldx, int B, const uint4* __restrict__ w, int K, int N,
+                                                               const float* __restrict__ nw, float eps, float* __restrict__ y, int ldy) {
+    extern __shared__ float part[];  // [8][RT*NT*4][64] partial tiles, then [8][4][RT*16] ss partials, then [RT*16] row scales
+    float* ssp = part + (size_t)8 * RT * NT * 4 * 64;
+    float* srow = ssp + 8 * 4 * RT * 16;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kq = lane >> 4, r = lane & 15;
+    const int nb0 = blockIdx.x * NT, row0 = blockIdx.y * RT * 16, kblocks = K >> 5, kb0 = wave * PER;
+    f32x4 a0[PER][RT], a1[PER][RT], n0[PER], n1[PER]; u32x4 bq[PER][NT];
+#pragma unroll
+    for (int s = 0; s < PER; ++s) {
+        const size_t kk = (size_t)(kb0 + s) * 32 + 4 * kq;
+        n0[s] = *(const f32x4*)(nw + kk); n1[s] = *(const f32x4*)(nw + kk + 16);
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int row = min(row0 + 16 * i + r, B - 1);
+            const float* p = x + (size_t)row * ldx + kk;
+            a0[s][i] = *(const f32x4*)p; a1[s][i] = *(const f32x4*)(p + 16);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bq[s][j] = ((const u32x4*)w)[((size_t)(nb0 + j) * kblocks + kb0 + s) * 64 + lane];
+    }
+    // every operand of the slice is requested before anything is consumed: the empty asm statements pin the loaded values
+    // here (without them the compiler sinks half of the loads between the MFMAs and the slice pays several round trips)
+#pragma unroll
+    for (int s = 0; s < PER; ++s) {
+        asm volatile("" : "+v"(n0[s]), "+v"(n1[s]));
+#pragma unroll
+        for (int i = 0; i < RT; ++i) asm volatile("" : "+v"(a0[s][i]), "+v"(a1[s][i]));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(bq[s][j]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[RT][NT];
+    float ss[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        ss[i] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int s = 0; s < PER; ++s) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const f32x4 u = a0[s][i], v = a1[s][i];
+            ss[i] = fmaf(u.x, u.x, ss[i]); ss[i] = fmaf(u.y, u.y, ss[i]); ss[i] = fmaf(u.z, u.z, ss[i]); ss[i] = fmaf(u.w, u.w, ss[i]);
+            ss[i] = fmaf(v.x, v.x, ss[i]); ss[i] = fmaf(v.y, v.y, ss[i]); ss[i] = fmaf(v.z, v.z, ss[i]); ss[i] = fmaf(v.w, v.w, ss[i]);
+            bf16x8 a;
+            a[0] = (__bf16)(u.x * n0[s].x); a[1] = (__bf16)(u.y * n0[s].y); a[2] = (__bf16)(u.z * n0[s].z); a[3] = (__bf16)(u.w * n0[s].w);
+            a[4] = (__bf16)(v.x * n1[s].x); a[5] = (__bf16)(v.y * n1[s].y); a[6] = (__bf16)(v.z * n1[s].z); a[7] = (__bf16)(v.w * n1[s].w);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                union { u32x4 u4; bf16x8 v8; } b; b.u4 = bq[s][j];
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b.v8, acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        ssp[(wave * 4 + kq) * (RT * 16) + 16 * i + r] = ss[i];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[((size_t)wave * (RT * NT * 4) + (i * NT + j) * 4 + e) * 64 + lane] = acc[i][j][e];
+    }
+    __syncthreads();
+    if (threadIdx.x < RT * 16) {
+        float tot = 0.0f;
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) {
+            const float* c = ssp + (size_t)wv * 4 * (RT * 16) + threadIdx.x;
+            const float S = (c[0] + c[RT * 16]) + (c[2 * RT * 16] + c[3 * RT * 16]);
+            tot = wv == 0 ? S : tot + S;
+        }
+        srow[threadIdx.x] = 1.0f / sqrtf(tot / (float)K + eps);
+    }
+    __syncthreads();
+    // gate lanes (column < 8 of a tile) finish one output each: swiglu(s * gate, s * up), up = the same row 8 columns further
+    for (int o = threadIdx.x; o < RT * NT * 4 * 64; o += 512) {
+        const int l = o & 63;
+        if ((l & 15) >= 8) continue;
+        float g = part[o], u = part[o + 8];
+#pragma unroll
+        for (int wv = 1; wv < 8; ++wv) { g = g + part[(size_t)wv * (RT * NT * 4 * 64) + o]; u = u + part[(size_t)wv * (RT * NT * 4 * 64) + o + 8]; }
+        const int e = (o >> 6) & 3, t = o >> 8, i = t / NT, j = t - i * NT;
+        const int rl = 16 * i + 4 * (l >> 4) + e, row = row0 + rl;
+        const float sc = srow[rl];
+        if (row < B) y[(size_t)row * ldy + (size_t)(nb0 + j) * 8 + (l & 15)] = q3_swiglu(sc * g, sc * u);
+    }
+}
+
+int q3_launch_gemm_bf16_norm_swiglu(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy,
+                                    hipStream_t s) {
+    if (B < 1 || N % 48 || K != 1024) return -1;
+    const dim3 grid(N / 48, (B + 31) / 32);
+    const size_t lds = ((size_t)8 * 2 * 3 * 4 * 64 + 8 * 4 * 32 + 32) * 4;
+    hipLaunchKernelGGL((k_gemm_bf16_norm_swiglu<2, 3, 4>), grid, dim3(512), lds, s, x, ldx, B, w, K, N, nw, eps, y, ldy);
     return 0;
 }
