@@ -94,7 +94,8 @@ def main():
     ap.add_argument("--no-single", action="store_true", help="skip the batch=1 RTF / first-chunk leg")
     ap.add_argument("--n-ctx", type=int, default=4096)
     ap.add_argument("--no-probe", action="store_true", help="skip the in-situ dominant-kernel measurement (roofline.achieved falls back to the whole frame step)")
-    ap.add_argument("--probe-only", action="store_true", help="run only the probe leg (the command profiled for profiles/*/probe_kernel_stats.csv)")
+    ap.add_argument("--probe-only", nargs="?", const="talker", default=None, choices=["talker", "predictor"],
+                    help="run only the probe leg (the command profiled for profiles/*/probe_kernel_stats.csv): the Talker's gate/up (default) or the Predictor's")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -144,25 +145,27 @@ def main():
         qd.gather_pcm(dist, [o.pcm if o.pcm is not None else np.zeros(0, dtype=np.float32) for o in outs], rank, world,
                       device=tdev, dtype=torch.float16, to_numpy=False)
 
-    def probe_leg():
-        """Dominant kernel, in situ: the same batch of 64 utterances for 24 forced frames (codes only, so nothing else
-        shares the GPU), frame steps launched eagerly with HIP events on the decode stream around the Predictor gate/up
-        GEMM of pass 1 / layer 0 (k_gemm_ring<2, 3, 2, true> at M = 64, K = 1024, N = 6144)."""
-        eng.probe(True)
+    def probe_leg(mode=2):
+        """One GEMM, in situ: the same batch of 64 utterances for 24 forced frames (codes only, so nothing else shares the GPU),
+        frame steps launched eagerly with HIP events on the decode stream around it. mode 2: the Talker's layer-0 gate/up GEMM
+        (k_gemm_ring<2, 3, 4, true>, exact f32 MFMA, M = 64, K = 2048, N = 12288 — the largest GEMM instance of the frame step);
+        mode 1: the Predictor's pass-1 / layer-0 gate/up (k_gemm_bf16_norm_swiglu, bf16 MFMA, M = 64, K = 1024, N = 6144)."""
+        eng.probe(mode)
         preqs = [dict(r, min_frames=24, force_eos_at=24, max_steps=32, want_pcm=0) for r in reqs]
         for _ in range(2):
             pouts = eng.generate_batch(preqs)
         ptm = eng.timings()
-        eng.probe(False)
+        eng.probe(0)
         assert all(o.status == 0 and o.n_frames == 24 for o in pouts)
         m = cfg.model
-        rows, K, N = len(preqs), m.p_d_model, 2 * m.p_d_ffn
+        rows = len(preqs)
+        K, N = (m.t_d_model, 2 * m.t_d_ffn) if mode == 2 else (m.p_d_model, 2 * m.p_d_ffn)
         flops = 2.0 * rows * K * N
         nbytes = 2.0 * N * K + 4.0 * rows * K + 4.0 * rows * (N // 2)
         return {"kernel_ms": ptm.probe_kernel_ms, "empty_ms": ptm.probe_empty_ms, "launches": int(ptm.probe_count), "rows": rows, "K": K, "N": N, "flops": flops, "bytes": nbytes}
 
     if args.probe_only:
-        pr = probe_leg()
+        pr = probe_leg(2 if args.probe_only == "talker" else 1)
         if rank == 0:
             print(json.dumps({"probe": pr}), flush=True)
         eng.close()
@@ -227,7 +230,7 @@ def main():
                 "hbm_GBs": round(hbm_gbs, 1), "frac_of_8TBs": round(hbm_gbs / HBM_PEAK_GBS, 4), "mfma_bound": bool(mfma_bound)},
         }
         if not args.no_probe:
-            pr = probe_leg()
+            pr = probe_leg(2)
             # The bracket also times the closing event packet. An EMPTY bracket on the same stream (empty_ms) bounds that
             # overhead from above, so the kernel's own duration lies in [kernel_ms - empty_ms, kernel_ms]; rocprofv3 puts it
             # in between (profiles/README.md). `achieved` uses the whole bracket: a lower bound on the kernel's rate.
@@ -241,15 +244,29 @@ def main():
             line["roofline"] = {
                 "bound": "mfma", "achieved": round(k_tf, 2), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(k_tf / F32_MFMA_PEAK_TF, 4),
                 "traffic": traffic,
-                "kernel": "k_gemm_ring<2, 3, 2, true>: Predictor gate/up GEMM + fused RMSNorm + SwiGLU, M=%d K=%d N=%d (the decode loop's largest "
-                          "instance of the k_gemm_ring family, which holds ~69%% of all kernel time in profiles/r01/bench_b64_eager_kernel_stats.csv)" % (pr["rows"], pr["K"], pr["N"]),
+                "kernel": "k_gemm_ring<2, 3, 4, true>: Talker gate/up GEMM + fused RMSNorm + SwiGLU, M=%d K=%d N=%d (exact f32 MFMA; the largest "
+                          "instance of the k_gemm_ring family, which holds ~60%% of all kernel time in profiles/r01/bench_b64_eager_kernel_stats.csv; "
+                          "28 launches per frame step)" % (pr["rows"], pr["K"], pr["N"]),
                 "launch_us": round(k_ms * 1e3, 2), "empty_bracket_us": round(pr["empty_ms"] * 1e3, 2),
                 "launch_us_minus_empty_bracket": round((pr["kernel_ms"] - pr["empty_ms"]) * 1e3, 2), "launches_timed": pr["launches"],
                 "algorithmic_flops_per_launch": int(pr["flops"]), "algorithmic_bytes_per_launch": int(pr["bytes"]),
-                "how": "HIP events on the decode stream around every launch of this kernel in pass 1 / layer 0, eager frame steps, "
-                       "64 live utterances, codes only (q3tts_k_probe); rocprofv3 of the same leg: profiles/r01/probe_kernel_stats.csv",
+                "how": "HIP events on the decode stream around every launch of this kernel in layer 0 of the Talker step, eager frame steps, "
+                       "64 live utterances, codes only (q3tts_k_probe mode 2); rocprofv3 of the same leg: profiles/r01/probe_kernel_stats.csv",
                 "peak_note": "f32-input MFMA dense peak 157.3 TF (MI355X_MICROARCH.md); the exact decoder accumulates on v_mfma_f32_16x16x4_f32; "
                              "arithmetic intensity %.0f flop/B > ridge 19.7" % (pr["flops"] / pr["bytes"])}
+            # the Predictor's gate/up, the kernel this line was quoted on earlier in the round, now runs on the bf16 MFMA:
+            # bf16 ridge = 2500 TF / 8 TB/s = 312 flop/B, so it is HBM-bound; reported next to the headline kernel
+            pb = probe_leg(1)
+            b_ms = pb["kernel_ms"]
+            b_gbs = pb["bytes"] / (b_ms * 1e-3) / 1e9 if b_ms > 0 else 0.0
+            line["roofline_bf16_kernel"] = {
+                "bound": "hbm", "achieved": round(b_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "k_gemm_bf16_norm_swiglu<2, 3, 4>: Predictor gate/up GEMM + fused RMSNorm + SwiGLU on v_mfma_f32_16x16x32_bf16, "
+                          "M=%d K=%d N=%d (75 launches per frame step; bit-exact against the oracle's integer restatement of the instruction)" % (pb["rows"], pb["K"], pb["N"]),
+                "launch_us": round(b_ms * 1e3, 2), "empty_bracket_us": round(pb["empty_ms"] * 1e3, 2),
+                "launch_us_minus_empty_bracket": round((pb["kernel_ms"] - pb["empty_ms"]) * 1e3, 2), "launches_timed": pb["launches"],
+                "algorithmic_flops_per_launch": int(pb["flops"]), "algorithmic_bytes_per_launch": int(pb["bytes"]),
+                "tflops": round(pb["flops"] / (b_ms * 1e-3) / 1e12, 2) if b_ms > 0 else 0.0}
         else:
             line["roofline"] = {"bound": "mfma" if mfma_bound else "hbm", "achieved": round(mfma_tf if mfma_bound else hbm_gbs, 2),
                                 "peak": F32_MFMA_PEAK_TF if mfma_bound else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma_bound else "GB/s",

@@ -273,9 +273,10 @@ int q3tts_k_vocoder(q3tts_engine* e, const int32_t* codes, int32_t n_frames, int
  * reader the engine uses for weights_path. out may be NULL to query nelem / dims (ggml order: dims4[0] is the row length)
  * / ggml type (0 F32, 1 F16, 8 Q8_0, 30 BF16). Needs no GPU. */
 int q3tts_k_gguf_read(const char* path, const char* tensor, float* out, int64_t cap, int64_t* nelem, int64_t* dims4, int32_t* ggml_type);
-/* Measurement mode for bench.py: frame steps are launched eagerly (no graph replay) and the Predictor gate/up GEMM of
- * pass 1 / layer 0 is bracketed by HIP events on its own stream; q3tts_timings.probe_kernel_ms / probe_count report it
- * for the frame steps that ran at the full row count. enable = 0 restores graph replay. */
+/* Measurement mode for bench.py: frame steps are launched eagerly (no graph replay) and one GEMM of every frame is bracketed
+ * by HIP events on its own stream — enable = 2: the Talker's layer-0 gate/up GEMM (k_gemm_ring, exact f32 MFMA, the largest
+ * GEMM of the frame step); enable = 1: the Predictor's pass-1 / layer-0 gate/up GEMM (k_gemm_bf16_norm_swiglu). q3tts_timings
+ * .probe_kernel_ms / probe_count report it for the frame steps that ran at the full row count. enable = 0 restores graph replay. */
 int q3tts_k_probe(q3tts_engine* e, int32_t enable);
 /* n_cases independent chains of `chain` v_mfma_f32_16x16x32_bf16 into one accumulator tile: a [n][chain][16][32] bf16 bits,
  * b [n][chain][32][16], c / d [n][16][16] f32. Pins the instruction's accumulation arithmetic. */

@@ -490,6 +490,7 @@ typedef struct {
     float* out_norm; uint16_t* head_t; int head_n;
     float *kc, *vc; int n_ctx; /* [L][Hkv][n_ctx][hd] */
     float *cs, *sn;
+    int bf16_ffn;  /* gate/up in the canonical bf16-MFMA order: the Predictor, when d is 512 or 1024 */
 } tfm;
 
 struct q3o_model {
@@ -554,6 +555,52 @@ static void tfm_free(tfm* t) {
 }
 
 /* x [n][d] updated in place through all layers; rows are positions pos0.. of one sequence */
+float q3o_mfma_bf16_dot32(const uint16_t* a, const uint16_t* b, float c);
+/* row prologue of the bf16 order: xn = bf16(x * nw); returns s = 1/sqrtf(ss/K + eps), ss in the order of k_gemm_bf16_norm_swiglu */
+static float norm_bf16_row(const float* xr, int K, const float* nw, float eps, uint16_t* xn) {
+    const int per = K / 256;
+    float tot = 0.0f;
+    for (int sl = 0; sl < 8; ++sl) {
+        float c[4];
+        for (int kq = 0; kq < 4; ++kq) {
+            float a = 0.0f;
+            for (int st = 0; st < per; ++st) {
+                const int k0 = (sl * per + st) * 32;
+                for (int e = 0; e < 8; ++e) { const float v = xr[k0 + (e < 4 ? 4 * kq + e : 16 + 4 * kq + (e - 4))]; a = fmaf(v, v, a); }
+            }
+            c[kq] = a;
+        }
+        const float S = (c[0] + c[1]) + (c[2] + c[3]);
+        tot = sl == 0 ? S : tot + S;
+    }
+    for (int k = 0; k < K; ++k) xn[k] = q3o_bf16(xr[k] * nw[k]);
+    return 1.0f / sqrtf(tot / (float)K + eps);
+}
+/* canonical bf16 GEMM on transposed weights wt [K][ldw]: out[r][n] for n in [0, ncols) */
+static void gemm_bf16_t(const uint16_t* xb, int n_rows, int K, const uint16_t* wt, int ldw, int ncols, float* out, int ldo) {
+    const int per = K / 256;
+#pragma omp parallel for schedule(static) collapse(2) num_threads(g_threads > 0 ? g_threads : 1)
+    for (int r = 0; r < n_rows; ++r)
+        for (int n = 0; n < ncols; ++n) {
+            float tot = 0.0f;
+            for (int sl = 0; sl < 8; ++sl) {
+                float acc = 0.0f;
+                for (int st = 0; st < per; ++st) {
+                    const int k0 = (sl * per + st) * 32;
+                    uint16_t av[32], bv[32];
+                    for (int g = 0; g < 4; ++g)
+                        for (int e = 0; e < 8; ++e) {
+                            const int k = k0 + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4));
+                            av[8 * g + e] = xb[(size_t)r * K + k]; bv[8 * g + e] = wt[(size_t)k * ldw + n];
+                        }
+                    acc = q3o_mfma_bf16_dot32(av, bv, acc);
+                }
+                tot = sl == 0 ? acc : tot + acc;
+            }
+            out[(size_t)r * ldo + n] = tot;
+        }
+}
+
 static void tfm_layers(tfm* t, float* x, int n, int pos0, float eps) {
     const int d = t->d, nq = t->Hq * t->hd, nkv = t->Hkv * t->hd, nqkv = nq + 2 * nkv, F = t->F;
     float* xh = malloc((size_t)n * (d > F ? d : F) * 4);
@@ -571,9 +618,16 @@ static void tfm_layers(tfm* t, float* x, int n, int pos0, float eps) {
         attn_rows(qkv, n, pos0, t->Hq, t->Hkv, t->hd, t->qn[l], t->kn[l], eps, t->cs, t->sn, t->kc + co, t->vc + co, t->n_ctx, att);
         gemm_t(att, n, nq, nq, t->wo_t[l], d, 0, d, y, d);
         for (size_t i = 0; i < (size_t)n * d; ++i) x[i] = x[i] + y[i];
-        for (int r = 0; r < n; ++r) sc[r] = norm_gemm_row(x + (size_t)r * d, d, t->ffn_norm[l], eps, xh + (size_t)r * d);
-        gemm_t(xh, n, d, d, t->wg_t[l], F, 0, F, g, F);
-        gemm_t(xh, n, d, d, t->wu_t[l], F, 0, F, u, F);
+        if (t->bf16_ffn) {
+            uint16_t* xb = (uint16_t*)xh;  /* n * d bf16 values fit in the f32 scratch */
+            for (int r = 0; r < n; ++r) sc[r] = norm_bf16_row(x + (size_t)r * d, d, t->ffn_norm[l], eps, xb + (size_t)r * d);
+            gemm_bf16_t(xb, n, d, t->wg_t[l], F, F, g, F);
+            gemm_bf16_t(xb, n, d, t->wu_t[l], F, F, u, F);
+        } else {
+            for (int r = 0; r < n; ++r) sc[r] = norm_gemm_row(x + (size_t)r * d, d, t->ffn_norm[l], eps, xh + (size_t)r * d);
+            gemm_t(xh, n, d, d, t->wg_t[l], F, 0, F, g, F);
+            gemm_t(xh, n, d, d, t->wu_t[l], F, 0, F, u, F);
+        }
         scale_rows(g, n, F, F, sc);
         scale_rows(u, n, F, F, sc);
         for (size_t i = 0; i < (size_t)n * F; ++i) g[i] = swiglu(g[i], u[i]);
@@ -591,6 +645,7 @@ q3o_model* q3o_create(const q3o_model_config* c, uint64_t seed, int32_t n_ctx, i
              c->t_vocab, c->t_rope_theta, c->t_mrope_sections, n_ctx);
     tfm_init(&m->P, seed, G_PRED, c->p_n_layer, c->p_d_model, c->p_n_head, c->p_n_kv_head, c->p_head_dim, c->p_d_ffn,
              (c->n_codebooks - 1) * c->codebook_size, c->p_rope_theta, NULL, 64);
+    m->P.bf16_ffn = (c->p_d_model == 512 || c->p_d_model == 1024) && (2 * c->p_d_ffn) % 32 == 0;  /* the rule of q3_gemm_bf16_norm_swiglu_ok() */
     m->proj_t = malloc((size_t)c->d_embed * c->p_d_model * 2);
     gen_mat_t(seed, TID(G_ASSET, 0, WA_PROJ_W), c->p_d_model, c->d_embed, 0.02f, m->proj_t, c->p_d_model, 0);
     m->proj_b = gen_f32(seed, TID(G_ASSET, 0, WA_PROJ_B), c->p_d_model, 0.0f, 0.02f);

@@ -262,7 +262,10 @@ static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, int rows, const int*
         g = Q3Gemm{}; g.x = x; g.ldx = t.d; g.B = rows; g.w = t.wgu[l]; g.K = t.d; g.N = 2 * t.F; g.norm_w = t.ffn_norm[l]; g.eps = eps;
         g.y = sc.h; g.ldy = t.F; g.epi = Q3_EPI_SWIGLU;
         if (probe && l == 0) hipEventRecord(probe[0], s);
-        q3_launch_gemm(g, s);
+        // the Predictor's gate/up runs on the bf16 MFMA in its own canonical order; the Talker (whose prefill shares
+        // the exact kernels) and every other GEMM stay on the exact f32 path
+        if (&t == &e->P && q3_gemm_bf16_norm_swiglu_ok(g.K, g.N)) q3_launch_gemm_bf16_norm_swiglu(g.x, g.ldx, g.B, g.w, g.K, g.N, g.norm_w, g.eps, g.y, g.ldy, s);
+        else q3_launch_gemm(g, s);
         if (probe && l == 0) hipEventRecord(probe[1], s);
         g = Q3Gemm{}; g.x = sc.h; g.ldx = t.F; g.B = rows; g.w = t.wd[l]; g.K = t.F; g.N = t.d; g.y = x; g.ldy = t.d; g.epi = Q3_EPI_RESID;
         q3_launch_gemm(g, s);
@@ -298,14 +301,16 @@ static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
             g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);
         }
         hipEvent_t* pe = nullptr;
-        if (e->probe && q == 1 && B == L.nb && e->probe_i + 2 <= 8) { pe = &e->probe_ev[e->probe_i]; e->probe_i += 2; }
+        if (e->probe == 1 && q == 1 && B == L.nb && e->probe_i + 2 <= 8) { pe = &e->probe_ev[e->probe_i]; e->probe_i += 2; }
         run_layers(e, e->P, L.px, rows, q == 0 ? L.posA : L.pos_q + (size_t)q * L.nb, q == 0 ? L.slotA : L.slot_id, L.sc, s, q > 0, pe);
         g = Q3Gemm{}; g.x = q == 0 ? L.px + dp : L.px; g.ldx = q == 0 ? 2 * dp : dp; g.B = B; g.w = e->P.head + head_tile_stride * q;
         g.K = dp; g.N = cbs; g.norm_w = e->P.out_norm; g.eps = eps; g.keys = L.keys + (q + 1); g.key_stride = ncb; g.epi = Q3_EPI_ARGMAX;
         q3_launch_gemm(g, s);
     }
     pred_next(ncb - 1);
-    run_layers(e, e->T, L.xT, B, L.row_pos_t, L.slot_id, L.sc, s, true);
+    hipEvent_t* pt = nullptr;  // probe mode 2: the Talker's layer-0 gate/up GEMM (the largest exact GEMM of the frame step)
+    if (e->probe == 2 && B == L.nb && e->probe_i + 2 <= 8) { pt = &e->probe_ev[e->probe_i]; e->probe_i += 2; }
+    run_layers(e, e->T, L.xT, B, L.row_pos_t, L.slot_id, L.sc, s, true, pt);
     Q3Gemm g{}; g.x = L.xT; g.ldx = m.t_d_model; g.B = B; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab; g.norm_w = e->T.out_norm; g.eps = eps;
     g.y = L.logits; g.ldy = m.t_vocab; g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);
 }
@@ -1255,12 +1260,10 @@ extern "C" int q3tts_k_gemm_bf16(int32_t device, const uint16_t* x, int32_t B, i
     return Q3TTS_OK;
 }
 
-int q3_launch_gemm_bf16_norm_swiglu(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy,
-                                    hipStream_t s);
-// prototype: fused RMSNorm + bf16-MFMA GEMM + SwiGLU (the Predictor's gate/up, K = 1024); w: logical [2F][K], gate rows then up rows
+// fused RMSNorm + bf16-MFMA GEMM + SwiGLU (the Predictor's gate/up, K = 1024); w: logical [2F][K], gate rows then up rows
 extern "C" int q3tts_k_gemm_bf16_norm_swiglu(int32_t device, const float* x, int32_t B, int32_t K, const uint16_t* w, int32_t N, const float* norm_w,
                                              float eps, float* y, int32_t iters, float* mean_ms) {
-    if (!x || !w || !y || !norm_w || B <= 0 || K != 1024 || N % 96) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bf16 norm/swiglu hook: K = 1024, N % 96 == 0");
+    if (!x || !w || !y || !norm_w || B <= 0 || !q3_gemm_bf16_norm_swiglu_ok(K, N)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bf16 norm/swiglu hook: K in {512, 1024}, N % 32 == 0");
     HK(hipSetDevice(device));
     const int F = N / 2;
     DevBuf dx, dw, dwt, dn, dy;
@@ -1345,7 +1348,7 @@ extern "C" int q3tts_k_probe(q3tts_engine* e, int32_t enable) {
         e->probe_ev.resize(10, nullptr);  // 4 frames x 2 + one empty bracket per chunk (event overhead calibration)
         for (auto& ev : e->probe_ev) Q3_HIP(e, hipEventCreate(&ev));
     }
-    e->probe = enable ? 1 : 0;
+    e->probe = enable == 2 ? 2 : (enable ? 1 : 0);
     return Q3TTS_OK;
 }
 

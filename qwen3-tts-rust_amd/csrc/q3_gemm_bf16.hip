@@ -176,11 +176,21 @@ __global__ __launch_bounds__(512) void k_gemm_bf16_norm_swiglu(const float* __re
     }
 }
 
+// shapes this path takes (a function of the model configuration only, never of the row count: the oracle applies the same rule)
+bool q3_gemm_bf16_norm_swiglu_ok(int K, int N) { return (K == 512 || K == 1024) && N % 32 == 0; }
+
+template <int NT, int PER>
+static void launch_bf16_ns(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy, hipStream_t s) {
+    const dim3 grid(N / (16 * NT), (B + 31) / 32);
+    const size_t lds = ((size_t)8 * 2 * NT * 4 * 64 + 8 * 4 * 32 + 32) * 4;
+    hipLaunchKernelGGL((k_gemm_bf16_norm_swiglu<2, NT, PER>), grid, dim3(512), lds, s, x, ldx, B, w, K, N, nw, eps, y, ldy);
+}
 int q3_launch_gemm_bf16_norm_swiglu(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy,
                                     hipStream_t s) {
-    if (B < 1 || N % 48 || K != 1024) return -1;
-    const dim3 grid(N / 48, (B + 31) / 32);
-    const size_t lds = ((size_t)8 * 2 * 3 * 4 * 64 + 8 * 4 * 32 + 32) * 4;
-    hipLaunchKernelGGL((k_gemm_bf16_norm_swiglu<2, 3, 4>), grid, dim3(512), lds, s, x, ldx, B, w, K, N, nw, eps, y, ldy);
+    if (B < 1 || !q3_gemm_bf16_norm_swiglu_ok(K, N)) return -1;
+    const int tiles = N / 16, NT = tiles % 3 == 0 ? 3 : (tiles % 2 == 0 ? 2 : 1);
+#define L(NT_) do { if (K == 1024) launch_bf16_ns<NT_, 4>(x, ldx, B, w, K, N, nw, eps, y, ldy, s); else launch_bf16_ns<NT_, 2>(x, ldx, B, w, K, N, nw, eps, y, ldy, s); } while (0)
+    if (NT == 3) L(3); else if (NT == 2) L(2); else L(1);
+#undef L
     return 0;
 }

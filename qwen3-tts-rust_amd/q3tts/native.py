@@ -199,8 +199,10 @@ class NativeEngine:
         return out
 
     def probe(self, enable):
-        """Measurement mode (bench.py): eager frame steps with HIP events around the Predictor gate/up GEMM."""
-        self._check(self.lib.q3tts_k_probe(self.h, int(bool(enable))), "q3tts_k_probe")
+        """Measurement mode (bench.py): eager frame steps with HIP events around one GEMM per frame — 2 (or True): the Talker's
+        layer-0 gate/up (exact kernel); 1: the Predictor's pass-1 gate/up (bf16-MFMA kernel); 0 / False: off."""
+        mode = 2 if enable is True else int(enable)
+        self._check(self.lib.q3tts_k_probe(self.h, mode), "q3tts_k_probe")
 
     def talker_prefill(self, embd):
         e = np.ascontiguousarray(embd, dtype=np.float32)
