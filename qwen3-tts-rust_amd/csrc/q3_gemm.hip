@@ -29,6 +29,10 @@
 
 #include "q3_kernels.h"
 
+#ifndef Q3_XCD_MAP
+#define Q3_XCD_MAP 1  // -DQ3_XCD_MAP=0: plain blockIdx -> tile mapping (A/B measurements)
+#endif
+
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // once-read weight stream: non-temporal 16-byte load (MI355X_MICROARCH.md, row nt-weights)
 __device__ __forceinline__ uint4 ntload16(const uint4* p) {
@@ -213,7 +217,15 @@ __global__ __launch_bounds__(512, (RT <= 2 && NT == 1 && BPS > 0 && BPS <= 2) ? 
     constexpr int XPF = XPF0 < WPF ? XPF0 : WPF;  // the ring slot of block kb is kb % XPF == j % XPF only if XPF divides WPF
     constexpr int CP = NT * 16 + 1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int nbt = blockIdx.x, row0 = blockIdx.y * (RT * 16);
+    // XCD-aware tile mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in linear-id order. With two
+    // row chunks the two workgroups that read the same weight columns are made neighbours in time on the SAME XCD (linear ids 8
+    // apart), so the second one finds the weight tiles in that L2 instead of fetching them again a whole dispatch round later.
+    int nbt_ = blockIdx.x, rc_ = blockIdx.y;
+    if (gridDim.y == 2 && (gridDim.x & 7) == 0 && Q3_XCD_MAP) {
+        const int id = blockIdx.x + gridDim.x * blockIdx.y;
+        rc_ = (id >> 3) & 1; nbt_ = (id & 7) + ((id >> 4) << 3);
+    }
+    const int nbt = nbt_, row0 = rc_ * (RT * 16);
     STAMP(0);
     const int nrows = min(RT * 16, g.B - row0);
     const int K = g.K;
