@@ -285,10 +285,13 @@ int q3tts_k_mfma_bf16(int32_t device, const uint16_t* a, const uint16_t* b, cons
  * N % 48 == 0; y[B][N] f32 equals oracle q3o_gemm_bf16 bit for bit */
 int q3tts_k_gemm_bf16(int32_t device, const uint16_t* x, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, float* y, int32_t iters,
                       float* mean_kernel_ms);
-/* PROTOTYPE: the same with the fused RMSNorm prologue and SwiGLU epilogue (x f32 [B][K], K = 1024, w [N = 2F][K] gate rows then up
- * rows, y [B][F]); equals oracle q3o_gemm_bf16_norm_swiglu bit for bit */
+/* the Predictor's gate/up as the engine runs it: fused RMSNorm prologue and SwiGLU epilogue in the bf16 order (x f32 [B][K], K in
+ * {512, 1024}, w [N = 2F][K] gate rows then up rows, y [B][F]); equals oracle q3o_gemm_bf16_norm_swiglu bit for bit */
 int q3tts_k_gemm_bf16_norm_swiglu(int32_t device, const float* x, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, const float* norm_w,
                                   float eps, float* y, int32_t iters, float* mean_kernel_ms);
+/* the same with a plain store (the Predictor's QKV): y[B][N] = s_r * raw; equals oracle q3o_gemm_bf16_norm_store */
+int q3tts_k_gemm_bf16_norm_store(int32_t device, const float* x, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, const float* norm_w,
+                                 float eps, float* y, int32_t iters, float* mean_kernel_ms);
 /* rand 0.8 StdRng (ChaCha12) stream: seed_from_u64(seed) then n x gen::<f32>() */
 int q3tts_k_rng_f32(uint64_t seed, int32_t n, float* out);
 

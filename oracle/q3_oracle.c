@@ -611,8 +611,14 @@ static void tfm_layers(tfm* t, float* x, int n, int pos0, float eps) {
     float* y = malloc((size_t)n * d * 4);
     float* sc = malloc((size_t)n * 4);
     for (int l = 0; l < t->L; ++l) {
-        for (int r = 0; r < n; ++r) sc[r] = norm_gemm_row(x + (size_t)r * d, d, t->attn_norm[l], eps, xh + (size_t)r * d);
-        gemm_t(xh, n, d, d, t->wqkv_t[l], nqkv, 0, nqkv, qkv, nqkv);
+        if (t->bf16_ffn && nqkv % 32 == 0) {  /* the Predictor's QKV in the bf16 order as well (same rule as the device) */
+            uint16_t* xb = (uint16_t*)xh;
+            for (int r = 0; r < n; ++r) sc[r] = norm_bf16_row(x + (size_t)r * d, d, t->attn_norm[l], eps, xb + (size_t)r * d);
+            gemm_bf16_t(xb, n, d, t->wqkv_t[l], nqkv, nqkv, qkv, nqkv);
+        } else {
+            for (int r = 0; r < n; ++r) sc[r] = norm_gemm_row(x + (size_t)r * d, d, t->attn_norm[l], eps, xh + (size_t)r * d);
+            gemm_t(xh, n, d, d, t->wqkv_t[l], nqkv, 0, nqkv, qkv, nqkv);
+        }
         scale_rows(qkv, n, nqkv, nqkv, sc);
         size_t co = (size_t)l * t->Hkv * t->n_ctx * t->hd;
         attn_rows(qkv, n, pos0, t->Hq, t->Hkv, t->hd, t->qn[l], t->kn[l], eps, t->cs, t->sn, t->kc + co, t->vc + co, t->n_ctx, att);
@@ -929,4 +935,14 @@ void q3o_gemm_bf16_norm_swiglu(const float* x, int32_t B, int32_t K, const uint1
     for (int b = 0; b < B; ++b)
         for (int j = 0; j < F; ++j) y[(size_t)b * F + j] = swiglu(sc[b] * raw[(size_t)b * N + j], sc[b] * raw[(size_t)b * N + F + j]);
     free(raw); free(sc); free(xn);
+}
+
+/* fused RMSNorm + canonical bf16 GEMM, plain store (the Predictor's QKV): y = s * raw */
+void q3o_gemm_bf16_norm_store(const float* x, int32_t B, int32_t K, const uint16_t* w, int32_t N, const float* nw, float eps, float* y) {
+    uint16_t* xn = (uint16_t*)malloc((size_t)B * K * 2);
+    float* sc = (float*)malloc((size_t)B * 4);
+    for (int b = 0; b < B; ++b) sc[b] = norm_bf16_row(x + (size_t)b * K, K, nw, eps, xn + (size_t)b * K);
+    q3o_gemm_bf16(xn, B, K, w, N, y);
+    for (int b = 0; b < B; ++b) for (int n = 0; n < N; ++n) y[(size_t)b * N + n] = sc[b] * y[(size_t)b * N + n];
+    free(sc); free(xn);
 }

@@ -247,7 +247,10 @@ static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, int rows, const int*
     for (int l = 0; l < t.L; ++l) {
         Q3Gemm g{};
         g.x = x; g.ldx = t.d; g.B = rows; g.w = t.wqkv[l]; g.K = t.d; g.N = t.nqkv; g.norm_w = t.attn_norm[l]; g.eps = eps;
-        g.y = sc.qkv; g.ldy = t.nqkv; g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);
+        g.y = sc.qkv; g.ldy = t.nqkv; g.epi = Q3_EPI_STORE;
+        // the Predictor's norm-fused GEMMs (QKV here, gate/up below) run on the bf16 MFMA in their canonical order
+        if (&t == &e->P && q3_gemm_bf16_norm_ok(g.K, g.N)) q3_launch_gemm_bf16_norm_store(g.x, g.ldx, g.B, g.w, g.K, g.N, g.norm_w, g.eps, g.y, g.ldy, s);
+        else q3_launch_gemm(g, s);
         Q3QkPrep qp{}; qp.qkv = sc.qkv; qp.ld = t.nqkv; qp.rows = rows; qp.Hq = t.Hq; qp.Hkv = t.Hkv; qp.hd = t.hd;
         qp.qnw = t.qn[l]; qp.knw = t.kn[l]; qp.eps = eps; qp.cs = t.cs; qp.sn = t.sn;
         qp.kc = t.kc + l * t.layer_stride; qp.vc = t.vc + l * t.layer_stride; qp.n_ctx = t.n_ctx; qp.row_pos = row_pos; qp.row_slot = row_slot;
@@ -1278,6 +1281,35 @@ extern "C" int q3tts_k_gemm_bf16_norm_swiglu(int32_t device, const float* x, int
     if (go()) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bf16 norm/swiglu gemm: shape");
     HK(hipDeviceSynchronize());
     HK(hipMemcpy(y, dy.p, (size_t)B * F * 4, hipMemcpyDeviceToHost));
+    if (iters > 0 && mean_ms) {
+        hipEvent_t a, b; HK(hipEventCreate(&a)); HK(hipEventCreate(&b));
+        go();
+        HK(hipEventRecord(a, nullptr));
+        for (int i = 0; i < iters; ++i) go();
+        HK(hipEventRecord(b, nullptr)); HK(hipEventSynchronize(b));
+        float ms = 0; hipEventElapsedTime(&ms, a, b); *mean_ms = ms / iters;
+        hipEventDestroy(a); hipEventDestroy(b);
+    }
+    return Q3TTS_OK;
+}
+
+// fused RMSNorm + bf16-MFMA GEMM, plain store (the Predictor's QKV): y[B][N] = s_r * raw
+extern "C" int q3tts_k_gemm_bf16_norm_store(int32_t device, const float* x, int32_t B, int32_t K, const uint16_t* w, int32_t N, const float* norm_w,
+                                            float eps, float* y, int32_t iters, float* mean_ms) {
+    if (!x || !w || !y || !norm_w || B <= 0 || !q3_gemm_bf16_norm_ok(K, N)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bf16 norm hook: K in {512, 1024}, N % 32 == 0");
+    HK(hipSetDevice(device));
+    DevBuf dx, dw, dwt, dn, dy;
+    if (dx.alloc((size_t)B * K * 4) || dw.alloc((size_t)N * K * 2) || dwt.alloc((size_t)N * K * 2) || dn.alloc((size_t)K * 4) || dy.alloc((size_t)B * N * 4))
+        return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
+    HK(hipMemcpy(dx.p, x, (size_t)B * K * 4, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dw.p, w, (size_t)N * K * 2, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dn.p, norm_w, (size_t)K * 4, hipMemcpyHostToDevice));
+    Q3Fill f{}; f.dst = (uint4*)dwt.p; f.N = N; f.K = K; f.mode = 0; f.row0 = 0; f.rows = N; f.src_a = (const uint16_t*)dw.p;
+    q3_launch_fill_tiled(f, nullptr);
+    auto go = [&]() { return q3_launch_gemm_bf16_norm_store((const float*)dx.p, K, B, (const uint4*)dwt.p, K, N, (const float*)dn.p, eps, (float*)dy.p, N, nullptr); };
+    if (go()) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bf16 norm gemm: shape");
+    HK(hipDeviceSynchronize());
+    HK(hipMemcpy(y, dy.p, (size_t)B * N * 4, hipMemcpyDeviceToHost));
     if (iters > 0 && mean_ms) {
         hipEvent_t a, b; HK(hipEventCreate(&a)); HK(hipEventCreate(&b));
         go();

@@ -84,7 +84,7 @@ int q3_launch_gemm_bf16(const uint16_t* x, int ldx, int B, const uint4* w, int K
 //   ss = S_0 + ... + S_7, s_r = 1 / sqrtf(ss / K + eps)                                  
 // The A operand is still the f32 residual stream (the first integration step of §16): converted in the kernel.
 // ---------------------------------------------------------------------------------------------------------------
-template <int RT, int NT, int PER>
+template <int RT, int NT, int PER, int EPI>  // EPI: Q3_EPI_SWIGLU, or Q3_EPI_STORE (y = s_r * raw: the Predictor's QKV)
 __global__ __launch_bounds__(512) void k_gemm_bf16_norm_swiglu(const float* __restrict__ x, int ldx, int B, const uint4* __restrict__ w, int K, int N,
                                                                const float* __restrict__ nw, float eps, float* __restrict__ y, int ldy) {
     extern __shared__ float part[];  // [8][RT*NT*4][64] partial tiles, then [8][4][RT*16] ss partials, then [RT*16] row scales
@@ -162,35 +162,51 @@ __global__ __launch_bounds__(512) void k_gemm_bf16_norm_swiglu(const float* __re
         srow[threadIdx.x] = 1.0f / sqrtf(tot / (float)K + eps);
     }
     __syncthreads();
-    // gate lanes (column < 8 of a tile) finish one output each: swiglu(s * gate, s * up), up = the same row 8 columns further
     for (int o = threadIdx.x; o < RT * NT * 4 * 64; o += 512) {
-        const int l = o & 63;
-        if ((l & 15) >= 8) continue;
-        float g = part[o], u = part[o + 8];
-#pragma unroll
-        for (int wv = 1; wv < 8; ++wv) { g = g + part[(size_t)wv * (RT * NT * 4 * 64) + o]; u = u + part[(size_t)wv * (RT * NT * 4 * 64) + o + 8]; }
-        const int e = (o >> 6) & 3, t = o >> 8, i = t / NT, j = t - i * NT;
+        const int l = o & 63, e = (o >> 6) & 3, t = o >> 8, i = t / NT, j = t - i * NT;
         const int rl = 16 * i + 4 * (l >> 4) + e, row = row0 + rl;
         const float sc = srow[rl];
-        if (row < B) y[(size_t)row * ldy + (size_t)(nb0 + j) * 8 + (l & 15)] = q3_swiglu(sc * g, sc * u);
+        if (EPI == Q3_EPI_SWIGLU) {
+            // gate lanes (column < 8 of a tile) finish one output each: swiglu(s * gate, s * up), up = the same row 8 columns further
+            if ((l & 15) >= 8) continue;
+            float g = part[o], u = part[o + 8];
+#pragma unroll
+            for (int wv = 1; wv < 8; ++wv) { g = g + part[(size_t)wv * (RT * NT * 4 * 64) + o]; u = u + part[(size_t)wv * (RT * NT * 4 * 64) + o + 8]; }
+            if (row < B) y[(size_t)row * ldy + (size_t)(nb0 + j) * 8 + (l & 15)] = q3_swiglu(sc * g, sc * u);
+        } else {
+            float v = part[o];
+#pragma unroll
+            for (int wv = 1; wv < 8; ++wv) v = v + part[(size_t)wv * (RT * NT * 4 * 64) + o];
+            if (row < B) y[(size_t)row * ldy + (size_t)(nb0 + j) * 16 + (l & 15)] = sc * v;
+        }
     }
 }
 
 // shapes this path takes (a function of the model configuration only, never of the row count: the oracle applies the same rule)
-bool q3_gemm_bf16_norm_swiglu_ok(int K, int N) { return (K == 512 || K == 1024) && N % 32 == 0; }
+bool q3_gemm_bf16_norm_ok(int K, int N) { return (K == 512 || K == 1024) && N % 32 == 0; }
+bool q3_gemm_bf16_norm_swiglu_ok(int K, int N) { return q3_gemm_bf16_norm_ok(K, N); }
 
-template <int NT, int PER>
-static void launch_bf16_ns(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy, hipStream_t s) {
+template <int NT, int PER, int EPI>
+static void launch_bf16_n(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy, hipStream_t s) {
     const dim3 grid(N / (16 * NT), (B + 31) / 32);
     const size_t lds = ((size_t)8 * 2 * NT * 4 * 64 + 8 * 4 * 32 + 32) * 4;
-    hipLaunchKernelGGL((k_gemm_bf16_norm_swiglu<2, NT, PER>), grid, dim3(512), lds, s, x, ldx, B, w, K, N, nw, eps, y, ldy);
+    hipLaunchKernelGGL((k_gemm_bf16_norm_swiglu<2, NT, PER, EPI>), grid, dim3(512), lds, s, x, ldx, B, w, K, N, nw, eps, y, ldy);
 }
-int q3_launch_gemm_bf16_norm_swiglu(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy,
-                                    hipStream_t s) {
-    if (B < 1 || !q3_gemm_bf16_norm_swiglu_ok(K, N)) return -1;
+template <int EPI>
+static int launch_bf16_norm(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy, hipStream_t s) {
+    if (B < 1 || !q3_gemm_bf16_norm_ok(K, N)) return -1;
     const int tiles = N / 16, NT = tiles % 3 == 0 ? 3 : (tiles % 2 == 0 ? 2 : 1);
-#define L(NT_) do { if (K == 1024) launch_bf16_ns<NT_, 4>(x, ldx, B, w, K, N, nw, eps, y, ldy, s); else launch_bf16_ns<NT_, 2>(x, ldx, B, w, K, N, nw, eps, y, ldy, s); } while (0)
+#define L(NT_) do { if (K == 1024) launch_bf16_n<NT_, 4, EPI>(x, ldx, B, w, K, N, nw, eps, y, ldy, s); else launch_bf16_n<NT_, 2, EPI>(x, ldx, B, w, K, N, nw, eps, y, ldy, s); } while (0)
     if (NT == 3) L(3); else if (NT == 2) L(2); else L(1);
 #undef L
     return 0;
+}
+int q3_launch_gemm_bf16_norm_swiglu(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy,
+                                    hipStream_t s) {
+    return launch_bf16_norm<Q3_EPI_SWIGLU>(x, ldx, B, w, K, N, nw, eps, y, ldy, s);
+}
+// y[B][N] = s_r * canonical bf16 GEMM of bf16(x * nw) (fused RMSNorm prologue, plain store): the Predictor's QKV
+int q3_launch_gemm_bf16_norm_store(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy,
+                                   hipStream_t s) {
+    return launch_bf16_norm<Q3_EPI_STORE>(x, ldx, B, w, K, N, nw, eps, y, ldy, s);
 }

@@ -23,6 +23,9 @@ void q3_launch_gemm(const Q3Gemm& g, hipStream_t s);
 // Predictor gate/up in the canonical bf16-MFMA order (q3_gemm_bf16.hip): fused RMSNorm prologue on f32 rows, SwiGLU
 // epilogue; weights in the same tiled gate/up-interleaved layout. _ok(): the shapes it takes (K = d_model in {512, 1024}).
 bool q3_gemm_bf16_norm_swiglu_ok(int K, int N);
+bool q3_gemm_bf16_norm_ok(int K, int N);
+int q3_launch_gemm_bf16_norm_store(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy,
+                                   hipStream_t s);
 int q3_launch_gemm_bf16_norm_swiglu(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy,
                                     hipStream_t s);
 

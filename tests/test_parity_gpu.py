@@ -577,3 +577,27 @@ def test_bf16_gemm_norm_swiglu_matches_oracle(oracle, B, K, N):
     assert np.abs(y - y_exact).max() <= 0.05 * np.abs(y_exact).max()   # same function up to the bf16 rounding of the activations
     if (B, K) == (64, 1024):
         print(f"M=64 K=1024 N=6144 RMSNorm + GEMM + SwiGLU, back-to-back launches: bf16-MFMA prototype {ms.value * 1e3:.2f} us, exact kernel {ms_exact * 1e3:.2f} us")
+
+
+@pytest.mark.parametrize("B,K,N", [(64, 1024, 4096), (128, 1024, 4096), (1, 1024, 4096), (23, 512, 1024), (64, 1024, 96)])
+def test_bf16_gemm_norm_store_matches_oracle(oracle, B, K, N):
+    """The Predictor's QKV launch in the bf16 order (fused RMSNorm prologue, plain store): bit-exact against the oracle."""
+    from q3tts import _abi, native
+    lib = _abi.load_library()
+    L = oracle.lib()
+    L.q3o_gemm_bf16_norm_store.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_void_p]
+    L.q3o_gemm_bf16_norm_store.restype = None
+    rng = np.random.default_rng(200 + B + N)
+    x = _rand(rng, (B, K), 3.0); x[:, 3:9] *= 25.0
+    w = _bf16_bits(_rand(rng, (N, K), 0.02))
+    nw = (1.0 + _rand(rng, (K,), 0.05)).astype(np.float32)
+    ref = np.zeros((B, N), dtype=np.float32)
+    L.q3o_gemm_bf16_norm_store(x.ctypes.data, B, K, w.ctypes.data, N, nw.ctypes.data, 1e-6, ref.ctypes.data)
+    y = np.zeros((B, N), dtype=np.float32)
+    ms = C.c_float(0)
+    assert lib.q3tts_k_gemm_bf16_norm_store(0, x.ctypes.data, B, K, w.ctypes.data, N, nw.ctypes.data, 1e-6, y.ctypes.data, 200, C.byref(ms)) == 0
+    assert np.array_equal(_bits(y), _bits(ref))
+    y_exact, _, ms_exact = native.k_gemm_exact(x, w, norm_w=nw, eps=1e-6, epilogue=0, iters=200)
+    assert np.abs(y - y_exact).max() <= 0.03 * np.abs(y_exact).max()
+    if (B, N) == (64, 4096):
+        print(f"M=64 K=1024 N=4096 RMSNorm + GEMM, back-to-back launches: bf16-MFMA kernel {ms.value * 1e3:.2f} us, exact kernel {ms_exact * 1e3:.2f} us")
