@@ -1,6 +1,9 @@
-// q3_gemm_bf16.hip — PROTOTYPE of the canonical bf16-MFMA GEMM. Not used by the engine yet: it exists to
-// show, measured and bit-exact against the oracle, what the decoder's GEMMs gain from v_mfma_f32_16x16x32_bf16 now that
-// the instruction's accumulation arithmetic is restated (oracle/q3_oracle.c::q3o_mfma_bf16_dot32).
+// q3_gemm_bf16.hip — the canonical bf16-MFMA GEMM: GEMMs on v_mfma_f32_16x16x32_bf16 that stay bit-exact
+// against the CPU oracle because the instruction's accumulation arithmetic is restated there
+// (oracle/q3_oracle.c::q3o_mfma_bf16_dot32, pinned by tests and by hardware golden vectors).
+//   k_gemm_bf16_norm_swiglu<..., EPI>   IN THE ENGINE: the Predictor's norm-fused GEMMs — gate/up (SwiGLU epilogue) and QKV (store)
+//   k_gemm_bf16<...>                    prototype behind q3tts_k_gemm_bf16: plain GEMM on bf16 activation rows (the form O / down
+//                                       take once their producers emit bf16)
 //
 // Canonical order: y[b][n] = ((((s_0 + s_1) + s_2) + ...) + s_7), s_w = the chain of MFMA steps over K-slice w (K/8
 // contiguous columns, 32 per instruction, ascending), each instruction consuming its 32 products lane group by lane group:
