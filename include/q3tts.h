@@ -292,6 +292,9 @@ int q3tts_k_gemm_bf16_norm_swiglu(int32_t device, const float* x, int32_t B, int
 /* the same with a plain store (the Predictor's QKV): y[B][N] = s_r * raw; equals oracle q3o_gemm_bf16_norm_store */
 int q3tts_k_gemm_bf16_norm_store(int32_t device, const float* x, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, const float* norm_w,
                                  float eps, float* y, int32_t iters, float* mean_kernel_ms);
+/* y[B][N] += canonical bf16 GEMM of bf16 rows (the Predictor's O / down projections; K in {512, 1024, 2048, 3072}); y in / out */
+int q3tts_k_gemm_bf16_resid(int32_t device, const uint16_t* x, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, float* y, int32_t iters,
+                            float* mean_kernel_ms);
 /* rand 0.8 StdRng (ChaCha12) stream: seed_from_u64(seed) then n x gen::<f32>() */
 int q3tts_k_rng_f32(uint64_t seed, int32_t n, float* out);
 

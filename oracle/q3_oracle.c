@@ -490,7 +490,8 @@ typedef struct {
     float* out_norm; uint16_t* head_t; int head_n;
     float *kc, *vc; int n_ctx; /* [L][Hkv][n_ctx][hd] */
     float *cs, *sn;
-    int bf16_ffn;  /* gate/up in the canonical bf16-MFMA order: the Predictor, when d is 512 or 1024 */
+    int bf16_ffn;  /* norm-fused GEMMs (QKV, gate/up) in the canonical bf16-MFMA order: the Predictor, when d is 512 or 1024 */
+    int bf16_all;  /* O and down as well, on bf16-rounded attention / SwiGLU rows (K in {512, 1024, 2048, 3072}) */
 } tfm;
 
 struct q3o_model {
@@ -603,7 +604,7 @@ static void gemm_bf16_t(const uint16_t* xb, int n_rows, int K, const uint16_t* w
 
 static void tfm_layers(tfm* t, float* x, int n, int pos0, float eps) {
     const int d = t->d, nq = t->Hq * t->hd, nkv = t->Hkv * t->hd, nqkv = nq + 2 * nkv, F = t->F;
-    float* xh = malloc((size_t)n * (d > F ? d : F) * 4);
+    float* xh = malloc((size_t)n * (d > F ? d : F) * 4 + (size_t)n * nq * 2);
     float* qkv = malloc((size_t)n * nqkv * 4);
     float* att = malloc((size_t)n * nq * 4);
     float* g = malloc((size_t)n * F * 4);
@@ -611,7 +612,7 @@ static void tfm_layers(tfm* t, float* x, int n, int pos0, float eps) {
     float* y = malloc((size_t)n * d * 4);
     float* sc = malloc((size_t)n * 4);
     for (int l = 0; l < t->L; ++l) {
-        if (t->bf16_ffn && nqkv % 32 == 0) {  /* the Predictor's QKV in the bf16 order as well (same rule as the device) */
+        if (t->bf16_ffn) {  /* the Predictor's QKV in the bf16 order (same rule as the device) */
             uint16_t* xb = (uint16_t*)xh;
             for (int r = 0; r < n; ++r) sc[r] = norm_bf16_row(x + (size_t)r * d, d, t->attn_norm[l], eps, xb + (size_t)r * d);
             gemm_bf16_t(xb, n, d, t->wqkv_t[l], nqkv, nqkv, qkv, nqkv);
@@ -622,7 +623,11 @@ static void tfm_layers(tfm* t, float* x, int n, int pos0, float eps) {
         scale_rows(qkv, n, nqkv, nqkv, sc);
         size_t co = (size_t)l * t->Hkv * t->n_ctx * t->hd;
         attn_rows(qkv, n, pos0, t->Hq, t->Hkv, t->hd, t->qn[l], t->kn[l], eps, t->cs, t->sn, t->kc + co, t->vc + co, t->n_ctx, att);
-        gemm_t(att, n, nq, nq, t->wo_t[l], d, 0, d, y, d);
+        if (t->bf16_all) {
+            uint16_t* ab = (uint16_t*)xh;  /* scratch: sized for n * max(d, F) floats plus n * nq bf16 values */
+            for (size_t i = 0; i < (size_t)n * nq; ++i) ab[i] = q3o_bf16(att[i]);
+            gemm_bf16_t(ab, n, nq, t->wo_t[l], d, d, y, d);
+        } else gemm_t(att, n, nq, nq, t->wo_t[l], d, 0, d, y, d);
         for (size_t i = 0; i < (size_t)n * d; ++i) x[i] = x[i] + y[i];
         if (t->bf16_ffn) {
             uint16_t* xb = (uint16_t*)xh;  /* n * d bf16 values fit in the f32 scratch */
@@ -637,7 +642,11 @@ static void tfm_layers(tfm* t, float* x, int n, int pos0, float eps) {
         scale_rows(g, n, F, F, sc);
         scale_rows(u, n, F, F, sc);
         for (size_t i = 0; i < (size_t)n * F; ++i) g[i] = swiglu(g[i], u[i]);
-        gemm_t(g, n, F, F, t->wd_t[l], d, 0, d, y, d);
+        if (t->bf16_all) {
+            uint16_t* gb = (uint16_t*)xh;
+            for (size_t i = 0; i < (size_t)n * F; ++i) gb[i] = q3o_bf16(g[i]);
+            gemm_bf16_t(gb, n, F, t->wd_t[l], d, d, y, d);
+        } else gemm_t(g, n, F, F, t->wd_t[l], d, 0, d, y, d);
         for (size_t i = 0; i < (size_t)n * d; ++i) x[i] = x[i] + y[i];
     }
     free(xh); free(qkv); free(att); free(g); free(u); free(y); free(sc);
@@ -651,7 +660,12 @@ q3o_model* q3o_create(const q3o_model_config* c, uint64_t seed, int32_t n_ctx, i
              c->t_vocab, c->t_rope_theta, c->t_mrope_sections, n_ctx);
     tfm_init(&m->P, seed, G_PRED, c->p_n_layer, c->p_d_model, c->p_n_head, c->p_n_kv_head, c->p_head_dim, c->p_d_ffn,
              (c->n_codebooks - 1) * c->codebook_size, c->p_rope_theta, NULL, 64);
-    m->P.bf16_ffn = (c->p_d_model == 512 || c->p_d_model == 1024) && (2 * c->p_d_ffn) % 32 == 0;  /* the rule of q3_gemm_bf16_norm_swiglu_ok() */
+    {   /* the rules of run_layers() in q3_engine.hip: functions of the model shape only */
+        const int pd = c->p_d_model, pnq = c->p_n_head * c->p_head_dim, pnqkv = pnq + 2 * c->p_n_kv_head * c->p_head_dim, pF = c->p_d_ffn;
+        const int plain_nq = pnq == 512 || pnq == 1024 || pnq == 2048 || pnq == 3072, plain_F = pF == 512 || pF == 1024 || pF == 2048 || pF == 3072;
+        m->P.bf16_ffn = (pd == 512 || pd == 1024) && pnqkv % 32 == 0 && (2 * pF) % 32 == 0;
+        m->P.bf16_all = m->P.bf16_ffn && plain_nq && plain_F && pd % 16 == 0;
+    }
     m->proj_t = malloc((size_t)c->d_embed * c->p_d_model * 2);
     gen_mat_t(seed, TID(G_ASSET, 0, WA_PROJ_W), c->p_d_model, c->d_embed, 0.02f, m->proj_t, c->p_d_model, 0);
     m->proj_b = gen_f32(seed, TID(G_ASSET, 0, WA_PROJ_B), c->p_d_model, 0.0f, 0.02f);
@@ -945,4 +959,12 @@ void q3o_gemm_bf16_norm_store(const float* x, int32_t B, int32_t K, const uint16
     q3o_gemm_bf16(xn, B, K, w, N, y);
     for (int b = 0; b < B; ++b) for (int n = 0; n < N; ++n) y[(size_t)b * N + n] = sc[b] * y[(size_t)b * N + n];
     free(sc); free(xn);
+}
+
+/* y += canonical bf16 GEMM of bf16 rows (the Predictor's O / down projections) */
+void q3o_gemm_bf16_resid(const uint16_t* x, int32_t B, int32_t K, const uint16_t* w, int32_t N, float* y) {
+    float* raw = (float*)malloc((size_t)B * N * 4);
+    q3o_gemm_bf16(x, B, K, w, N, raw);
+    for (size_t i = 0; i < (size_t)B * N; ++i) y[i] = y[i] + raw[i];
+    free(raw);
 }

@@ -91,6 +91,7 @@ float q3o_mfma_bf16_dot32(const uint16_t* a, const uint16_t* b, float c);
 void q3o_gemm_bf16(const uint16_t* x_bf16, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, float* y);
 void q3o_gemm_bf16_norm_swiglu(const float* x, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, const float* norm_w, float eps, float* y);
 void q3o_gemm_bf16_norm_store(const float* x, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, const float* norm_w, float eps, float* y);
+void q3o_gemm_bf16_resid(const uint16_t* x_bf16, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, float* y_inout);
 /* H4 sampler: src/models/llama/mod.rs:666-772 */
 int32_t q3o_sample(const float* logits, int32_t limit, float temperature, int32_t top_k, float top_p, float r);
 /* rand 0.8 StdRng: seed_from_u64 + gen::<f32>() */

@@ -244,12 +244,17 @@ static int alloc_scratch(q3tts_engine* e, Q3Scratch& sc, int rows, int nqkv, int
 static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, int rows, const int* row_pos, const int* row_slot, Q3Scratch& sc, hipStream_t s,
                        bool one_row_per_slot = false, hipEvent_t* probe = nullptr) {
     const float eps = e->cfg.model.rms_eps;
+    // the Predictor's layer GEMMs run on the bf16 MFMA in their canonical order: QKV and gate/up with the RMSNorm
+    // fused on f32 rows, O and down on bf16 rows written by the attention kernel / the SwiGLU epilogue. The rule depends on the
+    // model shape only (the oracle applies the same one); the Talker, whose prefill shares the exact kernels, stays exact.
+    const bool pb = &t == &e->P && q3_gemm_bf16_norm_ok(t.d, t.nqkv) && q3_gemm_bf16_norm_ok(t.d, 2 * t.F);
+    const bool pb_all = pb && q3_gemm_bf16_plain_ok(t.nq) && q3_gemm_bf16_plain_ok(t.F) && t.d % 16 == 0;
     for (int l = 0; l < t.L; ++l) {
         Q3Gemm g{};
         g.x = x; g.ldx = t.d; g.B = rows; g.w = t.wqkv[l]; g.K = t.d; g.N = t.nqkv; g.norm_w = t.attn_norm[l]; g.eps = eps;
         g.y = sc.qkv; g.ldy = t.nqkv; g.epi = Q3_EPI_STORE;
         // the Predictor's norm-fused GEMMs (QKV here, gate/up below) run on the bf16 MFMA in their canonical order
-        if (&t == &e->P && q3_gemm_bf16_norm_ok(g.K, g.N)) q3_launch_gemm_bf16_norm_store(g.x, g.ldx, g.B, g.w, g.K, g.N, g.norm_w, g.eps, g.y, g.ldy, s);
+        if (pb) q3_launch_gemm_bf16_norm_store(g.x, g.ldx, g.B, g.w, g.K, g.N, g.norm_w, g.eps, g.y, g.ldy, s);
         else q3_launch_gemm(g, s);
         Q3QkPrep qp{}; qp.qkv = sc.qkv; qp.ld = t.nqkv; qp.rows = rows; qp.Hq = t.Hq; qp.Hkv = t.Hkv; qp.hd = t.hd;
         qp.qnw = t.qn[l]; qp.knw = t.kn[l]; qp.eps = eps; qp.cs = t.cs; qp.sn = t.sn;
@@ -258,20 +263,22 @@ static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, int rows, const int*
         if (!fused) q3_launch_qk_prep(qp, s);
         Q3Attend at{}; at.qkv = sc.qkv; at.ld = t.nqkv; at.rows = rows; at.out = sc.att; at.ldo = t.nq; at.Hq = t.Hq; at.Hkv = t.Hkv; at.hd = t.hd;
         at.kc = qp.kc; at.vc = qp.vc; at.n_ctx = t.n_ctx; at.row_pos = row_pos; at.row_slot = row_slot;
-        at.fused = fused; at.prep = qp;
+        at.fused = fused; at.prep = qp; at.out_bf16 = pb_all ? 1 : 0;
         q3_launch_attend(at, s);
         g = Q3Gemm{}; g.x = sc.att; g.ldx = t.nq; g.B = rows; g.w = t.wo[l]; g.K = t.nq; g.N = t.d; g.y = x; g.ldy = t.d; g.epi = Q3_EPI_RESID;
-        q3_launch_gemm(g, s);
+        if (pb_all) q3_launch_gemm_bf16_resid((const uint16_t*)sc.att, t.nq, rows, t.wo[l], t.nq, t.d, x, t.d, s);
+        else q3_launch_gemm(g, s);
         g = Q3Gemm{}; g.x = x; g.ldx = t.d; g.B = rows; g.w = t.wgu[l]; g.K = t.d; g.N = 2 * t.F; g.norm_w = t.ffn_norm[l]; g.eps = eps;
         g.y = sc.h; g.ldy = t.F; g.epi = Q3_EPI_SWIGLU;
         if (probe && l == 0) hipEventRecord(probe[0], s);
         // the Predictor's gate/up runs on the bf16 MFMA in its own canonical order; the Talker (whose prefill shares
         // the exact kernels) and every other GEMM stay on the exact f32 path
-        if (&t == &e->P && q3_gemm_bf16_norm_swiglu_ok(g.K, g.N)) q3_launch_gemm_bf16_norm_swiglu(g.x, g.ldx, g.B, g.w, g.K, g.N, g.norm_w, g.eps, g.y, g.ldy, s);
+        if (pb) q3_launch_gemm_bf16_norm_swiglu(g.x, g.ldx, g.B, g.w, g.K, g.N, g.norm_w, g.eps, g.y, g.ldy, s, pb_all ? 1 : 0);
         else q3_launch_gemm(g, s);
         if (probe && l == 0) hipEventRecord(probe[1], s);
         g = Q3Gemm{}; g.x = sc.h; g.ldx = t.F; g.B = rows; g.w = t.wd[l]; g.K = t.F; g.N = t.d; g.y = x; g.ldy = t.d; g.epi = Q3_EPI_RESID;
-        q3_launch_gemm(g, s);
+        if (pb_all) q3_launch_gemm_bf16_resid((const uint16_t*)sc.h, t.F, rows, t.wd[l], t.F, t.d, x, t.d, s);
+        else q3_launch_gemm(g, s);
     }
 }
 
@@ -1277,7 +1284,7 @@ extern "C" int q3tts_k_gemm_bf16_norm_swiglu(int32_t device, const float* x, int
     HK(hipMemcpy(dn.p, norm_w, (size_t)K * 4, hipMemcpyHostToDevice));
     Q3Fill f{}; f.dst = (uint4*)dwt.p; f.N = N; f.K = K; f.mode = 1; f.src_a = (const uint16_t*)dw.p; f.src_b = (const uint16_t*)dw.p + (size_t)F * K;
     q3_launch_fill_tiled(f, nullptr);
-    auto go = [&]() { return q3_launch_gemm_bf16_norm_swiglu((const float*)dx.p, K, B, (const uint4*)dwt.p, K, N, (const float*)dn.p, eps, (float*)dy.p, F, nullptr); };
+    auto go = [&]() { return q3_launch_gemm_bf16_norm_swiglu((const float*)dx.p, K, B, (const uint4*)dwt.p, K, N, (const float*)dn.p, eps, (float*)dy.p, F, nullptr, 0); };
     if (go()) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bf16 norm/swiglu gemm: shape");
     HK(hipDeviceSynchronize());
     HK(hipMemcpy(y, dy.p, (size_t)B * F * 4, hipMemcpyDeviceToHost));
@@ -1308,6 +1315,34 @@ extern "C" int q3tts_k_gemm_bf16_norm_store(int32_t device, const float* x, int3
     q3_launch_fill_tiled(f, nullptr);
     auto go = [&]() { return q3_launch_gemm_bf16_norm_store((const float*)dx.p, K, B, (const uint4*)dwt.p, K, N, (const float*)dn.p, eps, (float*)dy.p, N, nullptr); };
     if (go()) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bf16 norm gemm: shape");
+    HK(hipDeviceSynchronize());
+    HK(hipMemcpy(y, dy.p, (size_t)B * N * 4, hipMemcpyDeviceToHost));
+    if (iters > 0 && mean_ms) {
+        hipEvent_t a, b; HK(hipEventCreate(&a)); HK(hipEventCreate(&b));
+        go();
+        HK(hipEventRecord(a, nullptr));
+        for (int i = 0; i < iters; ++i) go();
+        HK(hipEventRecord(b, nullptr)); HK(hipEventSynchronize(b));
+        float ms = 0; hipEventElapsedTime(&ms, a, b); *mean_ms = ms / iters;
+        hipEventDestroy(a); hipEventDestroy(b);
+    }
+    return Q3TTS_OK;
+}
+
+// y[B][N] += canonical bf16 GEMM of bf16 rows (the Predictor's O / down projections): x, w bf16 bits; y in/out
+extern "C" int q3tts_k_gemm_bf16_resid(int32_t device, const uint16_t* x, int32_t B, int32_t K, const uint16_t* w, int32_t N, float* y, int32_t iters,
+                                       float* mean_ms) {
+    if (!x || !w || !y || B <= 0 || N % 16 || !q3_gemm_bf16_plain_ok(K)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bf16 resid hook: K in {512, 1024, 2048, 3072}, N % 16 == 0");
+    HK(hipSetDevice(device));
+    DevBuf dx, dw, dwt, dy;
+    if (dx.alloc((size_t)B * K * 2) || dw.alloc((size_t)N * K * 2) || dwt.alloc((size_t)N * K * 2) || dy.alloc((size_t)B * N * 4)) return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
+    HK(hipMemcpy(dx.p, x, (size_t)B * K * 2, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dw.p, w, (size_t)N * K * 2, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dy.p, y, (size_t)B * N * 4, hipMemcpyHostToDevice));
+    Q3Fill f{}; f.dst = (uint4*)dwt.p; f.N = N; f.K = K; f.mode = 0; f.row0 = 0; f.rows = N; f.src_a = (const uint16_t*)dw.p;
+    q3_launch_fill_tiled(f, nullptr);
+    auto go = [&]() { return q3_launch_gemm_bf16_resid((const uint16_t*)dx.p, K, B, (const uint4*)dwt.p, K, N, (float*)dy.p, N, nullptr); };
+    if (go()) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bf16 resid gemm: shape");
     HK(hipDeviceSynchronize());
     HK(hipMemcpy(y, dy.p, (size_t)B * N * 4, hipMemcpyDeviceToHost));
     if (iters > 0 && mean_ms) {

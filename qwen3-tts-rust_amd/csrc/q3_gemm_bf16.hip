@@ -16,7 +16,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <int RT, int NT, int PER>
+template <int RT, int NT, int PER, bool RESID>
 __global__ __launch_bounds__(512) void k_gemm_bf16(const uint16_t* __restrict__ x, int ldx, int B, const uint4* __restrict__ w, int K, int N,
                                                    float* __restrict__ y, int ldy) {
     extern __shared__ float part[];  // [8 waves][RT*NT*4 regs][64 lanes]
@@ -66,7 +66,10 @@ __global__ __launch_bounds__(512) void k_gemm_bf16(const uint16_t* __restrict__ 
         for (int wv = 1; wv < 8; ++wv) v = v + part[(size_t)wv * (RT * NT * 4 * 64) + o];
         const int l = o & 63, e = (o >> 6) & 3, t = o >> 8, i = t / NT, j = t - i * NT;
         const int row = row0 + 16 * i + 4 * (l >> 4) + e;
-        if (row < B) y[(size_t)row * ldy + (size_t)(nb0 + j) * 16 + (l & 15)] = v;
+        if (row < B) {
+            float* yp = y + (size_t)row * ldy + (size_t)(nb0 + j) * 16 + (l & 15);
+            *yp = RESID ? *yp + v : v;
+        }
     }
 }
 
@@ -75,8 +78,8 @@ int q3_launch_gemm_bf16(const uint16_t* x, int ldx, int B, const uint4* w, int K
     if (B < 1 || N % 48 || (K != 1024 && K != 2048)) return -1;
     const dim3 grid(N / 48, (B + 31) / 32);
     const size_t lds = (size_t)8 * 2 * 3 * 4 * 64 * 4;
-    if (K == 1024) hipLaunchKernelGGL((k_gemm_bf16<2, 3, 4>), grid, dim3(512), lds, s, x, ldx, B, w, K, N, y, ldy);
-    else hipLaunchKernelGGL((k_gemm_bf16<2, 3, 8>), grid, dim3(512), lds, s, x, ldx, B, w, K, N, y, ldy);
+    if (K == 1024) hipLaunchKernelGGL((k_gemm_bf16<2, 3, 4, false>), grid, dim3(512), lds, s, x, ldx, B, w, K, N, y, ldy);
+    else hipLaunchKernelGGL((k_gemm_bf16<2, 3, 8, false>), grid, dim3(512), lds, s, x, ldx, B, w, K, N, y, ldy);
     return 0;
 }
 
@@ -89,7 +92,7 @@ int q3_launch_gemm_bf16(const uint16_t* x, int ldx, int B, const uint4* w, int K
 // ---------------------------------------------------------------------------------------------------------------
 template <int RT, int NT, int PER, int EPI>  // EPI: Q3_EPI_SWIGLU, or Q3_EPI_STORE (y = s_r * raw: the Predictor's QKV)
 __global__ __launch_bounds__(512) void k_gemm_bf16_norm_swiglu(const float* __restrict__ x, int ldx, int B, const uint4* __restrict__ w, int K, int N,
-                                                               const float* __restrict__ nw, float eps, float* __restrict__ y, int ldy) {
+                                                               const float* __restrict__ nw, float eps, float* __restrict__ y, int ldy, int y_bf16) {
     extern __shared__ float part[];  // [8][RT*NT*4][64] partial tiles, then [8][4][RT*16] ss partials, then [RT*16] row scales
     float* ssp = part + (size_t)8 * RT * NT * 4 * 64;
     float* srow = ssp + 8 * 4 * RT * 16;
@@ -175,7 +178,11 @@ __global__ __launch_bounds__(512) void k_gemm_bf16_norm_swiglu(const float* __re
             float g = part[o], u = part[o + 8];
 #pragma unroll
             for (int wv = 1; wv < 8; ++wv) { g = g + part[(size_t)wv * (RT * NT * 4 * 64) + o]; u = u + part[(size_t)wv * (RT * NT * 4 * 64) + o + 8]; }
-            if (row < B) y[(size_t)row * ldy + (size_t)(nb0 + j) * 8 + (l & 15)] = q3_swiglu(sc * g, sc * u);
+            if (row < B) {
+                const size_t oi = (size_t)row * ldy + (size_t)(nb0 + j) * 8 + (l & 15);
+                const float val = q3_swiglu(sc * g, sc * u);
+                if (y_bf16) ((uint16_t*)y)[oi] = q3_bf16(val); else y[oi] = val;  // bf16 when the consumer is the bf16 down projection
+            }
         } else {
             float v = part[o];
 #pragma unroll
@@ -190,26 +197,39 @@ bool q3_gemm_bf16_norm_ok(int K, int N) { return (K == 512 || K == 1024) && N % 
 bool q3_gemm_bf16_norm_swiglu_ok(int K, int N) { return q3_gemm_bf16_norm_ok(K, N); }
 
 template <int NT, int PER, int EPI>
-static void launch_bf16_n(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy, hipStream_t s) {
+static void launch_bf16_n(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy, hipStream_t s, int yb) {
     const dim3 grid(N / (16 * NT), (B + 31) / 32);
     const size_t lds = ((size_t)8 * 2 * NT * 4 * 64 + 8 * 4 * 32 + 32) * 4;
-    hipLaunchKernelGGL((k_gemm_bf16_norm_swiglu<2, NT, PER, EPI>), grid, dim3(512), lds, s, x, ldx, B, w, K, N, nw, eps, y, ldy);
+    hipLaunchKernelGGL((k_gemm_bf16_norm_swiglu<2, NT, PER, EPI>), grid, dim3(512), lds, s, x, ldx, B, w, K, N, nw, eps, y, ldy, yb);
 }
 template <int EPI>
-static int launch_bf16_norm(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy, hipStream_t s) {
+static int launch_bf16_norm(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy, hipStream_t s, int yb) {
     if (B < 1 || !q3_gemm_bf16_norm_ok(K, N)) return -1;
     const int tiles = N / 16, NT = tiles % 3 == 0 ? 3 : (tiles % 2 == 0 ? 2 : 1);
-#define L(NT_) do { if (K == 1024) launch_bf16_n<NT_, 4, EPI>(x, ldx, B, w, K, N, nw, eps, y, ldy, s); else launch_bf16_n<NT_, 2, EPI>(x, ldx, B, w, K, N, nw, eps, y, ldy, s); } while (0)
+#define L(NT_) do { if (K == 1024) launch_bf16_n<NT_, 4, EPI>(x, ldx, B, w, K, N, nw, eps, y, ldy, s, yb); else launch_bf16_n<NT_, 2, EPI>(x, ldx, B, w, K, N, nw, eps, y, ldy, s, yb); } while (0)
     if (NT == 3) L(3); else if (NT == 2) L(2); else L(1);
 #undef L
     return 0;
 }
 int q3_launch_gemm_bf16_norm_swiglu(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy,
-                                    hipStream_t s) {
-    return launch_bf16_norm<Q3_EPI_SWIGLU>(x, ldx, B, w, K, N, nw, eps, y, ldy, s);
+                                    hipStream_t s, int y_bf16) {
+    return launch_bf16_norm<Q3_EPI_SWIGLU>(x, ldx, B, w, K, N, nw, eps, y, ldy, s, y_bf16);
 }
 // y[B][N] = s_r * canonical bf16 GEMM of bf16(x * nw) (fused RMSNorm prologue, plain store): the Predictor's QKV
 int q3_launch_gemm_bf16_norm_store(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy,
                                    hipStream_t s) {
-    return launch_bf16_norm<Q3_EPI_STORE>(x, ldx, B, w, K, N, nw, eps, y, ldy, s);
+    return launch_bf16_norm<Q3_EPI_STORE>(x, ldx, B, w, K, N, nw, eps, y, ldy, s, 0);
+}
+
+// residual form for the Predictor's O and down projections: 16 x 16 tiles (N = d_model is small: 64 column tiles x B/16 row chunks
+// fill the chip), bf16 rows from the attention / SwiGLU producers, K / 256 steps per wave all in flight
+bool q3_gemm_bf16_plain_ok(int K) { return K == 512 || K == 1024 || K == 2048 || K == 3072; }
+int q3_launch_gemm_bf16_resid(const uint16_t* x, int ldx, int B, const uint4* w, int K, int N, float* y, int ldy, hipStream_t s) {
+    if (B < 1 || N % 16 || !q3_gemm_bf16_plain_ok(K)) return -1;
+    const dim3 grid(N / 16, (B + 15) / 16);
+    const size_t lds = (size_t)8 * 4 * 64 * 4;
+#define L(PER_) hipLaunchKernelGGL((k_gemm_bf16<1, 1, PER_, true>), grid, dim3(512), lds, s, x, ldx, B, w, K, N, y, ldy)
+    switch (K >> 8) { case 2: L(2); break; case 4: L(4); break; case 8: L(8); break; default: L(12); break; }
+#undef L
+    return 0;
 }

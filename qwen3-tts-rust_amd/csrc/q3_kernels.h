@@ -27,7 +27,10 @@ bool q3_gemm_bf16_norm_ok(int K, int N);
 int q3_launch_gemm_bf16_norm_store(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy,
                                    hipStream_t s);
 int q3_launch_gemm_bf16_norm_swiglu(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy,
-                                    hipStream_t s);
+                                    hipStream_t s, int y_bf16 = 0);
+// y[B][N] += canonical bf16 GEMM of bf16 rows x (residual epilogue): the Predictor's O and down projections
+bool q3_gemm_bf16_plain_ok(int K);
+int q3_launch_gemm_bf16_resid(const uint16_t* x, int ldx, int B, const uint4* w, int K, int N, float* y, int ldy, hipStream_t s);
 
 // weight tiling: dst tiled [N/16][K/32][64 lanes][8], source either synthetic or a row-major bf16 staging buffer
 struct Q3Fill {
@@ -56,6 +59,7 @@ void q3_launch_qk_prep(const Q3QkPrep& a, hipStream_t s);
 struct Q3Attend {
     const float* qkv; int ld; int rows;
     float* out; int ldo;
+    int out_bf16;     // 1: out is a bf16 buffer (uint16 bits, ldo in elements): the consumer is a bf16-MFMA GEMM (Predictor)
     int Hq, Hkv, hd;
     const uint16_t* kc; const uint16_t* vc; int n_ctx;
     const int* row_pos; const int* row_slot;

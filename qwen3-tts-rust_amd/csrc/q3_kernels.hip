@@ -288,7 +288,8 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
                     r3 = ow[(h2 * 4 + 3) * hd + d];
         const float ov = ((r0 + r1) + r2) + r3;
         const float l = ((lw[h2 * 4] + lw[h2 * 4 + 1]) + lw[h2 * 4 + 2]) + lw[h2 * 4 + 3];
-        a.out[(size_t)row * a.ldo + (size_t)(g * R + h2) * hd + d] = ov / l;
+        const size_t oi = (size_t)row * a.ldo + (size_t)(g * R + h2) * hd + d;
+        if (a.out_bf16) ((uint16_t*)a.out)[oi] = q3_bf16(ov / l); else a.out[oi] = ov / l;
     }
 }
 void q3_launch_attend(const Q3Attend& a, hipStream_t s) {

@@ -601,3 +601,27 @@ def test_bf16_gemm_norm_store_matches_oracle(oracle, B, K, N):
     assert np.abs(y - y_exact).max() <= 0.03 * np.abs(y_exact).max()
     if (B, N) == (64, 4096):
         print(f"M=64 K=1024 N=4096 RMSNorm + GEMM, back-to-back launches: bf16-MFMA kernel {ms.value * 1e3:.2f} us, exact kernel {ms_exact * 1e3:.2f} us")
+
+
+@pytest.mark.parametrize("B,K,N", [(64, 2048, 1024), (64, 3072, 1024), (128, 2048, 1024), (1, 3072, 1024), (23, 512, 512), (7, 1024, 48)])
+def test_bf16_gemm_resid_matches_oracle(oracle, B, K, N):
+    """The Predictor's O / down projections in the bf16 order (bf16 rows in, residual epilogue): bit-exact against the oracle."""
+    from q3tts import _abi, native
+    lib = _abi.load_library()
+    L = oracle.lib()
+    L.q3o_gemm_bf16_resid.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+    L.q3o_gemm_bf16_resid.restype = None
+    rng = np.random.default_rng(300 + B + K)
+    xb = _bf16_bits(_rand(rng, (B, K), 1.5)); wb = _bf16_bits(_rand(rng, (N, K), 0.02))
+    y0 = _rand(rng, (B, N), 2.0)
+    ref = y0.copy()
+    L.q3o_gemm_bf16_resid(xb.ctypes.data, B, K, wb.ctypes.data, N, ref.ctypes.data)
+    y = y0.copy()
+    ms = C.c_float(0)
+    assert lib.q3tts_k_gemm_bf16_resid(0, xb.ctypes.data, B, K, wb.ctypes.data, N, y.ctypes.data, 0, C.byref(ms)) == 0
+    assert np.array_equal(_bits(y), _bits(ref)) and not np.array_equal(y, y0)
+    if (B, N) == (64, 1024):
+        yt = y0.copy()
+        lib.q3tts_k_gemm_bf16_resid(0, xb.ctypes.data, B, K, wb.ctypes.data, N, yt.ctypes.data, 200, C.byref(ms))
+        _, _, ms_exact = native.k_gemm_exact((xb.astype(np.uint32) << 16).view(np.float32), wb, epilogue=0, iters=200)
+        print(f"M=64 K={K} N=1024 back-to-back launches: bf16-MFMA residual kernel {ms.value * 1e3:.2f} us, exact kernel {ms_exact * 1e3:.2f} us")
