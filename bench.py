@@ -245,7 +245,7 @@ def main():
                 "bound": "mfma", "achieved": round(k_tf, 2), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(k_tf / F32_MFMA_PEAK_TF, 4),
                 "traffic": traffic,
                 "kernel": "k_gemm_ring<2, 3, 4, true>: Talker gate/up GEMM + fused RMSNorm + SwiGLU, M=%d K=%d N=%d (exact f32 MFMA; the largest "
-                          "instance of the k_gemm_ring family, which holds ~60%% of all kernel time in profiles/r01/bench_b64_eager_kernel_stats.csv; "
+                          "instance of the k_gemm_ring family, which holds ~36%% of all kernel time in profiles/r01/bench_b64_eager_kernel_stats.csv (the Predictor's layer GEMMs, 31%%, run on the bf16 MFMA); "
                           "28 launches per frame step)" % (pr["rows"], pr["K"], pr["N"]),
                 "launch_us": round(k_ms * 1e3, 2), "empty_bracket_us": round(pr["empty_ms"] * 1e3, 2),
                 "launch_us_minus_empty_bracket": round((pr["kernel_ms"] - pr["empty_ms"]) * 1e3, 2), "launches_timed": pr["launches"],
