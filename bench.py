@@ -322,21 +322,6 @@ def main():
             "front_end_ms_p50": round(float(np.median(fe)), 2), "first_chunk_ms_p50": round(float(np.median(cf)), 2),
             "first_chunk_incl_front_end_ms_p50": round(float(np.median(np.asarray(fe) + np.asarray(cf))), 2)}
         e1.close()
-    if rank == 0 and world == 1 and not args.no_single:
-        # groundwork number: the prototype canonical bf16-MFMA GEMM next to the exact kernel the engine runs, same
-        # shape as `roofline` (M = 64, K = 1024, N = 6144), 300 back-to-back launches each through the test hooks
-        import ctypes as C
-        rr = np.random.default_rng(3)
-        xg = rr.standard_normal((64, 1024)).astype(np.float32); wg = (rr.standard_normal((6144, 1024)) * 0.02).astype(np.float32)
-        to_bf = lambda a: ((a.view(np.uint32).astype(np.uint64) + 0x7FFF + ((a.view(np.uint32).astype(np.uint64) >> 16) & 1)) >> 16).astype(np.uint16)
-        xb, wb = to_bf(xg), to_bf(wg)
-        yb = np.zeros((64, 6144), np.float32); msb = C.c_float(0)
-        lib = _abi.load_library()
-        if lib.q3tts_k_gemm_bf16(local_rank, xb.ctypes.data, 64, 1024, wb.ctypes.data, 6144, yb.ctypes.data, 300, C.byref(msb)) == 0:
-            _, _, ms_exact = native.k_gemm_exact((xb.astype(np.uint32) << 16).view(np.float32), wb, epilogue=0, device=local_rank, iters=300)
-            line["bf16_gemm_prototype"] = {"what": "k_gemm_bf16 (v_mfma_f32_16x16x32_bf16, bit-exact against the oracle's integer restatement; not used by the "
-                                                   "engine yet) vs k_gemm_ring (exact f32 MFMA), M=64 K=1024 N=6144, plain store, back-to-back launches",
-                                           "us_per_launch": round(msb.value * 1e3, 2), "exact_kernel_us_per_launch": round(ms_exact * 1e3, 2)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = min(16, os.cpu_count() or 1)
         line["cpu_baseline"] = cpu_baseline(cfg, spk, cfg.with_vocoder, threads)

@@ -274,27 +274,29 @@ int q3tts_k_vocoder(q3tts_engine* e, const int32_t* codes, int32_t n_frames, int
  * / ggml type (0 F32, 1 F16, 8 Q8_0, 30 BF16). Needs no GPU. */
 int q3tts_k_gguf_read(const char* path, const char* tensor, float* out, int64_t cap, int64_t* nelem, int64_t* dims4, int32_t* ggml_type);
 /* Measurement mode for bench.py: frame steps are launched eagerly (no graph replay) and one GEMM of every frame is bracketed
- * by HIP events on its own stream — enable = 2: the Talker's layer-0 gate/up GEMM (k_gemm_ring, exact f32 MFMA, the largest
- * GEMM of the frame step); enable = 1: the Predictor's pass-1 / layer-0 gate/up GEMM (k_gemm_bf16_norm_swiglu). q3tts_timings
+ * by HIP events on its own stream — enable = 2: the Talker's layer-0 gate/up GEMM (k_bgemm, the largest GEMM of the frame
+ * step); enable = 1: the Predictor's pass-1 / layer-0 gate/up GEMM. q3tts_timings
  * .probe_kernel_ms / probe_count report it for the frame steps that ran at the full row count. enable = 0 restores graph replay. */
 int q3tts_k_probe(q3tts_engine* e, int32_t enable);
 /* n_cases independent chains of `chain` v_mfma_f32_16x16x32_bf16 into one accumulator tile: a [n][chain][16][32] bf16 bits,
- * b [n][chain][32][16], c / d [n][16][16] f32. Pins the instruction's accumulation arithmetic (DESIGN.md §16). */
+ * b [n][chain][32][16], c / d [n][16][16] f32. Pins the instruction's accumulation arithmetic (DESIGN.md §4.1). */
 int q3tts_k_mfma_bf16(int32_t device, const uint16_t* a, const uint16_t* b, const float* c, float* d, int32_t n_cases, int32_t chain);
-/* PROTOTYPE (not used by the engine): canonical bf16-MFMA GEMM of DESIGN.md §16; x / w are bf16 bit patterns, K in {1024, 2048},
- * N % 48 == 0; y[B][N] f32 equals oracle q3o_gemm_bf16 bit for bit */
-int q3tts_k_gemm_bf16(int32_t device, const uint16_t* x, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, float* y, int32_t iters,
-                      float* mean_kernel_ms);
-/* the Predictor's gate/up as the engine runs it: fused RMSNorm prologue and SwiGLU epilogue in the bf16 order (x f32 [B][K], K in
- * {512, 1024}, w [N = 2F][K] gate rows then up rows, y [B][F]); equals oracle q3o_gemm_bf16_norm_swiglu bit for bit */
-int q3tts_k_gemm_bf16_norm_swiglu(int32_t device, const float* x, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, const float* norm_w,
-                                  float eps, float* y, int32_t iters, float* mean_kernel_ms);
-/* the same with a plain store (the Predictor's QKV): y[B][N] = s_r * raw; equals oracle q3o_gemm_bf16_norm_store */
-int q3tts_k_gemm_bf16_norm_store(int32_t device, const float* x, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, const float* norm_w,
-                                 float eps, float* y, int32_t iters, float* mean_kernel_ms);
-/* y[B][N] += canonical bf16 GEMM of bf16 rows (the Predictor's O / down projections; K in {512, 1024, 2048, 3072}); y in / out */
-int q3tts_k_gemm_bf16_resid(int32_t device, const uint16_t* x, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, float* y, int32_t iters,
-                            float* mean_kernel_ms);
+/* The decoder's GEMM as the engine launches it (csrc/q3_bgemm.hip): bf16 rows xb [B][K] x W [N][K] (bf16 bit
+ * patterns, row-major; tiled on the device) on v_mfma_f32_16x16x32_bf16, K % 256 == 0, N % 16 == 0. ssp [B][ntiles] (or NULL) are
+ * the producer's per-tile sums of squares: s_r = 1 / sqrtf(SS(ssp) / d_norm + eps).
+ *   epilogue 0: y[B][N] = s_r * RAW            1: y += RAW (y in/out); with nw_next[N] also yb[B][N] = bf16(y * nw_next), ssp_out[B][N/16]
+ *            2: yb[B][N/2] = bf16(swiglu(s_r * RAW_gate, s_r * RAW_up)), W = the N/2 gate rows then the N/2 up rows
+ *            3: keys[B] = argmax key over s_r * RAW
+ * Equals oracle q3o_bgemm bit for bit for every row count (the tile shape the launcher picks never changes a result). */
+int q3tts_k_bgemm(int32_t device, const uint16_t* xb, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, const float* ssp, int32_t ntiles,
+                  int32_t d_norm, float eps, int32_t epilogue, const float* nw_next, float* y, uint16_t* yb, float* ssp_out, uint64_t* keys,
+                  int32_t iters, float* mean_kernel_ms);
+/* H6 — Assets::project (src/assets_manager.rs:383-399) in the reference's own f32 sequence: y[r][o] = bias[o]; y += x[r][i] * w[o][i]
+ * for i ascending (w f32 row-major [n_out][n_in]). nw != NULL: also the rows' norm inputs xb = bf16(y * nw), ssp [rows][n_out/16]. */
+int q3tts_k_project(int32_t device, const float* x, int32_t rows, int32_t n_in, const float* w, const float* bias, int32_t n_out, const float* nw,
+                    float* y, uint16_t* xb, float* ssp);
+/* producer side of the split RMSNorm for plain f32 rows: xb = bf16(x * nw), ssp[r][t] = sum of squares of tile t */
+int q3tts_k_norm_inputs(int32_t device, const float* x, int32_t rows, int32_t d, const float* nw, uint16_t* xb, float* ssp);
 /* rand 0.8 StdRng (ChaCha12) stream: seed_from_u64(seed) then n x gen::<f32>() */
 int q3tts_k_rng_f32(uint64_t seed, int32_t n, float* out);
 

@@ -5,8 +5,8 @@
  * TEST INFRASTRUCTURE ONLY (see q3_oracle.h). PARITY UNPINNED against the reference
  * binaries (llama.cpp b7885 / onnxruntime 1.23.2 are not in /root/reference and the
  * reference holds no tests or golden vectors); host logic follows the cited lines of
- * /root/reference exactly, transformer math follows the standard Qwen3 decoder with the
- * canonical fp32 summation orders of DESIGN.md §4.
+ * /root/reference exactly, transformer math follows the standard Qwen3 decoder in the
+ * canonical order of DESIGN.md §4 (bf16 GEMM operands on the restated MFMA: q3_oracle_bf16.c).
  *
  * Build: see oracle/Makefile (gcc -O3 -mavx2 -mfma -ffp-contract=off -fopenmp).
  * -ffp-contract=off matters: every fused multiply-add in the spec is an explicit fmaf().
@@ -483,22 +483,29 @@ int32_t q3o_chunk_plan(int32_t n_frames, int32_t* cf, int32_t* cl, int32_t max_c
 /* ------------------------------------------------------------------------------------------ */
 /* model                                                                                        */
 /* ------------------------------------------------------------------------------------------ */
+/* q3_oracle_bf16.c: the canonical bf16-MFMA arithmetic both transformers run in */
+void q3o_permute_rows_bf16(const uint16_t* src, int32_t rows, int32_t K, uint16_t* dst);
+void q3o_bgemm_raw_p(const uint16_t* xp, int32_t rows, int32_t K, const uint16_t* wp, int32_t N, float* out, int32_t ldo, int32_t threads);
+
 typedef struct {
     int L, d, Hq, Hkv, hd, F;
-    float** attn_norm; uint16_t** wqkv_t; float** qn; float** kn; uint16_t** wo_t; float** ffn_norm;
-    uint16_t** wg_t; uint16_t** wu_t; uint16_t** wd_t;
-    float* out_norm; uint16_t* head_t; int head_n;
+    /* matrices: bf16, row-major [N][K], the k of every 32-block permuted to the MFMA operand order (q3_oracle_bf16.c) */
+    float** attn_norm; uint16_t** wqkv; float** qn; float** kn; uint16_t** wo; float** ffn_norm;
+    uint16_t** wg; uint16_t** wu; uint16_t** wd;
+    float* out_norm; uint16_t* head; int head_n;
     float *kc, *vc; int n_ctx; /* [L][Hkv][n_ctx][hd] */
     float *cs, *sn;
-    int bf16_ffn;  /* norm-fused GEMMs (QKV, gate/up) in the canonical bf16-MFMA order: the Predictor, when d is 512 or 1024 */
-    int bf16_all;  /* O and down as well, on bf16-rounded attention / SwiGLU rows (K in {512, 1024, 2048, 3072}) */
 } tfm;
 
 struct q3o_model {
     q3o_model_config c; uint64_t seed; int n_ctx;
     tfm T, P;
-    uint16_t* proj_t; float* proj_b;
+    float* proj_w; float* proj_b;  /* f32 [p_d_model][d_embed], as the reference keeps them (src/assets_manager.rs:212-241) */
+    int arith;                     /* 0: canonical bf16-MFMA order (what the device computes); 1: plain f32 (structure pinning, tests) */
 };
+
+static inline int kperm32(int p) { const int g = p >> 3, e = p & 7; return e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4); }
+static inline int kpos32(int k) { return 8 * ((k & 15) >> 2) + (k & 3) + ((k & 16) ? 4 : 0); }  /* inverse of kperm32 */
 
 static float* gen_f32(uint64_t seed, uint32_t tid, size_t n, float base, float std) {
     float* p = (float*)malloc(n * 4);
@@ -506,40 +513,46 @@ static float* gen_f32(uint64_t seed, uint32_t tid, size_t n, float base, float s
     for (size_t i = 0; i < n; ++i) p[i] = base + q3o_synth(seed, tid, i, scale);
     return p;
 }
-/* logical [N][K] tensor -> transposed bf16 [K][ldw] at column offset col0 */
-static void gen_mat_t(uint64_t seed, uint32_t tid, int N, int K, float std, uint16_t* dst, int ldw, int col0) {
+/* logical [N][K] tensor -> bf16 rows in operand order */
+static uint16_t* gen_mat_p(uint64_t seed, uint32_t tid, int N, int K, float std) {
+    uint16_t* dst = (uint16_t*)malloc((size_t)N * K * 2);
     const float scale = std / IH4_STD;
 #pragma omp parallel for schedule(static) num_threads(g_threads > 0 ? g_threads : 1)
     for (int n = 0; n < N; ++n)
-        for (int k = 0; k < K; ++k) dst[(size_t)k * ldw + col0 + n] = q3o_bf16(q3o_synth(seed, tid, (size_t)n * K + k, scale));
+        for (int k0 = 0; k0 < K; k0 += 32)
+            for (int p = 0; p < 32; ++p)
+                dst[(size_t)n * K + k0 + p] = q3o_bf16(q3o_synth(seed, tid, (size_t)n * K + k0 + kperm32(p), scale));
+    return dst;
 }
+static inline float w_nat(const uint16_t* wp, int K, int n, int k) { return bf16f(wp[(size_t)n * K + (k & ~31) + kpos32(k & 31)]); }
 
 static void tfm_init(tfm* t, uint64_t seed, int grp, int L, int d, int Hq, int Hkv, int hd, int F, int head_n, float theta,
                      const int* sections, int n_ctx) {
     t->L = L; t->d = d; t->Hq = Hq; t->Hkv = Hkv; t->hd = hd; t->F = F; t->head_n = head_n; t->n_ctx = n_ctx;
-    t->attn_norm = calloc(L, sizeof(void*)); t->wqkv_t = calloc(L, sizeof(void*)); t->qn = calloc(L, sizeof(void*));
-    t->kn = calloc(L, sizeof(void*)); t->wo_t = calloc(L, sizeof(void*)); t->ffn_norm = calloc(L, sizeof(void*));
-    t->wg_t = calloc(L, sizeof(void*)); t->wu_t = calloc(L, sizeof(void*)); t->wd_t = calloc(L, sizeof(void*));
+    t->attn_norm = calloc(L, sizeof(void*)); t->wqkv = calloc(L, sizeof(void*)); t->qn = calloc(L, sizeof(void*));
+    t->kn = calloc(L, sizeof(void*)); t->wo = calloc(L, sizeof(void*)); t->ffn_norm = calloc(L, sizeof(void*));
+    t->wg = calloc(L, sizeof(void*)); t->wu = calloc(L, sizeof(void*)); t->wd = calloc(L, sizeof(void*));
     const int nq = Hq * hd, nkv = Hkv * hd, nqkv = nq + 2 * nkv;
     for (int l = 0; l < L; ++l) {
         t->attn_norm[l] = gen_f32(seed, TID(grp, l, W_ATTN_NORM), d, 1.0f, 0.05f);
         t->ffn_norm[l] = gen_f32(seed, TID(grp, l, W_FFN_NORM), d, 1.0f, 0.05f);
         t->qn[l] = gen_f32(seed, TID(grp, l, W_QNORM), hd, 1.0f, 0.05f);
         t->kn[l] = gen_f32(seed, TID(grp, l, W_KNORM), hd, 1.0f, 0.05f);
-        t->wqkv_t[l] = malloc((size_t)d * nqkv * 2);
-        gen_mat_t(seed, TID(grp, l, W_Q), nq, d, 0.02f, t->wqkv_t[l], nqkv, 0);
-        gen_mat_t(seed, TID(grp, l, W_K), nkv, d, 0.02f, t->wqkv_t[l], nqkv, nq);
-        gen_mat_t(seed, TID(grp, l, W_V), nkv, d, 0.02f, t->wqkv_t[l], nqkv, nq + nkv);
-        t->wo_t[l] = malloc((size_t)nq * d * 2);
-        gen_mat_t(seed, TID(grp, l, W_O), d, nq, 0.02f, t->wo_t[l], d, 0);
-        t->wg_t[l] = malloc((size_t)d * F * 2); t->wu_t[l] = malloc((size_t)d * F * 2); t->wd_t[l] = malloc((size_t)d * F * 2);
-        gen_mat_t(seed, TID(grp, l, W_GATE), F, d, 0.02f, t->wg_t[l], F, 0);
-        gen_mat_t(seed, TID(grp, l, W_UP), F, d, 0.02f, t->wu_t[l], F, 0);
-        gen_mat_t(seed, TID(grp, l, W_DOWN), d, F, 0.02f, t->wd_t[l], d, 0);
+        t->wqkv[l] = (uint16_t*)malloc((size_t)nqkv * d * 2);
+        uint16_t* q = gen_mat_p(seed, TID(grp, l, W_Q), nq, d, 0.02f);
+        uint16_t* k = gen_mat_p(seed, TID(grp, l, W_K), nkv, d, 0.02f);
+        uint16_t* v = gen_mat_p(seed, TID(grp, l, W_V), nkv, d, 0.02f);
+        memcpy(t->wqkv[l], q, (size_t)nq * d * 2);
+        memcpy(t->wqkv[l] + (size_t)nq * d, k, (size_t)nkv * d * 2);
+        memcpy(t->wqkv[l] + (size_t)(nq + nkv) * d, v, (size_t)nkv * d * 2);
+        free(q); free(k); free(v);
+        t->wo[l] = gen_mat_p(seed, TID(grp, l, W_O), d, nq, 0.02f);
+        t->wg[l] = gen_mat_p(seed, TID(grp, l, W_GATE), F, d, 0.02f);
+        t->wu[l] = gen_mat_p(seed, TID(grp, l, W_UP), F, d, 0.02f);
+        t->wd[l] = gen_mat_p(seed, TID(grp, l, W_DOWN), d, F, 0.02f);
     }
     t->out_norm = gen_f32(seed, TID(grp, L_MODEL, WM_OUT_NORM), d, 1.0f, 0.05f);
-    t->head_t = malloc((size_t)d * head_n * 2);
-    gen_mat_t(seed, TID(grp, L_MODEL, WM_HEAD), head_n, d, 0.02f, t->head_t, head_n, 0);
+    t->head = gen_mat_p(seed, TID(grp, L_MODEL, WM_HEAD), head_n, d, 0.02f);
     t->kc = calloc((size_t)L * Hkv * n_ctx * hd, 4);
     t->vc = calloc((size_t)L * Hkv * n_ctx * hd, 4);
     t->cs = malloc((size_t)n_ctx * (hd / 2) * 4); t->sn = malloc((size_t)n_ctx * (hd / 2) * 4);
@@ -547,109 +560,138 @@ static void tfm_init(tfm* t, uint64_t seed, int grp, int L, int d, int Hq, int H
 }
 static void tfm_free(tfm* t) {
     for (int l = 0; l < t->L; ++l) {
-        free(t->attn_norm[l]); free(t->wqkv_t[l]); free(t->qn[l]); free(t->kn[l]); free(t->wo_t[l]); free(t->ffn_norm[l]);
-        free(t->wg_t[l]); free(t->wu_t[l]); free(t->wd_t[l]);
+        free(t->attn_norm[l]); free(t->wqkv[l]); free(t->qn[l]); free(t->kn[l]); free(t->wo[l]); free(t->ffn_norm[l]);
+        free(t->wg[l]); free(t->wu[l]); free(t->wd[l]);
     }
-    free(t->attn_norm); free(t->wqkv_t); free(t->qn); free(t->kn); free(t->wo_t); free(t->ffn_norm);
-    free(t->wg_t); free(t->wu_t); free(t->wd_t); free(t->out_norm); free(t->head_t); free(t->kc); free(t->vc);
+    free(t->attn_norm); free(t->wqkv); free(t->qn); free(t->kn); free(t->wo); free(t->ffn_norm);
+    free(t->wg); free(t->wu); free(t->wd); free(t->out_norm); free(t->head); free(t->kc); free(t->vc);
     free(t->cs); free(t->sn);
 }
 
-/* x [n][d] updated in place through all layers; rows are positions pos0.. of one sequence */
-float q3o_mfma_bf16_dot32(const uint16_t* a, const uint16_t* b, float c);
-/* row prologue of the bf16 order: xn = bf16(x * nw); returns s = 1/sqrtf(ss/K + eps), ss in the order of k_gemm_bf16_norm_swiglu */
-static float norm_bf16_row(const float* xr, int K, const float* nw, float eps, uint16_t* xn) {
-    const int per = K / 256;
-    float tot = 0.0f;
-    for (int sl = 0; sl < 8; ++sl) {
-        float c[4];
-        for (int kq = 0; kq < 4; ++kq) {
-            float a = 0.0f;
-            for (int st = 0; st < per; ++st) {
-                const int k0 = (sl * per + st) * 32;
-                for (int e = 0; e < 8; ++e) { const float v = xr[k0 + (e < 4 ? 4 * kq + e : 16 + 4 * kq + (e - 4))]; a = fmaf(v, v, a); }
-            }
-            c[kq] = a;
-        }
-        const float S = (c[0] + c[1]) + (c[2] + c[3]);
-        tot = sl == 0 ? S : tot + S;
-    }
-    for (int k = 0; k < K; ++k) xn[k] = q3o_bf16(xr[k] * nw[k]);
-    return 1.0f / sqrtf(tot / (float)K + eps);
-}
-/* canonical bf16 GEMM on transposed weights wt [K][ldw]: out[r][n] for n in [0, ncols) */
-static void gemm_bf16_t(const uint16_t* xb, int n_rows, int K, const uint16_t* wt, int ldw, int ncols, float* out, int ldo) {
-    const int per = K / 256;
-#pragma omp parallel for schedule(static) collapse(2) num_threads(g_threads > 0 ? g_threads : 1)
-    for (int r = 0; r < n_rows; ++r)
-        for (int n = 0; n < ncols; ++n) {
-            float tot = 0.0f;
-            for (int sl = 0; sl < 8; ++sl) {
-                float acc = 0.0f;
-                for (int st = 0; st < per; ++st) {
-                    const int k0 = (sl * per + st) * 32;
-                    uint16_t av[32], bv[32];
-                    for (int g = 0; g < 4; ++g)
-                        for (int e = 0; e < 8; ++e) {
-                            const int k = k0 + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4));
-                            av[8 * g + e] = xb[(size_t)r * K + k]; bv[8 * g + e] = wt[(size_t)k * ldw + n];
-                        }
-                    acc = q3o_mfma_bf16_dot32(av, bv, acc);
-                }
-                tot = sl == 0 ? acc : tot + acc;
-            }
-            out[(size_t)r * ldo + n] = tot;
-        }
+/* RAW of natural-order bf16 rows against one of the model's matrices */
+static void bgemm_rows(const uint16_t* ab, int n, int K, const uint16_t* wp, int N, float* out, int ldo) {
+    uint16_t* ap = (uint16_t*)malloc((size_t)n * K * 2);
+    q3o_permute_rows_bf16(ab, n, K, ap);
+    q3o_bgemm_raw_p(ap, n, K, wp, N, out, ldo, g_threads > 0 ? g_threads : 1);
+    free(ap);
 }
 
-static void tfm_layers(tfm* t, float* x, int n, int pos0, float eps) {
-    const int d = t->d, nq = t->Hq * t->hd, nkv = t->Hkv * t->hd, nqkv = nq + 2 * nkv, F = t->F;
-    float* xh = malloc((size_t)n * (d > F ? d : F) * 4 + (size_t)n * nq * 2);
+/* One transformer over n rows (positions pos0.. of one sequence), canonical arithmetic. x [n][d] is the f32 residual stream,
+ * updated in place. On entry xb / ssp are the norm inputs of x for attn_norm[0] (q3o_norm_inputs); on exit for out_norm.
+ * Device: run_layers in q3_engine.hip — bgemm(QKV) -> k_attend -> bgemm(O, residual + norm outputs) -> bgemm(gate/up, SwiGLU)
+ * -> bgemm(down, residual + norm outputs). */
+static void tfm_layers(tfm* t, float* x, uint16_t* xb, float* ssp, int n, int pos0, float eps) {
+    const int d = t->d, nq = t->Hq * t->hd, nkv = t->Hkv * t->hd, nqkv = nq + 2 * nkv, F = t->F, nt = d / 16;
     float* qkv = malloc((size_t)n * nqkv * 4);
     float* att = malloc((size_t)n * nq * 4);
+    uint16_t* ab = malloc((size_t)n * (nq > F ? nq : F) * 2);
     float* g = malloc((size_t)n * F * 4);
     float* u = malloc((size_t)n * F * 4);
     float* y = malloc((size_t)n * d * 4);
     float* sc = malloc((size_t)n * 4);
     for (int l = 0; l < t->L; ++l) {
-        if (t->bf16_ffn) {  /* the Predictor's QKV in the bf16 order (same rule as the device) */
-            uint16_t* xb = (uint16_t*)xh;
-            for (int r = 0; r < n; ++r) sc[r] = norm_bf16_row(x + (size_t)r * d, d, t->attn_norm[l], eps, xb + (size_t)r * d);
-            gemm_bf16_t(xb, n, d, t->wqkv_t[l], nqkv, nqkv, qkv, nqkv);
-        } else {
-            for (int r = 0; r < n; ++r) sc[r] = norm_gemm_row(x + (size_t)r * d, d, t->attn_norm[l], eps, xh + (size_t)r * d);
-            gemm_t(xh, n, d, d, t->wqkv_t[l], nqkv, 0, nqkv, qkv, nqkv);
-        }
+        for (int r = 0; r < n; ++r) sc[r] = q3o_row_scale(ssp + (size_t)r * nt, nt, d, eps);
+        bgemm_rows(xb, n, d, t->wqkv[l], nqkv, qkv, nqkv);
         scale_rows(qkv, n, nqkv, nqkv, sc);
         size_t co = (size_t)l * t->Hkv * t->n_ctx * t->hd;
         attn_rows(qkv, n, pos0, t->Hq, t->Hkv, t->hd, t->qn[l], t->kn[l], eps, t->cs, t->sn, t->kc + co, t->vc + co, t->n_ctx, att);
-        if (t->bf16_all) {
-            uint16_t* ab = (uint16_t*)xh;  /* scratch: sized for n * max(d, F) floats plus n * nq bf16 values */
-            for (size_t i = 0; i < (size_t)n * nq; ++i) ab[i] = q3o_bf16(att[i]);
-            gemm_bf16_t(ab, n, nq, t->wo_t[l], d, d, y, d);
-        } else gemm_t(att, n, nq, nq, t->wo_t[l], d, 0, d, y, d);
+        for (size_t i = 0; i < (size_t)n * nq; ++i) ab[i] = q3o_bf16(att[i]);
+        bgemm_rows(ab, n, nq, t->wo[l], d, y, d);
         for (size_t i = 0; i < (size_t)n * d; ++i) x[i] = x[i] + y[i];
-        if (t->bf16_ffn) {
-            uint16_t* xb = (uint16_t*)xh;  /* n * d bf16 values fit in the f32 scratch */
-            for (int r = 0; r < n; ++r) sc[r] = norm_bf16_row(x + (size_t)r * d, d, t->ffn_norm[l], eps, xb + (size_t)r * d);
-            gemm_bf16_t(xb, n, d, t->wg_t[l], F, F, g, F);
-            gemm_bf16_t(xb, n, d, t->wu_t[l], F, F, u, F);
-        } else {
-            for (int r = 0; r < n; ++r) sc[r] = norm_gemm_row(x + (size_t)r * d, d, t->ffn_norm[l], eps, xh + (size_t)r * d);
-            gemm_t(xh, n, d, d, t->wg_t[l], F, 0, F, g, F);
-            gemm_t(xh, n, d, d, t->wu_t[l], F, 0, F, u, F);
-        }
+        for (int r = 0; r < n; ++r) q3o_norm_inputs(x + (size_t)r * d, d, t->ffn_norm[l], xb + (size_t)r * d, ssp + (size_t)r * nt);
+        for (int r = 0; r < n; ++r) sc[r] = q3o_row_scale(ssp + (size_t)r * nt, nt, d, eps);
+        bgemm_rows(xb, n, d, t->wg[l], F, g, F);
+        bgemm_rows(xb, n, d, t->wu[l], F, u, F);
         scale_rows(g, n, F, F, sc);
         scale_rows(u, n, F, F, sc);
-        for (size_t i = 0; i < (size_t)n * F; ++i) g[i] = swiglu(g[i], u[i]);
-        if (t->bf16_all) {
-            uint16_t* gb = (uint16_t*)xh;
-            for (size_t i = 0; i < (size_t)n * F; ++i) gb[i] = q3o_bf16(g[i]);
-            gemm_bf16_t(gb, n, F, t->wd_t[l], d, d, y, d);
-        } else gemm_t(g, n, F, F, t->wd_t[l], d, 0, d, y, d);
+        for (size_t i = 0; i < (size_t)n * F; ++i) ab[i] = q3o_bf16(swiglu(g[i], u[i]));
+        bgemm_rows(ab, n, F, t->wd[l], d, y, d);
         for (size_t i = 0; i < (size_t)n * d; ++i) x[i] = x[i] + y[i];
+        const float* nxt = l + 1 < t->L ? t->attn_norm[l + 1] : t->out_norm;
+        for (int r = 0; r < n; ++r) q3o_norm_inputs(x + (size_t)r * d, d, nxt, xb + (size_t)r * d, ssp + (size_t)r * nt);
     }
-    free(xh); free(qkv); free(att); free(g); free(u); free(y); free(sc);
+    free(qkv); free(att); free(ab); free(g); free(u); free(y); free(sc);
+}
+
+/* ---- plain f32 arithmetic of the same structure (arith == 1): what the family code computes up to summation order; used by
+ * tests/test_decoder_family_cpu.py to pin the STRUCTURE (norm placement, NeoX pairing, GQA mapping, QK-norm) against
+ * transformers' Qwen3, and to state the distance between the canonical bf16 order and f32 ---------------------------------- */
+static void rmsnorm_plain(const float* x, int d, const float* w, float eps, float* y) {
+    double ss = 0.0;
+    for (int i = 0; i < d; ++i) ss += (double)x[i] * (double)x[i];
+    const float rinv = (float)(1.0 / sqrt(ss / (double)d + (double)eps));
+    for (int i = 0; i < d; ++i) y[i] = (x[i] * rinv) * w[i];
+}
+static void gemm_plain(const float* x, int n, int K, const uint16_t* wp, int N, float* out, int ldo) {
+#pragma omp parallel for schedule(static) num_threads(g_threads > 0 ? g_threads : 1)
+    for (int c = 0; c < N; ++c)
+        for (int r = 0; r < n; ++r) {
+            double acc = 0.0;
+            for (int k = 0; k < K; ++k) acc += (double)x[(size_t)r * K + k] * (double)w_nat(wp, K, c, k);
+            out[(size_t)r * ldo + c] = (float)acc;
+        }
+}
+static void attn_rows_plain(const float* qkv, int n_rows, int pos0, int Hq, int Hkv, int hd, const float* qnw, const float* knw,
+                            float eps, const float* cs, const float* sn, float* kc, float* vc, int n_ctx, float* out) {
+    const int ld = (Hq + 2 * Hkv) * hd, R = Hq / Hkv, half = hd / 2;
+    float* tmp = (float*)malloc((size_t)hd * 4);
+    for (int r = 0; r < n_rows; ++r) {
+        const int pos = pos0 + r;
+        const float* row = qkv + (size_t)r * ld;
+        for (int g = 0; g < Hkv; ++g) {
+            rmsnorm_plain(row + (size_t)(Hq + g) * hd, hd, knw, eps, tmp);
+            rope_apply(tmp, hd, cs + (size_t)pos * half, sn + (size_t)pos * half);
+            memcpy(kc + ((size_t)g * n_ctx + pos) * hd, tmp, (size_t)hd * 4);
+            memcpy(vc + ((size_t)g * n_ctx + pos) * hd, row + (size_t)(Hq + Hkv + g) * hd, (size_t)hd * 4);
+        }
+        for (int h = 0; h < Hq; ++h) {
+            const int g = h / R, T = pos + 1;
+            rmsnorm_plain(row + (size_t)h * hd, hd, qnw, eps, tmp);
+            rope_apply(tmp, hd, cs + (size_t)pos * half, sn + (size_t)pos * half);
+            double* p = (double*)malloc((size_t)T * 8);
+            double m = -1e300, l = 0.0;
+            for (int t = 0; t < T; ++t) {
+                const float* kr = kc + ((size_t)g * n_ctx + t) * hd;
+                double s = 0.0;
+                for (int dd = 0; dd < hd; ++dd) s += (double)tmp[dd] * (double)kr[dd];
+                p[t] = s / sqrt((double)hd);
+                if (p[t] > m) m = p[t];
+            }
+            for (int t = 0; t < T; ++t) { p[t] = exp(p[t] - m); l += p[t]; }
+            float* o = out + (size_t)r * Hq * hd + (size_t)h * hd;
+            for (int dd = 0; dd < hd; ++dd) {
+                double a = 0.0;
+                for (int t = 0; t < T; ++t) a += p[t] * (double)vc[((size_t)g * n_ctx + t) * hd + dd];
+                o[dd] = (float)(a / l);
+            }
+            free(p);
+        }
+    }
+    free(tmp);
+}
+static void tfm_layers_plain(tfm* t, float* x, int n, int pos0, float eps) {
+    const int d = t->d, nq = t->Hq * t->hd, nkv = t->Hkv * t->hd, nqkv = nq + 2 * nkv, F = t->F;
+    float* xn = malloc((size_t)n * d * 4);
+    float* qkv = malloc((size_t)n * nqkv * 4);
+    float* att = malloc((size_t)n * nq * 4);
+    float* g = malloc((size_t)n * F * 4);
+    float* u = malloc((size_t)n * F * 4);
+    float* y = malloc((size_t)n * d * 4);
+    for (int l = 0; l < t->L; ++l) {
+        for (int r = 0; r < n; ++r) rmsnorm_plain(x + (size_t)r * d, d, t->attn_norm[l], eps, xn + (size_t)r * d);
+        gemm_plain(xn, n, d, t->wqkv[l], nqkv, qkv, nqkv);
+        size_t co = (size_t)l * t->Hkv * t->n_ctx * t->hd;
+        attn_rows_plain(qkv, n, pos0, t->Hq, t->Hkv, t->hd, t->qn[l], t->kn[l], eps, t->cs, t->sn, t->kc + co, t->vc + co, t->n_ctx, att);
+        gemm_plain(att, n, nq, t->wo[l], d, y, d);
+        for (size_t i = 0; i < (size_t)n * d; ++i) x[i] += y[i];
+        for (int r = 0; r < n; ++r) rmsnorm_plain(x + (size_t)r * d, d, t->ffn_norm[l], eps, xn + (size_t)r * d);
+        gemm_plain(xn, n, d, t->wg[l], F, g, F);
+        gemm_plain(xn, n, d, t->wu[l], F, u, F);
+        for (size_t i = 0; i < (size_t)n * F; ++i) g[i] = (float)((double)g[i] / (1.0 + exp(-(double)g[i]))) * u[i];
+        gemm_plain(g, n, F, t->wd[l], d, y, d);
+        for (size_t i = 0; i < (size_t)n * d; ++i) x[i] += y[i];
+    }
+    free(xn); free(qkv); free(att); free(g); free(u); free(y);
 }
 
 q3o_model* q3o_create(const q3o_model_config* c, uint64_t seed, int32_t n_ctx, int32_t n_threads) {
@@ -660,20 +702,41 @@ q3o_model* q3o_create(const q3o_model_config* c, uint64_t seed, int32_t n_ctx, i
              c->t_vocab, c->t_rope_theta, c->t_mrope_sections, n_ctx);
     tfm_init(&m->P, seed, G_PRED, c->p_n_layer, c->p_d_model, c->p_n_head, c->p_n_kv_head, c->p_head_dim, c->p_d_ffn,
              (c->n_codebooks - 1) * c->codebook_size, c->p_rope_theta, NULL, 64);
-    {   /* the rules of run_layers() in q3_engine.hip: functions of the model shape only */
-        const int pd = c->p_d_model, pnq = c->p_n_head * c->p_head_dim, pnqkv = pnq + 2 * c->p_n_kv_head * c->p_head_dim, pF = c->p_d_ffn;
-        const int plain_nq = pnq == 512 || pnq == 1024 || pnq == 2048 || pnq == 3072, plain_F = pF == 512 || pF == 1024 || pF == 2048 || pF == 3072;
-        m->P.bf16_ffn = (pd == 512 || pd == 1024) && pnqkv % 32 == 0 && (2 * pF) % 32 == 0;
-        m->P.bf16_all = m->P.bf16_ffn && plain_nq && plain_F && pd % 16 == 0;
+    {   /* proj.weight / proj.bias: f32 tensors (the synthetic values are bf16-representable, like every synthetic matrix) */
+        const size_t n = (size_t)c->p_d_model * c->d_embed;
+        m->proj_w = (float*)malloc(n * 4);
+        const float scale = 0.02f / IH4_STD;
+        for (size_t i = 0; i < n; ++i) m->proj_w[i] = round_bf16(q3o_synth(seed, TID(G_ASSET, 0, WA_PROJ_W), i, scale));
     }
-    m->proj_t = malloc((size_t)c->d_embed * c->p_d_model * 2);
-    gen_mat_t(seed, TID(G_ASSET, 0, WA_PROJ_W), c->p_d_model, c->d_embed, 0.02f, m->proj_t, c->p_d_model, 0);
     m->proj_b = gen_f32(seed, TID(G_ASSET, 0, WA_PROJ_B), c->p_d_model, 0.0f, 0.02f);
     return m;
 }
 void q3o_destroy(q3o_model* m) {
     if (!m) return;
-    tfm_free(&m->T); tfm_free(&m->P); free(m->proj_t); free(m->proj_b); free(m);
+    tfm_free(&m->T); tfm_free(&m->P); free(m->proj_w); free(m->proj_b); free(m);
+}
+void q3o_set_arith(q3o_model* m, int32_t arith) { m->arith = arith; }
+/* natural-order f32 copies of the synthetic tensors, for loading the same model into the family code (tests) */
+const float* q3o_norm_weight(const q3o_model* m, int32_t talker, int32_t layer, int32_t which) {
+    const tfm* t = talker ? &m->T : &m->P;
+    if (layer < 0) return t->out_norm;
+    return which == 0 ? t->attn_norm[layer] : which == 1 ? t->ffn_norm[layer] : which == 2 ? t->qn[layer] : t->kn[layer];
+}
+/* which: 0 qkv (fused rows q | k | v), 1 o, 2 gate, 3 up, 4 down, 5 head (layer ignored); out [N][K] f32 */
+int32_t q3o_matrix(const q3o_model* m, int32_t talker, int32_t layer, int32_t which, float* out) {
+    const tfm* t = talker ? &m->T : &m->P;
+    const int nq = t->Hq * t->hd, nqkv = nq + 2 * t->Hkv * t->hd;
+    const uint16_t* w; int N, K;
+    switch (which) {
+        case 0: w = t->wqkv[layer]; N = nqkv; K = t->d; break;
+        case 1: w = t->wo[layer]; N = t->d; K = nq; break;
+        case 2: w = t->wg[layer]; N = t->F; K = t->d; break;
+        case 3: w = t->wu[layer]; N = t->F; K = t->d; break;
+        case 4: w = t->wd[layer]; N = t->d; K = t->F; break;
+        default: w = t->head; N = t->head_n; K = t->d; break;
+    }
+    if (out) for (int n = 0; n < N; ++n) for (int k = 0; k < K; ++k) out[(size_t)n * K + k] = w_nat(w, K, n, k);
+    return N;
 }
 
 /* embedding tables are generated on demand (bf16-representable f32, like the shipped presets) */
@@ -697,10 +760,22 @@ void q3o_codec_embedding(const q3o_model* m, int32_t q, int32_t code, float* out
         for (int i = 0; i < d; ++i) out[i] = 0.0f;
     }
 }
-void q3o_project(const q3o_model* m, const float* x, float* y) { /* src/assets_manager.rs:383-399 */
-    const int dp = m->c.p_d_model;
-    gemm_t(x, 1, m->c.d_embed, m->c.d_embed, m->proj_t, dp, 0, dp, y, dp);
-    for (int i = 0; i < dp; ++i) y[i] = y[i] + m->proj_b[i];
+/* H6 — Assets::project, src/assets_manager.rs:383-399, in the reference's OWN arithmetic: the accumulator starts from the bias
+ * and takes `sum += h * w` (one f32 multiply, one f32 add) over the inputs in ascending order. This is one of the few
+ * floating-point sequences the crate itself spells out, so here the oracle (and the device kernel k_project) is pinned. */
+void q3o_project_rows(const float* w, const float* bias, int32_t n_in, int32_t n_out, const float* x, int32_t rows, float* y) {
+#pragma omp parallel for schedule(static) collapse(2) num_threads(g_threads > 0 ? g_threads : 1)
+    for (int r = 0; r < rows; ++r)
+        for (int o = 0; o < n_out; ++o) {
+            float sum = bias[o];
+            const float* wr = w + (size_t)o * n_in;
+            const float* xr = x + (size_t)r * n_in;
+            for (int i = 0; i < n_in; ++i) sum += xr[i] * wr[i];
+            y[(size_t)r * n_out + o] = sum;
+        }
+}
+void q3o_project(const q3o_model* m, const float* x, float* y) {
+    q3o_project_rows(m->proj_w, m->proj_b, m->c.d_embed, m->c.p_d_model, x, 1, y);
 }
 
 /* H1 — src/tts/prompt.rs */
@@ -760,23 +835,40 @@ int32_t q3o_build_prompt(const q3o_model* m, const q3o_prompt_desc* p, float* ou
     return n;
 }
 
-/* final norm + lm_head (optionally a column slice) of ONE row */
-static void head_row(tfm* t, const float* xrow, float eps, int col0, int ncols, float* hidden_out, float* logits) {
-    float* xh = malloc((size_t)t->d * 4);
-    if (hidden_out) q3o_rmsnorm(xrow, t->d, t->out_norm, eps, hidden_out); /* standalone canonical RMSNorm (§4.2) */
-    const float sc = norm_gemm_row(xrow, t->d, t->out_norm, eps, xh);
-    gemm_t(xh, 1, t->d, t->d, t->head_t, t->head_n, col0, ncols, logits, ncols);
+/* final norm + lm_head (optionally a column slice) of ONE row whose norm inputs for out_norm are xb / ssp */
+static void head_row(const q3o_model* m, tfm* t, const float* xrow, const uint16_t* xb, const float* ssp, float eps, int col0, int ncols,
+                     float* hidden_out, float* logits) {
+    if (m->arith == 1) {
+        float* xn = malloc((size_t)t->d * 4);
+        rmsnorm_plain(xrow, t->d, t->out_norm, eps, xn);
+        if (hidden_out) memcpy(hidden_out, xn, (size_t)t->d * 4);
+        gemm_plain(xn, 1, t->d, t->head + (size_t)col0 * t->d, ncols, logits, ncols);
+        free(xn);
+        return;
+    }
+    if (hidden_out) q3o_rmsnorm(xrow, t->d, t->out_norm, eps, hidden_out); /* standalone canonical RMSNorm (§4.2): the projection's input */
+    const float sc = q3o_row_scale(ssp, t->d / 16, t->d, eps);
+    bgemm_rows(xb, 1, t->d, t->head + (size_t)col0 * t->d, ncols, logits, ncols);
     scale_rows(logits, 1, ncols, ncols, &sc);
-    free(xh);
+}
+
+/* rows through one transformer in the model's arithmetic; xb / ssp as in tfm_layers (ignored by the plain form) */
+static void run_tfm(const q3o_model* m, tfm* t, float* x, uint16_t* xb, float* ssp, int n, int pos0) {
+    if (m->arith == 1) { tfm_layers_plain(t, x, n, pos0, m->c.rms_eps); return; }
+    for (int r = 0; r < n; ++r) q3o_norm_inputs(x + (size_t)r * t->d, t->d, t->attn_norm[0], xb + (size_t)r * t->d, ssp + (size_t)r * (t->d / 16));
+    tfm_layers(t, x, xb, ssp, n, pos0, m->c.rms_eps);
 }
 
 void q3o_talker_prefill(q3o_model* m, const float* embd, int32_t n_tok, float* hidden_out, float* logits_out) {
     const int d = m->T.d;
     float* x = malloc((size_t)n_tok * d * 4);
+    uint16_t* xb = malloc((size_t)n_tok * d * 2);
+    float* ssp = malloc((size_t)n_tok * (d / 16) * 4);
     memcpy(x, embd, (size_t)n_tok * d * 4);
-    tfm_layers(&m->T, x, n_tok, 0, m->c.rms_eps);
-    head_row(&m->T, x + (size_t)(n_tok - 1) * d, m->c.rms_eps, 0, m->c.t_vocab, hidden_out, logits_out);
-    free(x);
+    run_tfm(m, &m->T, x, xb, ssp, n_tok, 0);
+    const size_t last = (size_t)(n_tok - 1);
+    head_row(m, &m->T, x + last * d, xb + last * d, ssp + last * (d / 16), m->c.rms_eps, 0, m->c.t_vocab, hidden_out, logits_out);
+    free(x); free(xb); free(ssp);
 }
 
 /* run_inference_stream — src/tts/engine.rs:445-656 (ids only; the vocoder side is q3o_vocoder_*) */
@@ -793,6 +885,8 @@ int32_t q3o_generate(q3o_model* m, const float* prompt, int32_t n_tok, float tem
     float* pad = malloc((size_t)de * 4);
     float* pin = malloc((size_t)2 * dp * 4);
     float* px = malloc((size_t)2 * dp * 4);
+    uint16_t* xb = malloc((size_t)2 * (d > dp ? d : dp) * 2);
+    float* ssp = malloc((size_t)2 * ((d > dp ? d : dp) / 16) * 4);
     stdrng rng; stdrng_seed_u64(&rng, seed); /* :473-485 */
     /* tts_pad: row 151671 of the text table when the table is that large, else zeros (src/assets_manager.rs:244-249) */
     if (c->tts_pad_id < c->text_vocab) q3o_text_embedding(m, c->tts_pad_id, pad);
@@ -815,8 +909,8 @@ int32_t q3o_generate(q3o_model* m, const float* prompt, int32_t n_tok, float tem
         q3o_project(m, emb, pin + dp);
         for (int i = 0; i < de; ++i) fb[i] = 0.0f + emb[i]; /* :584-585, :622-627 */
         memcpy(px, pin, (size_t)2 * dp * 4);
-        tfm_layers(&m->P, px, 2, 0, c->rms_eps);     /* :575-582 (cache cleared == positions restart at 0) */
-        head_row(&m->P, px + dp, c->rms_eps, 0, cbs, NULL, pl);
+        run_tfm(m, &m->P, px, xb, ssp, 2, 0);        /* :575-582 (cache cleared == positions restart at 0) */
+        head_row(m, &m->P, px + dp, xb + dp, ssp + dp / 16, c->rms_eps, 0, cbs, NULL, pl);
         for (int q = 1; q < ncb; ++q) {              /* :587 */
             float mv = -INFINITY; int mi = 0;        /* greedy :590-596 via :690-701 */
             for (int i = 0; i < cbs; ++i) if (pl[i] > mv) { mv = pl[i]; mi = i; }
@@ -825,146 +919,16 @@ int32_t q3o_generate(q3o_model* m, const float* prompt, int32_t n_tok, float tem
             for (int i = 0; i < de; ++i) fb[i] += emb[i];
             if (q < ncb - 1) {                       /* :602-610 */
                 q3o_project(m, emb, px);
-                tfm_layers(&m->P, px, 1, q + 1, c->rms_eps);
-                head_row(&m->P, px, c->rms_eps, q * cbs, cbs, NULL, pl);
+                run_tfm(m, &m->P, px, xb, ssp, 1, q + 1);
+                head_row(m, &m->P, px, xb, ssp, c->rms_eps, q * cbs, cbs, NULL, pl);
             }
         }
         ++n_frames;
         for (int i = 0; i < de; ++i) fb[i] += pad[i]; /* :628-630 */
-        tfm_layers(&m->T, fb, 1, cur_pos, c->rms_eps); /* :633-639 (fb is consumed as the residual stream) */
-        head_row(&m->T, fb, c->rms_eps, 0, c->t_vocab, hidden, logits);
+        run_tfm(m, &m->T, fb, xb, ssp, 1, cur_pos);   /* :633-639 (fb is consumed as the residual stream) */
+        head_row(m, &m->T, fb, xb, ssp, c->rms_eps, 0, c->t_vocab, hidden, logits);
         ++cur_pos;                                   /* :641 */
     }
-    free(hidden); free(logits); free(pl); free(emb); free(fb); free(pad); free(pin); free(px);
+    free(hidden); free(logits); free(pl); free(emb); free(fb); free(pad); free(pin); free(px); free(xb); free(ssp);
     return n_frames;
-}
-
-/* ------------------------------------------------------------------------------------------ */
-/* v_mfma_f32_16x16x32_bf16 on gfx950, one output element, restated in integer arithmetic.     */
-/* Measured on MI355X (tools/probe_bf16_*.py, profiles/r01/bf16_mfma_arithmetic.md; pinned by  */
-/* tests/test_parity_gpu.py::test_bf16_mfma_arithmetic_model). The 32 products are taken in    */
-/* four steps of 8 (k = 8g .. 8g+7 = the operands of lane group g), g ascending. One step:     */
-/*   E = max over the non-zero products of exponent(a_k) + exponent(b_k);  q = 2^(E - 24)      */
-/*   P = sum of the exact products a_k*b_k, each truncated toward zero to a multiple of q      */
-/*   s = P + floor_q(acc)                      (exact; the accumulator is truncated downwards) */
-/*   s is cut (downwards, two's complement) to its 32 leading bits, then rounded to nearest    */
-/*   even into the f32 accumulator.                                                            */
-/* Domain: finite, normal operands (no NaN / Inf / subnormals), |acc| / 2^E < 2^60.            */
-/* ------------------------------------------------------------------------------------------ */
-float q3o_mfma_bf16_dot32(const uint16_t* a, const uint16_t* b, float c) {
-    float acc = c;
-    for (int g = 0; g < 4; ++g) {
-        int E = -100000, any = 0;
-        for (int k = 8 * g; k < 8 * g + 8; ++k) {
-            if ((a[k] & 0x7fff) == 0 || (b[k] & 0x7fff) == 0) continue;
-            const int e = (int)((a[k] >> 7) & 0xff) + (int)((b[k] >> 7) & 0xff) - 254;
-            if (e > E) E = e;
-            any = 1;
-        }
-        if (!any) continue;
-        __int128 s = 0;  /* units of q = 2^(E - 24) */
-        for (int k = 8 * g; k < 8 * g + 8; ++k) {
-            if ((a[k] & 0x7fff) == 0 || (b[k] & 0x7fff) == 0) continue;
-            const int e = (int)((a[k] >> 7) & 0xff) + (int)((b[k] >> 7) & 0xff) - 254;
-            const int64_t m = (int64_t)((a[k] & 0x7f) | 0x80) * (int64_t)((b[k] & 0x7f) | 0x80);   /* value m * 2^(e - 14) */
-            const int sh = e - 14 - (E - 24);                                                      /* <= 10 */
-            const int64_t mag = sh >= 0 ? (m << sh) : (sh > -63 ? (m >> -sh) : 0);
-            s += ((a[k] ^ b[k]) & 0x8000) ? -(__int128)mag : (__int128)mag;
-        }
-        const uint32_t cu = f2u(acc);
-        if ((cu & 0x7fffffffu) != 0) {
-            __int128 m = (__int128)((cu & 0x7fffff) | 0x800000);                                    /* value m * 2^(ec - 23) */
-            if (cu >> 31) m = -m;
-            int sh = ((int)((cu >> 23) & 0xff) - 127) - 23 - (E - 24);
-            if (sh > 90) sh = 90;                                                                   /* outside the stated domain */
-            s += sh >= 0 ? (m << sh) : (sh > -120 ? (m >> -sh) : (m < 0 ? (__int128)-1 : (__int128)0));  /* arithmetic shift = floor */
-        }
-        if (s == 0) { acc = 0.0f; continue; }
-        /* keep the 32 leading bits (floor), then RNE to 24: both through exact integer steps */
-        unsigned __int128 mag = s < 0 ? (unsigned __int128)(-s) : (unsigned __int128)s;
-        int top = 0;
-        for (unsigned __int128 t = mag; t >>= 1;) ++top;
-        int drop = top - 31;
-        __int128 v = s;
-        if (drop > 0) v = s >> drop; else drop = 0;                                                 /* floor */
-        acc = ldexpf((float)(int64_t)v, E - 24 + drop);   /* |v| < 2^33: int64 -> f32 is round-to-nearest-even; scaling exact */
-    }
-    return acc;
-}
-
-/* canonical bf16-MFMA GEMM (prototype): x, w bf16 bits; 8 contiguous K-slices, each a chain of MFMA steps over
- * ascending 32-blocks whose lane group g holds k = 4g..4g+3 and 16+4g..16+4g+3; slice results added in slice order */
-void q3o_gemm_bf16(const uint16_t* x, int32_t B, int32_t K, const uint16_t* w, int32_t N, float* y) {
-    const int per = K / 256;  /* 32-blocks per slice */
-#pragma omp parallel for schedule(static) collapse(2)
-    for (int b = 0; b < B; ++b)
-        for (int n = 0; n < N; ++n) {
-            float tot = 0.0f;
-            for (int sl = 0; sl < 8; ++sl) {
-                float acc = 0.0f;
-                for (int st = 0; st < per; ++st) {
-                    const int k0 = (sl * per + st) * 32;
-                    uint16_t av[32], bv[32];
-                    for (int g = 0; g < 4; ++g)
-                        for (int e = 0; e < 8; ++e) {
-                            const int k = k0 + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4));
-                            av[8 * g + e] = x[(size_t)b * K + k]; bv[8 * g + e] = w[(size_t)n * K + k];
-                        }
-                    acc = q3o_mfma_bf16_dot32(av, bv, acc);
-                }
-                tot = sl == 0 ? acc : tot + acc;
-            }
-            y[(size_t)b * N + n] = tot;
-        }
-}
-
-/* fused RMSNorm + canonical bf16 GEMM + SwiGLU (prototype of the Predictor's gate/up; q3_gemm_bf16.hip):
- * ss: per slice w (8) and lane group kq (4) an fmaf chain over k = 32 kb + {4kq..4kq+3, 16+4kq..16+4kq+3}, kb ascending in the
- * slice; S_w = (c0 + c1) + (c2 + c3); ss = S_0 + ... + S_7; s = 1/sqrtf(ss/K + eps); xn = bf16(x * nw); y = s * raw */
-void q3o_gemm_bf16_norm_swiglu(const float* x, int32_t B, int32_t K, const uint16_t* w, int32_t N, const float* nw, float eps, float* y) {
-    const int F = N / 2, per = K / 256;
-    uint16_t* xn = (uint16_t*)malloc((size_t)B * K * 2);
-    float* sc = (float*)malloc((size_t)B * 4);
-    for (int b = 0; b < B; ++b) {
-        const float* xr = x + (size_t)b * K;
-        float tot = 0.0f;
-        for (int sl = 0; sl < 8; ++sl) {
-            float c[4];
-            for (int kq = 0; kq < 4; ++kq) {
-                float a = 0.0f;
-                for (int st = 0; st < per; ++st) {
-                    const int k0 = (sl * per + st) * 32;
-                    for (int e = 0; e < 8; ++e) { const float v = xr[k0 + (e < 4 ? 4 * kq + e : 16 + 4 * kq + (e - 4))]; a = fmaf(v, v, a); }
-                }
-                c[kq] = a;
-            }
-            const float S = (c[0] + c[1]) + (c[2] + c[3]);
-            tot = sl == 0 ? S : tot + S;
-        }
-        sc[b] = 1.0f / sqrtf(tot / (float)K + eps);
-        for (int k = 0; k < K; ++k) xn[(size_t)b * K + k] = q3o_bf16(xr[k] * nw[k]);
-    }
-    float* raw = (float*)malloc((size_t)B * N * 4);
-    q3o_gemm_bf16(xn, B, K, w, N, raw);
-    for (int b = 0; b < B; ++b)
-        for (int j = 0; j < F; ++j) y[(size_t)b * F + j] = swiglu(sc[b] * raw[(size_t)b * N + j], sc[b] * raw[(size_t)b * N + F + j]);
-    free(raw); free(sc); free(xn);
-}
-
-/* fused RMSNorm + canonical bf16 GEMM, plain store (the Predictor's QKV): y = s * raw */
-void q3o_gemm_bf16_norm_store(const float* x, int32_t B, int32_t K, const uint16_t* w, int32_t N, const float* nw, float eps, float* y) {
-    uint16_t* xn = (uint16_t*)malloc((size_t)B * K * 2);
-    float* sc = (float*)malloc((size_t)B * 4);
-    for (int b = 0; b < B; ++b) sc[b] = norm_bf16_row(x + (size_t)b * K, K, nw, eps, xn + (size_t)b * K);
-    q3o_gemm_bf16(xn, B, K, w, N, y);
-    for (int b = 0; b < B; ++b) for (int n = 0; n < N; ++n) y[(size_t)b * N + n] = sc[b] * y[(size_t)b * N + n];
-    free(sc); free(xn);
-}
-
-/* y += canonical bf16 GEMM of bf16 rows (the Predictor's O / down projections) */
-void q3o_gemm_bf16_resid(const uint16_t* x, int32_t B, int32_t K, const uint16_t* w, int32_t N, float* y) {
-    float* raw = (float*)malloc((size_t)B * N * 4);
-    q3o_gemm_bf16(x, B, K, w, N, raw);
-    for (size_t i = 0; i < (size_t)B * N; ++i) y[i] = y[i] + raw[i];
-    free(raw);
 }

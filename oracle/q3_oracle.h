@@ -8,9 +8,10 @@
  * path and its arithmetic lives in llama.cpp b7885 / onnxruntime
  * 1.23.2 binaries that are not in the repository and cannot be fetched. What IS
  * followed line by line is the host logic the crate owns (citations at each
- * function). The transformer math is the standard Qwen3 decoder definition with a
- * canonical fp32 summation order that the HIP kernels reproduce
- * bit for bit.
+ * function). The transformer math is the standard Qwen3 decoder definition (checked
+ * against transformers' Qwen3 in tests/test_decoder_family_cpu.py) in ONE canonical
+ * order (bf16 operands on the restated v_mfma_f32_16x16x32_bf16, fixed
+ * slice / tile / butterfly orders) that the HIP kernels reproduce bit for bit.
  *
  * The structs below restate include/q3tts.h field for field (same layout) so the
  * tests can fill one ctypes structure for both libraries; the oracle does not
@@ -86,12 +87,26 @@ void q3o_rmsnorm(const float* x, int32_t d, const float* w, float eps, float* y)
 void q3o_attention(const float* qkv, int32_t n_rows, int32_t pos0, int32_t n_head, int32_t n_kv_head,
                    int32_t head_dim, const float* q_norm_w, const float* k_norm_w, float eps, float rope_theta,
                    const int32_t* mrope_sections, float* out);
-/* one output element of v_mfma_f32_16x16x32_bf16 (gfx950), restated in integers: a[32], b[32] bf16 bits, c the accumulator */
+/* one output element of v_mfma_f32_16x16x32_bf16 (gfx950), restated in integers: a[32], b[32] bf16 bits in operand order
+ * (position 8g + e = operand e of lane group g), c the accumulator. _ref: the 128-bit form the 64-bit one is tested against. */
 float q3o_mfma_bf16_dot32(const uint16_t* a, const uint16_t* b, float c);
-void q3o_gemm_bf16(const uint16_t* x_bf16, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, float* y);
-void q3o_gemm_bf16_norm_swiglu(const float* x, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, const float* norm_w, float eps, float* y);
-void q3o_gemm_bf16_norm_store(const float* x, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, const float* norm_w, float eps, float* y);
-void q3o_gemm_bf16_resid(const uint16_t* x_bf16, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, float* y_inout);
+float q3o_mfma_bf16_dot32_ref(const uint16_t* a, const uint16_t* b, float c);
+/* the decoder's canonical arithmetic (q3_oracle_bf16.c) */
+void q3o_permute_rows_bf16(const uint16_t* src, int32_t rows, int32_t K, uint16_t* dst);
+void q3o_bgemm_raw_p(const uint16_t* xp, int32_t rows, int32_t K, const uint16_t* wp, int32_t N, float* out, int32_t ldo, int32_t threads);
+float q3o_tss16(const float* v16);
+void q3o_norm_inputs(const float* x, int32_t d, const float* nw, uint16_t* xb, float* ssp);
+float q3o_row_scale(const float* ssp, int32_t ntiles, int32_t d, float eps);
+/* kernel-level restatement of q3_bgemm.hip (natural-order operands): epi 0 y = s*raw (s = 1 when ssp == NULL), 1 x += raw
+ * (+ norm outputs when nw_next), 2 hb = bf16(swiglu) (w = F gate rows then F up rows), 3 argmax keys */
+void q3o_bgemm(const uint16_t* xb, int32_t B, int32_t K, const uint16_t* w, int32_t N, const float* ssp, int32_t ntiles, int32_t d_norm,
+               float eps, int32_t epi, const float* nw_next, float* y, uint16_t* yb, float* ssp_out, uint64_t* keys);
+/* H6 in the reference's own arithmetic (src/assets_manager.rs:383-399): bias first, sum += h * w in ascending order */
+void q3o_project_rows(const float* w, const float* bias, int32_t n_in, int32_t n_out, const float* x, int32_t rows, float* y);
+/* 0: canonical bf16-MFMA order (default, what the device computes); 1: plain f32 of the same structure (family pinning) */
+void q3o_set_arith(q3o_model* m, int32_t arith);
+const float* q3o_norm_weight(const q3o_model* m, int32_t talker, int32_t layer, int32_t which);
+int32_t q3o_matrix(const q3o_model* m, int32_t talker, int32_t layer, int32_t which, float* out);
 /* H4 sampler: src/models/llama/mod.rs:666-772 */
 int32_t q3o_sample(const float* logits, int32_t limit, float temperature, int32_t top_k, float top_p, float r);
 /* rand 0.8 StdRng: seed_from_u64 + gen::<f32>() */
@@ -105,7 +120,7 @@ int32_t q3o_build_prompt(const q3o_model* m, const q3o_prompt_desc* p, float* ou
 /* table access with the reference's OOB rules (src/assets_manager.rs:419-460) */
 void q3o_text_embedding(const q3o_model* m, int64_t id, float* out);
 void q3o_codec_embedding(const q3o_model* m, int32_t q, int32_t code, float* out);
-/* H6: src/assets_manager.rs:383-399 (canonical summation order, bias added last) */
+/* H6: src/assets_manager.rs:383-399, the reference's own f32 sequence (bias first, sequential sum += h * w) */
 void q3o_project(const q3o_model* m, const float* x2048, float* y1024);
 
 /* Talker prefill: hidden (post final norm) and logits of the last prompt row */

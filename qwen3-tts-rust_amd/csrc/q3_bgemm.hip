@@ -1,0 +1,256 @@
+// q3_bgemm.hip — the decoder's GEMM: bf16 rows x tiled bf16 weights on v_mfma_f32_16x16x32_bf16, bit-exact against the CPU
+// oracle because the instruction's accumulation arithmetic is restated there (oracle/q3_oracle_bf16.c, pinned by hardware
+// golden vectors). Serves K1/K2/K6-K9 of the Talker and P1-P4 of the Predictor (llama_decode behind
+// /root/reference/src/models/llama/mod.rs:442-451), decode and prefill alike.
+//
+// Canonical order: RAW[r][n] = ((((s_0 + s_1) + s_2) + ...) + s_7), s_w = the chain of MFMA steps over K-slice w
+// (K/8 contiguous columns, 32 per instruction, ascending); lane group g of an instruction holds k = 4g..4g+3 and 16+4g..16+4g+3 of
+// the 32-block — what the tiled weight layout of DESIGN.md §2.1 puts into one lane. A row's result never depends on the other
+// rows, the tile shape or the grid: every (RT, NT) instance and every row count give the same bits.
+//
+// RMSNorm is split between producer and consumer: a residual epilogue (EPI_RESID) writes, next to the f32
+// residual stream x, the consumer's A operand xb = bf16(x * nw_next) and one partial sum of squares per 16-column tile; the
+// norm GEMM that follows reduces the partials to the row scale s_r while its first operands are in flight and applies
+// y = s_r * RAW in its epilogue. No f32 activation is read by a GEMM, no pre-kernel, no second pass over x.
+//
+// Workgroup = 8 waves = the 8 K-slices of one (RT*16) x (NT*16) output tile; a wave keeps D steps of operands in flight
+// (register ring, refilled right after the MFMAs that consumed a slot); slice partials meet in LDS and are added in order.
+#include "q3_kernels.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bg_wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = v + __shfl_xor(v, m);
+    return v;
+}
+
+template <int RT, int NT, int D>
+__global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
+    extern __shared__ float part[];  // [8 waves][RT*NT*4 regs][64 lanes]
+    __shared__ float srow[64];
+    constexpr int TR = RT * NT * 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kq = lane >> 4, r = lane & 15;
+    // workgroups are dealt round-robin to the 8 XCDs in linear-id order: the row chunks of one column group get ids 8 apart
+    // (same XCD, neighbours in time), so the group's weight tiles are fetched into that L2 once
+    int cg = blockIdx.x, rc = blockIdx.y;
+    if (gridDim.y > 1 && (gridDim.x & 7) == 0) {
+        const int id = blockIdx.x + gridDim.x * blockIdx.y, G = gridDim.y;
+        rc = (id >> 3) % G; cg = (id & 7) + (id / (8 * G)) * 8;
+    }
+    const int nb0 = cg * NT, row0 = rc * RT * 16, kblocks = g.K >> 5, per = g.K >> 8, kb0 = wave * per;
+    const int B = g.B;
+    const uint16_t* ap[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) ap[i] = g.a + (size_t)min(row0 + 16 * i + r, B - 1) * g.lda + (size_t)kb0 * 32 + 4 * kq;
+    const u32x4* wp[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wp[j] = (const u32x4*)g.w + ((size_t)(nb0 + j) * kblocks + kb0) * 64 + lane;
+    uint2 alo[D][RT], ahi[D][RT]; u32x4 bq[D][NT];
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < per) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i) { alo[s][i] = *(const uint2*)(ap[i] + s * 32); ahi[s][i] = *(const uint2*)(ap[i] + s * 32 + 16); }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bq[s][j] = wp[j][(size_t)s * 64];
+        }
+    // RESID: the residual operand is fetched up front instead of at the very end
+    constexpr int NOUT = (TR * 64 + 511) / 512;
+    float yres[NOUT];
+    if (g.epi == Q3_EPI_RESID) {
+#pragma unroll
+        for (int it = 0; it < NOUT; ++it) {
+            const int o = threadIdx.x + it * 512;
+            const int l = o & 63, e = (o >> 6) & 3, t = o >> 8, i = t / NT, j = t - i * NT;
+            const int row = row0 + 16 * i + 4 * (l >> 4) + e;
+            yres[it] = (o < TR * 64 && row < B) ? g.y[(size_t)row * g.ldy + (size_t)(nb0 + j) * 16 + (l & 15)] : 0.0f;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // row scales (norm GEMMs): wave w reduces the tile partials of rows w, w + 8, ... while the operands are in flight —
+    // lane j adds its tiles j, j + 64, ... in ascending order, then the 64-lane butterfly
+    if (g.ssp) {
+        for (int rl = wave; rl < RT * 16; rl += 8) {
+            const float* sp = g.ssp + (size_t)min(row0 + rl, B - 1) * g.ld_ssp;
+            float a = 0.0f;
+            for (int t = lane; t < g.ntiles; t += 64) a = t == lane ? sp[t] : a + sp[t];
+            a = bg_wave_sum(a);
+            if (lane == 0) srow[rl] = 1.0f / sqrtf(a / (float)g.d_norm + g.eps);
+        }
+    }
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < per; s0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int s = s0 + d;
+            if (s < per) {
+#pragma unroll
+                for (int i = 0; i < RT; ++i) {
+                    union { uint4 u; bf16x8 v; } a; a.u = make_uint4(alo[d][i].x, alo[d][i].y, ahi[d][i].x, ahi[d][i].y);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        union { u32x4 u; bf16x8 v; } b; b.u = bq[d][j];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc[i][j], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + D < per) {
+#pragma unroll
+                    for (int i = 0; i < RT; ++i) { alo[d][i] = *(const uint2*)(ap[i] + (s + D) * 32); ahi[d][i] = *(const uint2*)(ap[i] + (s + D) * 32 + 16); }
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bq[d][j] = wp[j][(size_t)(s + D) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[((size_t)wave * TR + (i * NT + j) * 4 + e) * 64 + lane] = acc[i][j][e];
+    __syncthreads();
+    // slice partials combined in slice order; element (tile t, reg e, lane l) -> row 16 i + 4 (l >> 4) + e, col 16 j + (l & 15)
+    const int epi = g.epi;
+#pragma unroll
+    for (int it = 0; it < NOUT; ++it) {
+        const int o = threadIdx.x + it * 512;
+        if (o >= TR * 64) break;  // whole waves leave together (TR * 64 is a multiple of 256)
+        const int l = o & 63, e = (o >> 6) & 3, t = o >> 8, i = t / NT, j = t - i * NT;
+        const int rl = 16 * i + 4 * (l >> 4) + e, row = row0 + rl, c = l & 15;
+        const int col = (nb0 + j) * 16 + c;
+        const bool live = row < B;
+        const float sc = g.ssp ? srow[rl] : 1.0f;
+        if (epi == Q3_EPI_SWIGLU) {
+            // gate lanes (column < 8 of a tile) finish one output each: swiglu(s * gate, s * up), up = the same row 8 columns further
+            if (c >= 8) continue;
+            float gt = part[o], up = part[o + 8];
+#pragma unroll
+            for (int wv = 1; wv < 8; ++wv) { gt = gt + part[(size_t)wv * (TR * 64) + o]; up = up + part[(size_t)wv * (TR * 64) + o + 8]; }
+            if (live) g.yb[(size_t)row * g.ldyb + (size_t)(nb0 + j) * 8 + c] = q3_bf16(q3_swiglu(sc * gt, sc * up));
+            continue;
+        }
+        float v = part[o];
+#pragma unroll
+        for (int wv = 1; wv < 8; ++wv) v = v + part[(size_t)wv * (TR * 64) + o];
+        if (epi == Q3_EPI_STORE) {
+            if (live) g.y[(size_t)row * g.ldy + col] = g.ssp ? sc * v : v;
+        } else if (epi == Q3_EPI_RESID) {
+            const float xv = yres[it] + v;
+            if (live) g.y[(size_t)row * g.ldy + col] = xv;
+            if (g.nw_next) {  // the consumer's norm inputs: bf16(x * nw) and the tile's sum of squares (16-lane butterfly)
+                if (live) g.yb[(size_t)row * g.ldyb + col] = q3_bf16(xv * g.nw_next[col]);
+                float sq = xv * xv;
+                sq = sq + __shfl_xor(sq, 1); sq = sq + __shfl_xor(sq, 2); sq = sq + __shfl_xor(sq, 4); sq = sq + __shfl_xor(sq, 8);
+                if (live && c == 0) g.ssp_out[(size_t)row * g.ld_ssp_out + (nb0 + j)] = sq;
+            }
+        } else {  // Q3_EPI_ARGMAX: the largest key of the tile's 16 columns, one atomic per (row, tile)
+            unsigned long long key = q3_argmax_key(g.ssp ? sc * v : v, (uint32_t)col);
+#pragma unroll
+            for (int m = 1; m <= 8; m <<= 1) { const unsigned long long ok = __shfl_xor(key, m); key = ok > key ? ok : key; }
+            if (live && c == 0) atomicMax(g.keys + (size_t)row * g.key_stride, key);
+        }
+    }
+}
+
+template <int RT, int NT>
+struct BgInst {
+    static constexpr int D = RT * NT <= 2 ? 8 : 4;
+    static constexpr size_t lds = (size_t)8 * RT * NT * 4 * 64 * 4;
+    static void prepare() {  // dynamic LDS above 64 KiB has to be allowed per kernel
+        if (lds > 65536) hipFuncSetAttribute((const void*)k_bgemm<RT, NT, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    static void launch(const Q3BGemm& g, dim3 grid, hipStream_t s) { hipLaunchKernelGGL((k_bgemm<RT, NT, D>), grid, dim3(512), lds, s, g); }
+};
+// once per process, outside any stream capture (the engine calls it before it records its graphs)
+void q3_bgemm_prepare() {
+    static bool done = false;
+    if (done) return;
+    BgInst<1, 1>::prepare(); BgInst<1, 2>::prepare(); BgInst<1, 3>::prepare(); BgInst<2, 1>::prepare(); BgInst<2, 2>::prepare(); BgInst<2, 3>::prepare();
+    BgInst<3, 1>::prepare(); BgInst<3, 2>::prepare(); BgInst<3, 3>::prepare(); BgInst<4, 1>::prepare(); BgInst<4, 2>::prepare(); BgInst<4, 3>::prepare();
+    done = true;
+}
+
+// Tile choice: a launch is bound by the operand bytes a CU's load path takes in (x from L2, weights from HBM / L2), so pick the
+// (RT, NT) with the fewest bytes per workgroup-round — 32 (RT + NT) bytes per k — counted over ceil(workgroups / 256) rounds.
+// The choice never changes a result (see the header).
+int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s) {
+    if (g.B < 1 || g.N % 16 || g.K % 256 || g.K < 256 || !g.a || !g.w) return -1;
+    if (g.epi == Q3_EPI_SWIGLU && (!g.yb)) return -1;
+    if (g.ssp && g.ntiles < 1) return -1;
+    const int tiles = g.N / 16;
+    int bestRT = 1, bestNT = 1; long bestCost = -1;
+    for (int RT = 1; RT <= 4; ++RT)
+        for (int NT = 1; NT <= 3; ++NT) {
+            if (tiles % NT) continue;
+            if (g.B > 64 && RT != 4 && !(RT == 2 && g.B <= 128)) continue;  // many rows (prefill): 64-row chunks
+            const long chunks = (g.B + 16 * RT - 1) / (16 * RT);
+            if (g.B <= 64 && RT > 1 && 16 * (RT - 1) * chunks >= g.B) continue;  // a smaller RT covers the rows with the same chunk count
+            const long wgs = (long)(tiles / NT) * chunks, rounds = (wgs + 255) / 256;
+            const long cost = rounds * (32L * (RT + NT) * g.K + 24000L);  // + a fixed cost per round (ramp, reduction)
+            if (bestCost < 0 || cost < bestCost || (cost == bestCost && NT > bestNT)) { bestCost = cost; bestRT = RT; bestNT = NT; }
+        }
+    const dim3 grid(tiles / bestNT, (g.B + 16 * bestRT - 1) / (16 * bestRT));
+    q3_bgemm_prepare();
+#define L(RT_, NT_) if (bestRT == RT_ && bestNT == NT_) { BgInst<RT_, NT_>::launch(g, grid, s); return 0; }
+    L(1, 1) L(1, 2) L(1, 3) L(2, 1) L(2, 2) L(2, 3) L(3, 1) L(3, 2) L(3, 3) L(4, 1) L(4, 2) L(4, 3)
+#undef L
+    return -1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// norm inputs of f32 rows (prompt rows before prefill; test hook): xb = bf16(x * nw), ssp[t] = sum of squares of tile t.
+// 256 threads per row; 16 consecutive lanes own one tile.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_norm_inputs(const float* x, int ldx, int d, const float* nw, uint16_t* xb, int ldxb, float* ssp, int ld_ssp) {
+    const int row = blockIdx.x;
+    for (int i = threadIdx.x; i < d; i += 256) q3_norm_out(x[(size_t)row * ldx + i], nw[i], xb + (size_t)row * ldxb + i, ssp + (size_t)row * ld_ssp + (i >> 4), (i & 15) == 0);
+}
+void q3_launch_norm_inputs(const float* x, int ldx, int rows, int d, const float* nw, uint16_t* xb, int ldxb, float* ssp, int ld_ssp, hipStream_t s) {
+    hipLaunchKernelGGL(k_norm_inputs, dim3(rows), dim3(256), 0, s, x, ldx, d, nw, xb, ldxb, ssp, ld_ssp);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// H6 — Assets::project (/root/reference/src/assets_manager.rs:383-399) in the reference's OWN arithmetic: f32 weights, the
+// accumulator starts from the bias and takes `sum += h * w` (one f32 multiply, one f32 add: the build has -ffp-contract=off)
+// over the inputs in ascending order. One thread per output element (a 2048-long dependent chain: latency-bound by design);
+// 16 consecutive lanes = 16 consecutive outputs of one row, so the same kernel can emit the Predictor's norm inputs.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_project(Q3Project p) {
+    const int o = blockIdx.x * 16 + (threadIdx.x & 15), row = blockIdx.y * 16 + (threadIdx.x >> 4);
+    const int rr = min(row, p.rows - 1);
+    const float4* w4 = (const float4*)(p.w + (size_t)o * p.n_in);
+    const float4* x4 = (const float4*)(p.x + (size_t)rr * p.ldx);
+    float sum = p.bias[o];
+    for (int i = 0; i < (p.n_in >> 2); i += 4) {
+        const float4 wa = w4[i], wb = w4[i + 1], wc = w4[i + 2], wd = w4[i + 3];
+        const float4 xa = x4[i], xb = x4[i + 1], xc = x4[i + 2], xd = x4[i + 3];
+        sum += xa.x * wa.x; sum += xa.y * wa.y; sum += xa.z * wa.z; sum += xa.w * wa.w;
+        sum += xb.x * wb.x; sum += xb.y * wb.y; sum += xb.z * wb.z; sum += xb.w * wb.w;
+        sum += xc.x * wc.x; sum += xc.y * wc.y; sum += xc.z * wc.z; sum += xc.w * wc.w;
+        sum += xd.x * wd.x; sum += xd.y * wd.y; sum += xd.z * wd.z; sum += xd.w * wd.w;
+    }
+    const bool live = row < p.rows;
+    if (live) p.y[(size_t)row * p.ldy + o] = sum;
+    if (p.nw) {
+        uint16_t hb = q3_bf16(sum * p.nw[o]);
+        float sq = sum * sum;
+        sq = sq + __shfl_xor(sq, 1); sq = sq + __shfl_xor(sq, 2); sq = sq + __shfl_xor(sq, 4); sq = sq + __shfl_xor(sq, 8);
+        if (live) {
+            p.xb[(size_t)row * p.ldxb + o] = hb;
+            if ((threadIdx.x & 15) == 0) p.ssp[(size_t)row * p.ld_ssp + (o >> 4)] = sq;
+        }
+    }
+}
+int q3_launch_project(const Q3Project& p, hipStream_t s) {
+    if (p.rows < 1 || p.n_out % 16 || p.n_in % 16) return -1;
+    hipLaunchKernelGGL(k_project, dim3(p.n_out / 16, (p.rows + 15) / 16), dim3(256), 0, s, p);
+    return 0;
+}

@@ -25,7 +25,8 @@ struct Q3Tfm {
 };
 
 struct Q3Scratch {
-    float *qkv = nullptr, *att = nullptr, *h = nullptr;
+    float* qkv = nullptr;                   // [rows][nqkv] f32 (the attention kernel's input)
+    uint16_t *att = nullptr, *h = nullptr;  // bf16 rows: attention output [rows][nq], SwiGLU output [rows][F] (GEMM operands)
     int rows = 0;
 };
 
@@ -34,6 +35,9 @@ struct Q3Lane {
     int nb = 0;                       // row capacity = max_batch
     hipStream_t stream = nullptr;
     float *xT = nullptr, *logits = nullptr, *logits_tmp = nullptr, *X = nullptr, *fb = nullptr, *px = nullptr;
+    // norm inputs of the residual rows: bf16(x * nw) and the per-tile sums of squares, Talker [nb] / Predictor [2 nb]
+    uint16_t *xbT = nullptr, *xbP = nullptr;
+    float *sspT = nullptr, *sspP = nullptr;
     unsigned long long* keys = nullptr;
     int *row_pos_t = nullptr, *slot_id = nullptr, *posA = nullptr, *slotA = nullptr, *pos_q = nullptr, *perm = nullptr;
     Q3Scratch sc;
@@ -52,10 +56,11 @@ struct q3tts_engine {
     std::vector<float*> codec;            // host array of device pointers
     const float** codec_dev = nullptr;    // device array of the same pointers
     std::vector<float*> pproj;            // proj(codec table q) [rows_q][p_d_model] f32: the Predictor's inputs are gathers
-    uint4* proj_w = nullptr;
+    float* proj_w = nullptr;              // f32 [p_d_model][d_embed], as the reference keeps it (src/assets_manager.rs:212-241)
     float* proj_b = nullptr;
     float* tts_pad = nullptr;             // = text[tts_pad_id] (or tts_pad_own: zeros, when the loaded text table is too small)
     float* tts_pad_own = nullptr;
+    float* marker_row = nullptr;          // text[tts_pad_id] through the out-of-range rule (the clone prompt's per-frame marker)
     // decode state: B = max_batch slots. A frame step runs on `rows` = the smallest bucket (1, 2, 4, ... B) that holds
     // the live slots: rows [0, n_live) carry the live slots, the rest carry distinct idle slots (row -> slot map on the
     // device), so a draining batch stops paying for rows it no longer has.
@@ -70,6 +75,7 @@ struct q3tts_engine {
     Q3Scratch sc_pre;
     // prefill
     float* xp = nullptr;                  // [n_ctx][d]
+    uint16_t* xbp = nullptr; float* sspp = nullptr;  // norm inputs of the prefill rows
     int *pf_pos = nullptr, *pf_slot = nullptr;
     Q3PromptRow* prow_dev = nullptr; int prow_cap = 0;
     float* spk_dev = nullptr; int* refcodes_dev = nullptr;

@@ -239,46 +239,39 @@ static int alloc_scratch(q3tts_engine* e, Q3Scratch& sc, int rows, int nqkv, int
     return Q3TTS_OK;
 }
 
-// K1-K8 of SURVEY.md §8a: one decoder block per iteration, 6 launches (norm+QKV, qk-prep, attention, O+residual,
-// norm+gate/up+SwiGLU, down+residual)
-static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, int rows, const int* row_pos, const int* row_slot, Q3Scratch& sc, hipStream_t s,
-                       bool one_row_per_slot = false, hipEvent_t* probe = nullptr) {
+// K1-K8 of SURVEY.md §8a: one decoder block per iteration, 5 launches — QKV GEMM (row scale from the producer's tile partials),
+// attention (q/k norm + RoPE + KV append fused for decode rows), O GEMM (+ residual, + the FFN norm inputs), gate/up GEMM
+// (+ SwiGLU), down GEMM (+ residual, + the next block's / the head's norm inputs). x: f32 residual rows; xb / ssp: their norm
+// inputs for attn_norm[0] on entry, for out_norm on exit. Restated by oracle/q3_oracle.c tfm_layers.
+static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, uint16_t* xb, float* ssp, int rows, const int* row_pos, const int* row_slot, Q3Scratch& sc,
+                       hipStream_t s, bool one_row_per_slot = false, hipEvent_t* probe = nullptr) {
     const float eps = e->cfg.model.rms_eps;
-    // the Predictor's layer GEMMs run on the bf16 MFMA in their canonical order: QKV and gate/up with the RMSNorm
-    // fused on f32 rows, O and down on bf16 rows written by the attention kernel / the SwiGLU epilogue. The rule depends on the
-    // model shape only (the oracle applies the same one); the Talker, whose prefill shares the exact kernels, stays exact.
-    const bool pb = &t == &e->P && q3_gemm_bf16_norm_ok(t.d, t.nqkv) && q3_gemm_bf16_norm_ok(t.d, 2 * t.F);
-    const bool pb_all = pb && q3_gemm_bf16_plain_ok(t.nq) && q3_gemm_bf16_plain_ok(t.F) && t.d % 16 == 0;
+    const int nt = t.d / 16;
     for (int l = 0; l < t.L; ++l) {
-        Q3Gemm g{};
-        g.x = x; g.ldx = t.d; g.B = rows; g.w = t.wqkv[l]; g.K = t.d; g.N = t.nqkv; g.norm_w = t.attn_norm[l]; g.eps = eps;
-        g.y = sc.qkv; g.ldy = t.nqkv; g.epi = Q3_EPI_STORE;
-        // the Predictor's norm-fused GEMMs (QKV here, gate/up below) run on the bf16 MFMA in their canonical order
-        if (pb) q3_launch_gemm_bf16_norm_store(g.x, g.ldx, g.B, g.w, g.K, g.N, g.norm_w, g.eps, g.y, g.ldy, s);
-        else q3_launch_gemm(g, s);
+        Q3BGemm g{};
+        g.a = xb; g.lda = t.d; g.B = rows; g.w = t.wqkv[l]; g.K = t.d; g.N = t.nqkv; g.ssp = ssp; g.ld_ssp = nt; g.ntiles = nt; g.d_norm = t.d; g.eps = eps;
+        g.epi = Q3_EPI_STORE; g.y = sc.qkv; g.ldy = t.nqkv;
+        q3_launch_bgemm(g, s);
         Q3QkPrep qp{}; qp.qkv = sc.qkv; qp.ld = t.nqkv; qp.rows = rows; qp.Hq = t.Hq; qp.Hkv = t.Hkv; qp.hd = t.hd;
         qp.qnw = t.qn[l]; qp.knw = t.kn[l]; qp.eps = eps; qp.cs = t.cs; qp.sn = t.sn;
         qp.kc = t.kc + l * t.layer_stride; qp.vc = t.vc + l * t.layer_stride; qp.n_ctx = t.n_ctx; qp.row_pos = row_pos; qp.row_slot = row_slot;
         const bool fused = one_row_per_slot && t.Hq / t.Hkv >= 2;
         if (!fused) q3_launch_qk_prep(qp, s);
-        Q3Attend at{}; at.qkv = sc.qkv; at.ld = t.nqkv; at.rows = rows; at.out = sc.att; at.ldo = t.nq; at.Hq = t.Hq; at.Hkv = t.Hkv; at.hd = t.hd;
+        Q3Attend at{}; at.qkv = sc.qkv; at.ld = t.nqkv; at.rows = rows; at.out = (float*)sc.att; at.ldo = t.nq; at.Hq = t.Hq; at.Hkv = t.Hkv; at.hd = t.hd;
         at.kc = qp.kc; at.vc = qp.vc; at.n_ctx = t.n_ctx; at.row_pos = row_pos; at.row_slot = row_slot;
-        at.fused = fused; at.prep = qp; at.out_bf16 = pb_all ? 1 : 0;
+        at.fused = fused; at.prep = qp; at.out_bf16 = 1;
         q3_launch_attend(at, s);
-        g = Q3Gemm{}; g.x = sc.att; g.ldx = t.nq; g.B = rows; g.w = t.wo[l]; g.K = t.nq; g.N = t.d; g.y = x; g.ldy = t.d; g.epi = Q3_EPI_RESID;
-        if (pb_all) q3_launch_gemm_bf16_resid((const uint16_t*)sc.att, t.nq, rows, t.wo[l], t.nq, t.d, x, t.d, s);
-        else q3_launch_gemm(g, s);
-        g = Q3Gemm{}; g.x = x; g.ldx = t.d; g.B = rows; g.w = t.wgu[l]; g.K = t.d; g.N = 2 * t.F; g.norm_w = t.ffn_norm[l]; g.eps = eps;
-        g.y = sc.h; g.ldy = t.F; g.epi = Q3_EPI_SWIGLU;
+        g = Q3BGemm{}; g.a = sc.att; g.lda = t.nq; g.B = rows; g.w = t.wo[l]; g.K = t.nq; g.N = t.d; g.epi = Q3_EPI_RESID; g.y = x; g.ldy = t.d;
+        g.yb = xb; g.ldyb = t.d; g.nw_next = t.ffn_norm[l]; g.ssp_out = ssp; g.ld_ssp_out = nt;
+        q3_launch_bgemm(g, s);
+        g = Q3BGemm{}; g.a = xb; g.lda = t.d; g.B = rows; g.w = t.wgu[l]; g.K = t.d; g.N = 2 * t.F; g.ssp = ssp; g.ld_ssp = nt; g.ntiles = nt; g.d_norm = t.d;
+        g.eps = eps; g.epi = Q3_EPI_SWIGLU; g.yb = sc.h; g.ldyb = t.F;
         if (probe && l == 0) hipEventRecord(probe[0], s);
-        // the Predictor's gate/up runs on the bf16 MFMA in its own canonical order; the Talker (whose prefill shares
-        // the exact kernels) and every other GEMM stay on the exact f32 path
-        if (pb) q3_launch_gemm_bf16_norm_swiglu(g.x, g.ldx, g.B, g.w, g.K, g.N, g.norm_w, g.eps, g.y, g.ldy, s, pb_all ? 1 : 0);
-        else q3_launch_gemm(g, s);
+        q3_launch_bgemm(g, s);
         if (probe && l == 0) hipEventRecord(probe[1], s);
-        g = Q3Gemm{}; g.x = sc.h; g.ldx = t.F; g.B = rows; g.w = t.wd[l]; g.K = t.F; g.N = t.d; g.y = x; g.ldy = t.d; g.epi = Q3_EPI_RESID;
-        if (pb_all) q3_launch_gemm_bf16_resid((const uint16_t*)sc.h, t.F, rows, t.wd[l], t.F, t.d, x, t.d, s);
-        else q3_launch_gemm(g, s);
+        g = Q3BGemm{}; g.a = sc.h; g.lda = t.F; g.B = rows; g.w = t.wd[l]; g.K = t.F; g.N = t.d; g.epi = Q3_EPI_RESID; g.y = x; g.ldy = t.d;
+        g.yb = xb; g.ldyb = t.d; g.nw_next = l + 1 < t.L ? t.attn_norm[l + 1] : t.out_norm; g.ssp_out = ssp; g.ld_ssp_out = nt;
+        q3_launch_bgemm(g, s);
     }
 }
 
@@ -294,35 +287,42 @@ static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
     q3_launch_sample(sa, s);
     Q3PredInput pi{}; pi.xT = L.xT; pi.out_norm = e->T.out_norm; pi.eps = eps; pi.d = de; pi.codec0 = e->codec[0]; pi.codec0_rows = m.codec0_rows;
     pi.slots = slots; pi.row_slot = L.slot_id; pi.X = L.X; pi.fb = L.fb; pi.B = B; pi.pproj0 = e->pproj[0]; pi.proj_b = e->proj_b; pi.dp = dp; pi.px = L.px;
+    pi.nw = e->P.attn_norm[0]; pi.xb = L.xbP; pi.ssp = L.sspP;
     q3_launch_pred_input(pi, s);
+    {   // H6 (src/assets_manager.rs:383-399) for the hidden rows only: every code embedding arrives pre-projected
+        Q3Project pj{}; pj.x = L.X; pj.ldx = de; pj.rows = B; pj.w = e->proj_w; pj.bias = e->proj_b; pj.n_in = de; pj.n_out = dp; pj.y = L.px; pj.ldy = 2 * dp;
+        pj.nw = e->P.attn_norm[0]; pj.xb = L.xbP; pj.ldxb = 2 * dp; pj.ssp = L.sspP; pj.ld_ssp = 2 * (dp / 16);
+        q3_launch_project(pj, s);
+    }
     const size_t head_tile_stride = (size_t)(cbs / 16) * (dp / 32) * 64;  // uint4 per predictor head
     auto pred_next = [&](int q) {
         Q3PredNext pn{}; pn.keys = L.keys; pn.q = q; pn.ncb = ncb; pn.codec_q = e->codec[q]; pn.rows_q = m.codecq_rows; pn.d = de;
         pn.slots = slots; pn.row_slot = L.slot_id; pn.B = B; pn.codes = codes; pn.max_steps_cap = cap; pn.fb = L.fb;
         pn.tts_pad = e->tts_pad; pn.xT = L.xT; pn.row_pos_t = L.row_pos_t; pn.pproj_q = e->pproj[q]; pn.proj_b = e->proj_b; pn.dp = dp; pn.px = L.px;
+        const bool last = q == ncb - 1;
+        pn.nw = last ? e->T.attn_norm[0] : e->P.attn_norm[0]; pn.xb = last ? L.xbT : L.xbP; pn.ssp = last ? L.sspT : L.sspP;
         q3_launch_pred_next(pn, s);
     };
     for (int q = 0; q < ncb - 1; ++q) {  // pass q produces code_{q+1}
         const int rows = q == 0 ? 2 * B : B;
         if (q > 0) pred_next(q);
-        Q3Gemm g{};
-        if (q == 0) {  // H6 (src/assets_manager.rs:383-399) for the hidden rows only; every code embedding arrives pre-projected
-            g.x = L.X; g.ldx = de; g.B = B; g.w = e->proj_w; g.K = de; g.N = dp; g.bias = e->proj_b; g.y = L.px; g.ldy = 2 * dp;
-            g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);
-        }
         hipEvent_t* pe = nullptr;
         if (e->probe == 1 && q == 1 && B == L.nb && e->probe_i + 2 <= 8) { pe = &e->probe_ev[e->probe_i]; e->probe_i += 2; }
-        run_layers(e, e->P, L.px, rows, q == 0 ? L.posA : L.pos_q + (size_t)q * L.nb, q == 0 ? L.slotA : L.slot_id, L.sc, s, q > 0, pe);
-        g = Q3Gemm{}; g.x = q == 0 ? L.px + dp : L.px; g.ldx = q == 0 ? 2 * dp : dp; g.B = B; g.w = e->P.head + head_tile_stride * q;
-        g.K = dp; g.N = cbs; g.norm_w = e->P.out_norm; g.eps = eps; g.keys = L.keys + (q + 1); g.key_stride = ncb; g.epi = Q3_EPI_ARGMAX;
-        q3_launch_gemm(g, s);
+        run_layers(e, e->P, L.px, L.xbP, L.sspP, rows, q == 0 ? L.posA : L.pos_q + (size_t)q * L.nb, q == 0 ? L.slotA : L.slot_id, L.sc, s, q > 0, pe);
+        // head q on the rows that carry the newest position (pass 0: the odd rows), argmax epilogue
+        Q3BGemm g{}; g.a = q == 0 ? L.xbP + dp : L.xbP; g.lda = q == 0 ? 2 * dp : dp; g.B = B; g.w = e->P.head + head_tile_stride * q; g.K = dp; g.N = cbs;
+        g.ssp = q == 0 ? L.sspP + dp / 16 : L.sspP; g.ld_ssp = q == 0 ? 2 * (dp / 16) : dp / 16; g.ntiles = dp / 16; g.d_norm = dp; g.eps = eps;
+        g.epi = Q3_EPI_ARGMAX; g.keys = L.keys + (q + 1); g.key_stride = ncb;
+        q3_launch_bgemm(g, s);
     }
     pred_next(ncb - 1);
-    hipEvent_t* pt = nullptr;  // probe mode 2: the Talker's layer-0 gate/up GEMM (the largest exact GEMM of the frame step)
+    hipEvent_t* pt = nullptr;  // probe mode 2: the Talker's layer-0 gate/up GEMM (the largest GEMM of the frame step)
     if (e->probe == 2 && B == L.nb && e->probe_i + 2 <= 8) { pt = &e->probe_ev[e->probe_i]; e->probe_i += 2; }
-    run_layers(e, e->T, L.xT, B, L.row_pos_t, L.slot_id, L.sc, s, true, pt);
-    Q3Gemm g{}; g.x = L.xT; g.ldx = m.t_d_model; g.B = B; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab; g.norm_w = e->T.out_norm; g.eps = eps;
-    g.y = L.logits; g.ldy = m.t_vocab; g.epi = Q3_EPI_STORE; q3_launch_gemm(g, s);
+    run_layers(e, e->T, L.xT, L.xbT, L.sspT, B, L.row_pos_t, L.slot_id, L.sc, s, true, pt);
+    Q3BGemm g{}; g.a = L.xbT; g.lda = m.t_d_model; g.B = B; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab;
+    g.ssp = L.sspT; g.ld_ssp = m.t_d_model / 16; g.ntiles = m.t_d_model / 16; g.d_norm = m.t_d_model; g.eps = eps;
+    g.epi = Q3_EPI_STORE; g.y = L.logits; g.ldy = m.t_vocab;
+    q3_launch_bgemm(g, s);
 }
 
 static bool file_exists(const std::string& p) { FILE* f = fopen(p.c_str(), "rb"); if (f) fclose(f); return f != nullptr; }
@@ -339,24 +339,9 @@ static int upload_table(q3tts_engine* e, float** dst, const float* host, size_t 
     Q3_HIP(e, hipStreamSynchronize(e->stream));  // `host` may be a temporary of the caller
     return Q3TTS_OK;
 }
-static int upload_proj(q3tts_engine* e, const float* w, const float* b) {
+static int upload_proj(q3tts_engine* e, const float* w, const float* b) {  // proj.weight stays f32 (src/assets_manager.rs:212-241, :383-399)
     const q3tts_model_config& m = e->cfg.model;
-    const size_t n = (size_t)m.p_d_model * m.d_embed;
-    std::vector<uint16_t> h(n);
-    for (size_t i = 0; i < n; ++i) h[i] = host_bf16(w[i]);  // the projection runs on the bf16 GEMM (documented deviation)
-    void* stage = nullptr;
-    if (hipMalloc(&stage, n * 2) != hipSuccess) return q3_set_err(e, Q3TTS_ERR_OOM, "hipMalloc (projection staging)");
-    hipError_t er = hipMemcpy(stage, h.data(), n * 2, hipMemcpyHostToDevice);
-    int rc = Q3TTS_OK;
-    if (er == hipSuccess) rc = dalloc(e, &e->proj_w, n / 8);
-    if (er == hipSuccess && rc == Q3TTS_OK) {
-        Q3Fill f{}; f.dst = e->proj_w; f.N = m.p_d_model; f.K = m.d_embed; f.mode = 0; f.row0 = 0; f.rows = m.p_d_model; f.src_a = (const uint16_t*)stage;
-        q3_launch_fill_tiled(f, e->stream);
-        er = hipStreamSynchronize(e->stream);
-    }
-    hipFree(stage);
-    if (er != hipSuccess) return q3_set_err(e, Q3TTS_ERR_DEVICE, hipGetErrorString(er));
-    TRY(rc);
+    TRY(upload_table(e, &e->proj_w, w, (size_t)m.p_d_model * m.d_embed));
     return upload_table(e, &e->proj_b, b, (size_t)m.p_d_model);
 }
 // Assets::load (src/assets_manager.rs:14-26): qwen3_assets.gguf if present, else the NPY files. Table row counts come from
@@ -433,6 +418,7 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
 #define TRYC(x) do { int rc__ = (x); if (rc__ != Q3TTS_OK) return fail(rc__); } while (0)
 #define HIPC(call) do { hipError_t er__ = (call); if (er__ != hipSuccess) { q3_set_err(e, Q3TTS_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(er__)); return fail(Q3TTS_ERR_DEVICE); } } while (0)
     HIPC(hipSetDevice(cfg->device));
+    q3_bgemm_prepare();
     HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     // Q3TTS_VOC_SERIAL=1: the vocoder shares the decoder stream (no overlap): isolates its kernels in a profile
     if (getenv("Q3TTS_VOC_SERIAL") && atoi(getenv("Q3TTS_VOC_SERIAL"))) e->vstream = e->stream;
@@ -475,23 +461,22 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
     }
     { void* cd = nullptr; HIPC(hipMalloc(&cd, sizeof(float*) * 16)); e->codec_dev = (const float**)cd; }
     HIPC(hipMemcpyAsync((void*)e->codec_dev, e->codec.data(), sizeof(float*) * m.n_codebooks, hipMemcpyHostToDevice, s));
-    TRYC(dalloc(e, &e->proj_w, (size_t)m.p_d_model * m.d_embed / 8));
-    { Q3Fill f{}; f.seed = seed; f.scale = 0.02f / Q3_IH4_STD; f.dst = e->proj_w; f.N = m.p_d_model; f.K = m.d_embed; f.mode = 0; f.row0 = 0;
-      f.rows = m.p_d_model; f.tid_a = Q3_TID(Q3G_ASSET, 0, Q3WA_PROJ_W); q3_launch_fill_tiled(f, s); }
+    TRYC(dalloc(e, &e->proj_w, (size_t)m.p_d_model * m.d_embed));  // f32 [out][in]; synthetic values are bf16-representable like every synthetic matrix
+    q3_launch_fill_f32(e->proj_w, (size_t)m.p_d_model * m.d_embed, seed, Q3_TID(Q3G_ASSET, 0, Q3WA_PROJ_W), 0.0f, 0.02f / Q3_IH4_STD, 1, s);
     TRYC(dalloc(e, &e->proj_b, (size_t)m.p_d_model));
     q3_launch_fill_f32(e->proj_b, m.p_d_model, seed, Q3_TID(Q3G_ASSET, 0, Q3WA_PROJ_B), 0.0f, 0.02f / Q3_IH4_STD, 0, s);
     e->tts_pad = e->text + (size_t)m.tts_pad_id * m.d_embed;  // src/assets_manager.rs:244-249
     }
-    // pre-projected codec tables: proj(codec_q[code]) for every code, computed once with the exact GEMM (a row's result does
-    // not depend on the other rows, so a table row equals the on-the-fly projection bit for bit): the 15 Predictor passes
-    // after the first read their input with a gather instead of a GEMM launch each
+    // pre-projected codec tables: proj(codec_q[code]) for every code, computed once with the projection kernel (a row's result
+    // does not depend on the other rows, so a table row equals the on-the-fly projection bit for bit): the 15 Predictor passes
+    // after the first read their input with a gather instead of a projection launch each
     e->pproj.assign(m.n_codebooks, nullptr);
     for (int q = 0; q < m.n_codebooks; ++q) {
         const int rows = q == 0 ? m.codec0_rows : m.codecq_rows;
         TRYC(dalloc(e, &e->pproj[q], (size_t)rows * m.p_d_model));
-        Q3Gemm g{}; g.x = e->codec[q]; g.ldx = m.d_embed; g.B = rows; g.w = e->proj_w; g.K = m.d_embed; g.N = m.p_d_model; g.bias = e->proj_b;
-        g.y = e->pproj[q]; g.ldy = m.p_d_model; g.epi = Q3_EPI_STORE;
-        q3_launch_gemm(g, s);
+        Q3Project pj{}; pj.x = e->codec[q]; pj.ldx = m.d_embed; pj.rows = rows; pj.w = e->proj_w; pj.bias = e->proj_b; pj.n_in = m.d_embed; pj.n_out = m.p_d_model;
+        pj.y = e->pproj[q]; pj.ldy = m.p_d_model;
+        q3_launch_project(pj, s);
     }
     HIPC(hipStreamSynchronize(s));
     // decode state
@@ -510,6 +495,8 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
         TRYC(dalloc(e, &L.xT, (size_t)nb * m.t_d_model)); TRYC(dalloc(e, &L.logits, (size_t)nb * m.t_vocab)); TRYC(dalloc(e, &L.logits_tmp, (size_t)nb * std::max(m.t_vocab, m.t_d_model)));
         TRYC(dalloc(e, &L.X, (size_t)2 * nb * m.d_embed)); TRYC(dalloc(e, &L.fb, (size_t)nb * m.d_embed));
         TRYC(dalloc(e, &L.px, (size_t)2 * nb * m.p_d_model)); TRYC(dalloc(e, &L.keys, (size_t)nb * m.n_codebooks));
+        TRYC(dalloc(e, &L.xbT, (size_t)nb * m.t_d_model)); TRYC(dalloc(e, &L.sspT, (size_t)nb * (m.t_d_model / 16)));
+        TRYC(dalloc(e, &L.xbP, (size_t)2 * nb * m.p_d_model)); TRYC(dalloc(e, &L.sspP, (size_t)2 * nb * (m.p_d_model / 16)));
         TRYC(dalloc(e, &L.row_pos_t, (size_t)nb)); TRYC(dalloc(e, &L.slot_id, (size_t)nb)); TRYC(dalloc(e, &L.perm, (size_t)nb));
         TRYC(dalloc(e, &L.posA, (size_t)2 * nb)); TRYC(dalloc(e, &L.slotA, (size_t)2 * nb)); TRYC(dalloc(e, &L.pos_q, (size_t)m.n_codebooks * nb));
         std::vector<int> sid(nb), pa(2 * nb), sla(2 * nb), pq((size_t)m.n_codebooks * nb), rp(nb, -1);
@@ -522,19 +509,31 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
         HIPC(hipMemcpyAsync(L.row_pos_t, rp.data(), nb * 4, hipMemcpyHostToDevice, s));
         HIPC(hipStreamSynchronize(s));
         TRYC(alloc_scratch(e, L.sc, 2 * nb, nqkv_max, nq_max, F_max, std::max(m.t_d_model, m.p_d_model)));
-        for (int r = 1; r < nb; r *= 2) e->buckets.push_back(r);
+        // row buckets: 1, 2, 4, 8, then the multiples of 16 (the GEMM's row tiles are 16 wide: a 48-row step costs 3/4 of a 64-row one)
+        for (int r = 1; r < nb && r < 16; r *= 2) e->buckets.push_back(r);
+        for (int r = 16; r < nb; r += 16) e->buckets.push_back(r);
         e->buckets.push_back(nb);
         e->cur_bucket = (int)e->buckets.size() - 1;
         e->row_of_slot = sid; e->slot_of_row = sid;
     }
     TRYC(alloc_scratch(e, e->sc_pre, cfg->n_ctx, e->T.nqkv, e->T.nq, e->T.F, m.t_d_model));
     TRYC(dalloc(e, &e->xp, (size_t)cfg->n_ctx * m.t_d_model));
+    TRYC(dalloc(e, &e->xbp, (size_t)cfg->n_ctx * m.t_d_model)); TRYC(dalloc(e, &e->sspp, (size_t)cfg->n_ctx * (m.t_d_model / 16)));
     TRYC(dalloc(e, &e->pf_pos, (size_t)cfg->n_ctx)); TRYC(dalloc(e, &e->pf_slot, (size_t)cfg->n_ctx));
     { std::vector<int> pp(cfg->n_ctx); for (int i = 0; i < cfg->n_ctx; ++i) pp[i] = i;
       HIPC(hipMemcpyAsync(e->pf_pos, pp.data(), pp.size() * 4, hipMemcpyHostToDevice, s)); HIPC(hipStreamSynchronize(s)); }
     e->prow_cap = cfg->n_ctx;
     TRYC(dalloc(e, &e->prow_dev, (size_t)e->prow_cap)); TRYC(dalloc(e, &e->spk_dev, (size_t)m.d_embed));
     TRYC(dalloc(e, &e->refcodes_dev, (size_t)cfg->n_ctx * 16));
+    {   // the marker row text[151671] through the table's out-of-range rule (src/assets_manager.rs:444-460): a missing or short text
+        // table gives the fallback pattern, never a null / out-of-bounds read (the clone prompt adds this row to every reference frame)
+        TRYC(dalloc(e, &e->marker_row, (size_t)m.d_embed));
+        const Q3PromptRow mr{1, m.tts_pad_id, 0, 0};
+        HIPC(hipMemcpyAsync(e->prow_dev, &mr, sizeof(mr), hipMemcpyHostToDevice, s));
+        HIPC(hipStreamSynchronize(s));
+        q3_launch_prompt_rows(e->prow_dev, 1, e->text, m.text_vocab, e->codec_dev, m.codec0_rows, m.codecq_rows, m.n_codebooks, e->spk_dev, m.d_embed, e->marker_row, s);
+        HIPC(hipStreamSynchronize(s));
+    }
     if (cfg->with_vocoder) {
         TRYC(q3_voc_create(e));
         HIPC(hipHostMalloc((void**)&e->first_chunk_host, sizeof(float) * 4 * (size_t)q3_voc_samples_per_frame(e), hipHostMallocDefault));
@@ -576,6 +575,7 @@ extern "C" void q3tts_engine_destroy(q3tts_engine* e) {
         for (auto gr : L.graphs) if (gr) hipGraphDestroy(gr);
         hipFree(L.logits_tmp); hipFree(L.perm);
         hipFree(L.xT); hipFree(L.logits); hipFree(L.X); hipFree(L.fb); hipFree(L.px); hipFree(L.keys);
+        hipFree(L.xbT); hipFree(L.sspT); hipFree(L.xbP); hipFree(L.sspP);
         hipFree(L.row_pos_t); hipFree(L.slot_id); hipFree(L.posA); hipFree(L.slotA); hipFree(L.pos_q);
         hipFree(L.sc.qkv); hipFree(L.sc.att); hipFree(L.sc.h);
         if (L.ev_begin) hipEventDestroy(L.ev_begin); if (L.ev_end) hipEventDestroy(L.ev_end);
@@ -583,11 +583,11 @@ extern "C" void q3tts_engine_destroy(q3tts_engine* e) {
     }
     free_tfm(e->T); free_tfm(e->P);
     hipFree(e->text); for (auto p : e->codec) hipFree(p); for (auto p : e->pproj) hipFree(p); hipFree((void*)e->codec_dev); hipFree(e->proj_w); hipFree(e->proj_b);
-    hipFree(e->tts_pad_own);
+    hipFree(e->tts_pad_own); hipFree(e->marker_row);
     hipFree(e->slots); if (e->slots_host) hipHostFree(e->slots_host);
     hipFree(e->codes); hipFree(e->rng);
     hipFree(e->sc_pre.qkv); hipFree(e->sc_pre.att); hipFree(e->sc_pre.h);
-    hipFree(e->xp); hipFree(e->pf_pos); hipFree(e->pf_slot); hipFree(e->prow_dev); hipFree(e->spk_dev); hipFree(e->refcodes_dev);
+    hipFree(e->xp); hipFree(e->xbp); hipFree(e->sspp); hipFree(e->pf_pos); hipFree(e->pf_slot); hipFree(e->prow_dev); hipFree(e->spk_dev); hipFree(e->refcodes_dev);
     for (auto ev : e->fin_ev) if (ev) hipEventDestroy(ev);
     for (auto ev : e->probe_ev) if (ev) hipEventDestroy(ev);
     if (e->ev0) hipEventDestroy(e->ev0); if (e->ev1) hipEventDestroy(e->ev1); if (e->ev2) hipEventDestroy(e->ev2); if (e->ev3) hipEventDestroy(e->ev3);
@@ -658,7 +658,7 @@ static int build_prompt_dev(q3tts_engine* e, const q3tts_prompt_desc* p, float* 
     if (ref_row0 >= 0 && p->n_ref_frames > 0) {
         Q3_HIP(e, hipMemcpyAsync(e->refcodes_dev, p->ref_codes, (size_t)p->n_ref_frames * 16 * 4, hipMemcpyHostToDevice, s));
         Q3_HIP(e, hipStreamSynchronize(s));
-        q3_launch_prompt_ref_frames(e->refcodes_dev, p->n_ref_frames, e->text + (size_t)marker * m.d_embed, e->codec_dev, m.codec0_rows,
+        q3_launch_prompt_ref_frames(e->refcodes_dev, p->n_ref_frames, e->marker_row, e->codec_dev, m.codec0_rows,
                                     m.codecq_rows, m.n_codebooks, m.d_embed, out + (size_t)ref_row0 * m.d_embed, s);
     }
     *n_out = n;
@@ -766,16 +766,20 @@ static int admit_group(q3tts_engine* e, std::vector<Adm>& grp, int total) {
     Q3_HIP(e, hipMemcpyAsync(e->pf_pos, pos.data(), (size_t)total * 4, hipMemcpyHostToDevice, s));
     Q3_HIP(e, hipMemcpyAsync(e->pf_slot, slot.data(), (size_t)total * 4, hipMemcpyHostToDevice, s));
     Q3_HIP(e, hipStreamSynchronize(s));  // pos/slot are locals
-    run_layers(e, e->T, e->xp, total, e->pf_pos, e->pf_slot, e->sc_pre, s);
+    q3_launch_norm_inputs(e->xp, m.t_d_model, total, m.t_d_model, e->T.attn_norm[0], e->xbp, m.t_d_model, e->sspp, m.t_d_model / 16, s);
+    run_layers(e, e->T, e->xp, e->xbp, e->sspp, total, e->pf_pos, e->pf_slot, e->sc_pre, s);
+    Q3_HIP(e, hipGetLastError());
     for (const Adm& a : grp) {
         const q3tts_request* r = a.r;
         const int b = a.b;
         Q3Lane& L = e->lanes[0];
         const int row = e->row_of_slot[b];
         q3_launch_copy_rows(L.xT + (size_t)row * m.t_d_model, m.t_d_model, e->xp + (size_t)(a.row0 + a.n - 1) * m.t_d_model, m.t_d_model, 1, m.t_d_model, s);
-        Q3Gemm g{}; g.x = L.xT + (size_t)row * m.t_d_model; g.ldx = m.t_d_model; g.B = 1; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab;
-        g.norm_w = e->T.out_norm; g.eps = m.rms_eps; g.y = L.logits + (size_t)row * m.t_vocab; g.ldy = m.t_vocab; g.epi = Q3_EPI_STORE;
-        q3_launch_gemm(g, s);
+        const size_t lastr = (size_t)(a.row0 + a.n - 1);  // the last prompt row's norm inputs for out_norm came out of the last block
+        Q3BGemm g{}; g.a = e->xbp + lastr * m.t_d_model; g.lda = m.t_d_model; g.B = 1; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab;
+        g.ssp = e->sspp + lastr * (m.t_d_model / 16); g.ld_ssp = m.t_d_model / 16; g.ntiles = m.t_d_model / 16; g.d_norm = m.t_d_model; g.eps = m.rms_eps;
+        g.epi = Q3_EPI_STORE; g.y = L.logits + (size_t)row * m.t_vocab; g.ldy = m.t_vocab;
+        q3_launch_bgemm(g, s);
         // sampler stream (src/tts/engine.rs:473-485)
         float temperature = e->temperature, top_p = e->top_p; int top_k = e->top_k, has_seed = e->has_seed; uint64_t seed = e->seed;
         if (!r->use_engine_sampler) { temperature = r->temperature; top_k = r->top_k; top_p = r->top_p; has_seed = r->has_seed; seed = r->seed; }
@@ -1243,56 +1247,51 @@ extern "C" int q3tts_k_sample(int32_t device, const float* logits, int32_t n, in
     return Q3TTS_OK;
 }
 
-// prototype bf16-MFMA GEMM (q3_gemm_bf16.hip): x bf16 bits [B][K], w bf16 bits row-major [N][K] -> y [B][N]
-int q3_launch_gemm_bf16(const uint16_t* x, int ldx, int B, const uint4* w, int K, int N, float* y, int ldy, hipStream_t s);
-extern "C" int q3tts_k_gemm_bf16(int32_t device, const uint16_t* x, int32_t B, int32_t K, const uint16_t* w, int32_t N, float* y, int32_t iters,
-                                 float* mean_ms) {
-    if (!x || !w || !y || B <= 0 || (K != 1024 && K != 2048) || N % 48) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bf16 gemm hook: K in {1024, 2048}, N % 48 == 0");
-    HK(hipSetDevice(device));
-    DevBuf dx, dw, dwt, dy;
-    if (dx.alloc((size_t)B * K * 2) || dw.alloc((size_t)N * K * 2) || dwt.alloc((size_t)N * K * 2) || dy.alloc((size_t)B * N * 4)) return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
-    HK(hipMemcpy(dx.p, x, (size_t)B * K * 2, hipMemcpyHostToDevice));
-    HK(hipMemcpy(dw.p, w, (size_t)N * K * 2, hipMemcpyHostToDevice));
-    Q3Fill f{}; f.dst = (uint4*)dwt.p; f.N = N; f.K = K; f.mode = 0; f.row0 = 0; f.rows = N; f.src_a = (const uint16_t*)dw.p;
-    q3_launch_fill_tiled(f, nullptr);
-    if (q3_launch_gemm_bf16((const uint16_t*)dx.p, K, B, (const uint4*)dwt.p, K, N, (float*)dy.p, N, nullptr)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bf16 gemm: shape");
-    HK(hipDeviceSynchronize());
-    HK(hipMemcpy(y, dy.p, (size_t)B * N * 4, hipMemcpyDeviceToHost));
-    if (iters > 0 && mean_ms) {
-        hipEvent_t a, b; HK(hipEventCreate(&a)); HK(hipEventCreate(&b));
-        q3_launch_gemm_bf16((const uint16_t*)dx.p, K, B, (const uint4*)dwt.p, K, N, (float*)dy.p, N, nullptr);
-        HK(hipEventRecord(a, nullptr));
-        for (int i = 0; i < iters; ++i) q3_launch_gemm_bf16((const uint16_t*)dx.p, K, B, (const uint4*)dwt.p, K, N, (float*)dy.p, N, nullptr);
-        HK(hipEventRecord(b, nullptr)); HK(hipEventSynchronize(b));
-        float ms = 0; hipEventElapsedTime(&ms, a, b); *mean_ms = ms / iters;
-        hipEventDestroy(a); hipEventDestroy(b);
-    }
-    return Q3TTS_OK;
-}
-
-// fused RMSNorm + bf16-MFMA GEMM + SwiGLU (the Predictor's gate/up, K = 1024); w: logical [2F][K], gate rows then up rows
-extern "C" int q3tts_k_gemm_bf16_norm_swiglu(int32_t device, const float* x, int32_t B, int32_t K, const uint16_t* w, int32_t N, const float* norm_w,
-                                             float eps, float* y, int32_t iters, float* mean_ms) {
-    if (!x || !w || !y || !norm_w || B <= 0 || !q3_gemm_bf16_norm_swiglu_ok(K, N)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bf16 norm/swiglu hook: K in {512, 1024}, N % 32 == 0");
+// the decoder's GEMM through its launcher (q3_bgemm.hip): xb bf16 bits [B][K]; w bf16 bits row-major [N][K] (epi 2: the F gate rows,
+// then the F up rows); ssp [B][ntiles] or NULL; y in/out for epi 1. Mirrors oracle/q3_oracle_bf16.c q3o_bgemm.
+extern "C" int q3tts_k_bgemm(int32_t device, const uint16_t* xb, int32_t B, int32_t K, const uint16_t* w, int32_t N, const float* ssp, int32_t ntiles,
+                             int32_t d_norm, float eps, int32_t epi, const float* nw_next, float* y, uint16_t* yb, float* ssp_out, uint64_t* keys,
+                             int32_t iters, float* mean_ms) {
+    if (!xb || !w || B <= 0 || K % 256 || K < 256 || N % 16 || epi < 0 || epi > 3) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm hook: K % 256 == 0, N % 16 == 0");
+    if (epi == Q3_EPI_SWIGLU && (N % 32 || !yb)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm hook: swiglu needs N % 32 == 0 and yb");
+    if ((epi == Q3_EPI_STORE || epi == Q3_EPI_RESID) && !y) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm hook: y missing");
+    if (epi == Q3_EPI_ARGMAX && !keys) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm hook: keys missing");
+    if (epi == Q3_EPI_RESID && nw_next && (!yb || !ssp_out)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm hook: norm outputs missing");
     HK(hipSetDevice(device));
     const int F = N / 2;
-    DevBuf dx, dw, dwt, dn, dy;
-    if (dx.alloc((size_t)B * K * 4) || dw.alloc((size_t)N * K * 2) || dwt.alloc((size_t)N * K * 2) || dn.alloc((size_t)K * 4) || dy.alloc((size_t)B * F * 4))
+    DevBuf dx, dw, dwt, ds, dn, dy, dyb, dso, dk;
+    if (dx.alloc((size_t)B * K * 2) || dw.alloc((size_t)N * K * 2) || dwt.alloc((size_t)N * K * 2) || ds.alloc((size_t)B * (ntiles > 0 ? ntiles : 1) * 4) ||
+        dn.alloc((size_t)N * 4) || dy.alloc((size_t)B * N * 4) || dyb.alloc((size_t)B * N * 2) || dso.alloc((size_t)B * (N / 16) * 4) || dk.alloc((size_t)B * 8))
         return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
-    HK(hipMemcpy(dx.p, x, (size_t)B * K * 4, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dx.p, xb, (size_t)B * K * 2, hipMemcpyHostToDevice));
     HK(hipMemcpy(dw.p, w, (size_t)N * K * 2, hipMemcpyHostToDevice));
-    HK(hipMemcpy(dn.p, norm_w, (size_t)K * 4, hipMemcpyHostToDevice));
-    Q3Fill f{}; f.dst = (uint4*)dwt.p; f.N = N; f.K = K; f.mode = 1; f.src_a = (const uint16_t*)dw.p; f.src_b = (const uint16_t*)dw.p + (size_t)F * K;
+    if (ssp) HK(hipMemcpy(ds.p, ssp, (size_t)B * ntiles * 4, hipMemcpyHostToDevice));
+    if (nw_next) HK(hipMemcpy(dn.p, nw_next, (size_t)N * 4, hipMemcpyHostToDevice));
+    if (epi == Q3_EPI_RESID) HK(hipMemcpy(dy.p, y, (size_t)B * N * 4, hipMemcpyHostToDevice));
+    Q3Fill f{}; f.dst = (uint4*)dwt.p; f.N = N; f.K = K;
+    if (epi == Q3_EPI_SWIGLU) { f.mode = 1; f.src_a = (const uint16_t*)dw.p; f.src_b = (const uint16_t*)dw.p + (size_t)F * K; }
+    else { f.mode = 0; f.row0 = 0; f.rows = N; f.src_a = (const uint16_t*)dw.p; }
     q3_launch_fill_tiled(f, nullptr);
-    auto go = [&]() { return q3_launch_gemm_bf16_norm_swiglu((const float*)dx.p, K, B, (const uint4*)dwt.p, K, N, (const float*)dn.p, eps, (float*)dy.p, F, nullptr, 0); };
-    if (go()) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bf16 norm/swiglu gemm: shape");
+    Q3BGemm g{}; g.a = (const uint16_t*)dx.p; g.lda = K; g.B = B; g.w = (const uint4*)dwt.p; g.K = K; g.N = N;
+    g.ssp = ssp ? (const float*)ds.p : nullptr; g.ld_ssp = ntiles; g.ntiles = ntiles; g.d_norm = d_norm; g.eps = eps; g.epi = epi;
+    g.y = (float*)dy.p; g.ldy = N; g.yb = (uint16_t*)dyb.p; g.ldyb = epi == Q3_EPI_SWIGLU ? F : N;
+    g.nw_next = nw_next ? (const float*)dn.p : nullptr; g.ssp_out = (float*)dso.p; g.ld_ssp_out = N / 16;
+    g.keys = (unsigned long long*)dk.p; g.key_stride = 1;
+    if (q3_launch_bgemm(g, nullptr)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm: shape");
     HK(hipDeviceSynchronize());
-    HK(hipMemcpy(y, dy.p, (size_t)B * F * 4, hipMemcpyDeviceToHost));
+    if (epi == Q3_EPI_STORE || epi == Q3_EPI_RESID) HK(hipMemcpy(y, dy.p, (size_t)B * N * 4, hipMemcpyDeviceToHost));
+    if (epi == Q3_EPI_SWIGLU) HK(hipMemcpy(yb, dyb.p, (size_t)B * F * 2, hipMemcpyDeviceToHost));
+    if (epi == Q3_EPI_RESID && nw_next) {
+        HK(hipMemcpy(yb, dyb.p, (size_t)B * N * 2, hipMemcpyDeviceToHost));
+        HK(hipMemcpy(ssp_out, dso.p, (size_t)B * (N / 16) * 4, hipMemcpyDeviceToHost));
+    }
+    if (epi == Q3_EPI_ARGMAX) HK(hipMemcpy(keys, dk.p, (size_t)B * 8, hipMemcpyDeviceToHost));
     if (iters > 0 && mean_ms) {
+        if (epi == Q3_EPI_RESID) { g.epi = Q3_EPI_STORE; g.nw_next = nullptr; }
         hipEvent_t a, b; HK(hipEventCreate(&a)); HK(hipEventCreate(&b));
-        go();
+        q3_launch_bgemm(g, nullptr);
         HK(hipEventRecord(a, nullptr));
-        for (int i = 0; i < iters; ++i) go();
+        for (int i = 0; i < iters; ++i) q3_launch_bgemm(g, nullptr);
         HK(hipEventRecord(b, nullptr)); HK(hipEventSynchronize(b));
         float ms = 0; hipEventElapsedTime(&ms, a, b); *mean_ms = ms / iters;
         hipEventDestroy(a); hipEventDestroy(b);
@@ -1300,60 +1299,40 @@ extern "C" int q3tts_k_gemm_bf16_norm_swiglu(int32_t device, const float* x, int
     return Q3TTS_OK;
 }
 
-// fused RMSNorm + bf16-MFMA GEMM, plain store (the Predictor's QKV): y[B][N] = s_r * raw
-extern "C" int q3tts_k_gemm_bf16_norm_store(int32_t device, const float* x, int32_t B, int32_t K, const uint16_t* w, int32_t N, const float* norm_w,
-                                            float eps, float* y, int32_t iters, float* mean_ms) {
-    if (!x || !w || !y || !norm_w || B <= 0 || !q3_gemm_bf16_norm_ok(K, N)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bf16 norm hook: K in {512, 1024}, N % 32 == 0");
+// H6 through the projection kernel: y[rows][n_out] = bias + sum x * w (reference order); nw != NULL: the rows' norm inputs too
+extern "C" int q3tts_k_project(int32_t device, const float* x, int32_t rows, int32_t n_in, const float* w, const float* bias, int32_t n_out, const float* nw,
+                               float* y, uint16_t* xb, float* ssp) {
+    if (!x || !w || !bias || !y || rows <= 0 || n_in % 16 || n_out % 16 || (nw && (!xb || !ssp))) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "project hook: bad argument");
     HK(hipSetDevice(device));
-    DevBuf dx, dw, dwt, dn, dy;
-    if (dx.alloc((size_t)B * K * 4) || dw.alloc((size_t)N * K * 2) || dwt.alloc((size_t)N * K * 2) || dn.alloc((size_t)K * 4) || dy.alloc((size_t)B * N * 4))
+    DevBuf dx, dw, db, dn, dy, dxb, dss;
+    if (dx.alloc((size_t)rows * n_in * 4) || dw.alloc((size_t)n_out * n_in * 4) || db.alloc((size_t)n_out * 4) || dn.alloc((size_t)n_out * 4) ||
+        dy.alloc((size_t)rows * n_out * 4) || dxb.alloc((size_t)rows * n_out * 2) || dss.alloc((size_t)rows * (n_out / 16) * 4))
         return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
-    HK(hipMemcpy(dx.p, x, (size_t)B * K * 4, hipMemcpyHostToDevice));
-    HK(hipMemcpy(dw.p, w, (size_t)N * K * 2, hipMemcpyHostToDevice));
-    HK(hipMemcpy(dn.p, norm_w, (size_t)K * 4, hipMemcpyHostToDevice));
-    Q3Fill f{}; f.dst = (uint4*)dwt.p; f.N = N; f.K = K; f.mode = 0; f.row0 = 0; f.rows = N; f.src_a = (const uint16_t*)dw.p;
-    q3_launch_fill_tiled(f, nullptr);
-    auto go = [&]() { return q3_launch_gemm_bf16_norm_store((const float*)dx.p, K, B, (const uint4*)dwt.p, K, N, (const float*)dn.p, eps, (float*)dy.p, N, nullptr); };
-    if (go()) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bf16 norm gemm: shape");
+    HK(hipMemcpy(dx.p, x, (size_t)rows * n_in * 4, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dw.p, w, (size_t)n_out * n_in * 4, hipMemcpyHostToDevice));
+    HK(hipMemcpy(db.p, bias, (size_t)n_out * 4, hipMemcpyHostToDevice));
+    if (nw) HK(hipMemcpy(dn.p, nw, (size_t)n_out * 4, hipMemcpyHostToDevice));
+    Q3Project pj{}; pj.x = (const float*)dx.p; pj.ldx = n_in; pj.rows = rows; pj.w = (const float*)dw.p; pj.bias = (const float*)db.p; pj.n_in = n_in; pj.n_out = n_out;
+    pj.y = (float*)dy.p; pj.ldy = n_out; pj.nw = nw ? (const float*)dn.p : nullptr; pj.xb = (uint16_t*)dxb.p; pj.ldxb = n_out; pj.ssp = (float*)dss.p; pj.ld_ssp = n_out / 16;
+    if (q3_launch_project(pj, nullptr)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "project: shape");
     HK(hipDeviceSynchronize());
-    HK(hipMemcpy(y, dy.p, (size_t)B * N * 4, hipMemcpyDeviceToHost));
-    if (iters > 0 && mean_ms) {
-        hipEvent_t a, b; HK(hipEventCreate(&a)); HK(hipEventCreate(&b));
-        go();
-        HK(hipEventRecord(a, nullptr));
-        for (int i = 0; i < iters; ++i) go();
-        HK(hipEventRecord(b, nullptr)); HK(hipEventSynchronize(b));
-        float ms = 0; hipEventElapsedTime(&ms, a, b); *mean_ms = ms / iters;
-        hipEventDestroy(a); hipEventDestroy(b);
-    }
+    HK(hipMemcpy(y, dy.p, (size_t)rows * n_out * 4, hipMemcpyDeviceToHost));
+    if (nw) { HK(hipMemcpy(xb, dxb.p, (size_t)rows * n_out * 2, hipMemcpyDeviceToHost)); HK(hipMemcpy(ssp, dss.p, (size_t)rows * (n_out / 16) * 4, hipMemcpyDeviceToHost)); }
     return Q3TTS_OK;
 }
 
-// y[B][N] += canonical bf16 GEMM of bf16 rows (the Predictor's O / down projections): x, w bf16 bits; y in/out
-extern "C" int q3tts_k_gemm_bf16_resid(int32_t device, const uint16_t* x, int32_t B, int32_t K, const uint16_t* w, int32_t N, float* y, int32_t iters,
-                                       float* mean_ms) {
-    if (!x || !w || !y || B <= 0 || N % 16 || !q3_gemm_bf16_plain_ok(K)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bf16 resid hook: K in {512, 1024, 2048, 3072}, N % 16 == 0");
+// producer side of the split RMSNorm for plain f32 rows (d % 256 == 0)
+extern "C" int q3tts_k_norm_inputs(int32_t device, const float* x, int32_t rows, int32_t d, const float* nw, uint16_t* xb, float* ssp) {
+    if (!x || !nw || !xb || !ssp || rows <= 0 || d % 256) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "norm-inputs hook: d % 256 == 0");
     HK(hipSetDevice(device));
-    DevBuf dx, dw, dwt, dy;
-    if (dx.alloc((size_t)B * K * 2) || dw.alloc((size_t)N * K * 2) || dwt.alloc((size_t)N * K * 2) || dy.alloc((size_t)B * N * 4)) return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
-    HK(hipMemcpy(dx.p, x, (size_t)B * K * 2, hipMemcpyHostToDevice));
-    HK(hipMemcpy(dw.p, w, (size_t)N * K * 2, hipMemcpyHostToDevice));
-    HK(hipMemcpy(dy.p, y, (size_t)B * N * 4, hipMemcpyHostToDevice));
-    Q3Fill f{}; f.dst = (uint4*)dwt.p; f.N = N; f.K = K; f.mode = 0; f.row0 = 0; f.rows = N; f.src_a = (const uint16_t*)dw.p;
-    q3_launch_fill_tiled(f, nullptr);
-    auto go = [&]() { return q3_launch_gemm_bf16_resid((const uint16_t*)dx.p, K, B, (const uint4*)dwt.p, K, N, (float*)dy.p, N, nullptr); };
-    if (go()) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bf16 resid gemm: shape");
+    DevBuf dx, dn, dxb, dss;
+    if (dx.alloc((size_t)rows * d * 4) || dn.alloc((size_t)d * 4) || dxb.alloc((size_t)rows * d * 2) || dss.alloc((size_t)rows * (d / 16) * 4)) return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
+    HK(hipMemcpy(dx.p, x, (size_t)rows * d * 4, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dn.p, nw, (size_t)d * 4, hipMemcpyHostToDevice));
+    q3_launch_norm_inputs((const float*)dx.p, d, rows, d, (const float*)dn.p, (uint16_t*)dxb.p, d, (float*)dss.p, d / 16, nullptr);
     HK(hipDeviceSynchronize());
-    HK(hipMemcpy(y, dy.p, (size_t)B * N * 4, hipMemcpyDeviceToHost));
-    if (iters > 0 && mean_ms) {
-        hipEvent_t a, b; HK(hipEventCreate(&a)); HK(hipEventCreate(&b));
-        go();
-        HK(hipEventRecord(a, nullptr));
-        for (int i = 0; i < iters; ++i) go();
-        HK(hipEventRecord(b, nullptr)); HK(hipEventSynchronize(b));
-        float ms = 0; hipEventElapsedTime(&ms, a, b); *mean_ms = ms / iters;
-        hipEventDestroy(a); hipEventDestroy(b);
-    }
+    HK(hipMemcpy(xb, dxb.p, (size_t)rows * d * 2, hipMemcpyDeviceToHost));
+    HK(hipMemcpy(ssp, dss.p, (size_t)rows * (d / 16) * 4, hipMemcpyDeviceToHost));
     return Q3TTS_OK;
 }
 

@@ -20,17 +20,44 @@ struct Q3Gemm {
 #endif
 };
 void q3_launch_gemm(const Q3Gemm& g, hipStream_t s);
-// Predictor gate/up in the canonical bf16-MFMA order (q3_gemm_bf16.hip): fused RMSNorm prologue on f32 rows, SwiGLU
-// epilogue; weights in the same tiled gate/up-interleaved layout. _ok(): the shapes it takes (K = d_model in {512, 1024}).
-bool q3_gemm_bf16_norm_swiglu_ok(int K, int N);
-bool q3_gemm_bf16_norm_ok(int K, int N);
-int q3_launch_gemm_bf16_norm_store(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy,
-                                   hipStream_t s);
-int q3_launch_gemm_bf16_norm_swiglu(const float* x, int ldx, int B, const uint4* w, int K, int N, const float* nw, float eps, float* y, int ldy,
-                                    hipStream_t s, int y_bf16 = 0);
-// y[B][N] += canonical bf16 GEMM of bf16 rows x (residual epilogue): the Predictor's O and down projections
-bool q3_gemm_bf16_plain_ok(int K);
-int q3_launch_gemm_bf16_resid(const uint16_t* x, int ldx, int B, const uint4* w, int K, int N, float* y, int ldy, hipStream_t s);
+// The decoder's GEMM (q3_bgemm.hip): bf16 rows x tiled bf16 weights on v_mfma_f32_16x16x32_bf16 in the canonical
+// order RAW = (((s_0 + s_1) + ...) + s_7) over 8 K-slices. K % 256 == 0, N % 16 == 0.
+//   STORE   y[B][N] f32 = s_r * RAW (s_r from the producer's tile partials ssp; no scale when ssp == nullptr)
+//   RESID   y[B][N] f32 += RAW; with nw_next also yb[B][N] = bf16(y * nw_next) and ssp_out[B][N/16] (the consumer's norm inputs)
+//   SWIGLU  yb[B][N/2] = bf16(swiglu(s_r * RAW_gate, s_r * RAW_up)); each 16-column weight tile = 8 gate + 8 up columns
+//   ARGMAX  atomicMax(keys[row * key_stride], key(s_r * RAW, column))
+struct Q3BGemm {
+    const uint16_t* a; int lda; int B;          // bf16 rows
+    const uint4* w; int K, N;                   // tiled bf16
+    const float* ssp; int ld_ssp; int ntiles; int d_norm; float eps;  // row scale: s_r = 1 / sqrtf(SS(ssp[row][0..ntiles)) / d_norm + eps)
+    int epi;
+    float* y; int ldy;
+    uint16_t* yb; int ldyb;
+    const float* nw_next; float* ssp_out; int ld_ssp_out;
+    unsigned long long* keys; int key_stride;
+};
+int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s);
+void q3_bgemm_prepare();  // kernel attributes; call once outside stream capture
+// producer side of the split RMSNorm for plain f32 rows: xb = bf16(x * nw), ssp[row][t] = sum of squares of columns 16t..16t+15
+void q3_launch_norm_inputs(const float* x, int ldx, int rows, int d, const float* nw, uint16_t* xb, int ldxb, float* ssp, int ld_ssp, hipStream_t s);
+// H6 (src/assets_manager.rs:383-399) in the reference's own f32 sequence: y[row][o] = bias[o]; for i: y += x[row][i] * w[o][i].
+// nw != nullptr: also the norm inputs of y (xb, ssp) for the Predictor's first layer.
+struct Q3Project {
+    const float* x; int ldx; int rows;
+    const float* w; const float* bias; int n_in, n_out;   // w f32 row-major [n_out][n_in]
+    float* y; int ldy;
+    const float* nw; uint16_t* xb; int ldxb; float* ssp; int ld_ssp;
+};
+int q3_launch_project(const Q3Project& p, hipStream_t s);
+#ifdef __HIPCC__
+// one element of a norm-input row: 16 consecutive lanes own one tile (all of them must be active)
+__device__ __forceinline__ void q3_norm_out(float v, float nwv, uint16_t* xb_elem, float* ssp_tile, bool tile_leader) {
+    *xb_elem = q3_bf16(v * nwv);
+    float sq = v * v;
+    sq = sq + __shfl_xor(sq, 1); sq = sq + __shfl_xor(sq, 2); sq = sq + __shfl_xor(sq, 4); sq = sq + __shfl_xor(sq, 8);
+    if (tile_leader) *ssp_tile = sq;
+}
+#endif
 
 // weight tiling: dst tiled [N/16][K/32][64 lanes][8], source either synthetic or a row-major bf16 staging buffer
 struct Q3Fill {
@@ -90,6 +117,7 @@ struct Q3PredInput {
     const float* codec0; int codec0_rows;
     const float* pproj0; const float* proj_b; int dp;  // proj(codec0) table [codec0_rows][dp]; bias = proj(0)
     const Q3Slot* slots; const int* row_slot; float* X; float* px; float* fb; int B;
+    const float* nw; uint16_t* xb; float* ssp;         // norm inputs of px row 2b+1 for the Predictor's first layer (ld: dp, dp/16)
 };
 void q3_launch_pred_input(const Q3PredInput& a, hipStream_t s);
 
@@ -102,6 +130,7 @@ struct Q3PredNext {
     int* codes; int max_steps_cap;
     float* fb; const float* tts_pad; float* xT; int* row_pos_t;
     const float* pproj_q; const float* proj_b; int dp; float* px;  // q < ncb-1: px[b] = proj(codec_q[code]) from the table
+    const float* nw; uint16_t* xb; float* ssp;  // norm inputs of the row just written: px[b] (Predictor layer 0) or, last, xT[b] (Talker layer 0)
 };
 void q3_launch_pred_next(const Q3PredNext& a, hipStream_t s);
 

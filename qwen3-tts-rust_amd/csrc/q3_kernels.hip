@@ -296,6 +296,15 @@ void q3_launch_attend(const Q3Attend& a, hipStream_t s) {
     const int R = a.Hq / a.Hkv;
     const size_t lds = ((size_t)R * a.n_ctx + R * a.hd + R * 4 * a.hd + R * 8 + 2 * a.hd) * sizeof(float);
     dim3 grid(a.Hkv, a.rows);
+    static size_t attr = 0;  // the score buffer is R * n_ctx floats: above 64 KiB the dynamic LDS size has to be allowed per kernel
+    if (lds > 65536 && lds > attr) {
+        hipFuncSetAttribute((const void*)k_attend<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)k_attend<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)k_attend<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)k_attend<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)k_attend<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = lds;
+    }
     if (a.fused) {
         if (R == 2) hipLaunchKernelGGL((k_attend<2, true>), grid, dim3(512), lds, s, a);
         else hipLaunchKernelGGL((k_attend<4, true>), grid, dim3(1024), lds, s, a);
@@ -471,7 +480,12 @@ __global__ __launch_bounds__(256) void k_pred_input(Q3PredInput a) {
         a.fb[(size_t)b * d + i] = 0.0f + ev;
     }
     const float* pr = ok ? a.pproj0 + (size_t)code0 * a.dp : a.proj_b;  // proj(0) = bias
-    for (int i = tid; i < a.dp; i += 256) a.px[(size_t)(2 * b + 1) * a.dp + i] = pr[i];
+    const size_t r1 = (size_t)(2 * b + 1);
+    for (int i = tid; i < a.dp; i += 256) {  // (dp % 256 == 0: whole waves, 16 consecutive lanes per norm tile)
+        const float v = pr[i];
+        a.px[r1 * a.dp + i] = v;
+        q3_norm_out(v, a.nw[i], a.xb + r1 * a.dp + i, a.ssp + r1 * (a.dp >> 4) + (i >> 4), (i & 15) == 0);
+    }
 }
 void q3_launch_pred_input(const Q3PredInput& a, hipStream_t s) { hipLaunchKernelGGL(k_pred_input, dim3(a.B), dim3(256), 0, s, a); }
 
@@ -492,11 +506,18 @@ __global__ __launch_bounds__(256) void k_pred_next(Q3PredNext a) {
         const float ev = ok ? e[i] : 0.0f;
         float f = a.fb[(size_t)b * d + i] + ev;
         if (!last) a.fb[(size_t)b * d + i] = f;
-        else { f = f + a.tts_pad[i]; a.xT[(size_t)b * d + i] = f; }
+        else {  // the Talker's next input row and its norm inputs for layer 0
+            f = f + a.tts_pad[i]; a.xT[(size_t)b * d + i] = f;
+            q3_norm_out(f, a.nw[i], a.xb + (size_t)b * d + i, a.ssp + (size_t)b * (d >> 4) + (i >> 4), (i & 15) == 0);
+        }
     }
     if (!last) {
         const float* pr = ok ? a.pproj_q + (size_t)code * a.dp : a.proj_b;
-        for (int i = tid; i < a.dp; i += 256) a.px[(size_t)b * a.dp + i] = pr[i];
+        for (int i = tid; i < a.dp; i += 256) {
+            const float v = pr[i];
+            a.px[(size_t)b * a.dp + i] = v;
+            q3_norm_out(v, a.nw[i], a.xb + (size_t)b * a.dp + i, a.ssp + (size_t)b * (a.dp >> 4) + (i >> 4), (i & 15) == 0);
+        }
     }
     if (last) {
         __syncthreads();

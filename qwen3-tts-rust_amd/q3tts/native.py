@@ -249,6 +249,53 @@ def k_gemm_exact(x, w_bf16, norm_w=None, eps=1e-6, bias=None, epilogue=0, y_in=N
     return y, keys, ms.value
 
 
+def k_bgemm(xb, wb, ssp, d_norm, eps, epi, nw_next=None, y0=None, device=0, iters=0):
+    """The decoder's GEMM through its launcher (q3tts_k_bgemm): natural-order bf16 bit arrays in, the epilogue's outputs out."""
+    lib = _abi.load_library()
+    xb = np.ascontiguousarray(xb, dtype=np.uint16); wb = np.ascontiguousarray(wb, dtype=np.uint16)
+    B, K = xb.shape
+    N = wb.shape[0]
+    y = np.zeros((B, N), dtype=np.float32) if y0 is None else np.ascontiguousarray(y0, dtype=np.float32).copy()
+    yb = np.zeros((B, N // 2 if epi == 2 else N), dtype=np.uint16)
+    sso = np.zeros((B, N // 16), dtype=np.float32)
+    keys = np.zeros(B, dtype=np.uint64)
+    sp = None if ssp is None else np.ascontiguousarray(ssp, dtype=np.float32)
+    nw = None if nw_next is None else np.ascontiguousarray(nw_next, dtype=np.float32)
+    ms = C.c_float(0)
+    rc = lib.q3tts_k_bgemm(device, xb.ctypes.data, B, K, wb.ctypes.data, N, None if sp is None else sp.ctypes.data, 0 if sp is None else sp.shape[1],
+                           d_norm, eps, epi, None if nw is None else nw.ctypes.data, y.ctypes.data, yb.ctypes.data, sso.ctypes.data, keys.ctypes.data,
+                           iters, C.byref(ms))
+    if rc != 0:
+        raise _abi.Q3Error(f"q3tts_k_bgemm failed ({rc}): {lib.q3tts_last_error(None).decode()}")
+    return dict(y=y, yb=yb, ssp_out=sso, keys=keys, ms=ms.value)
+
+
+def k_project(x, w, bias, nw=None, device=0):
+    lib = _abi.load_library()
+    x = np.ascontiguousarray(x, dtype=np.float32); w = np.ascontiguousarray(w, dtype=np.float32); b = np.ascontiguousarray(bias, dtype=np.float32)
+    rows, n_in = x.shape
+    n_out = w.shape[0]
+    y = np.zeros((rows, n_out), dtype=np.float32)
+    xb = np.zeros((rows, n_out), dtype=np.uint16); ssp = np.zeros((rows, n_out // 16), dtype=np.float32)
+    nwa = None if nw is None else np.ascontiguousarray(nw, dtype=np.float32)
+    rc = lib.q3tts_k_project(device, x.ctypes.data, rows, n_in, w.ctypes.data, b.ctypes.data, n_out, None if nwa is None else nwa.ctypes.data,
+                             y.ctypes.data, xb.ctypes.data, ssp.ctypes.data)
+    if rc != 0:
+        raise _abi.Q3Error(f"q3tts_k_project failed ({rc}): {lib.q3tts_last_error(None).decode()}")
+    return y, xb, ssp
+
+
+def k_norm_inputs(x, nw, device=0):
+    lib = _abi.load_library()
+    x = np.ascontiguousarray(x, dtype=np.float32); nw = np.ascontiguousarray(nw, dtype=np.float32)
+    rows, d = x.shape
+    xb = np.zeros((rows, d), dtype=np.uint16); ssp = np.zeros((rows, d // 16), dtype=np.float32)
+    rc = lib.q3tts_k_norm_inputs(device, x.ctypes.data, rows, d, nw.ctypes.data, xb.ctypes.data, ssp.ctypes.data)
+    if rc != 0:
+        raise _abi.Q3Error(f"q3tts_k_norm_inputs failed ({rc}): {lib.q3tts_last_error(None).decode()}")
+    return xb, ssp
+
+
 def k_attention(qkv, pos0, n_head, n_kv_head, head_dim, q_norm_w, k_norm_w, eps, rope_theta, sections, device=0):
     lib = _abi.load_library()
     qkv = np.ascontiguousarray(qkv, dtype=np.float32)

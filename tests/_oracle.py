@@ -85,6 +85,26 @@ def lib():
     L.q3o_speaker_encode.restype = C.c_int32
     L.q3o_audio_encode.argtypes = [C.POINTER(_abi.CloneConfig), C.c_uint64, f32p, C.c_int64, i32p, C.c_int32, f32p]
     L.q3o_audio_encode.restype = C.c_int32
+    u16p = C.POINTER(C.c_uint16)
+    L.q3o_mfma_bf16_dot32.argtypes = [u16p, u16p, C.c_float]
+    L.q3o_mfma_bf16_dot32.restype = C.c_float
+    L.q3o_mfma_bf16_dot32_ref.argtypes = [u16p, u16p, C.c_float]
+    L.q3o_mfma_bf16_dot32_ref.restype = C.c_float
+    L.q3o_bgemm.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32,
+                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.q3o_bgemm.restype = None
+    L.q3o_project_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+    L.q3o_project_rows.restype = None
+    L.q3o_norm_inputs.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.q3o_norm_inputs.restype = None
+    L.q3o_row_scale.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float]
+    L.q3o_row_scale.restype = C.c_float
+    L.q3o_set_arith.argtypes = [vp, C.c_int32]
+    L.q3o_set_arith.restype = None
+    L.q3o_norm_weight.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
+    L.q3o_norm_weight.restype = f32p
+    L.q3o_matrix.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    L.q3o_matrix.restype = C.c_int32
     if hasattr(L, "q3o_vocoder_create"):
         L.q3o_vocoder_create.argtypes = [C.POINTER(_abi.VocoderConfig), C.c_uint64, C.c_int32]
         L.q3o_vocoder_create.restype = vp
@@ -121,6 +141,24 @@ class OracleModel:
     def __del__(self):
         self.close()
 
+    def set_arith(self, mode):
+        """0: the canonical bf16-MFMA order (default); 1: plain f32 of the same structure (family pinning)."""
+        self.L.q3o_set_arith(self.h, mode)
+
+    def matrix(self, talker, layer, which):
+        """Natural-order f32 copy of one synthetic matrix: which 0 qkv, 1 o, 2 gate, 3 up, 4 down, 5 head."""
+        n = self.L.q3o_matrix(self.h, int(talker), layer, which, None)
+        c = self.cfg
+        d, nq, F = (c.t_d_model, c.t_n_head * c.t_head_dim, c.t_d_ffn) if talker else (c.p_d_model, c.p_n_head * c.p_head_dim, c.p_d_ffn)
+        K = {0: d, 1: nq, 2: d, 3: d, 4: F, 5: d}[which]
+        out = np.zeros((n, K), dtype=np.float32)
+        self.L.q3o_matrix(self.h, int(talker), layer, which, out.ctypes.data)
+        return out
+
+    def norm_weight(self, talker, layer, which, n):
+        """which 0 attn_norm, 1 ffn_norm, 2 q_norm, 3 k_norm; layer < 0: the output norm."""
+        return np.ctypeslib.as_array(self.L.q3o_norm_weight(self.h, int(talker), layer, which), shape=(n,)).copy()
+
     def build_prompt(self, desc):
         n = self.L.q3o_build_prompt(self.h, C.byref(desc), None, 0)
         out = np.zeros((n, self.cfg.d_embed), dtype=np.float32)
@@ -141,6 +179,43 @@ class OracleModel:
         n = self.L.q3o_generate(self.h, ptr(embd, f32p), embd.shape[0], temperature, top_k, top_p, seed, max_steps,
                                 min_frames, force_eos_at, ptr(codes, i32p), C.byref(eos))
         return codes[:n].copy(), bool(eos.value)
+
+
+def bgemm(xb, wb, ssp, d_norm, eps, epi, nw_next=None, y0=None):
+    """oracle/q3_oracle_bf16.c q3o_bgemm on natural-order bf16 bit arrays; returns the outputs of the epilogue as a dict."""
+    xb = np.ascontiguousarray(xb, dtype=np.uint16); wb = np.ascontiguousarray(wb, dtype=np.uint16)
+    B, K = xb.shape
+    N = wb.shape[0]
+    y = np.zeros((B, N), dtype=np.float32) if y0 is None else np.ascontiguousarray(y0, dtype=np.float32).copy()
+    yb = np.zeros((B, N // 2 if epi == 2 else N), dtype=np.uint16)
+    sso = np.zeros((B, N // 16), dtype=np.float32)
+    keys = np.zeros(B, dtype=np.uint64)
+    sp = None if ssp is None else np.ascontiguousarray(ssp, dtype=np.float32)
+    nw = None if nw_next is None else np.ascontiguousarray(nw_next, dtype=np.float32)
+    lib().q3o_bgemm(xb.ctypes.data, B, K, wb.ctypes.data, N, None if sp is None else sp.ctypes.data, 0 if sp is None else sp.shape[1], d_norm, eps, epi,
+                    None if nw is None else nw.ctypes.data, y.ctypes.data, yb.ctypes.data, sso.ctypes.data, keys.ctypes.data)
+    return dict(y=y, yb=yb, ssp_out=sso, keys=keys)
+
+
+def project_rows(w, b, x):
+    w = np.ascontiguousarray(w, dtype=np.float32); b = np.ascontiguousarray(b, dtype=np.float32); x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.zeros((x.shape[0], w.shape[0]), dtype=np.float32)
+    lib().q3o_project_rows(w.ctypes.data, b.ctypes.data, w.shape[1], w.shape[0], x.ctypes.data, x.shape[0], y.ctypes.data)
+    return y
+
+
+def norm_inputs(x, nw):
+    x = np.ascontiguousarray(x, dtype=np.float32); nw = np.ascontiguousarray(nw, dtype=np.float32)
+    rows, d = x.shape
+    xb = np.zeros((rows, d), dtype=np.uint16); ssp = np.zeros((rows, d // 16), dtype=np.float32)
+    for r in range(rows):
+        lib().q3o_norm_inputs(x[r].ctypes.data, d, nw.ctypes.data, xb[r].ctypes.data, ssp[r].ctypes.data)
+    return xb, ssp
+
+
+def row_scale(ssp_row, d, eps):
+    sp = np.ascontiguousarray(ssp_row, dtype=np.float32)
+    return float(lib().q3o_row_scale(sp.ctypes.data, sp.size, d, eps))
 
 
 # ---- the synthetic model as files (loader parity): same tensor ids / scales as oracle/q3_oracle.c tfm_init, q3o_create
