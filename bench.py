@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 
 FRAME_SEC = 0.08  # 1 frame = 16 codes = 1920 samples @ 24 kHz (reference: src/tts/engine.rs:509-512,653)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-F32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
 
 
 def vivian():
@@ -148,8 +148,8 @@ def main():
     def probe_leg(mode=2):
         """One GEMM, in situ: the same batch of 64 utterances for 24 forced frames (codes only, so nothing else shares the GPU),
         frame steps launched eagerly with HIP events on the decode stream around it. mode 2: the Talker's layer-0 gate/up GEMM
-        (k_gemm_ring<2, 3, 4, true>, exact f32 MFMA, M = 64, K = 2048, N = 12288 — the largest GEMM instance of the frame step);
-        mode 1: the Predictor's pass-1 / layer-0 gate/up (k_gemm_bf16_norm_swiglu, bf16 MFMA, M = 64, K = 1024, N = 6144)."""
+        (k_bgemm, M = 64, K = 2048, N = 12288 — the largest GEMM of the frame step); mode 1: the Predictor's pass-1 / layer-0 gate/up
+        (k_bgemm, M = 64, K = 1024, N = 6144)."""
         eng.probe(mode)
         preqs = [dict(r, min_frames=24, force_eos_at=24, max_steps=32, want_pcm=0) for r in reqs]
         for _ in range(2):
@@ -161,7 +161,7 @@ def main():
         rows = len(preqs)
         K, N = (m.t_d_model, 2 * m.t_d_ffn) if mode == 2 else (m.p_d_model, 2 * m.p_d_ffn)
         flops = 2.0 * rows * K * N
-        nbytes = 2.0 * N * K + 4.0 * rows * K + 4.0 * rows * (N // 2)
+        nbytes = 2.0 * N * K + 2.0 * rows * K + 4.0 * rows * (K // 16) + 2.0 * rows * (N // 2)  # weights + bf16 rows + tile partials + bf16 SwiGLU rows
         return {"kernel_ms": ptm.probe_kernel_ms, "empty_ms": ptm.probe_empty_ms, "launches": int(ptm.probe_count), "rows": rows, "K": K, "N": N, "flops": flops, "bytes": nbytes}
 
     if args.probe_only:
@@ -207,8 +207,8 @@ def main():
         frame_step_ms = dec_ms / max(1, steps_dev)
         hbm_gbs = bytes_step / (frame_step_ms * 1e-3) / 1e9 if frame_step_ms > 0 else 0.0
         mfma_tf = flops_step / (frame_step_ms * 1e-3) / 1e12 if frame_step_ms > 0 else 0.0
-        # arithmetic intensity = flops/bytes; the f32-input MFMA ridge is 157.3 TF / 8 TB/s = 19.7 flop/B
-        mfma_bound = bytes_step > 0 and flops_step / bytes_step > F32_MFMA_PEAK_TF * 1e3 / HBM_PEAK_GBS
+        # arithmetic intensity = flops/bytes against the bf16 ridge 2500 TF / 8 TB/s = 312 flop/B: the decoder is HBM-bound at every batch in scope
+        mfma_bound = bytes_step > 0 and flops_step / bytes_step > BF16_MFMA_PEAK_TF * 1e3 / HBM_PEAK_GBS
         tm = eng.timings()
         line = {
             "metric": "audio_sec_per_s", "value": round(value, 2), "unit": "audio-sec/s", "n_gpus": world, "steps": args.steps,
@@ -226,7 +226,7 @@ def main():
                 "what": "one frame step = sample + 15 Predictor passes + Talker step over the live row bucket (graph replay)",
                 "ms": round(frame_step_ms, 4), "mean_live_utterances": round(live, 2), "mean_rows": round(tm.mean_rows, 2),
                 "algorithmic_flops": int(flops_step), "algorithmic_bytes": int(bytes_step),
-                "tflops": round(mfma_tf, 2), "frac_of_f32_mfma_peak": round(mfma_tf / F32_MFMA_PEAK_TF, 4),
+                "tflops": round(mfma_tf, 2), "frac_of_bf16_mfma_peak": round(mfma_tf / BF16_MFMA_PEAK_TF, 4),
                 "hbm_GBs": round(hbm_gbs, 1), "frac_of_8TBs": round(hbm_gbs / HBM_PEAK_GBS, 4), "mfma_bound": bool(mfma_bound)},
         }
         if not args.no_probe:
@@ -235,42 +235,39 @@ def main():
             # overhead from above, so the kernel's own duration lies in [kernel_ms - empty_ms, kernel_ms]; rocprofv3 puts it
             # in between (profiles/README.md). `achieved` uses the whole bracket: a lower bound on the kernel's rate.
             k_ms = pr["kernel_ms"]
-            k_tf = pr["flops"] / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-            traffic = None
-            tpath = os.path.join(REPO, "profiles", "r01", "pmc_traffic.json")
+            k_gbs = pr["bytes"] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+            traffic, traffic_src = None, None
+            tpath = os.path.join(REPO, "profiles", "r02", "pmc_traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
                     traffic = json.load(f).get("hbm_bytes_per_launch")
+                traffic_src = "profiled offline (two rocprofv3 --pmc passes over `bench.py --probe-only`, profiles/r02/pmc_traffic.json), not measured in this run"
             line["roofline"] = {
-                "bound": "mfma", "achieved": round(k_tf, 2), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(k_tf / F32_MFMA_PEAK_TF, 4),
-                "traffic": traffic,
-                "kernel": "k_gemm_ring<2, 3, 4, true>: Talker gate/up GEMM + fused RMSNorm + SwiGLU, M=%d K=%d N=%d (exact f32 MFMA; the largest "
-                          "instance of the k_gemm_ring family, which holds ~36%% of all kernel time in profiles/r01/bench_b64_eager_kernel_stats.csv (the Predictor's layer GEMMs, 31%%, run on the bf16 MFMA); "
-                          "28 launches per frame step)" % (pr["rows"], pr["K"], pr["N"]),
+                "bound": "hbm", "achieved": round(k_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(k_gbs / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": "k_bgemm: Talker gate/up GEMM (row scale of the split RMSNorm + SwiGLU epilogue) on v_mfma_f32_16x16x32_bf16, M=%d K=%d N=%d, "
+                          "28 launches per frame step, the largest GEMM of the step; bf16 ridge 2500 TF / 8 TB/s = 312 flop/B > %.0f flop/B => HBM-bound" %
+                          (pr["rows"], pr["K"], pr["N"], pr["flops"] / pr["bytes"]),
                 "launch_us": round(k_ms * 1e3, 2), "empty_bracket_us": round(pr["empty_ms"] * 1e3, 2),
                 "launch_us_minus_empty_bracket": round((pr["kernel_ms"] - pr["empty_ms"]) * 1e3, 2), "launches_timed": pr["launches"],
                 "algorithmic_flops_per_launch": int(pr["flops"]), "algorithmic_bytes_per_launch": int(pr["bytes"]),
+                "tflops": round(pr["flops"] / (k_ms * 1e-3) / 1e12, 2) if k_ms > 0 else 0.0,
                 "how": "HIP events on the decode stream around every launch of this kernel in layer 0 of the Talker step, eager frame steps, "
-                       "64 live utterances, codes only (q3tts_k_probe mode 2); rocprofv3 of the same leg: profiles/r01/probe_kernel_stats.csv",
-                "peak_note": "f32-input MFMA dense peak 157.3 TF (MI355X_MICROARCH.md); the exact decoder accumulates on v_mfma_f32_16x16x4_f32; "
-                             "arithmetic intensity %.0f flop/B > ridge 19.7" % (pr["flops"] / pr["bytes"])}
-            # the Predictor's gate/up, the kernel this line was quoted on earlier in the round, now runs on the bf16 MFMA:
-            # bf16 ridge = 2500 TF / 8 TB/s = 312 flop/B, so it is HBM-bound; reported next to the headline kernel
+                       "64 live utterances, codes only (q3tts_k_probe mode 2); rocprofv3 of the same leg: profiles/r02/probe_kernel_stats.csv"}
             pb = probe_leg(1)
             b_ms = pb["kernel_ms"]
             b_gbs = pb["bytes"] / (b_ms * 1e-3) / 1e9 if b_ms > 0 else 0.0
-            line["roofline_bf16_kernel"] = {
+            line["roofline_predictor_kernel"] = {
                 "bound": "hbm", "achieved": round(b_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b_gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "k_gemm_bf16_norm_swiglu<2, 3, 4>: Predictor gate/up GEMM + fused RMSNorm + SwiGLU on v_mfma_f32_16x16x32_bf16, "
-                          "M=%d K=%d N=%d (75 launches per frame step; bit-exact against the oracle's integer restatement of the instruction)" % (pb["rows"], pb["K"], pb["N"]),
+                "kernel": "k_bgemm: Predictor gate/up GEMM, M=%d K=%d N=%d (75 launches per frame step; weights re-read 15x per frame, Infinity-Cache resident)" % (pb["rows"], pb["K"], pb["N"]),
                 "launch_us": round(b_ms * 1e3, 2), "empty_bracket_us": round(pb["empty_ms"] * 1e3, 2),
                 "launch_us_minus_empty_bracket": round((pb["kernel_ms"] - pb["empty_ms"]) * 1e3, 2), "launches_timed": pb["launches"],
                 "algorithmic_flops_per_launch": int(pb["flops"]), "algorithmic_bytes_per_launch": int(pb["bytes"]),
                 "tflops": round(pb["flops"] / (b_ms * 1e-3) / 1e12, 2) if b_ms > 0 else 0.0}
         else:
             line["roofline"] = {"bound": "mfma" if mfma_bound else "hbm", "achieved": round(mfma_tf if mfma_bound else hbm_gbs, 2),
-                                "peak": F32_MFMA_PEAK_TF if mfma_bound else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
-                                "frac": round(mfma_tf / F32_MFMA_PEAK_TF if mfma_bound else hbm_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                "peak": BF16_MFMA_PEAK_TF if mfma_bound else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                                "frac": round(mfma_tf / BF16_MFMA_PEAK_TF if mfma_bound else hbm_gbs / HBM_PEAK_GBS, 4), "traffic": None,
                                 "kernel": "whole frame step (no per-kernel probe in this run)"}
         if args.no_vocoder:
             line["invalid"] = "diagnostic run without the vocoder"

@@ -41,18 +41,21 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
     }
     const int nb0 = cg * NT, row0 = rc * RT * 16, kblocks = g.K >> 5, per = g.K >> 8, kb0 = wave * per;
     const int B = g.B;
-    const uint16_t* ap[RT];
+    const u32x4* ap[RT];  // A-tiled rows: one contiguous KiB per (row tile, k block) when the row tile is aligned, 16 B per lane always
 #pragma unroll
-    for (int i = 0; i < RT; ++i) ap[i] = g.a + (size_t)min(row0 + 16 * i + r, B - 1) * g.lda + (size_t)kb0 * 32 + 4 * kq;
+    for (int i = 0; i < RT; ++i) {
+        const int R = g.a_row0 + min(row0 + 16 * i + r, B - 1);
+        ap[i] = (const u32x4*)g.a + ((size_t)(R >> 4) * kblocks + kb0) * 64 + kq * 16 + (R & 15);
+    }
     const u32x4* wp[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) wp[j] = (const u32x4*)g.w + ((size_t)(nb0 + j) * kblocks + kb0) * 64 + lane;
-    uint2 alo[D][RT], ahi[D][RT]; u32x4 bq[D][NT];
+    u32x4 aq[D][RT], bq[D][NT];
 #pragma unroll
     for (int s = 0; s < D; ++s)
         if (s < per) {
 #pragma unroll
-            for (int i = 0; i < RT; ++i) { alo[s][i] = *(const uint2*)(ap[i] + s * 32); ahi[s][i] = *(const uint2*)(ap[i] + s * 32 + 16); }
+            for (int i = 0; i < RT; ++i) aq[s][i] = ap[i][(size_t)s * 64];
 #pragma unroll
             for (int j = 0; j < NT; ++j) bq[s][j] = wp[j][(size_t)s * 64];
         }
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
             if (s < per) {
 #pragma unroll
                 for (int i = 0; i < RT; ++i) {
-                    union { uint4 u; bf16x8 v; } a; a.u = make_uint4(alo[d][i].x, alo[d][i].y, ahi[d][i].x, ahi[d][i].y);
+                    union { u32x4 u; bf16x8 v; } a; a.u = aq[d][i];
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
                         union { u32x4 u; bf16x8 v; } b; b.u = bq[d][j];
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (s + D < per) {
 #pragma unroll
-                    for (int i = 0; i < RT; ++i) { alo[d][i] = *(const uint2*)(ap[i] + (s + D) * 32); ahi[d][i] = *(const uint2*)(ap[i] + (s + D) * 32 + 16); }
+                    for (int i = 0; i < RT; ++i) aq[d][i] = ap[i][(size_t)(s + D) * 64];
 #pragma unroll
                     for (int j = 0; j < NT; ++j) bq[d][j] = wp[j][(size_t)(s + D) * 64];
                 }
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
             float gt = part[o], up = part[o + 8];
 #pragma unroll
             for (int wv = 1; wv < 8; ++wv) { gt = gt + part[(size_t)wv * (TR * 64) + o]; up = up + part[(size_t)wv * (TR * 64) + o + 8]; }
-            if (live) g.yb[(size_t)row * g.ldyb + (size_t)(nb0 + j) * 8 + c] = q3_bf16(q3_swiglu(sc * gt, sc * up));
+            if (live) g.yb[q3_atile_off(row, (nb0 + j) * 8 + c, g.N >> 6)] = q3_bf16(q3_swiglu(sc * gt, sc * up));
             continue;
         }
         float v = part[o];
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
             const float xv = yres[it] + v;
             if (live) g.y[(size_t)row * g.ldy + col] = xv;
             if (g.nw_next) {  // the consumer's norm inputs: bf16(x * nw) and the tile's sum of squares (16-lane butterfly)
-                if (live) g.yb[(size_t)row * g.ldyb + col] = q3_bf16(xv * g.nw_next[col]);
+                if (live) g.yb[q3_atile_off(row, col, g.N >> 5)] = q3_bf16(xv * g.nw_next[col]);
                 float sq = xv * xv;
                 sq = sq + __shfl_xor(sq, 1); sq = sq + __shfl_xor(sq, 2); sq = sq + __shfl_xor(sq, 4); sq = sq + __shfl_xor(sq, 8);
                 if (live && c == 0) g.ssp_out[(size_t)row * g.ld_ssp_out + (nb0 + j)] = sq;
@@ -182,7 +185,8 @@ void q3_bgemm_prepare() {
 // (RT, NT) with the fewest bytes per workgroup-round — 32 (RT + NT) bytes per k — counted over ceil(workgroups / 256) rounds.
 // The choice never changes a result (see the header).
 int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s) {
-    if (g.B < 1 || g.N % 16 || g.K % 256 || g.K < 256 || !g.a || !g.w) return -1;
+    if (g.B < 1 || g.N % 16 || g.K % 256 || g.K < 256 || !g.a || !g.w || g.a_row0 < 0) return -1;
+    if (g.yb && ((g.epi == Q3_EPI_RESID && g.N % 32) || (g.epi == Q3_EPI_SWIGLU && g.N % 64))) return -1;  // the A-tiled output has N (N/2) columns in 32-blocks
     if (g.epi == Q3_EPI_SWIGLU && (!g.yb)) return -1;
     if (g.ssp && g.ntiles < 1) return -1;
     const int tiles = g.N / 16;
@@ -209,12 +213,14 @@ int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s) {
 // norm inputs of f32 rows (prompt rows before prefill; test hook): xb = bf16(x * nw), ssp[t] = sum of squares of tile t.
 // 256 threads per row; 16 consecutive lanes own one tile.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_norm_inputs(const float* x, int ldx, int d, const float* nw, uint16_t* xb, int ldxb, float* ssp, int ld_ssp) {
+__global__ __launch_bounds__(256) void k_norm_inputs(const float* x, int ldx, int d, const float* nw, uint16_t* xb, int xb_row0, float* ssp, int ld_ssp) {
     const int row = blockIdx.x;
-    for (int i = threadIdx.x; i < d; i += 256) q3_norm_out(x[(size_t)row * ldx + i], nw[i], xb + (size_t)row * ldxb + i, ssp + (size_t)row * ld_ssp + (i >> 4), (i & 15) == 0);
+    for (int i = threadIdx.x; i < d; i += 256)
+        q3_norm_out(x[(size_t)row * ldx + i], nw[i], xb + q3_atile_off(xb_row0 + row, i, d >> 5), ssp + (size_t)row * ld_ssp + (i >> 4), (i & 15) == 0);
 }
-void q3_launch_norm_inputs(const float* x, int ldx, int rows, int d, const float* nw, uint16_t* xb, int ldxb, float* ssp, int ld_ssp, hipStream_t s) {
-    hipLaunchKernelGGL(k_norm_inputs, dim3(rows), dim3(256), 0, s, x, ldx, d, nw, xb, ldxb, ssp, ld_ssp);
+// rows [0, rows) of x -> A-tiled rows [xb_row0, xb_row0 + rows) of xb, ssp rows [0, rows)
+void q3_launch_norm_inputs(const float* x, int ldx, int rows, int d, const float* nw, uint16_t* xb, int xb_row0, float* ssp, int ld_ssp, hipStream_t s) {
+    hipLaunchKernelGGL(k_norm_inputs, dim3(rows), dim3(256), 0, s, x, ldx, d, nw, xb, xb_row0, ssp, ld_ssp);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -224,18 +230,31 @@ void q3_launch_norm_inputs(const float* x, int ldx, int rows, int d, const float
 // 16 consecutive lanes = 16 consecutive outputs of one row, so the same kernel can emit the Predictor's norm inputs.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_project(Q3Project p) {
-    const int o = blockIdx.x * 16 + (threadIdx.x & 15), row = blockIdx.y * 16 + (threadIdx.x >> 4);
-    const int rr = min(row, p.rows - 1);
-    const float4* w4 = (const float4*)(p.w + (size_t)o * p.n_in);
-    const float4* x4 = (const float4*)(p.x + (size_t)rr * p.ldx);
+    // tile = 16 rows x 16 outputs, one thread per output element; the operands of 64 inputs at a time are staged through LDS by
+    // coalesced loads (a thread reading its own weight row straight from memory touches 16 cache lines per wave-load). The
+    // row stride of 68 floats keeps the 16 weight rows of a 128-bit LDS read on distinct banks.
+    constexpr int KC = 64, LD = KC + 4;
+    __shared__ __attribute__((aligned(16))) float ws[2][16 * LD];
+    __shared__ __attribute__((aligned(16))) float xs[2][16 * LD];
+    const int tid = threadIdx.x, oc = tid & 15, rr = tid >> 4;
+    const int o = blockIdx.x * 16 + oc, row = blockIdx.y * 16 + rr;
+    // staging role: thread t loads 4 consecutive inputs (t & 15) of weight row / activation row (t >> 4)
+    const float* wsrc = p.w + (size_t)(blockIdx.x * 16 + rr) * p.n_in + 4 * oc;
+    const float* xsrc = p.x + (size_t)min(blockIdx.y * 16 + rr, p.rows - 1) * p.ldx + 4 * oc;
     float sum = p.bias[o];
-    for (int i = 0; i < (p.n_in >> 2); i += 4) {
-        const float4 wa = w4[i], wb = w4[i + 1], wc = w4[i + 2], wd = w4[i + 3];
-        const float4 xa = x4[i], xb = x4[i + 1], xc = x4[i + 2], xd = x4[i + 3];
-        sum += xa.x * wa.x; sum += xa.y * wa.y; sum += xa.z * wa.z; sum += xa.w * wa.w;
-        sum += xb.x * wb.x; sum += xb.y * wb.y; sum += xb.z * wb.z; sum += xb.w * wb.w;
-        sum += xc.x * wc.x; sum += xc.y * wc.y; sum += xc.z * wc.z; sum += xc.w * wc.w;
-        sum += xd.x * wd.x; sum += xd.y * wd.y; sum += xd.z * wd.z; sum += xd.w * wd.w;
+    const int nch = p.n_in / KC;
+    float4 wv = *(const float4*)wsrc, xv = *(const float4*)xsrc;
+    for (int c = 0; c < nch; ++c) {
+        float* wl = ws[c & 1]; float* xl = xs[c & 1];
+        *(float4*)(wl + rr * LD + 4 * oc) = wv; *(float4*)(xl + rr * LD + 4 * oc) = xv;
+        if (c + 1 < nch) { wv = *(const float4*)(wsrc + (c + 1) * KC); xv = *(const float4*)(xsrc + (c + 1) * KC); }
+        __syncthreads();  // (two buffers: the stores of chunk c + 2 come after the barrier of chunk c + 1, which every reader of chunk c has passed)
+        const float* wr = wl + oc * LD; const float* xr = xl + rr * LD;
+#pragma unroll
+        for (int k = 0; k < KC; k += 4) {
+            const float4 a = *(const float4*)(xr + k), w4 = *(const float4*)(wr + k);
+            sum += a.x * w4.x; sum += a.y * w4.y; sum += a.z * w4.z; sum += a.w * w4.w;
+        }
     }
     const bool live = row < p.rows;
     if (live) p.y[(size_t)row * p.ldy + o] = sum;
@@ -244,13 +263,13 @@ __global__ __launch_bounds__(256) void k_project(Q3Project p) {
         float sq = sum * sum;
         sq = sq + __shfl_xor(sq, 1); sq = sq + __shfl_xor(sq, 2); sq = sq + __shfl_xor(sq, 4); sq = sq + __shfl_xor(sq, 8);
         if (live) {
-            p.xb[(size_t)row * p.ldxb + o] = hb;
-            if ((threadIdx.x & 15) == 0) p.ssp[(size_t)row * p.ld_ssp + (o >> 4)] = sq;
+            p.xb[q3_atile_off(row, o, p.n_out >> 5)] = hb;
+            if (oc == 0) p.ssp[(size_t)row * p.ld_ssp + (o >> 4)] = sq;
         }
     }
 }
 int q3_launch_project(const Q3Project& p, hipStream_t s) {
-    if (p.rows < 1 || p.n_out % 16 || p.n_in % 16) return -1;
+    if (p.rows < 1 || p.n_out % 16 || p.n_in % 64 || p.ldx % 4) return -1;
     hipLaunchKernelGGL(k_project, dim3(p.n_out / 16, (p.rows + 15) / 16), dim3(256), 0, s, p);
     return 0;
 }

@@ -235,7 +235,8 @@ static void free_tfm(Q3Tfm& t) {
 
 static int alloc_scratch(q3tts_engine* e, Q3Scratch& sc, int rows, int nqkv, int nq, int F, int dmax) {
     sc.rows = rows;
-    TRY(dalloc(e, &sc.qkv, (size_t)rows * nqkv)); TRY(dalloc(e, &sc.att, (size_t)rows * nq)); TRY(dalloc(e, &sc.h, (size_t)rows * F));
+    const size_t r16 = ((size_t)rows + 15) & ~(size_t)15;  // A-tiled buffers hold whole 16-row tiles
+    TRY(dalloc(e, &sc.qkv, (size_t)rows * nqkv)); TRY(dalloc(e, &sc.att, r16 * nq)); TRY(dalloc(e, &sc.h, r16 * F));
     return Q3TTS_OK;
 }
 
@@ -249,7 +250,7 @@ static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, uint16_t* xb, float*
     const int nt = t.d / 16;
     for (int l = 0; l < t.L; ++l) {
         Q3BGemm g{};
-        g.a = xb; g.lda = t.d; g.B = rows; g.w = t.wqkv[l]; g.K = t.d; g.N = t.nqkv; g.ssp = ssp; g.ld_ssp = nt; g.ntiles = nt; g.d_norm = t.d; g.eps = eps;
+        g.a = xb; g.B = rows; g.w = t.wqkv[l]; g.K = t.d; g.N = t.nqkv; g.ssp = ssp; g.ld_ssp = nt; g.ntiles = nt; g.d_norm = t.d; g.eps = eps;
         g.epi = Q3_EPI_STORE; g.y = sc.qkv; g.ldy = t.nqkv;
         q3_launch_bgemm(g, s);
         Q3QkPrep qp{}; qp.qkv = sc.qkv; qp.ld = t.nqkv; qp.rows = rows; qp.Hq = t.Hq; qp.Hkv = t.Hkv; qp.hd = t.hd;
@@ -261,16 +262,16 @@ static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, uint16_t* xb, float*
         at.kc = qp.kc; at.vc = qp.vc; at.n_ctx = t.n_ctx; at.row_pos = row_pos; at.row_slot = row_slot;
         at.fused = fused; at.prep = qp; at.out_bf16 = 1;
         q3_launch_attend(at, s);
-        g = Q3BGemm{}; g.a = sc.att; g.lda = t.nq; g.B = rows; g.w = t.wo[l]; g.K = t.nq; g.N = t.d; g.epi = Q3_EPI_RESID; g.y = x; g.ldy = t.d;
-        g.yb = xb; g.ldyb = t.d; g.nw_next = t.ffn_norm[l]; g.ssp_out = ssp; g.ld_ssp_out = nt;
+        g = Q3BGemm{}; g.a = sc.att; g.B = rows; g.w = t.wo[l]; g.K = t.nq; g.N = t.d; g.epi = Q3_EPI_RESID; g.y = x; g.ldy = t.d;
+        g.yb = xb; g.nw_next = t.ffn_norm[l]; g.ssp_out = ssp; g.ld_ssp_out = nt;
         q3_launch_bgemm(g, s);
-        g = Q3BGemm{}; g.a = xb; g.lda = t.d; g.B = rows; g.w = t.wgu[l]; g.K = t.d; g.N = 2 * t.F; g.ssp = ssp; g.ld_ssp = nt; g.ntiles = nt; g.d_norm = t.d;
-        g.eps = eps; g.epi = Q3_EPI_SWIGLU; g.yb = sc.h; g.ldyb = t.F;
+        g = Q3BGemm{}; g.a = xb; g.B = rows; g.w = t.wgu[l]; g.K = t.d; g.N = 2 * t.F; g.ssp = ssp; g.ld_ssp = nt; g.ntiles = nt; g.d_norm = t.d;
+        g.eps = eps; g.epi = Q3_EPI_SWIGLU; g.yb = sc.h;
         if (probe && l == 0) hipEventRecord(probe[0], s);
         q3_launch_bgemm(g, s);
         if (probe && l == 0) hipEventRecord(probe[1], s);
-        g = Q3BGemm{}; g.a = sc.h; g.lda = t.F; g.B = rows; g.w = t.wd[l]; g.K = t.F; g.N = t.d; g.epi = Q3_EPI_RESID; g.y = x; g.ldy = t.d;
-        g.yb = xb; g.ldyb = t.d; g.nw_next = l + 1 < t.L ? t.attn_norm[l + 1] : t.out_norm; g.ssp_out = ssp; g.ld_ssp_out = nt;
+        g = Q3BGemm{}; g.a = sc.h; g.B = rows; g.w = t.wd[l]; g.K = t.F; g.N = t.d; g.epi = Q3_EPI_RESID; g.y = x; g.ldy = t.d;
+        g.yb = xb; g.nw_next = l + 1 < t.L ? t.attn_norm[l + 1] : t.out_norm; g.ssp_out = ssp; g.ld_ssp_out = nt;
         q3_launch_bgemm(g, s);
     }
 }
@@ -290,8 +291,8 @@ static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
     pi.nw = e->P.attn_norm[0]; pi.xb = L.xbP; pi.ssp = L.sspP;
     q3_launch_pred_input(pi, s);
     {   // H6 (src/assets_manager.rs:383-399) for the hidden rows only: every code embedding arrives pre-projected
-        Q3Project pj{}; pj.x = L.X; pj.ldx = de; pj.rows = B; pj.w = e->proj_w; pj.bias = e->proj_b; pj.n_in = de; pj.n_out = dp; pj.y = L.px; pj.ldy = 2 * dp;
-        pj.nw = e->P.attn_norm[0]; pj.xb = L.xbP; pj.ldxb = 2 * dp; pj.ssp = L.sspP; pj.ld_ssp = 2 * (dp / 16);
+        Q3Project pj{}; pj.x = L.X; pj.ldx = de; pj.rows = B; pj.w = e->proj_w; pj.bias = e->proj_b; pj.n_in = de; pj.n_out = dp; pj.y = L.px; pj.ldy = dp;
+        pj.nw = e->P.attn_norm[0]; pj.xb = L.xbP; pj.ssp = L.sspP; pj.ld_ssp = dp / 16;  // rows [0, B) of pass A
         q3_launch_project(pj, s);
     }
     const size_t head_tile_stride = (size_t)(cbs / 16) * (dp / 32) * 64;  // uint4 per predictor head
@@ -309,9 +310,9 @@ static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
         hipEvent_t* pe = nullptr;
         if (e->probe == 1 && q == 1 && B == L.nb && e->probe_i + 2 <= 8) { pe = &e->probe_ev[e->probe_i]; e->probe_i += 2; }
         run_layers(e, e->P, L.px, L.xbP, L.sspP, rows, q == 0 ? L.posA : L.pos_q + (size_t)q * L.nb, q == 0 ? L.slotA : L.slot_id, L.sc, s, q > 0, pe);
-        // head q on the rows that carry the newest position (pass 0: the odd rows), argmax epilogue
-        Q3BGemm g{}; g.a = q == 0 ? L.xbP + dp : L.xbP; g.lda = q == 0 ? 2 * dp : dp; g.B = B; g.w = e->P.head + head_tile_stride * q; g.K = dp; g.N = cbs;
-        g.ssp = q == 0 ? L.sspP + dp / 16 : L.sspP; g.ld_ssp = q == 0 ? 2 * (dp / 16) : dp / 16; g.ntiles = dp / 16; g.d_norm = dp; g.eps = eps;
+        // head q on the rows that carry the newest position (pass 0: rows [B, 2B)), argmax epilogue
+        Q3BGemm g{}; g.a = L.xbP; g.a_row0 = q == 0 ? B : 0; g.B = B; g.w = e->P.head + head_tile_stride * q; g.K = dp; g.N = cbs;
+        g.ssp = q == 0 ? L.sspP + (size_t)B * (dp / 16) : L.sspP; g.ld_ssp = dp / 16; g.ntiles = dp / 16; g.d_norm = dp; g.eps = eps;
         g.epi = Q3_EPI_ARGMAX; g.keys = L.keys + (q + 1); g.key_stride = ncb;
         q3_launch_bgemm(g, s);
     }
@@ -319,7 +320,7 @@ static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
     hipEvent_t* pt = nullptr;  // probe mode 2: the Talker's layer-0 gate/up GEMM (the largest GEMM of the frame step)
     if (e->probe == 2 && B == L.nb && e->probe_i + 2 <= 8) { pt = &e->probe_ev[e->probe_i]; e->probe_i += 2; }
     run_layers(e, e->T, L.xT, L.xbT, L.sspT, B, L.row_pos_t, L.slot_id, L.sc, s, true, pt);
-    Q3BGemm g{}; g.a = L.xbT; g.lda = m.t_d_model; g.B = B; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab;
+    Q3BGemm g{}; g.a = L.xbT; g.B = B; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab;
     g.ssp = L.sspT; g.ld_ssp = m.t_d_model / 16; g.ntiles = m.t_d_model / 16; g.d_norm = m.t_d_model; g.eps = eps;
     g.epi = Q3_EPI_STORE; g.y = L.logits; g.ldy = m.t_vocab;
     q3_launch_bgemm(g, s);
@@ -495,12 +496,15 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
         TRYC(dalloc(e, &L.xT, (size_t)nb * m.t_d_model)); TRYC(dalloc(e, &L.logits, (size_t)nb * m.t_vocab)); TRYC(dalloc(e, &L.logits_tmp, (size_t)nb * std::max(m.t_vocab, m.t_d_model)));
         TRYC(dalloc(e, &L.X, (size_t)2 * nb * m.d_embed)); TRYC(dalloc(e, &L.fb, (size_t)nb * m.d_embed));
         TRYC(dalloc(e, &L.px, (size_t)2 * nb * m.p_d_model)); TRYC(dalloc(e, &L.keys, (size_t)nb * m.n_codebooks));
-        TRYC(dalloc(e, &L.xbT, (size_t)nb * m.t_d_model)); TRYC(dalloc(e, &L.sspT, (size_t)nb * (m.t_d_model / 16)));
-        TRYC(dalloc(e, &L.xbP, (size_t)2 * nb * m.p_d_model)); TRYC(dalloc(e, &L.sspP, (size_t)2 * nb * (m.p_d_model / 16)));
+        const size_t nb16 = ((size_t)nb + 15) & ~(size_t)15, nb2_16 = ((size_t)2 * nb + 15) & ~(size_t)15;  // A-tiled buffers hold whole 16-row tiles
+        TRYC(dalloc(e, &L.xbT, nb16 * m.t_d_model)); TRYC(dalloc(e, &L.sspT, (size_t)nb * (m.t_d_model / 16)));
+        TRYC(dalloc(e, &L.xbP, nb2_16 * m.p_d_model)); TRYC(dalloc(e, &L.sspP, (size_t)2 * nb * (m.p_d_model / 16)));
         TRYC(dalloc(e, &L.row_pos_t, (size_t)nb)); TRYC(dalloc(e, &L.slot_id, (size_t)nb)); TRYC(dalloc(e, &L.perm, (size_t)nb));
         TRYC(dalloc(e, &L.posA, (size_t)2 * nb)); TRYC(dalloc(e, &L.slotA, (size_t)2 * nb)); TRYC(dalloc(e, &L.pos_q, (size_t)m.n_codebooks * nb));
         std::vector<int> sid(nb), pa(2 * nb), sla(2 * nb), pq((size_t)m.n_codebooks * nb), rp(nb, -1);
-        for (int b = 0; b < nb; ++b) { sid[b] = b; pa[2 * b] = 0; pa[2 * b + 1] = 1; sla[2 * b] = sla[2 * b + 1] = b; }
+        // pass A of the Predictor runs 2 rows per slot: rows [0, rows) at position 0 (the projected hidden state), rows [rows, 2 rows) at
+        // position 1 (the code row); the maps follow the current row bucket (plan_rows)
+        for (int b = 0; b < nb; ++b) { sid[b] = b; pa[b] = 0; pa[nb + b] = 1; sla[b] = sla[nb + b] = b; }
         for (int q = 0; q < m.n_codebooks; ++q) for (int b = 0; b < nb; ++b) pq[(size_t)q * nb + b] = q + 1;  // src/tts/engine.rs:604
         HIPC(hipMemcpyAsync(L.slot_id, sid.data(), nb * 4, hipMemcpyHostToDevice, s));
         HIPC(hipMemcpyAsync(L.posA, pa.data(), 2 * nb * 4, hipMemcpyHostToDevice, s));
@@ -518,7 +522,7 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
     }
     TRYC(alloc_scratch(e, e->sc_pre, cfg->n_ctx, e->T.nqkv, e->T.nq, e->T.F, m.t_d_model));
     TRYC(dalloc(e, &e->xp, (size_t)cfg->n_ctx * m.t_d_model));
-    TRYC(dalloc(e, &e->xbp, (size_t)cfg->n_ctx * m.t_d_model)); TRYC(dalloc(e, &e->sspp, (size_t)cfg->n_ctx * (m.t_d_model / 16)));
+    TRYC(dalloc(e, &e->xbp, (((size_t)cfg->n_ctx + 15) & ~(size_t)15) * m.t_d_model)); TRYC(dalloc(e, &e->sspp, (size_t)cfg->n_ctx * (m.t_d_model / 16)));
     TRYC(dalloc(e, &e->pf_pos, (size_t)cfg->n_ctx)); TRYC(dalloc(e, &e->pf_slot, (size_t)cfg->n_ctx));
     { std::vector<int> pp(cfg->n_ctx); for (int i = 0; i < cfg->n_ctx; ++i) pp[i] = i;
       HIPC(hipMemcpyAsync(e->pf_pos, pp.data(), pp.size() * 4, hipMemcpyHostToDevice, s)); HIPC(hipStreamSynchronize(s)); }
@@ -695,15 +699,18 @@ static int plan_rows(q3tts_engine* e, const std::vector<int>& live_in) {
     bool ok = bi == e->cur_bucket;
     if (ok) for (int b : live) if (e->row_of_slot[b] >= e->buckets[bi]) { ok = false; break; }
     if (ok) return Q3TTS_OK;
-    std::vector<int> slot_of_row(B, -1), perm(B), used(B, 0), sla(2 * (size_t)B);
+    std::vector<int> slot_of_row(B, -1), perm(B), used(B, 0), sla(2 * (size_t)B, 0), pa(2 * (size_t)B, 0);
     int r = 0;
     for (int b : live) { slot_of_row[r++] = b; used[b] = 1; }
     for (int b = 0; b < B && r < B; ++b) if (!used[b]) slot_of_row[r++] = b;
-    for (r = 0; r < B; ++r) { perm[r] = e->row_of_slot[slot_of_row[r]]; sla[2 * r] = sla[2 * r + 1] = slot_of_row[r]; }
+    const int bs = e->buckets[bi];  // pass A: rows [0, bs) at position 0, rows [bs, 2 bs) at position 1
+    for (r = 0; r < B; ++r) perm[r] = e->row_of_slot[slot_of_row[r]];
+    for (r = 0; r < bs; ++r) { sla[r] = sla[bs + r] = slot_of_row[r]; pa[bs + r] = 1; }
     hipStream_t s = e->stream;
     Q3_HIP(e, hipMemcpyAsync(L.perm, perm.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
     Q3_HIP(e, hipMemcpyAsync(L.slot_id, slot_of_row.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
     Q3_HIP(e, hipMemcpyAsync(L.slotA, sla.data(), (size_t)2 * B * 4, hipMemcpyHostToDevice, s));
+    Q3_HIP(e, hipMemcpyAsync(L.posA, pa.data(), (size_t)2 * B * 4, hipMemcpyHostToDevice, s));
     // row state that outlives a frame: the Talker logits (sampled at the next frame) and its last hidden row (the
     // Predictor's first input)
     q3_launch_gather_rows(L.logits_tmp, L.logits, L.perm, B, e->cfg.model.t_vocab, s);
@@ -766,7 +773,7 @@ static int admit_group(q3tts_engine* e, std::vector<Adm>& grp, int total) {
     Q3_HIP(e, hipMemcpyAsync(e->pf_pos, pos.data(), (size_t)total * 4, hipMemcpyHostToDevice, s));
     Q3_HIP(e, hipMemcpyAsync(e->pf_slot, slot.data(), (size_t)total * 4, hipMemcpyHostToDevice, s));
     Q3_HIP(e, hipStreamSynchronize(s));  // pos/slot are locals
-    q3_launch_norm_inputs(e->xp, m.t_d_model, total, m.t_d_model, e->T.attn_norm[0], e->xbp, m.t_d_model, e->sspp, m.t_d_model / 16, s);
+    q3_launch_norm_inputs(e->xp, m.t_d_model, total, m.t_d_model, e->T.attn_norm[0], e->xbp, 0, e->sspp, m.t_d_model / 16, s);
     run_layers(e, e->T, e->xp, e->xbp, e->sspp, total, e->pf_pos, e->pf_slot, e->sc_pre, s);
     Q3_HIP(e, hipGetLastError());
     for (const Adm& a : grp) {
@@ -776,7 +783,7 @@ static int admit_group(q3tts_engine* e, std::vector<Adm>& grp, int total) {
         const int row = e->row_of_slot[b];
         q3_launch_copy_rows(L.xT + (size_t)row * m.t_d_model, m.t_d_model, e->xp + (size_t)(a.row0 + a.n - 1) * m.t_d_model, m.t_d_model, 1, m.t_d_model, s);
         const size_t lastr = (size_t)(a.row0 + a.n - 1);  // the last prompt row's norm inputs for out_norm came out of the last block
-        Q3BGemm g{}; g.a = e->xbp + lastr * m.t_d_model; g.lda = m.t_d_model; g.B = 1; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab;
+        Q3BGemm g{}; g.a = e->xbp; g.a_row0 = (int)lastr; g.B = 1; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab;
         g.ssp = e->sspp + lastr * (m.t_d_model / 16); g.ld_ssp = m.t_d_model / 16; g.ntiles = m.t_d_model / 16; g.d_norm = m.t_d_model; g.eps = m.rms_eps;
         g.epi = Q3_EPI_STORE; g.y = L.logits + (size_t)row * m.t_vocab; g.ldy = m.t_vocab;
         q3_launch_bgemm(g, s);
@@ -1247,23 +1254,35 @@ extern "C" int q3tts_k_sample(int32_t device, const float* logits, int32_t n, in
     return Q3TTS_OK;
 }
 
+// natural row-major bf16 rows <-> the A-tiled layout of the device buffers (q3_kernels.h)
+static std::vector<uint16_t> atile_host(const uint16_t* src, int rows, int K) {
+    std::vector<uint16_t> out((((size_t)rows + 15) & ~(size_t)15) * K, 0);
+    for (int r = 0; r < rows; ++r) for (int k = 0; k < K; ++k) out[q3_atile_off(r, k, K >> 5)] = src[(size_t)r * K + k];
+    return out;
+}
+static void untile_host(const std::vector<uint16_t>& t, int rows, int K, uint16_t* dst) {
+    for (int r = 0; r < rows; ++r) for (int k = 0; k < K; ++k) dst[(size_t)r * K + k] = t[q3_atile_off(r, k, K >> 5)];
+}
+
 // the decoder's GEMM through its launcher (q3_bgemm.hip): xb bf16 bits [B][K]; w bf16 bits row-major [N][K] (epi 2: the F gate rows,
 // then the F up rows); ssp [B][ntiles] or NULL; y in/out for epi 1. Mirrors oracle/q3_oracle_bf16.c q3o_bgemm.
 extern "C" int q3tts_k_bgemm(int32_t device, const uint16_t* xb, int32_t B, int32_t K, const uint16_t* w, int32_t N, const float* ssp, int32_t ntiles,
                              int32_t d_norm, float eps, int32_t epi, const float* nw_next, float* y, uint16_t* yb, float* ssp_out, uint64_t* keys,
                              int32_t iters, float* mean_ms) {
     if (!xb || !w || B <= 0 || K % 256 || K < 256 || N % 16 || epi < 0 || epi > 3) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm hook: K % 256 == 0, N % 16 == 0");
-    if (epi == Q3_EPI_SWIGLU && (N % 32 || !yb)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm hook: swiglu needs N % 32 == 0 and yb");
+    if (epi == Q3_EPI_SWIGLU && (N % 64 || !yb)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm hook: swiglu needs N % 64 == 0 and yb");
+    if (epi == Q3_EPI_RESID && nw_next && N % 32) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm hook: norm outputs need N % 32 == 0");
     if ((epi == Q3_EPI_STORE || epi == Q3_EPI_RESID) && !y) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm hook: y missing");
     if (epi == Q3_EPI_ARGMAX && !keys) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm hook: keys missing");
     if (epi == Q3_EPI_RESID && nw_next && (!yb || !ssp_out)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm hook: norm outputs missing");
     HK(hipSetDevice(device));
     const int F = N / 2;
+    const size_t B16 = ((size_t)B + 15) & ~(size_t)15;
     DevBuf dx, dw, dwt, ds, dn, dy, dyb, dso, dk;
-    if (dx.alloc((size_t)B * K * 2) || dw.alloc((size_t)N * K * 2) || dwt.alloc((size_t)N * K * 2) || ds.alloc((size_t)B * (ntiles > 0 ? ntiles : 1) * 4) ||
-        dn.alloc((size_t)N * 4) || dy.alloc((size_t)B * N * 4) || dyb.alloc((size_t)B * N * 2) || dso.alloc((size_t)B * (N / 16) * 4) || dk.alloc((size_t)B * 8))
+    if (dx.alloc(B16 * K * 2) || dw.alloc((size_t)N * K * 2) || dwt.alloc((size_t)N * K * 2) || ds.alloc((size_t)B * (ntiles > 0 ? ntiles : 1) * 4) ||
+        dn.alloc((size_t)N * 4) || dy.alloc((size_t)B * N * 4) || dyb.alloc(B16 * N * 2) || dso.alloc((size_t)B * (N / 16) * 4) || dk.alloc((size_t)B * 8))
         return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
-    HK(hipMemcpy(dx.p, xb, (size_t)B * K * 2, hipMemcpyHostToDevice));
+    { const std::vector<uint16_t> xt = atile_host(xb, B, K); HK(hipMemcpy(dx.p, xt.data(), xt.size() * 2, hipMemcpyHostToDevice)); }
     HK(hipMemcpy(dw.p, w, (size_t)N * K * 2, hipMemcpyHostToDevice));
     if (ssp) HK(hipMemcpy(ds.p, ssp, (size_t)B * ntiles * 4, hipMemcpyHostToDevice));
     if (nw_next) HK(hipMemcpy(dn.p, nw_next, (size_t)N * 4, hipMemcpyHostToDevice));
@@ -1272,17 +1291,17 @@ extern "C" int q3tts_k_bgemm(int32_t device, const uint16_t* xb, int32_t B, int3
     if (epi == Q3_EPI_SWIGLU) { f.mode = 1; f.src_a = (const uint16_t*)dw.p; f.src_b = (const uint16_t*)dw.p + (size_t)F * K; }
     else { f.mode = 0; f.row0 = 0; f.rows = N; f.src_a = (const uint16_t*)dw.p; }
     q3_launch_fill_tiled(f, nullptr);
-    Q3BGemm g{}; g.a = (const uint16_t*)dx.p; g.lda = K; g.B = B; g.w = (const uint4*)dwt.p; g.K = K; g.N = N;
+    Q3BGemm g{}; g.a = (const uint16_t*)dx.p; g.a_row0 = 0; g.B = B; g.w = (const uint4*)dwt.p; g.K = K; g.N = N;
     g.ssp = ssp ? (const float*)ds.p : nullptr; g.ld_ssp = ntiles; g.ntiles = ntiles; g.d_norm = d_norm; g.eps = eps; g.epi = epi;
-    g.y = (float*)dy.p; g.ldy = N; g.yb = (uint16_t*)dyb.p; g.ldyb = epi == Q3_EPI_SWIGLU ? F : N;
+    g.y = (float*)dy.p; g.ldy = N; g.yb = (uint16_t*)dyb.p;
     g.nw_next = nw_next ? (const float*)dn.p : nullptr; g.ssp_out = (float*)dso.p; g.ld_ssp_out = N / 16;
     g.keys = (unsigned long long*)dk.p; g.key_stride = 1;
     if (q3_launch_bgemm(g, nullptr)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm: shape");
     HK(hipDeviceSynchronize());
     if (epi == Q3_EPI_STORE || epi == Q3_EPI_RESID) HK(hipMemcpy(y, dy.p, (size_t)B * N * 4, hipMemcpyDeviceToHost));
-    if (epi == Q3_EPI_SWIGLU) HK(hipMemcpy(yb, dyb.p, (size_t)B * F * 2, hipMemcpyDeviceToHost));
+    if (epi == Q3_EPI_SWIGLU) { std::vector<uint16_t> t(B16 * F); HK(hipMemcpy(t.data(), dyb.p, t.size() * 2, hipMemcpyDeviceToHost)); untile_host(t, B, F, yb); }
     if (epi == Q3_EPI_RESID && nw_next) {
-        HK(hipMemcpy(yb, dyb.p, (size_t)B * N * 2, hipMemcpyDeviceToHost));
+        { std::vector<uint16_t> t(B16 * N); HK(hipMemcpy(t.data(), dyb.p, t.size() * 2, hipMemcpyDeviceToHost)); untile_host(t, B, N, yb); }
         HK(hipMemcpy(ssp_out, dso.p, (size_t)B * (N / 16) * 4, hipMemcpyDeviceToHost));
     }
     if (epi == Q3_EPI_ARGMAX) HK(hipMemcpy(keys, dk.p, (size_t)B * 8, hipMemcpyDeviceToHost));
@@ -1302,22 +1321,27 @@ extern "C" int q3tts_k_bgemm(int32_t device, const uint16_t* xb, int32_t B, int3
 // H6 through the projection kernel: y[rows][n_out] = bias + sum x * w (reference order); nw != NULL: the rows' norm inputs too
 extern "C" int q3tts_k_project(int32_t device, const float* x, int32_t rows, int32_t n_in, const float* w, const float* bias, int32_t n_out, const float* nw,
                                float* y, uint16_t* xb, float* ssp) {
-    if (!x || !w || !bias || !y || rows <= 0 || n_in % 16 || n_out % 16 || (nw && (!xb || !ssp))) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "project hook: bad argument");
+    if (!x || !w || !bias || !y || rows <= 0 || n_in % 64 || n_out % 16 || (nw && (!xb || !ssp))) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "project hook: n_in % 64 == 0, n_out % 16 == 0");
     HK(hipSetDevice(device));
     DevBuf dx, dw, db, dn, dy, dxb, dss;
     if (dx.alloc((size_t)rows * n_in * 4) || dw.alloc((size_t)n_out * n_in * 4) || db.alloc((size_t)n_out * 4) || dn.alloc((size_t)n_out * 4) ||
-        dy.alloc((size_t)rows * n_out * 4) || dxb.alloc((size_t)rows * n_out * 2) || dss.alloc((size_t)rows * (n_out / 16) * 4))
+        dy.alloc((size_t)rows * n_out * 4) || dxb.alloc((((size_t)rows + 15) & ~(size_t)15) * n_out * 2) || dss.alloc((size_t)rows * (n_out / 16) * 4))
         return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
     HK(hipMemcpy(dx.p, x, (size_t)rows * n_in * 4, hipMemcpyHostToDevice));
     HK(hipMemcpy(dw.p, w, (size_t)n_out * n_in * 4, hipMemcpyHostToDevice));
     HK(hipMemcpy(db.p, bias, (size_t)n_out * 4, hipMemcpyHostToDevice));
     if (nw) HK(hipMemcpy(dn.p, nw, (size_t)n_out * 4, hipMemcpyHostToDevice));
     Q3Project pj{}; pj.x = (const float*)dx.p; pj.ldx = n_in; pj.rows = rows; pj.w = (const float*)dw.p; pj.bias = (const float*)db.p; pj.n_in = n_in; pj.n_out = n_out;
-    pj.y = (float*)dy.p; pj.ldy = n_out; pj.nw = nw ? (const float*)dn.p : nullptr; pj.xb = (uint16_t*)dxb.p; pj.ldxb = n_out; pj.ssp = (float*)dss.p; pj.ld_ssp = n_out / 16;
+    pj.y = (float*)dy.p; pj.ldy = n_out; pj.nw = nw ? (const float*)dn.p : nullptr; pj.xb = (uint16_t*)dxb.p; pj.ssp = (float*)dss.p; pj.ld_ssp = n_out / 16;
     if (q3_launch_project(pj, nullptr)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "project: shape");
     HK(hipDeviceSynchronize());
     HK(hipMemcpy(y, dy.p, (size_t)rows * n_out * 4, hipMemcpyDeviceToHost));
-    if (nw) { HK(hipMemcpy(xb, dxb.p, (size_t)rows * n_out * 2, hipMemcpyDeviceToHost)); HK(hipMemcpy(ssp, dss.p, (size_t)rows * (n_out / 16) * 4, hipMemcpyDeviceToHost)); }
+    if (nw) {
+        if (n_out % 32) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "project hook: norm outputs need n_out % 32 == 0");
+        std::vector<uint16_t> t((((size_t)rows + 15) & ~(size_t)15) * n_out);
+        HK(hipMemcpy(t.data(), dxb.p, t.size() * 2, hipMemcpyDeviceToHost)); untile_host(t, rows, n_out, xb);
+        HK(hipMemcpy(ssp, dss.p, (size_t)rows * (n_out / 16) * 4, hipMemcpyDeviceToHost));
+    }
     return Q3TTS_OK;
 }
 
@@ -1326,12 +1350,13 @@ extern "C" int q3tts_k_norm_inputs(int32_t device, const float* x, int32_t rows,
     if (!x || !nw || !xb || !ssp || rows <= 0 || d % 256) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "norm-inputs hook: d % 256 == 0");
     HK(hipSetDevice(device));
     DevBuf dx, dn, dxb, dss;
-    if (dx.alloc((size_t)rows * d * 4) || dn.alloc((size_t)d * 4) || dxb.alloc((size_t)rows * d * 2) || dss.alloc((size_t)rows * (d / 16) * 4)) return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
+    const size_t r16 = ((size_t)rows + 15) & ~(size_t)15;
+    if (dx.alloc((size_t)rows * d * 4) || dn.alloc((size_t)d * 4) || dxb.alloc(r16 * d * 2) || dss.alloc((size_t)rows * (d / 16) * 4)) return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
     HK(hipMemcpy(dx.p, x, (size_t)rows * d * 4, hipMemcpyHostToDevice));
     HK(hipMemcpy(dn.p, nw, (size_t)d * 4, hipMemcpyHostToDevice));
-    q3_launch_norm_inputs((const float*)dx.p, d, rows, d, (const float*)dn.p, (uint16_t*)dxb.p, d, (float*)dss.p, d / 16, nullptr);
+    q3_launch_norm_inputs((const float*)dx.p, d, rows, d, (const float*)dn.p, (uint16_t*)dxb.p, 0, (float*)dss.p, d / 16, nullptr);
     HK(hipDeviceSynchronize());
-    HK(hipMemcpy(xb, dxb.p, (size_t)rows * d * 2, hipMemcpyDeviceToHost));
+    { std::vector<uint16_t> t(r16 * d); HK(hipMemcpy(t.data(), dxb.p, t.size() * 2, hipMemcpyDeviceToHost)); untile_host(t, rows, d, xb); }
     HK(hipMemcpy(ssp, dss.p, (size_t)rows * (d / 16) * 4, hipMemcpyDeviceToHost));
     return Q3TTS_OK;
 }

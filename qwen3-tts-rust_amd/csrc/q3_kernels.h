@@ -23,34 +23,42 @@ void q3_launch_gemm(const Q3Gemm& g, hipStream_t s);
 // The decoder's GEMM (q3_bgemm.hip): bf16 rows x tiled bf16 weights on v_mfma_f32_16x16x32_bf16 in the canonical
 // order RAW = (((s_0 + s_1) + ...) + s_7) over 8 K-slices. K % 256 == 0, N % 16 == 0.
 //   STORE   y[B][N] f32 = s_r * RAW (s_r from the producer's tile partials ssp; no scale when ssp == nullptr)
-//   RESID   y[B][N] f32 += RAW; with nw_next also yb[B][N] = bf16(y * nw_next) and ssp_out[B][N/16] (the consumer's norm inputs)
-//   SWIGLU  yb[B][N/2] = bf16(swiglu(s_r * RAW_gate, s_r * RAW_up)); each 16-column weight tile = 8 gate + 8 up columns
+//   RESID   y[B][N] f32 += RAW; with nw_next also yb = bf16(y * nw_next) (A-tiled) and ssp_out[B][N/16] (the consumer's norm inputs)
+//   SWIGLU  yb = bf16(swiglu(s_r * RAW_gate, s_r * RAW_up)) (A-tiled, N/2 columns); each 16-column weight tile = 8 gate + 8 up columns
 //   ARGMAX  atomicMax(keys[row * key_stride], key(s_r * RAW, column))
+// bf16 activation rows live in the SAME fragment-tiled layout as the weights ("A-tiled"): tile (rt = row/16, kb = k/32) is 1 KiB,
+// lane l = (kq = l>>4, r = l&15) owns the 16 bytes holding A[rt*16 + r][kb*32 + {4kq..4kq+3, 16+4kq..16+4kq+3}], so one wave-load of
+// an A fragment is one contiguous KiB (a row-major load would touch 16 cache lines for 32 bytes each). Buffers hold
+// ceil(rows/16)*16 rows. q3_atile_off(row, k, K/32) = element offset of A[row][k].
+Q3_HD size_t q3_atile_off(int row, int k, int kblocks) {
+    const int c = k & 31;
+    return ((((size_t)(row >> 4) * kblocks + (k >> 5)) * 64 + ((c & 15) >> 2) * 16 + (row & 15)) << 3) + (c & 3) + ((c & 16) >> 2);
+}
 struct Q3BGemm {
-    const uint16_t* a; int lda; int B;          // bf16 rows
+    const uint16_t* a; int a_row0; int B;       // A-tiled bf16 rows [a_row0, a_row0 + B) of a buffer with K columns
     const uint4* w; int K, N;                   // tiled bf16
     const float* ssp; int ld_ssp; int ntiles; int d_norm; float eps;  // row scale: s_r = 1 / sqrtf(SS(ssp[row][0..ntiles)) / d_norm + eps)
     int epi;
     float* y; int ldy;
-    uint16_t* yb; int ldyb;
+    uint16_t* yb;                               // A-tiled bf16 output (RESID: N columns; SWIGLU: N/2 columns), rows as y
     const float* nw_next; float* ssp_out; int ld_ssp_out;
     unsigned long long* keys; int key_stride;
 };
 int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s);
 void q3_bgemm_prepare();  // kernel attributes; call once outside stream capture
 // producer side of the split RMSNorm for plain f32 rows: xb = bf16(x * nw), ssp[row][t] = sum of squares of columns 16t..16t+15
-void q3_launch_norm_inputs(const float* x, int ldx, int rows, int d, const float* nw, uint16_t* xb, int ldxb, float* ssp, int ld_ssp, hipStream_t s);
+void q3_launch_norm_inputs(const float* x, int ldx, int rows, int d, const float* nw, uint16_t* xb, int xb_row0, float* ssp, int ld_ssp, hipStream_t s);
 // H6 (src/assets_manager.rs:383-399) in the reference's own f32 sequence: y[row][o] = bias[o]; for i: y += x[row][i] * w[o][i].
 // nw != nullptr: also the norm inputs of y (xb, ssp) for the Predictor's first layer.
 struct Q3Project {
     const float* x; int ldx; int rows;
     const float* w; const float* bias; int n_in, n_out;   // w f32 row-major [n_out][n_in]
     float* y; int ldy;
-    const float* nw; uint16_t* xb; int ldxb; float* ssp; int ld_ssp;
+    const float* nw; uint16_t* xb; float* ssp; int ld_ssp;   // xb A-tiled (n_out columns), rows as y
 };
 int q3_launch_project(const Q3Project& p, hipStream_t s);
 #ifdef __HIPCC__
-// one element of a norm-input row: 16 consecutive lanes own one tile (all of them must be active)
+// one element of a norm-input row: 16 consecutive lanes own one tile (all of them must be active); xb_elem = the A-tiled slot
 __device__ __forceinline__ void q3_norm_out(float v, float nwv, uint16_t* xb_elem, float* ssp_tile, bool tile_leader) {
     *xb_elem = q3_bf16(v * nwv);
     float sq = v * v;
@@ -86,7 +94,7 @@ void q3_launch_qk_prep(const Q3QkPrep& a, hipStream_t s);
 struct Q3Attend {
     const float* qkv; int ld; int rows;
     float* out; int ldo;
-    int out_bf16;     // 1: out is a bf16 buffer (uint16 bits, ldo in elements): the consumer is a bf16-MFMA GEMM (Predictor)
+    int out_bf16;     // 1: out is an A-tiled bf16 buffer with Hq*hd columns (the O projection's operand); 0: f32 rows [row][ldo] (test hook)
     int Hq, Hkv, hd;
     const uint16_t* kc; const uint16_t* vc; int n_ctx;
     const int* row_pos; const int* row_slot;
@@ -109,7 +117,8 @@ void q3_launch_sample(const Q3Sample& a, hipStream_t s);
 void q3_launch_sample_rows(const float* logits, int n, int ld, int limit, float temperature, int top_k, float top_p,
                            const float* r, int* out, hipStream_t s);
 
-// predictor input of pass A: X[b] = rmsnorm(xT[b]) (projected by a GEMM into px[2b]); px[2b+1] = proj(codec0[code0]) taken
+// predictor input of pass A (rows [0, B): the projected hidden rows, rows [B, 2B): the code rows):
+// X[b] = rmsnorm(xT[b]) (projected by k_project into px[b]); px[B + b] = proj(codec0[code0]) taken
 // from the pre-projected table (row-independent exact GEMM: the table row IS what projecting on the fly gives);
 // fb[b] = 0 + codec0[code0]
 struct Q3PredInput {
@@ -117,7 +126,7 @@ struct Q3PredInput {
     const float* codec0; int codec0_rows;
     const float* pproj0; const float* proj_b; int dp;  // proj(codec0) table [codec0_rows][dp]; bias = proj(0)
     const Q3Slot* slots; const int* row_slot; float* X; float* px; float* fb; int B;
-    const float* nw; uint16_t* xb; float* ssp;         // norm inputs of px row 2b+1 for the Predictor's first layer (ld: dp, dp/16)
+    const float* nw; uint16_t* xb; float* ssp;         // norm inputs of px row B + b (the code row; A-tiled xb, ssp ld dp/16)
 };
 void q3_launch_pred_input(const Q3PredInput& a, hipStream_t s);
 

@@ -289,7 +289,8 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
         const float ov = ((r0 + r1) + r2) + r3;
         const float l = ((lw[h2 * 4] + lw[h2 * 4 + 1]) + lw[h2 * 4 + 2]) + lw[h2 * 4 + 3];
         const size_t oi = (size_t)row * a.ldo + (size_t)(g * R + h2) * hd + d;
-        if (a.out_bf16) ((uint16_t*)a.out)[oi] = q3_bf16(ov / l); else a.out[oi] = ov / l;
+        if (a.out_bf16) ((uint16_t*)a.out)[q3_atile_off(row, (g * R + h2) * hd + d, (a.Hq * hd) >> 5)] = q3_bf16(ov / l);  // the O projection's A-tiled operand
+        else a.out[oi] = ov / l;
     }
 }
 void q3_launch_attend(const Q3Attend& a, hipStream_t s) {
@@ -480,11 +481,11 @@ __global__ __launch_bounds__(256) void k_pred_input(Q3PredInput a) {
         a.fb[(size_t)b * d + i] = 0.0f + ev;
     }
     const float* pr = ok ? a.pproj0 + (size_t)code0 * a.dp : a.proj_b;  // proj(0) = bias
-    const size_t r1 = (size_t)(2 * b + 1);
+    const int r1 = a.B + b;  // pass A rows: [0, B) the projected hidden rows, [B, 2B) the code rows
     for (int i = tid; i < a.dp; i += 256) {  // (dp % 256 == 0: whole waves, 16 consecutive lanes per norm tile)
         const float v = pr[i];
-        a.px[r1 * a.dp + i] = v;
-        q3_norm_out(v, a.nw[i], a.xb + r1 * a.dp + i, a.ssp + r1 * (a.dp >> 4) + (i >> 4), (i & 15) == 0);
+        a.px[(size_t)r1 * a.dp + i] = v;
+        q3_norm_out(v, a.nw[i], a.xb + q3_atile_off(r1, i, a.dp >> 5), a.ssp + (size_t)r1 * (a.dp >> 4) + (i >> 4), (i & 15) == 0);
     }
 }
 void q3_launch_pred_input(const Q3PredInput& a, hipStream_t s) { hipLaunchKernelGGL(k_pred_input, dim3(a.B), dim3(256), 0, s, a); }
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(256) void k_pred_next(Q3PredNext a) {
         if (!last) a.fb[(size_t)b * d + i] = f;
         else {  // the Talker's next input row and its norm inputs for layer 0
             f = f + a.tts_pad[i]; a.xT[(size_t)b * d + i] = f;
-            q3_norm_out(f, a.nw[i], a.xb + (size_t)b * d + i, a.ssp + (size_t)b * (d >> 4) + (i >> 4), (i & 15) == 0);
+            q3_norm_out(f, a.nw[i], a.xb + q3_atile_off(b, i, d >> 5), a.ssp + (size_t)b * (d >> 4) + (i >> 4), (i & 15) == 0);
         }
     }
     if (!last) {
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(256) void k_pred_next(Q3PredNext a) {
         for (int i = tid; i < a.dp; i += 256) {
             const float v = pr[i];
             a.px[(size_t)b * a.dp + i] = v;
-            q3_norm_out(v, a.nw[i], a.xb + (size_t)b * a.dp + i, a.ssp + (size_t)b * (a.dp >> 4) + (i >> 4), (i & 15) == 0);
+            q3_norm_out(v, a.nw[i], a.xb + q3_atile_off(b, i, a.dp >> 5), a.ssp + (size_t)b * (a.dp >> 4) + (i >> 4), (i & 15) == 0);
         }
     }
     if (last) {

@@ -558,7 +558,7 @@ def test_bgemm_is_a_gemm(oracle, native):
     assert np.abs(got["y"] - xf @ wf.T).max() <= 2e-5 * np.abs(xf @ wf.T).max()
 
 
-@pytest.mark.parametrize("B,K,N", [(64, 2048, 2048), (64, 6144, 2048), (64, 2048, 1024), (64, 3072, 1024), (1, 6144, 2048), (23, 512, 512), (7, 1024, 48), (130, 2048, 2048), (36, 1024, 512)])
+@pytest.mark.parametrize("B,K,N", [(64, 2048, 2048), (64, 6144, 2048), (64, 2048, 1024), (64, 3072, 1024), (1, 6144, 2048), (23, 512, 512), (7, 1024, 96), (130, 2048, 2048), (36, 1024, 512)])
 def test_bgemm_residual_and_norm_outputs_match_oracle(oracle, native, B, K, N):
     """O / down projections: x += RAW, and the consumer's norm inputs (bf16(x * nw_next), per-tile sums of squares) out of the same epilogue."""
     ref, got, _, _ = _bgemm_case(oracle, native, B, K, N, 1, False, 300 + B + K)
@@ -567,7 +567,7 @@ def test_bgemm_residual_and_norm_outputs_match_oracle(oracle, native, B, K, N):
     assert np.array_equal(_bits(got["ssp_out"]), _bits(ref["ssp_out"]))
 
 
-@pytest.mark.parametrize("B,K,N", [(64, 2048, 12288), (64, 1024, 6144), (37, 1024, 6144), (1, 2048, 12288), (128, 1024, 6144), (9, 512, 1024), (64, 512, 1024), (20, 512, 160)])
+@pytest.mark.parametrize("B,K,N", [(64, 2048, 12288), (64, 1024, 6144), (37, 1024, 6144), (1, 2048, 12288), (128, 1024, 6144), (9, 512, 1024), (64, 512, 1024), (20, 512, 192)])
 def test_bgemm_swiglu_matches_oracle(oracle, native, B, K, N):
     ref, got, _, _ = _bgemm_case(oracle, native, B, K, N, 2, True, 100 + B + N)
     assert np.array_equal(got["yb"], ref["yb"])
@@ -587,7 +587,7 @@ def test_bgemm_argmax_ties_resolve_to_the_first_index(oracle, native):
     assert np.array_equal(native.k_bgemm(xb, wb, None, 512, 1e-6, 3)["keys"], oracle.bgemm(xb, wb, None, 512, 1e-6, 3)["keys"])
 
 
-@pytest.mark.parametrize("rows,n_in,n_out", [(1, 2048, 1024), (64, 2048, 1024), (37, 512, 512), (130, 256, 48)])
+@pytest.mark.parametrize("rows,n_in,n_out", [(1, 2048, 1024), (64, 2048, 1024), (37, 512, 512), (130, 256, 96)])
 def test_projection_follows_the_reference_sequence(oracle, native, rows, n_in, n_out):
     """H6 (src/assets_manager.rs:383-399): `sum = bias; sum += h * w` in ascending input order, f32 weights. The device kernel
     and the oracle both follow that sequence, and so does a literal numpy float32 loop on a few outputs."""
