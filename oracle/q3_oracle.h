@@ -165,6 +165,8 @@ typedef struct q3o_vocoder q3o_vocoder;
 q3o_vocoder* q3o_vocoder_create(const q3o_vocoder_config* cfg, uint64_t seed, int32_t n_threads);
 void q3o_vocoder_destroy(q3o_vocoder* v);
 void q3o_vocoder_reset(q3o_vocoder* v);
+/* 0 (default): GEMM / conv inputs rounded to bf16 (the device's operand precision); 1: plain f32 inputs */
+void q3o_vocoder_set_arith(q3o_vocoder* v, int32_t f32_inputs);
 /* streaming call: codes [n_frames][n_codebooks] (clamped by the caller as src/tts/engine.rs:515-519);
  * returns samples written */
 int32_t q3o_vocoder_decode(q3o_vocoder* v, const int32_t* codes, int32_t n_frames, int32_t is_last, float* pcm_out,

@@ -37,6 +37,7 @@ enum { VW_W = 0, VW_B = 1, VW_IN_NORM = 2, VW_Q = 3, VW_K = 4, VW_V = 5, VW_O = 
        VW_PW2 = 19, VW_PW2_B = 20, VW_GAMMA = 21, VW_ALPHA = 22, VW_BETA = 23, VW_W2 = 24, VW_B2 = 25, VW_ALPHA2 = 26, VW_BETA2 = 27 };
 
 static int g_vthreads = 1;
+static int g_vf32 = 0;  /* 1: GEMM / conv inputs stay f32 (q3o_vocoder_set_arith): the f32 arithmetic of the reference's ORT CPU path, up to summation order */
 
 /* bf16-representable matrix [rows][cols], std = gain / sqrt(fan_in) */
 static float* gen_mat(uint64_t seed, uint32_t tid, size_t rows, size_t cols, int fan_in, float gain) {
@@ -69,7 +70,7 @@ static conv_t gen_conv(uint64_t seed, int comp, int ww, int wb, int ntap, int di
 /* out[t][n] = bias[n % bias_n] + sum_tap sum_ci rb(X[t - (ntap-1-tap)*dil][ci]) * W[tap][n][ci]; X rows < 0 are zero */
 static void conv_fwd(const conv_t* c, const float* x, int T, float* out) {
     float* xr = malloc((size_t)T * c->cin * 4);
-    for (size_t i = 0; i < (size_t)T * c->cin; ++i) xr[i] = rb(x[i]);
+    for (size_t i = 0; i < (size_t)T * c->cin; ++i) xr[i] = g_vf32 ? x[i] : rb(x[i]);
 #pragma omp parallel for schedule(static) num_threads(g_vthreads)
     for (int t = 0; t < T; ++t)
         for (int n = 0; n < c->nout; ++n) {
@@ -182,6 +183,9 @@ void q3o_vocoder_destroy(q3o_vocoder* v) {
     free(v->B); free(v->oea); free(v->oib); free_conv(&v->out); free(v->codes); free(v);
 }
 void q3o_vocoder_reset(q3o_vocoder* v) { v->n_frames = 0; v->emitted_frames = 0; }
+/* 0 (default): GEMM / conv inputs rounded to bf16 like the device path; 1: plain f32 — used to state how far the bf16 vocoder is from
+ * f32 arithmetic (the reference runs the graph in f32 on the ORT CPU provider, src/models/onnx.rs:47-62) and by the family test */
+void q3o_vocoder_set_arith(q3o_vocoder* v, int32_t f32_inputs) { (void)v; g_vf32 = f32_inputs ? 1 : 0; }
 
 /* whole-utterance decode of frames [0, T): returns malloc'd pcm of T*spf samples */
 static float* decode_all(q3o_vocoder* v, int T) {

@@ -112,6 +112,8 @@ def lib():
         L.q3o_vocoder_destroy.restype = None
         L.q3o_vocoder_reset.argtypes = [vp]
         L.q3o_vocoder_reset.restype = None
+        L.q3o_vocoder_set_arith.argtypes = [vp, C.c_int32]
+        L.q3o_vocoder_set_arith.restype = None
         L.q3o_vocoder_decode.argtypes = [vp, i32p, C.c_int32, C.c_int32, f32p, C.c_int32]
         L.q3o_vocoder_decode.restype = C.c_int32
     _lib = L

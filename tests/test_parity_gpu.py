@@ -237,7 +237,12 @@ def test_errors_are_loud(tiny):
 
 
 # ---- vocoder (V1-V6): PCM within an RMS tolerance of the CPU restatement ------------------------------------------
-PCM_RMS_TOL = 2e-3  # of full scale (+-1.0); bf16 MFMA vs scalar f32 accumulation order + libm vs device sin/erf/exp
+PCM_RMS_TOL = 2e-3  # of full scale (+-1.0), small vocoder shapes; bf16 MFMA vs scalar f32 accumulation order + libm vs device sin/erf/exp
+# The full shape is deeper and wider (8 transformer layers, 4 decoder blocks from 1536 channels): each bf16-operand GEMM adds its
+# 2^-9 relative rounding, so the device (bf16 operands, MFMA accumulation) sits further from BOTH oracles — the one that rounds GEMM
+# inputs to bf16 like the device, and the plain-f32 one (the reference's ORT CPU arithmetic up to summation order). Measured on
+# MI355X, 8 frames of the synthetic model: 2.5e-3 / see the printed values; signal RMS is ~0.3, i.e. ~40 dB below the signal.
+PCM_RMS_TOL_FULL = 5e-3
 
 
 @pytest.fixture(scope="module")
@@ -616,3 +621,127 @@ def test_norm_inputs_match_oracle(oracle, native, rows, d):
     # and together with the consumer's reduction it is an RMSNorm
     s = np.array([oracle.row_scale(ssp_ref[r], d, 1e-6) for r in range(rows)])
     assert np.allclose(s, 1.0 / np.sqrt((x.astype(np.float64) ** 2).mean(axis=1) + 1e-6), rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# parity at the benchmarked shape and batch (BASELINE.json configs[1] / configs[2]): the full 1.7B shape, and 64 slots
+# ---------------------------------------------------------------------------------------------------------------
+def test_full_shape_single_utterance_ids_and_pcm(oracle):
+    """configs[1] at the shape bench.py runs (28 x 2048 Talker, 5 x 1024 Predictor, 15 heads x 2048, full vocoder): one utterance,
+    n_text = 20 (31 prompt rows), greedy, 8 frames — prompt rows, prefill logits and all 8 x 16 codec ids equal the oracle's bit for
+    bit, PCM within the RMS tolerance (the achieved value is printed). The oracle needs ~1 s per frame on 16 threads."""
+    import os
+    import time
+    from q3tts import _abi, native
+    cfg = _abi.full_config_py()
+    cfg.max_batch, cfg.n_ctx, cfg.max_steps_cap = 2, 256, 64
+    threads = min(16, os.cpu_count() or 4)
+    om = oracle.OracleModel(cfg.model, seed=0, n_ctx=256, n_threads=threads)
+    eng = native.NativeEngine(cfg)
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "speakers", "vivian.json")) as f:
+            import json
+            spk = np.asarray(json.load(f)["spk_emb"], dtype=np.float32)
+        ids = np.random.default_rng(1234).integers(0, 151643, size=20)
+        desc, keep = oracle.make_prompt_desc(ids, spk_emb=spk)
+        pe = om.build_prompt(desc)
+        assert pe.shape == (31, 2048) and np.array_equal(_bits(eng.build_prompt(desc)), _bits(pe))
+        t0 = time.time()
+        h_ref, l_ref = om.talker_prefill(pe)
+        h, l = eng.talker_prefill(pe)
+        assert np.array_equal(_bits(l), _bits(l_ref)) and np.array_equal(_bits(h), _bits(h_ref))
+        ref, _ = om.generate(pe, temperature=0.0, max_steps=8, min_frames=8)
+        res = eng.generate(desc=desc, temperature=0.0, max_steps=8, min_frames=8, want_pcm=1)
+        assert ref.shape == (8, 16) and np.array_equal(res.codes, ref)
+        L = oracle.lib()
+        v = L.q3o_vocoder_create(C.byref(cfg.vocoder), 0, threads)
+        try:
+            ref_pcm = _oracle_pcm(oracle, v, np.clip(ref, 0, cfg.vocoder.codebook_size - 1).astype(np.int32))
+        finally:
+            L.q3o_vocoder_destroy(v)
+        rms = float(np.sqrt(np.mean((res.pcm - ref_pcm) ** 2)))
+        print(f"full shape, 8 greedy frames: ids equal; PCM RMS error {rms:.2e} (tolerance {PCM_RMS_TOL_FULL:.0e}, signal RMS {float(np.sqrt(np.mean(ref_pcm ** 2))):.2f}); "
+              f"oracle {time.time() - t0:.1f} s on {threads} threads")
+        assert res.pcm.shape == ref_pcm.shape == (8 * 1920,) and rms <= PCM_RMS_TOL_FULL
+        # a sampled pair on two slots at once (row bucket 2), same shape
+        reqs, refs = [], []
+        for i in range(2):
+            kw = dict(temperature=0.7, top_k=40, top_p=0.9, seed=1000 + i, max_steps=5, min_frames=3 + i, force_eos_at=3 + i)
+            refs.append(om.generate(pe, **kw)[0])
+            reqs.append(dict(desc=desc, **kw))
+        for o, r in zip(eng.generate_batch(reqs), refs):
+            assert o.status == 0 and np.array_equal(o.codes, r)
+    finally:
+        eng.close()
+        om.close()
+
+
+def test_64_slots_mixed_lengths_sampled_ids_and_pcm(oracle):
+    """configs[2] on the small shape the oracle finishes quickly: max_batch = 64, 100 mixed-length sampled requests — the row buckets
+    cross 64 -> 48 -> 32 -> 16 -> 8 -> ... -> 1, slots are re-used by the 36 requests that wait, results are handed over deferred. Every
+    request's ids equal the oracle's; PCM of a sample of them within tolerance."""
+    from q3tts import _abi, native
+    cfg = _abi.tiny_config(max_batch=64, n_ctx=256, with_vocoder=1)
+    eng = native.NativeEngine(cfg)
+    om = oracle.OracleModel(cfg.model, seed=0, n_ctx=256, n_threads=4)
+    L = oracle.lib()
+    v = L.q3o_vocoder_create(C.byref(cfg.vocoder), 0, 4)
+    try:
+        rng = np.random.default_rng(64)
+        reqs, refs = [], []
+        for i in range(100):
+            n_text = int(rng.integers(3, 30)); target = int(rng.integers(2, 41))
+            desc, keep = oracle.make_prompt_desc(rng.integers(0, 151643, size=n_text), spk_emb=_spk(cfg.model.d_embed))
+            pe = om.build_prompt(desc)
+            kw = dict(temperature=0.7, top_k=40, top_p=0.9, seed=1000 + i, max_steps=48, min_frames=target, force_eos_at=target)
+            refs.append(om.generate(pe, **kw)[0])
+            reqs.append(dict(embd=pe, want_pcm=1, **kw))
+        outs = eng.generate_batch(reqs)
+        tm = eng.timings()
+        worst = 0.0
+        for i, (o, r) in enumerate(zip(outs, refs)):
+            assert o.status == 0 and o.codes.shape == r.shape and np.array_equal(o.codes, r), i
+            if i % 9 == 0:
+                ref_pcm = _oracle_pcm(oracle, v, np.clip(r, 0, cfg.vocoder.codebook_size - 1).astype(np.int32))
+                assert o.pcm.shape == ref_pcm.shape
+                worst = max(worst, float(np.sqrt(np.mean((o.pcm - ref_pcm) ** 2))))
+        print(f"64 slots, 100 requests: ids equal; worst PCM RMS {worst:.2e}; mean live {tm.mean_live_slots:.1f}, mean rows {tm.mean_rows:.1f}")
+        assert worst <= PCM_RMS_TOL
+        assert tm.mean_rows - tm.mean_live_slots <= 8.0  # row buckets in multiples of 16: at most 15 padding rows, fewer on average
+    finally:
+        eng.close()
+        om.close()
+        L.q3o_vocoder_destroy(v)
+
+
+@pytest.mark.parametrize("n_frames", [4, 7])
+def test_full_shape_vocoder_pcm_vs_oracle(oracle, n_frames):
+    """V1-V6 at the full shape (d 1024, 8 layers x 16 heads x 64, window 72, 1536 -> 768 -> 384 -> 192 -> 96): PCM vs the oracle,
+    streaming in 4-frame chunks == one call."""
+    import os
+    from q3tts import _abi, native
+    cfg = _abi.full_config_py()
+    cfg.max_batch, cfg.n_ctx, cfg.max_steps_cap = 1, 128, 32
+    # the decoder is not under test here: shrink it so the engine comes up quickly
+    m = cfg.model
+    m.t_n_layer, m.p_n_layer = 1, 1
+    eng = native.NativeEngine(cfg)
+    L = oracle.lib()
+    v = L.q3o_vocoder_create(C.byref(cfg.vocoder), 0, min(16, os.cpu_count() or 4))
+    try:
+        codes = np.random.default_rng(n_frames).integers(0, cfg.vocoder.codebook_size, size=(n_frames, 16)).astype(np.int32)
+        ref = _oracle_pcm(oracle, v, codes)
+        L.q3o_vocoder_set_arith(v, 1)
+        try:
+            ref32 = _oracle_pcm(oracle, v, codes)   # plain f32 GEMM inputs: the reference's ORT CPU arithmetic up to summation order
+        finally:
+            L.q3o_vocoder_set_arith(v, 0)
+        one = eng.vocoder(codes)
+        e = lambda a, b: float(np.sqrt(np.mean((a - b) ** 2)))
+        print(f"full-shape vocoder, {n_frames} frames, PCM RMS: device vs bf16-input oracle {e(one, ref):.2e}, device vs f32 oracle {e(one, ref32):.2e}, "
+              f"bf16-input oracle vs f32 oracle {e(ref, ref32):.2e}; signal RMS {float(np.sqrt(np.mean(ref32 ** 2))):.2f}")
+        assert one.shape == ref.shape == (n_frames * 1920,) and e(one, ref) <= PCM_RMS_TOL_FULL and e(one, ref32) <= PCM_RMS_TOL_FULL
+        assert np.array_equal(eng.vocoder(codes, chunk_frames=4), one)
+    finally:
+        eng.close()
+        L.q3o_vocoder_destroy(v)
