@@ -167,6 +167,11 @@ void q3o_vocoder_destroy(q3o_vocoder* v);
 void q3o_vocoder_reset(q3o_vocoder* v);
 /* 0 (default): GEMM / conv inputs rounded to bf16 (the device's operand precision); 1: plain f32 inputs */
 void q3o_vocoder_set_arith(q3o_vocoder* v, int32_t f32_inputs);
+/* tests: intermediate tensors of one whole decode (stage 1 transformer input, 2 transformer output, 3 up-sampled latent, 4 PCM before
+ * the clamp) and the synthetic tensors by id, for loading the same model into the family code */
+int32_t q3o_vocoder_stage(q3o_vocoder* v, const int32_t* codes, int32_t n_frames, int32_t stage, float* out);
+void q3o_vocoder_mat(const q3o_vocoder* v, int32_t comp, int32_t which, int64_t rows, int64_t cols, int32_t fan_in, float gain, float* out);
+void q3o_vocoder_vec(const q3o_vocoder* v, int32_t comp, int32_t which, int64_t n, float base, float std, float* out);
 /* streaming call: codes [n_frames][n_codebooks] (clamped by the caller as src/tts/engine.rs:515-519);
  * returns samples written */
 int32_t q3o_vocoder_decode(q3o_vocoder* v, const int32_t* codes, int32_t n_frames, int32_t is_last, float* pcm_out,

@@ -183,11 +183,22 @@ void q3o_vocoder_destroy(q3o_vocoder* v) {
     free(v->B); free(v->oea); free(v->oib); free_conv(&v->out); free(v->codes); free(v);
 }
 void q3o_vocoder_reset(q3o_vocoder* v) { v->n_frames = 0; v->emitted_frames = 0; }
+/* synthetic tensors by (component, which) id for the family test: the same generator calls as q3o_vocoder_create */
+void q3o_vocoder_mat(const q3o_vocoder* v, int32_t comp, int32_t which, int64_t rows, int64_t cols, int32_t fan_in, float gain, float* out) {
+    float* p = gen_mat(v->seed, VTID(comp, which), (size_t)rows, (size_t)cols, fan_in, gain); memcpy(out, p, (size_t)rows * cols * 4); free(p);
+}
+void q3o_vocoder_vec(const q3o_vocoder* v, int32_t comp, int32_t which, int64_t n, float base, float std, float* out) {
+    float* p = gen_vec(v->seed, VTID(comp, which), (size_t)n, base, std); memcpy(out, p, (size_t)n * 4); free(p);
+}
 /* 0 (default): GEMM / conv inputs rounded to bf16 like the device path; 1: plain f32 — used to state how far the bf16 vocoder is from
  * f32 arithmetic (the reference runs the graph in f32 on the ORT CPU provider, src/models/onnx.rs:47-62) and by the family test */
 void q3o_vocoder_set_arith(q3o_vocoder* v, int32_t f32_inputs) { (void)v; g_vf32 = f32_inputs ? 1 : 0; }
 
 /* whole-utterance decode of frames [0, T): returns malloc'd pcm of T*spf samples */
+/* stage / stage_out (tests): 1 the transformer's input [T][d], 2 its output after the final norm [T][d], 3 the up-sampled latent
+ * [T * prod(upsample_ratios)][d], 4 the PCM before the clamp */
+static int g_stage = 0; static float* g_stage_out = NULL;
+#define STAGE(k, ptr, n) do { if (g_stage == (k) && g_stage_out) memcpy(g_stage_out, (ptr), (size_t)(n) * 4); } while (0)
 static float* decode_all(q3o_vocoder* v, int T) {
     const q3o_vocoder_config* c = &v->c;
     const int d = c->latent_dim, H = c->n_head, hd = c->head_dim, HH = H * hd, F = c->d_ffn, W = c->sliding_window;
@@ -203,6 +214,7 @@ static float* decode_all(q3o_vocoder* v, int T) {
     /* V2: causal pre-conv */
     float* x = malloc((size_t)T * d * 4);
     conv_fwd(&v->pre, e, T, x); free(e);
+    STAGE(1, x, (size_t)T * d);
     /* V3: sliding-window transformer */
     float* xn = malloc((size_t)T * d * 4); float* q = malloc((size_t)T * HH * 4); float* k = malloc((size_t)T * HH * 4);
     float* vv = malloc((size_t)T * HH * 4); float* att = malloc((size_t)T * HH * 4); float* y = malloc((size_t)T * d * 4);
@@ -248,6 +260,7 @@ static float* decode_all(q3o_vocoder* v, int T) {
         for (int t = 0; t < T; ++t) for (int i = 0; i < d; ++i) x[(size_t)t * d + i] += L->ls_mlp[i] * y[(size_t)t * d + i];
     }
     rmsnorm_rows(x, T, d, v->final_norm, c->rms_eps, xn);
+    STAGE(2, xn, (size_t)T * d);
     free(q); free(k); free(vv); free(att); free(y); free(g); free(u); free(x);
     /* V5a: upsample stages */
     float* cur = xn; int Tc = T;
@@ -279,6 +292,7 @@ static float* decode_all(q3o_vocoder* v, int T) {
         for (int t = 0; t < Tc; ++t) for (int i = 0; i < d; ++i) up[(size_t)t * d + i] += p->gamma[i] * dw[(size_t)t * d + i];
         free(dw); cur = up;
     }
+    STAGE(3, cur, (size_t)Tc * d);
     /* V5b: decoder */
     int ch = c->decoder_dim;
     float* z = malloc((size_t)Tc * ch * 4);
@@ -304,8 +318,22 @@ static float* decode_all(q3o_vocoder* v, int T) {
     snake(z, Tc, ch, v->oea, v->oib);
     float* pcm = malloc((size_t)Tc * 4);
     conv_fwd(&v->out, z, Tc, pcm); free(z);
+    STAGE(4, pcm, Tc);
     for (int t = 0; t < Tc; ++t) { if (pcm[t] > 1.0f) pcm[t] = 1.0f; if (pcm[t] < -1.0f) pcm[t] = -1.0f; }
     return pcm;
+}
+
+/* one whole-utterance decode of `codes` with an intermediate tensor copied out (see decode_all); returns the PCM sample count */
+int32_t q3o_vocoder_stage(q3o_vocoder* v, const int32_t* codes, int32_t n_frames, int32_t stage, float* out) {
+    const int ncb = v->c.n_codebooks;
+    int32_t* keep = v->codes; const int kn = v->n_frames;
+    v->codes = (int32_t*)malloc((size_t)n_frames * ncb * sizeof(int32_t));
+    memcpy(v->codes, codes, (size_t)n_frames * ncb * sizeof(int32_t));
+    g_stage = stage; g_stage_out = out;
+    float* pcm = decode_all(v, n_frames);
+    g_stage = 0; g_stage_out = NULL;
+    free(pcm); free(v->codes); v->codes = keep; v->n_frames = kn;
+    return n_frames * v->spf;
 }
 
 int32_t q3o_vocoder_decode(q3o_vocoder* v, const int32_t* codes, int32_t n_frames, int32_t is_last, float* pcm_out, int32_t max_samples) {
