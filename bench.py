@@ -2,16 +2,19 @@
 """bench.py — headline benchmark of the MI355X-native Qwen3-TTS hot path.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU; RCCL only gathers the output PCM)
+  N > 1: one rank per GPU. Under torch.distributed.run the ranks come from the environment; a plain `python bench.py --gpus N`
+  starts the N rank processes itself (children, before this process touches a GPU) and relays rank 0's JSON line.
 
-A "step" is one pass of the hot path over one batch of synthetic utterances: BASELINE.json configs[2]
-(batch = 64 mixed-length prompts per GPU, temperature 0.7 / top-k 40 / top-p 0.9, prompt -> codec ids -> 24 kHz PCM).
-Weights are seeded synthetic bf16 tensors of the Qwen3-TTS-12Hz-1.7B shape (no checkpoints offline).
-Prints ONE JSON line on rank 0.
+A "step" is one pass of the hot path over one batch of synthetic utterances: BASELINE.json configs[2] per GPU (batch = 64
+mixed-length prompts, temperature 0.7 / top-k 40 / top-p 0.9, prompt ids -> codec ids -> 24 kHz PCM); with N GPUs that is
+configs[3] (N x 64 utterances sharded by global index, RCCL only gathers the PCM). Weights are seeded synthetic bf16 tensors of the
+Qwen3-TTS-12Hz-1.7B shape (no checkpoints offline). Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,6 +27,7 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 FRAME_SEC = 0.08  # 1 frame = 16 codes = 1920 samples @ 24 kHz (reference: src/tts/engine.rs:509-512,653)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
+ROUND = "r02"
 
 
 def vivian():
@@ -31,7 +35,7 @@ def vivian():
         return np.asarray(json.load(f)["spk_emb"], dtype=np.float32)
 
 
-def make_workload(n_per_gpu, rank, world, spk, keepalive):
+def make_workload(n_per_gpu, rank, world, spk, keepalive, want_pcm):
     """the GLOBAL list of n_per_gpu*world utterances is a function of the global index
     only (n_text ~ U{8..64}, n_frames ~ U{25..250} with EOS forced at the target, sampler seed 1000 + index);
     rank r owns {i : i mod world == r}, so per-utterance results do not depend on the number of GPUs."""
@@ -46,41 +50,105 @@ def make_workload(n_per_gpu, rank, world, spk, keepalive):
         desc, keep = make_prompt_desc(ids, spk_emb=spk)
         keepalive.append((desc, keep))
         reqs.append(dict(desc=desc, temperature=0.7, top_k=40, top_p=0.9, seed=qd.global_seed(1000, gi), max_steps=256,
-                         min_frames=target, force_eos_at=target, want_pcm=1))
+                         min_frames=target, force_eos_at=target, want_pcm=want_pcm))
         frames.append(target)
     return reqs, frames
 
 
-def cpu_baseline(cfg, spk, with_voc, threads):
-    """The oracle (CPU restatement, kind "port") on a bounded sample of config 1: one utterance, n_text = 20, greedy."""
+def vocoder_macs_per_frame(v):
+    """Multiply-accumulates of the vocoder per 12.5 Hz frame, from the loaded configuration (~2.56 G at the default shape)."""
+    d, H, F = v.latent_dim, v.n_head * v.head_dim, v.d_ffn
+    macs = v.pre_conv_kernel * v.codebook_dim * d
+    macs += v.n_layer * (4 * d * H + 3 * d * F + 2 * min(v.sliding_window, 72) * H)
+    pos = 1
+    for u in range(v.n_upsample):
+        r = v.upsample_ratios[u]
+        pos *= r
+        macs += pos * (d * d + 7 * d + 8 * d * d)          # ConvTranspose (per output position) + depthwise k7 + two pointwise convs
+    macs += pos * 7 * d * v.decoder_dim
+    ch = v.decoder_dim
+    for b in range(v.n_dec_blocks):
+        r = v.dec_rates[b]
+        pos *= r
+        co = ch // 2
+        macs += pos * (2 * ch * co + 3 * (7 * co * co + co * co))
+        ch = co
+    macs += pos * 7 * ch
+    return float(macs)
+
+
+def cpu_baseline(cfg, spk, with_voc, gpu_codes, gpu_pcm):
+    """The oracle (CPU restatement, kind "port") on bounded samples of config 1 (one utterance, n_text = 20, greedy): at 4 threads
+    (what the reference configures: src/models/llama/mod.rs:420-428, src/tts/engine.rs:136) and at all host cores. The all-cores leg
+    doubles as the parity check of the run: its codes must equal the GPU's single-utterance codes, and the PCM RMS is reported."""
     import ctypes as C
     import _oracle as O
-    n_frames = 16  # ~10 s of CPU work on the box's host cores (bounded sample)
+    L = O.lib()
+    ncores = os.cpu_count() or 1
+    all_thr = min(ncores, 64)
     t0 = time.time()
-    om = O.OracleModel(cfg.model, seed=cfg.synth_seed, n_ctx=256, n_threads=threads)
+    om = O.OracleModel(cfg.model, seed=cfg.synth_seed, n_ctx=256, n_threads=all_thr)
     t_load = time.time() - t0
     ids = np.random.default_rng(1234).integers(0, 151643, size=20)
     desc, keep = O.make_prompt_desc(ids, spk_emb=spk)
-    t0 = time.time()
     pe = om.build_prompt(desc)
-    codes, _ = om.generate(pe, temperature=0.0, max_steps=n_frames, min_frames=n_frames)
-    t_ar = time.time() - t0
-    t_voc = 0.0
-    L = O.lib()
-    if with_voc and hasattr(L, "q3o_vocoder_create"):
-        v = L.q3o_vocoder_create(C.byref(cfg.vocoder), cfg.synth_seed, threads)
-        cc = np.clip(codes, 0, cfg.vocoder.codebook_size - 1).astype(np.int32)
-        pcm = np.zeros(cc.shape[0] * 1920 + 64, dtype=np.float32)
+    legs = []
+    codes_all = None
+    for thr, nfr in ((all_thr, 16), (4, 6)):
+        L.q3o_set_threads(thr)
         t0 = time.time()
-        L.q3o_vocoder_decode(v, O.ptr(cc, O.i32p), cc.shape[0], 1, O.ptr(pcm, O.f32p), pcm.size)
-        t_voc = time.time() - t0
-        L.q3o_vocoder_destroy(v)
+        codes, _ = om.generate(pe, temperature=0.0, max_steps=nfr, min_frames=nfr)
+        t_ar = time.time() - t0
+        t_voc, pcm = 0.0, None
+        if with_voc:
+            v = L.q3o_vocoder_create(C.byref(cfg.vocoder), cfg.synth_seed, thr)
+            cc = np.clip(codes, 0, cfg.vocoder.codebook_size - 1).astype(np.int32)
+            pcm = np.zeros(cc.shape[0] * 1920 + 64, dtype=np.float32)
+            t0 = time.time()
+            n = L.q3o_vocoder_decode(v, O.ptr(cc, O.i32p), cc.shape[0], 1, O.ptr(pcm, O.f32p), pcm.size)
+            t_voc = time.time() - t0
+            L.q3o_vocoder_destroy(v)
+            pcm = pcm[:n]
+        wall = t_ar + t_voc
+        legs.append({"value": round(codes.shape[0] * FRAME_SEC / wall, 4), "unit": "audio-sec/s", "cores": thr, "rtf": round(wall / (codes.shape[0] * FRAME_SEC), 3),
+                     "sample": f"config 1: 1 utterance, n_text=20 (31 prompt rows), greedy, {codes.shape[0]} frames: decoder {t_ar:.1f}s (prefill included) + vocoder {t_voc:.1f}s"})
+        if thr == all_thr:
+            codes_all, pcm_all = codes, pcm
     om.close()
-    wall = t_ar + t_voc
-    return {"value": round(codes.shape[0] * FRAME_SEC / wall, 4), "unit": "audio-sec/s", "cores": threads, "kind": "port",
-            "sample": f"config 1: 1 utterance, n_text=20 (31 prompt rows), greedy, {codes.shape[0]} frames, AR {t_ar:.1f}s + vocoder "
-                      f"{t_voc:.1f}s (synthetic weight generation {t_load:.1f}s excluded); CPU restatement, not llama.cpp/ORT",
-            "rtf": round(wall / (codes.shape[0] * FRAME_SEC), 3)}
+    parity = None
+    if gpu_codes is not None:
+        n = min(gpu_codes.shape[0], codes_all.shape[0])
+        ids_equal = bool(np.array_equal(gpu_codes[:n], codes_all[:n]))
+        parity = {"what": f"single-utterance leg vs the oracle, first {n} greedy frames of config 1 at the full shape", "ids_equal": ids_equal}
+        if gpu_pcm is not None and pcm_all is not None:
+            m = min(gpu_pcm.size, pcm_all.size, n * 1920)
+            parity["pcm_rms_error"] = float(np.sqrt(np.mean((gpu_pcm[:m] - pcm_all[:m]) ** 2)))
+            parity["pcm_signal_rms"] = float(np.sqrt(np.mean(pcm_all[:m] ** 2)))
+        assert ids_equal, "codec ids of the GPU path differ from the CPU oracle at the benchmarked shape"
+    main_leg = dict(legs[0])
+    main_leg.update({"kind": "port", "host_cores": ncores,
+                     "note": f"CPU restatement (oracle/), not llama.cpp/ORT: the reference's CPU path cannot run here; synthetic weight generation {t_load:.1f}s excluded",
+                     "four_threads": legs[1]})
+    return main_leg, parity
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (this parent never initialises a GPU) and
+    relay rank 0's JSON line."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = max(rc, p.wait())
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return rc
 
 
 def main():
@@ -94,9 +162,12 @@ def main():
     ap.add_argument("--no-single", action="store_true", help="skip the batch=1 RTF / first-chunk leg")
     ap.add_argument("--n-ctx", type=int, default=4096)
     ap.add_argument("--no-probe", action="store_true", help="skip the in-situ dominant-kernel measurement (roofline.achieved falls back to the whole frame step)")
-    ap.add_argument("--probe-only", nargs="?", const="talker", default=None, choices=["talker", "predictor"],
-                    help="run only the probe leg (the command profiled for profiles/*/probe_kernel_stats.csv): the Talker's gate/up (default) or the Predictor's")
+    ap.add_argument("--probe-only", nargs="?", const="talker", default=None, choices=["talker", "predictor", "vocoder"],
+                    help=f"run only one probe leg (the commands profiled for profiles/{ROUND}/*): the Talker's gate/up (default), the Predictor's, or the vocoder alone")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -107,7 +178,6 @@ def main():
     backend = os.environ.get("Q3TTS_DIST_BACKEND", "nccl")
     if os.environ.get("Q3TTS_ONE_GPU", "0") not in ("", "0"):
         local_rank = 0
-    tdev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -118,32 +188,41 @@ def main():
             dist.init_process_group(backend)
 
     from q3tts import _abi, native
+    from q3tts import dist as qd
     cfg = _abi.full_config_py()
     cfg.device, cfg.max_batch, cfg.n_ctx, cfg.max_steps_cap = local_rank, min(64, args.batch), args.n_ctx, 512
     cfg.with_vocoder = 0 if args.no_vocoder else 1
     eng = native.NativeEngine(cfg)
     spk = vivian()
     keepalive = []
-    reqs, frames = make_workload(args.batch, rank, world, spk, keepalive)
-    if args.no_vocoder:
-        for r in reqs:
-            r["want_pcm"] = 0
+    dev_gather = world > 1 and cfg.with_vocoder
+    if dev_gather:
+        eng.set_device_pcm(True)   # the gather reads the PCM where the vocoder wrote it; no per-rank host copy
+    reqs, frames = make_workload(args.batch, rank, world, spk, keepalive, 0 if args.no_vocoder else (2 if dev_gather else 1))
 
     def sync_all():
         if dist is not None:
             import torch
-            if tdev == "cuda":
+            if backend == "nccl":
                 torch.cuda.synchronize()
             dist.barrier()
 
     def gather_pcm(outs):
-        """RCCL over xGMI: lengths all-gather + padded gather of the PCM to rank 0 (the only collective on the path)."""
-        if dist is None:
-            return
+        """RCCL over xGMI: one all_gather of the lengths, one padded gather of the i16 PCM from device memory to rank 0, which then
+        holds every utterance on its host (the only collective on the path). Returns the seconds spent (0 when N = 1)."""
+        if dist is None or not dev_gather:
+            return 0.0
         import torch
-        from q3tts import dist as qd
-        qd.gather_pcm(dist, [o.pcm if o.pcm is not None else np.zeros(0, dtype=np.float32) for o in outs], rank, world,
-                      device=tdev, dtype=torch.float16, to_numpy=False)
+        t0 = time.perf_counter()
+        rows = qd.device_pcm_tensor(eng, torch.device("cuda", local_rank))
+        if backend != "nccl":
+            rows = rows.cpu()
+        g = qd.gather_pcm_device(dist, rows, [o.n_samples for o in outs], rank, world, as_i16=True)
+        if rank == 0:
+            host = [t.cpu() for t in g[0]]  # noqa: F841  (rank 0 ends with every utterance's PCM in host memory)
+        elif backend == "nccl":
+            torch.cuda.synchronize()
+        return time.perf_counter() - t0
 
     def probe_leg(mode=2):
         """One GEMM, in situ: the same batch of 64 utterances for 24 forced frames (codes only, so nothing else shares the GPU),
@@ -162,26 +241,39 @@ def main():
         K, N = (m.t_d_model, 2 * m.t_d_ffn) if mode == 2 else (m.p_d_model, 2 * m.p_d_ffn)
         flops = 2.0 * rows * K * N
         nbytes = 2.0 * N * K + 2.0 * rows * K + 4.0 * rows * (K // 16) + 2.0 * rows * (N // 2)  # weights + bf16 rows + tile partials + bf16 SwiGLU rows
-        return {"kernel_ms": ptm.probe_kernel_ms, "empty_ms": ptm.probe_empty_ms, "launches": int(ptm.probe_count), "rows": rows, "K": K, "N": N, "flops": flops, "bytes": nbytes}
+        return {"kernel_ms": ptm.probe_kernel_ms, "empty_ms": ptm.probe_empty_ms, "launches": int(ptm.probe_count), "rows": rows, "K": K, "N": N,
+                "flops": flops, "bytes": nbytes, "frame_step_ms": ptm.frame_step_ms}
+
+    def vocoder_leg():
+        ms = eng.vocoder_bench(min(64, cfg.max_batch), 8)
+        fl = 2.0 * vocoder_macs_per_frame(cfg.vocoder)
+        nfr = min(64, cfg.max_batch) * 4
+        tf = fl * nfr / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": round(tf, 1), "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / BF16_MFMA_PEAK_TF, 4), "traffic": None,
+                "kernel": "the vocoder's kernels together (k_vgemm_lds / k_vgemm_small / k_voc_resunit / k_voc_*): one batched 4-frame call for 64 slots, "
+                          "nothing else on the GPU", "ms_per_call": round(ms, 3), "frames_per_call": nfr, "algorithmic_flops_per_frame": int(fl),
+                "how": "HIP events on the stream around 8 batched calls (q3tts_k_vocoder_bench); FLOPs from the loaded vocoder configuration"}
 
     if args.probe_only:
-        pr = probe_leg(2 if args.probe_only == "talker" else 1)
+        pr = vocoder_leg() if args.probe_only == "vocoder" else probe_leg(2 if args.probe_only == "talker" else 1)
         if rank == 0:
             print(json.dumps({"probe": pr}), flush=True)
         eng.close()
         return
 
     for _ in range(args.warmup):
-        outs = eng.generate_batch(reqs)
-        gather_pcm(outs)
+        gather_pcm(eng.generate_batch(reqs))
     sync_all()
     t0 = time.perf_counter()
     step_frames = 0
     dec_ms = steps_dev = bytes_step = flops_step = live = 0
+    t_gather = 0.0
+    utt_rtf = []
     for _ in range(args.steps):
         outs = eng.generate_batch(reqs)
-        gather_pcm(outs)
+        t_gather += gather_pcm(outs)
         step_frames += sum(o.n_frames for o in outs)
+        utt_rtf += [o.total_ms / (o.n_frames * 80.0) for o in outs if o.n_frames > 0]
         tm = eng.timings()
         dec_ms += tm.decode_ms
         steps_dev += tm.frame_steps
@@ -192,13 +284,14 @@ def main():
     assert [o.n_frames for o in outs] == frames, "forced lengths not honoured"
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed, float(step_frames)], dtype=torch.float64, device=tdev)
+        tdev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed, float(step_frames), elapsed - t_gather], dtype=torch.float64, device=tdev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed, total_frames = float(tmax[0].item()), float(t[1].item())
+        elapsed, total_frames, elapsed_nog = float(tmax[0].item()), float(t[1].item()), float(tmax[2].item())
     else:
-        total_frames = float(step_frames)
+        total_frames, elapsed_nog = float(step_frames), elapsed
 
     line = None
     if rank == 0:
@@ -207,28 +300,32 @@ def main():
         frame_step_ms = dec_ms / max(1, steps_dev)
         hbm_gbs = bytes_step / (frame_step_ms * 1e-3) / 1e9 if frame_step_ms > 0 else 0.0
         mfma_tf = flops_step / (frame_step_ms * 1e-3) / 1e12 if frame_step_ms > 0 else 0.0
-        # arithmetic intensity = flops/bytes against the bf16 ridge 2500 TF / 8 TB/s = 312 flop/B: the decoder is HBM-bound at every batch in scope
-        mfma_bound = bytes_step > 0 and flops_step / bytes_step > BF16_MFMA_PEAK_TF * 1e3 / HBM_PEAK_GBS
         tm = eng.timings()
+        rt = np.asarray(utt_rtf) if utt_rtf else np.zeros(1)
         line = {
             "metric": "audio_sec_per_s", "value": round(value, 2), "unit": "audio-sec/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: batch=%d mixed-length prompts per GPU (n_text~U{8..64}, n_frames~U{25..250} "
+            "config": {"workload": "BASELINE.json configs[%d]: batch=%d mixed-length prompts per GPU (n_text~U{8..64}, n_frames~U{25..250} "
                                    "EOS-forced), temperature=0.7 top-k=40 top-p=0.9, prompt ids -> codec ids -> 24 kHz PCM%s" %
-                                   (args.batch, " + RCCL PCM gather" if world > 1 else ""),
+                                   (3 if world > 1 else 2, args.batch, " on %d GPUs, utterances sharded by global index, one RCCL gather of the i16 PCM to rank 0" % world if world > 1 else ""),
                        "shape": "Qwen3-TTS-12Hz-1.7B (28x2048 Talker, 5x1024 Predictor, 8-layer codec vocoder), seeded synthetic bf16 weights",
                        "utterances_per_gpu": args.batch, "n_ctx": args.n_ctx, "with_vocoder": not args.no_vocoder},
             "rtf_per_utterance": round(frame_step_ms / 80.0, 5),
+            "rtf_per_utterance_what": "frame_step_ms / 80 ms: the real-time factor every live utterance of the batch advances at",
+            "utterance_latency_rtf": {"what": "(batch start -> this utterance's PCM complete) / its audio seconds, over the utterances of the timed steps on rank 0",
+                                      "mean": round(float(rt.mean()), 4), "p50": round(float(np.median(rt)), 4), "p95": round(float(np.percentile(rt, 95)), 4)},
             "frame_step_ms": round(frame_step_ms, 4),
             "stage_ms_last_step": {"prefill": round(tm.prefill_ms, 2), "decode": round(tm.decode_ms, 2), "vocoder_host_wait": round(tm.vocoder_ms, 2)},
             "frame_step": {
-                "what": "one frame step = sample + 15 Predictor passes + Talker step over the live row bucket (graph replay)",
+                "what": "one frame step = sample + 15 Predictor passes + Talker step over the live row bucket (graph replay; the vocoder shares the GPU on its own stream)",
                 "ms": round(frame_step_ms, 4), "mean_live_utterances": round(live, 2), "mean_rows": round(tm.mean_rows, 2),
                 "algorithmic_flops": int(flops_step), "algorithmic_bytes": int(bytes_step),
-                "tflops": round(mfma_tf, 2), "frac_of_bf16_mfma_peak": round(mfma_tf / BF16_MFMA_PEAK_TF, 4),
-                "hbm_GBs": round(hbm_gbs, 1), "frac_of_8TBs": round(hbm_gbs / HBM_PEAK_GBS, 4), "mfma_bound": bool(mfma_bound)},
+                "tflops": round(mfma_tf, 2), "hbm_GBs": round(hbm_gbs, 1), "frac_of_8TBs": round(hbm_gbs / HBM_PEAK_GBS, 4)},
         }
+        if world > 1:
+            line["value_without_gather"] = round(audio_sec / elapsed_nog, 2)
+            line["gather_ms_per_step"] = round(t_gather / args.steps * 1e3, 3)
         if not args.no_probe:
             pr = probe_leg(2)
             # The bracket also times the closing event packet. An EMPTY bracket on the same stream (empty_ms) bounds that
@@ -237,11 +334,11 @@ def main():
             k_ms = pr["kernel_ms"]
             k_gbs = pr["bytes"] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
             traffic, traffic_src = None, None
-            tpath = os.path.join(REPO, "profiles", "r02", "pmc_traffic.json")
+            tpath = os.path.join(REPO, "profiles", ROUND, "pmc_traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
                     traffic = json.load(f).get("hbm_bytes_per_launch")
-                traffic_src = "profiled offline (two rocprofv3 --pmc passes over `bench.py --probe-only`, profiles/r02/pmc_traffic.json), not measured in this run"
+                traffic_src = f"profiled offline (two rocprofv3 --pmc passes over `bench.py --probe-only`, profiles/{ROUND}/pmc_traffic.json), not measured in this run"
             line["roofline"] = {
                 "bound": "hbm", "achieved": round(k_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(k_gbs / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
@@ -253,7 +350,8 @@ def main():
                 "algorithmic_flops_per_launch": int(pr["flops"]), "algorithmic_bytes_per_launch": int(pr["bytes"]),
                 "tflops": round(pr["flops"] / (k_ms * 1e-3) / 1e12, 2) if k_ms > 0 else 0.0,
                 "how": "HIP events on the decode stream around every launch of this kernel in layer 0 of the Talker step, eager frame steps, "
-                       "64 live utterances, codes only (q3tts_k_probe mode 2); rocprofv3 of the same leg: profiles/r02/probe_kernel_stats.csv"}
+                       f"64 live utterances, codes only (q3tts_k_probe mode 2); rocprofv3 of the same leg: profiles/{ROUND}/probe_kernel_stats.csv"}
+            line["frame_step_64_rows_codes_only_ms"] = round(pr["frame_step_ms"], 4)
             pb = probe_leg(1)
             b_ms = pb["kernel_ms"]
             b_gbs = pb["bytes"] / (b_ms * 1e-3) / 1e9 if b_ms > 0 else 0.0
@@ -264,15 +362,16 @@ def main():
                 "launch_us_minus_empty_bracket": round((pb["kernel_ms"] - pb["empty_ms"]) * 1e3, 2), "launches_timed": pb["launches"],
                 "algorithmic_flops_per_launch": int(pb["flops"]), "algorithmic_bytes_per_launch": int(pb["bytes"]),
                 "tflops": round(pb["flops"] / (b_ms * 1e-3) / 1e12, 2) if b_ms > 0 else 0.0}
+            if cfg.with_vocoder:
+                line["roofline_vocoder"] = vocoder_leg()
         else:
-            line["roofline"] = {"bound": "mfma" if mfma_bound else "hbm", "achieved": round(mfma_tf if mfma_bound else hbm_gbs, 2),
-                                "peak": BF16_MFMA_PEAK_TF if mfma_bound else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma_bound else "GB/s",
-                                "frac": round(mfma_tf / BF16_MFMA_PEAK_TF if mfma_bound else hbm_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            line["roofline"] = {"bound": "hbm", "achieved": round(hbm_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_gbs / HBM_PEAK_GBS, 4), "traffic": None,
                                 "kernel": "whole frame step (no per-kernel probe in this run)"}
         if args.no_vocoder:
             line["invalid"] = "diagnostic run without the vocoder"
 
     # batch = 1 leg (BASELINE configs[1] / configs[4]): RTF and p50 first-chunk latency, outside the timed region
+    gpu_codes = gpu_pcm = None
     if rank == 0 and not args.no_single:
         eng.close()
         cfg1 = _abi.full_config_py()
@@ -287,11 +386,16 @@ def main():
             o = e1.generate(desc=desc, temperature=0.0, max_steps=64, min_frames=64, want_pcm=cfg.with_vocoder)
             dt = time.perf_counter() - t1
             if it >= 2:
-                firsts.append(o.first_chunk_ms)
                 rtfs.append(dt / (o.n_frames * FRAME_SEC))
+        gpu_codes, gpu_pcm = o.codes, o.pcm
         t1m = e1.timings()
-        line["single_utterance"] = {"workload": "BASELINE.json configs[1]: 1 utterance, n_text=20, greedy, 64 frames",
+        for it in range(54):   # first-chunk latency: median over >= 50 runs; 8 frames each
+            o = e1.generate(desc=desc, temperature=0.0, max_steps=8, min_frames=8, want_pcm=cfg.with_vocoder)
+            if it >= 2:
+                firsts.append(o.first_chunk_ms)
+        line["single_utterance"] = {"workload": "BASELINE.json configs[1]: 1 utterance, n_text=20, greedy, 64 frames (RTF over 10 runs); first chunk over %d runs" % len(firsts),
                                     "rtf_p50": round(float(np.median(rtfs)), 5), "first_chunk_ms_p50": round(float(np.median(firsts)), 2),
+                                    "first_chunk_ms_p95": round(float(np.percentile(firsts, 95)), 2),
                                     "frame_step_ms": round(t1m.frame_step_ms, 4),
                                     "hbm_GBs": round(t1m.algo_bytes_per_step / (t1m.frame_step_ms * 1e-3) / 1e9, 1) if t1m.frame_step_ms else 0}
         # BASELINE configs[4], clone variant: a 3 s (72 000-sample) synthetic reference clip goes through the device
@@ -320,8 +424,9 @@ def main():
             "first_chunk_incl_front_end_ms_p50": round(float(np.median(np.asarray(fe) + np.asarray(cf))), 2)}
         e1.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        threads = min(16, os.cpu_count() or 1)
-        line["cpu_baseline"] = cpu_baseline(cfg, spk, cfg.with_vocoder, threads)
+        line["cpu_baseline"], parity = cpu_baseline(cfg, spk, cfg.with_vocoder, gpu_codes, gpu_pcm)
+        if parity:
+            line["parity_in_this_run"] = parity
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

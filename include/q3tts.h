@@ -135,6 +135,13 @@ typedef struct q3tts_prompt_desc {
  * (free with q3tts_free). */
 int q3tts_build_prompt(q3tts_engine* e, const q3tts_prompt_desc* p, float** out_embd, int32_t* out_n_tok);
 void q3tts_free(void* p);
+/* Device-resident results for the multi-GPU gather (the one collective of the path reads device memory). With
+ * enable = 1 every q3tts_generate_batch call also keeps request i's PCM in row i of an engine-owned device buffer [n][stride] f32,
+ * valid until the next call on this engine; requests with want_pcm = 2 skip the host copy. q3tts_get_device_pcm returns the buffer
+ * of the last call (base may be NULL before the first one). The reference has no counterpart: it is one utterance at a time on one
+ * device (src/models/llama/mod.rs:413, n_seq_max = 1). */
+int q3tts_set_device_pcm(q3tts_engine* e, int32_t enable);
+int q3tts_get_device_pcm(q3tts_engine* e, float** base, int64_t* stride_samples, int32_t* n_rows);
 
 /* ---- generation (run_inference_stream: src/tts/engine.rs:445-656) ------------------------------ */
 typedef struct q3tts_request {
@@ -145,7 +152,7 @@ typedef struct q3tts_request {
     int32_t max_steps;    /* 0 -> engine value */
     int32_t min_frames;   /* bench control: EOS logit masked while n_frames < min_frames (0 = reference) */
     int32_t force_eos_at; /* bench control: EOS forced at this step (<0 = off) */
-    int32_t want_pcm;     /* 0: codec ids only */
+    int32_t want_pcm;     /* 0: codec ids only; 1: PCM in host memory; 2: PCM kept on the device only (q3tts_set_device_pcm) */
 } q3tts_request;
 
 typedef struct q3tts_result {
@@ -269,6 +276,9 @@ int q3tts_k_talker_prefill(q3tts_engine* e, const float* embd, int32_t n_tok, fl
 /* Vocoder: codes [n_frames][n_codebooks] -> pcm; chunk_frames frames per streaming call (0 = one call) */
 int q3tts_k_vocoder(q3tts_engine* e, const int32_t* codes, int32_t n_frames, int32_t chunk_frames, float* pcm_out,
                     int32_t* n_samples_out);
+/* Measurement (bench.py roofline_vocoder): the batched vocoder alone, n_slots slots x `chunks` 4-frame calls with nothing else on the
+ * GPU; *ms_per_chunk = mean duration of one batched call (n_slots x 4 frames of PCM) by HIP events on its stream. */
+int q3tts_k_vocoder_bench(q3tts_engine* e, int32_t n_slots, int32_t chunks, float* ms_per_chunk);
 /* Host-only: one tensor of a GGUF file (or the array of an .npy file; `tensor` is then ignored) as f32, through the same
  * reader the engine uses for weights_path. out may be NULL to query nelem / dims (ggml order: dims4[0] is the row length)
  * / ggml type (0 F32, 1 F16, 8 Q8_0, 30 BF16). Needs no GPU. */

@@ -716,6 +716,7 @@ void q3o_destroy(q3o_model* m) {
     tfm_free(&m->T); tfm_free(&m->P); free(m->proj_w); free(m->proj_b); free(m);
 }
 void q3o_set_arith(q3o_model* m, int32_t arith) { m->arith = arith; }
+void q3o_set_threads(int32_t n) { g_threads = n > 0 ? n : 1; }  /* OpenMP threads of the GEMMs (bench.py: the 4-thread and all-cores legs) */
 /* natural-order f32 copies of the synthetic tensors, for loading the same model into the family code (tests) */
 const float* q3o_norm_weight(const q3o_model* m, int32_t talker, int32_t layer, int32_t which) {
     const tfm* t = talker ? &m->T : &m->P;

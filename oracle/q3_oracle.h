@@ -105,6 +105,7 @@ void q3o_bgemm(const uint16_t* xb, int32_t B, int32_t K, const uint16_t* w, int3
 void q3o_project_rows(const float* w, const float* bias, int32_t n_in, int32_t n_out, const float* x, int32_t rows, float* y);
 /* 0: canonical bf16-MFMA order (default, what the device computes); 1: plain f32 of the same structure (family pinning) */
 void q3o_set_arith(q3o_model* m, int32_t arith);
+void q3o_set_threads(int32_t n);
 const float* q3o_norm_weight(const q3o_model* m, int32_t talker, int32_t layer, int32_t which);
 int32_t q3o_matrix(const q3o_model* m, int32_t talker, int32_t layer, int32_t which, float* out);
 /* H4 sampler: src/models/llama/mod.rs:666-772 */

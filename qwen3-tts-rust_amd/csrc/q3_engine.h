@@ -94,6 +94,8 @@ struct q3tts_engine {
     std::vector<hipEvent_t> probe_ev;   // 2 per frame of a chunk
     int probe_i = 0;
     double probe_ms = 0, probe_empty_ms = 0; long long probe_cnt = 0, probe_empty_cnt = 0, row_steps = 0;
+    // q3tts_set_device_pcm: packed device copy of the last batch's PCM, one row of dev_pcm_stride samples per request
+    int dev_pcm_on = 0; float* dev_pcm = nullptr; int dev_pcm_n = 0; size_t dev_pcm_stride = 0;
     float* first_chunk_host = nullptr;  // pinned landing buffer of the first 4-frame PCM chunk (first-chunk latency)
 };
 

@@ -587,7 +587,7 @@ extern "C" void q3tts_engine_destroy(q3tts_engine* e) {
     }
     free_tfm(e->T); free_tfm(e->P);
     hipFree(e->text); for (auto p : e->codec) hipFree(p); for (auto p : e->pproj) hipFree(p); hipFree((void*)e->codec_dev); hipFree(e->proj_w); hipFree(e->proj_b);
-    hipFree(e->tts_pad_own); hipFree(e->marker_row);
+    hipFree(e->tts_pad_own); hipFree(e->marker_row); hipFree(e->dev_pcm);
     hipFree(e->slots); if (e->slots_host) hipHostFree(e->slots_host);
     hipFree(e->codes); hipFree(e->rng);
     hipFree(e->sc_pre.qkv); hipFree(e->sc_pre.att); hipFree(e->sc_pre.h);
@@ -612,6 +612,19 @@ extern "C" int q3tts_set_max_steps(q3tts_engine* e, int32_t n) {
     return Q3TTS_OK;
 }
 extern "C" void q3tts_free(void* p) { free(p); }
+// Device-resident results for multi-GPU gathers: with enable = 1 every q3tts_generate_batch call also keeps each
+// request's PCM in row i of an engine-owned device buffer [n][stride] f32 (valid until the next call); requests with want_pcm = 2
+// skip the host copy altogether.
+extern "C" int q3tts_set_device_pcm(q3tts_engine* e, int32_t enable) {
+    if (!e) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "null engine");
+    e->dev_pcm_on = enable ? 1 : 0;
+    return Q3TTS_OK;
+}
+extern "C" int q3tts_get_device_pcm(q3tts_engine* e, float** base, int64_t* stride_samples, int32_t* n_rows) {
+    if (!e || !base || !stride_samples || !n_rows) return q3_set_err(e, Q3TTS_ERR_INVALID, "null argument");
+    *base = e->dev_pcm; *stride_samples = (int64_t)e->dev_pcm_stride; *n_rows = e->dev_pcm_n;
+    return Q3TTS_OK;
+}
 
 // ------------------------------------------------------------------------------------------------
 // H1 prompt builder: row list on the host (src/tts/prompt.rs:141-277, :28-118), gathers on the device
@@ -894,7 +907,7 @@ void pin_free(float* q) {
 // vocoder chunk, `fin_ev` is recorded after it and the caller completes the result later (complete_result), so the next
 // decode chunk is launched while the vocoder is still working.
 static int finalize(q3tts_engine* e, int b, const q3tts_request* r, q3tts_result* o, const SlotRun& sr, double t0, bool defer = false,
-                    hipEvent_t fin_ev = nullptr) {
+                    hipEvent_t fin_ev = nullptr, int ri = -1) {
     const int ncb = e->cfg.model.n_codebooks;
     const Q3Slot& st = e->slots_host[b];
     o->n_frames = st.n_frames; o->hit_eos = st.hit_eos;
@@ -904,7 +917,16 @@ static int finalize(q3tts_engine* e, int b, const q3tts_request* r, q3tts_result
         Q3_HIP(e, hipMemcpyAsync(o->codes, e->codes + (size_t)b * e->cfg.max_steps_cap * ncb, sizeof(int32_t) * (size_t)st.n_frames * ncb,
                                  hipMemcpyDeviceToHost, e->stream));
     o->sample_rate = e->cfg.vocoder.sample_rate;
-    if (r->want_pcm && e->voc) {
+    if (r->want_pcm && e->voc && e->dev_pcm && ri >= 0 && ri < e->dev_pcm_n) {
+        // device copy of the utterance's PCM (q3tts_set_device_pcm): row ri of the packed buffer, for collectives that read device memory
+        const int ns = q3_voc_samples(e, b);
+        if (ns > 0) Q3_HIP(e, hipMemcpyAsync(e->dev_pcm + (size_t)ri * e->dev_pcm_stride, q3_voc_pcm(e, b), sizeof(float) * (size_t)ns, hipMemcpyDeviceToDevice, e->vstream));
+    }
+    if (r->want_pcm == 2 && e->voc) {  // device only: no host copy
+        o->n_samples = q3_voc_samples(e, b);
+        if (defer) Q3_HIP(e, hipEventRecord(fin_ev, e->vstream));
+        else Q3_HIP(e, hipStreamSynchronize(e->vstream));
+    } else if (r->want_pcm && e->voc) {
         const int ns = q3_voc_samples(e, b);
         o->n_samples = ns;
         o->pcm = pin_alloc(sizeof(float) * (size_t)std::max(1, ns));
@@ -933,8 +955,19 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
     if (!e || !reqs || !outs || n <= 0) return q3_set_err(e, Q3TTS_ERR_INVALID, "null/empty argument");
     Q3_HIP(e, hipSetDevice(e->cfg.device));
     for (int i = 0; i < n; ++i) { memset(&outs[i], 0, sizeof(outs[i])); outs[i].status = Q3TTS_ERR_STATE; }
-    for (int i = 0; i < n; ++i)
+    for (int i = 0; i < n; ++i) {
         if (reqs[i].want_pcm && !e->voc) return q3_set_err(e, Q3TTS_ERR_STATE, "want_pcm on an engine created with with_vocoder = 0");
+        if (reqs[i].want_pcm == 2 && !e->dev_pcm_on) return q3_set_err(e, Q3TTS_ERR_STATE, "want_pcm = 2 (device only) needs q3tts_set_device_pcm(engine, 1)");
+    }
+    if (e->dev_pcm_on && e->voc) {  // one row of max_steps_cap frames per request of this call
+        const size_t stride = (size_t)e->cfg.max_steps_cap * q3_voc_samples_per_frame(e);
+        if (e->dev_pcm_n < n || e->dev_pcm_stride != stride) {
+            if (e->dev_pcm) { Q3_HIP(e, hipStreamSynchronize(e->vstream)); hipFree(e->dev_pcm); e->dev_pcm = nullptr; e->dev_pcm_n = 0; }
+            void* p = nullptr;
+            if (hipMalloc(&p, (size_t)n * stride * sizeof(float)) != hipSuccess) return q3_set_err(e, Q3TTS_ERR_OOM, "hipMalloc (device PCM)");
+            e->dev_pcm = (float*)p; e->dev_pcm_n = n; e->dev_pcm_stride = stride;
+        }
+    }
     const int B = e->B, CH = 4;  // 4-frame chunks: src/tts/engine.rs:509-512
     const int spf = e->voc ? q3_voc_samples_per_frame(e) : 0;
     std::vector<SlotRun> run(B);
@@ -1015,13 +1048,16 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
             }
             voc_ms += now_ms() - tv0;
         }
+        // results whose PCM copy has landed are completed now, so total_ms is an utterance's own latency (to one chunk's granularity)
+        for (int j = 0; j < B; ++j)
+            if (pending[j] >= 0 && hipEventQuery(e->fin_ev[j]) == hipSuccess) TRY(drain(j));
         for (int b = 0; b < B; ++b) {
             if (run[b].req < 0 || e->slots_host[b].active) continue;
             if (e->voc) q3_voc_mark_last(e, b);
             // hand the slot's results over without waiting for the vocoder (completed at slot reuse / at the end)
             for (int j = 0; j < B; ++j)
                 if (pending[j] >= 0 && hipEventQuery(e->fin_ev[j]) == hipSuccess) TRY(drain(j));
-            TRY(finalize(e, b, &reqs[run[b].req], &outs[run[b].req], run[b], t0, true, e->fin_ev[b]));
+            TRY(finalize(e, b, &reqs[run[b].req], &outs[run[b].req], run[b], t0, true, e->fin_ev[b], run[b].req));
             pending[b] = run[b].req;
             run[b].req = -1; ++done;
         }

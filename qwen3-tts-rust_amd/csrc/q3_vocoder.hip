@@ -1053,3 +1053,32 @@ extern "C" int q3tts_k_vocoder(q3tts_engine* e, const int32_t* codes, int32_t n_
     *n_samples_out = ns;
     return Q3TTS_OK;
 }
+
+// Measurement hook (bench.py's roofline_vocoder): the batched vocoder alone — n_slots slots x 4-frame chunks, `chunks` calls on the
+// engine's stream with nothing else on the GPU, HIP events around them. Codes are seeded pseudo-random. *ms_per_chunk = the mean
+// duration of one batched 4-frame call (n_slots x 4 frames of PCM).
+extern "C" int q3tts_k_vocoder_bench(q3tts_engine* e, int32_t n_slots, int32_t chunks, float* ms_per_chunk) {
+    if (!e || !ms_per_chunk || n_slots <= 0 || chunks <= 0) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder bench: bad argument");
+    if (!e->voc) return q3_set_err(e, Q3TTS_ERR_STATE, "engine created with with_vocoder = 0");
+    if (n_slots > e->B || n_slots > VOC_MAX_NS || (chunks + 2) * 4 > e->cfg.max_steps_cap) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder bench: shape exceeds the engine's");
+    Q3_HIP(e, hipSetDevice(e->cfg.device));
+    const int ncb = e->cfg.model.n_codebooks, cap = e->cfg.max_steps_cap, cbs = e->cfg.vocoder.codebook_size;
+    hipStream_t s = e->stream;
+    std::vector<int32_t> codes((size_t)n_slots * cap * ncb);
+    uint64_t st = 0x9E3779B97F4A7C15ULL;
+    for (auto& c : codes) { st = q3_mix64(st + 0x1234567); c = (int32_t)(st % (uint64_t)cbs); }
+    Q3_HIP(e, hipMemcpyAsync(e->codes, codes.data(), codes.size() * 4, hipMemcpyHostToDevice, s));
+    Q3_HIP(e, hipStreamSynchronize(s));
+    std::vector<int> slots(n_slots);
+    for (int i = 0; i < n_slots; ++i) { slots[i] = i; VTRY(q3_voc_reset(e, i)); }
+    for (int w = 0; w < 2; ++w) VTRY(q3_voc_decode_batch(e, slots.data(), nullptr, n_slots, 4, s));  // warm-up (and fills the sliding window)
+    Q3_HIP(e, hipEventRecord(e->ev0, s));
+    for (int c = 0; c < chunks; ++c) VTRY(q3_voc_decode_batch(e, slots.data(), nullptr, n_slots, 4, s));
+    Q3_HIP(e, hipEventRecord(e->ev2, s));
+    Q3_HIP(e, hipStreamSynchronize(s));
+    float ms = 0.0f;
+    Q3_HIP(e, hipEventElapsedTime(&ms, e->ev0, e->ev2));
+    *ms_per_chunk = ms / (float)chunks;
+    for (int i = 0; i < n_slots; ++i) VTRY(q3_voc_reset(e, i));
+    return Q3TTS_OK;
+}

@@ -115,7 +115,7 @@ SYMBOLS = [
     "q3tts_set_max_steps", "q3tts_build_prompt", "q3tts_free", "q3tts_generate", "q3tts_generate_batch",
     "q3tts_result_free", "q3tts_stream_begin", "q3tts_stream_poll", "q3tts_stream_end",
     "q3tts_get_timings", "q3tts_k_gemm_exact", "q3tts_k_attention", "q3tts_k_sample", "q3tts_k_talker_prefill",
-    "q3tts_k_vocoder", "q3tts_k_rng_f32", "q3tts_k_probe", "q3tts_k_gguf_read", "q3tts_mel_frames", "q3tts_mel",
+    "q3tts_k_vocoder", "q3tts_k_vocoder_bench", "q3tts_set_device_pcm", "q3tts_get_device_pcm", "q3tts_k_rng_f32", "q3tts_k_probe", "q3tts_k_gguf_read", "q3tts_mel_frames", "q3tts_mel",
     "q3tts_clone_default_config", "q3tts_clone_init", "q3tts_clone_audio_frames", "q3tts_clone_audio_encode",
     "q3tts_clone_speaker_encode", "q3tts_k_speaker_from_mel", "q3tts_k_audio_latent",
     "q3tts_k_mfma_bf16", "q3tts_k_bgemm", "q3tts_k_project", "q3tts_k_norm_inputs", "q3tts_tokenizer_load", "q3tts_tokenizer_free", "q3tts_tokenizer_vocab_size", "q3tts_tokenizer_encode", "q3tts_tokenizer_decode",
@@ -170,6 +170,9 @@ def load_library(path=None):
                                    f32p, i32p]
     lib.q3tts_k_talker_prefill.argtypes = [vp, f32p, C.c_int32, f32p, f32p]
     lib.q3tts_k_vocoder.argtypes = [vp, i32p, C.c_int32, C.c_int32, f32p, i32p]
+    lib.q3tts_k_vocoder_bench.argtypes = [vp, C.c_int32, C.c_int32, f32p]
+    lib.q3tts_set_device_pcm.argtypes = [vp, C.c_int32]
+    lib.q3tts_get_device_pcm.argtypes = [vp, C.POINTER(f32p), C.POINTER(C.c_int64), i32p]
     lib.q3tts_k_rng_f32.argtypes = [C.c_uint64, C.c_int32, f32p]
     lib.q3tts_k_probe.argtypes = [C.c_void_p, C.c_int32]
     lib.q3tts_mel_frames.argtypes = [C.c_int64]

@@ -55,6 +55,53 @@ def gather_pcm(dist, pcm_list, rank, world, device="cpu", dtype=None, to_numpy=T
     return out
 
 
+class _DevArray:
+    """A device allocation of libq3tts seen through __cuda_array_interface__ (zero-copy torch view)."""
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+def device_pcm_tensor(engine, device):
+    """torch view [rows][stride] f32 of the engine's packed device PCM of the last batch (q3tts_get_device_pcm)."""
+    import torch
+    ptr, stride, n = engine.device_pcm()
+    if not ptr or n <= 0:
+        return torch.zeros((0, 1), dtype=torch.float32, device=device)
+    return torch.as_tensor(_DevArray(ptr, (n, stride)), device=device)
+
+
+def gather_pcm_device(dist, pcm_rows, n_samples, rank, world, as_i16=True):
+    """The path's ONE collective, straight from device memory: pcm_rows [n][stride] f32 on the device (row i =
+    utterance i of this rank), n_samples[i] valid samples each. Lengths travel in one all_gather, the PCM (i16 as the reference
+    saves it, src/utils/audio.rs:30-46, or f32) in one padded gather to rank 0. Returns on rank 0 (list of per-rank tensors
+    [max_n][max_len], lengths [world][max_n]); elsewhere None. Works over gloo as well (CPU tensors)."""
+    import torch
+    dev = pcm_rows.device
+    n_local = len(n_samples)
+    lens = torch.tensor([n_local] + [int(x) for x in n_samples], dtype=torch.int64, device=dev)
+    cnt = torch.tensor([n_local], dtype=torch.int64, device=dev)
+    cmax = cnt.clone()
+    dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+    max_n = int(cmax.item())
+    lens_pad = torch.zeros(max_n + 1, dtype=torch.int64, device=dev)
+    lens_pad[:n_local + 1] = lens
+    all_lens = [torch.zeros_like(lens_pad) for _ in range(world)]
+    dist.all_gather(all_lens, lens_pad)
+    max_len = max(1, int(torch.stack(all_lens)[:, 1:].max().item()))
+    buf = torch.zeros((max_n, max_len), dtype=torch.int16 if as_i16 else torch.float32, device=dev)
+    if n_local:
+        blk = pcm_rows[:n_local, :max_len]
+        mask = torch.arange(max_len, device=dev)[None, :] < lens[1:, None]
+        blk = torch.where(mask, blk, torch.zeros((), dtype=blk.dtype, device=dev))
+        buf[:n_local] = (blk.clamp(-1.0, 1.0) * 32767.0).round().to(torch.int16) if as_i16 else blk
+    wire = buf.view(torch.uint8)  # neither RCCL nor gloo has a 16-bit integer type: the i16 samples travel as bytes
+    gathered = [torch.zeros_like(wire) for _ in range(world)] if rank == 0 else None
+    dist.gather(wire, gathered, dst=0)
+    if rank != 0:
+        return None
+    return [g.view(buf.dtype) for g in gathered], torch.stack(all_lens)
+
+
 def reassemble(gathered, n_total, world):
     """Inverse of shard_indices on rank 0: list indexed by global utterance index."""
     res = [None] * n_total

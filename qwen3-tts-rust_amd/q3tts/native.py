@@ -115,6 +115,7 @@ class NativeEngine:
             pcm = np.ctypeslib.as_array(res.pcm, shape=(res.n_samples,)).copy() if res.n_samples > 0 else \
                 np.zeros(0, dtype=np.float32)
         out = GenResult(res.status, codes, pcm, bool(res.hit_eos), res.first_chunk_ms, res.total_ms, res.sample_rate)
+        out.n_samples = int(res.n_samples)
         self.lib.q3tts_result_free(C.byref(res))
         return out
 
@@ -136,6 +137,21 @@ class NativeEngine:
         res = (_abi.Result * n)()
         self._check(self.lib.q3tts_generate_batch(self.h, arr, n, res), "q3tts_generate_batch")
         return [self._unpack(res[i]) for i in range(n)]
+
+    def set_device_pcm(self, enable=True):
+        """Keep every batch's PCM on the device as well (row i of one buffer per generate_batch call): the multi-GPU gather reads it there."""
+        self._check(self.lib.q3tts_set_device_pcm(self.h, 1 if enable else 0), "q3tts_set_device_pcm")
+
+    def device_pcm(self):
+        """(device pointer, stride in samples, rows) of the last batch's packed PCM; wrap with torch via __cuda_array_interface__."""
+        base, stride, n = f32p(), C.c_int64(0), C.c_int32(0)
+        self._check(self.lib.q3tts_get_device_pcm(self.h, C.byref(base), C.byref(stride), C.byref(n)), "q3tts_get_device_pcm")
+        return (C.cast(base, C.c_void_p).value or 0), int(stride.value), int(n.value)
+
+    def vocoder_bench(self, n_slots, chunks):
+        ms = C.c_float(0)
+        self._check(self.lib.q3tts_k_vocoder_bench(self.h, n_slots, chunks, C.byref(ms)), "q3tts_k_vocoder_bench")
+        return ms.value
 
     def timings(self):
         t = _abi.Timings()

@@ -19,6 +19,23 @@ rank, world = dist.get_rank(), dist.get_world_size()
 n_total = 7
 mine = [fake_pcm(gi) for gi in qd.shard_indices(n_total, rank, world)]
 g = qd.gather_pcm(dist, mine, rank, world)
+# the device-gather form bench.py uses on N > 1 GPUs (here on CPU tensors over gloo): packed rows + lengths, i16 on the wire
+import torch  # noqa: E402
+stride = 100 + 37 * n_total
+rows = torch.zeros((len(mine), stride), dtype=torch.float32)
+for i, a in enumerate(mine):
+    rows[i, :a.size] = torch.from_numpy(a * 0.01)
+gd = qd.gather_pcm_device(dist, rows, [a.size for a in mine], rank, world, as_i16=True)
+if rank == 0:
+    tens, lens = gd
+    for r in range(world):
+        idx = qd.shard_indices(n_total, r, world)
+        assert int(lens[r, 0]) == len(idx)
+        for j, gi in enumerate(idx):
+            want = np.round(np.clip(fake_pcm(gi) * 0.01, -1, 1) * 32767.0).astype(np.int16)
+            assert int(lens[r, 1 + j]) == want.size and np.array_equal(tens[r][j, :want.size].numpy(), want), (r, j)
+else:
+    assert gd is None
 if rank == 0:
     full = qd.reassemble(g, n_total, world)
     assert all(np.array_equal(full[i], fake_pcm(i)) for i in range(n_total))

@@ -99,6 +99,8 @@ def lib():
     L.q3o_norm_inputs.restype = None
     L.q3o_row_scale.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float]
     L.q3o_row_scale.restype = C.c_float
+    L.q3o_set_threads.argtypes = [C.c_int32]
+    L.q3o_set_threads.restype = None
     L.q3o_set_arith.argtypes = [vp, C.c_int32]
     L.q3o_set_arith.restype = None
     L.q3o_norm_weight.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
