@@ -285,11 +285,10 @@ static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
     int* codes = e->codes;
     Q3Sample sa{}; sa.logits = L.logits; sa.ld = m.t_vocab; sa.limit = m.sample_limit; sa.eos = m.eos_code; sa.slots = slots; sa.B = B; sa.row_slot = L.slot_id;
     sa.rng = e->rng; sa.codes = codes; sa.max_steps_cap = cap; sa.ncb = ncb; sa.keys = L.keys;
-    q3_launch_sample(sa, s);
     Q3PredInput pi{}; pi.xT = L.xT; pi.out_norm = e->T.out_norm; pi.eps = eps; pi.d = de; pi.codec0 = e->codec[0]; pi.codec0_rows = m.codec0_rows;
     pi.slots = slots; pi.row_slot = L.slot_id; pi.X = L.X; pi.fb = L.fb; pi.B = B; pi.pproj0 = e->pproj[0]; pi.proj_b = e->proj_b; pi.dp = dp; pi.px = L.px;
     pi.nw = e->P.attn_norm[0]; pi.xb = L.xbP; pi.ssp = L.sspP;
-    q3_launch_pred_input(pi, s);
+    q3_launch_sample_input(sa, pi, s);
     {   // H6 (src/assets_manager.rs:383-399) for the hidden rows only: every code embedding arrives pre-projected
         Q3Project pj{}; pj.x = L.X; pj.ldx = de; pj.rows = B; pj.w = e->proj_w; pj.bias = e->proj_b; pj.n_in = de; pj.n_out = dp; pj.y = L.px; pj.ldy = dp;
         pj.nw = e->P.attn_norm[0]; pj.xb = L.xbP; pj.ssp = L.sspP; pj.ld_ssp = dp / 16;  // rows [0, B) of pass A

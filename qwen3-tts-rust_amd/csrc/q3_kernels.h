@@ -129,6 +129,7 @@ struct Q3PredInput {
     const float* nw; uint16_t* xb; float* ssp;         // norm inputs of px row B + b (the code row; A-tiled xb, ssp ld dp/16)
 };
 void q3_launch_pred_input(const Q3PredInput& a, hipStream_t s);
+void q3_launch_sample_input(const Q3Sample& a, const Q3PredInput& p, hipStream_t s);  // both in one launch (the frame's first kernel)
 
 // after pass q-1: code_q from the argmax key, record it, fb += codec_q[code_q]; q<ncb-1: px[b] = projected emb;
 // last: fb += tts_pad -> xT[b], row_pos_t[b] = cur_pos++, n_frames++

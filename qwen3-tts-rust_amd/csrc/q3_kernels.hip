@@ -341,26 +341,30 @@ __device__ int sample_row(const float* logits, int limit, float temperature, int
     if (select) {
         // top-k by selection: only the k largest keys are ever read below (:711-713), and the k-th round's block-wide
         // maximum IS the k-th entry of the sorted list (keys are unique: the index is part of the key). Each thread
-        // keeps its 16 candidates in registers; a round = local max, wave max, 4-way max through LDS, owner removes it.
+        // keeps its 16 candidates in registers and their maximum cached; a round = wave max, 4-way max through LDS (double
+        // buffered: one barrier per round), and only the owner of the winner removes it and refreshes its local maximum.
+        __shared__ unsigned long long wsel[2][4];
         unsigned long long loc[SAMP_MAX / 256];
+        unsigned long long lmax = 0;
 #pragma unroll
-        for (int j = 0; j < SAMP_MAX / 256; ++j) { const int i = tid + j * 256; loc[j] = i < limit ? q3_argmax_key(logits[i], (uint32_t)i) : 0ull; }
+        for (int j = 0; j < SAMP_MAX / 256; ++j) { const int i = tid + j * 256; loc[j] = i < limit ? q3_argmax_key(logits[i], (uint32_t)i) : 0ull; lmax = loc[j] > lmax ? loc[j] : lmax; }
         for (int r = 0; r < top_k_i; ++r) {
-            unsigned long long best = 0;
-#pragma unroll
-            for (int j = 0; j < SAMP_MAX / 256; ++j) best = loc[j] > best ? loc[j] : best;
+            unsigned long long best = lmax;
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(best, m); best = o > best ? o : best; }
-            if ((tid & 63) == 0) wbest[tid >> 6] = best;
+            if ((tid & 63) == 0) wsel[r & 1][tid >> 6] = best;
             __syncthreads();
-            unsigned long long b = wbest[0];
+            unsigned long long b = wsel[r & 1][0];
 #pragma unroll
-            for (int w = 1; w < 4; ++w) b = wbest[w] > b ? wbest[w] : b;
+            for (int w = 1; w < 4; ++w) b = wsel[r & 1][w] > b ? wsel[r & 1][w] : b;
             if (tid == 0) keys[r] = b;
+            if (lmax == b && b != 0ull) {  // (b == 0 only when fewer than top_k finite candidates remain: nothing to remove)
+                lmax = 0;
 #pragma unroll
-            for (int j = 0; j < SAMP_MAX / 256; ++j) loc[j] = (loc[j] == b) ? 0ull : loc[j];
-            __syncthreads();
+                for (int j = 0; j < SAMP_MAX / 256; ++j) { loc[j] = (loc[j] == b) ? 0ull : loc[j]; lmax = loc[j] > lmax ? loc[j] : lmax; }
+            }
         }
+        __syncthreads();
     }
     int NP = 64;
     while (NP < limit) NP <<= 1;
@@ -381,13 +385,20 @@ __device__ int sample_row(const float* logits, int limit, float temperature, int
             __syncthreads();
         }
     __shared__ int result;
-    if (tid == 0) {
-        int n = limit;
+    int n_all = limit;
+    {
         const size_t top_k = (size_t)(long long)top_k_i;                 // `top_k as usize` :646
-        if (top_k > 0 && top_k < (size_t)n) n = (int)top_k;              // :711-713
-        const float max_logit = n > 0 ? q3_key_value(keys[0]) : 0.0f;    // :716
+        if (top_k > 0 && top_k < (size_t)n_all) n_all = (int)top_k;      // :711-713
+    }
+    {   // :717-723, element-wise: evaluated by all threads; the sums below stay sequential in the reference's order
+        const float max_logit = n_all > 0 ? q3_key_value(keys[0]) : 0.0f;    // :716
+        for (int i = tid; i < n_all; i += 256) probs[i] = q3_expf((q3_key_value(keys[i]) - max_logit) / temperature);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n = n_all;
         float sum = 0.0f;
-        for (int i = 0; i < n; ++i) { const float e = q3_expf((q3_key_value(keys[i]) - max_logit) / temperature); probs[i] = e; sum += e; }
+        for (int i = 0; i < n; ++i) sum += probs[i];
         if (sum > 0.0f) for (int i = 0; i < n; ++i) probs[i] /= sum;     // :726-731
         if (top_p < 1.0f) {                                              // :734-753
             float cum = 0.0f; int cutoff = n;
@@ -408,18 +419,17 @@ __device__ int sample_row(const float* logits, int limit, float temperature, int
     return res;
 }
 
-__global__ __launch_bounds__(256) void k_sample(Q3Sample a) {
-    __shared__ unsigned long long keys[SAMP_MAX];
-    __shared__ float probs[SAMP_MAX];
-    const int b = blockIdx.x, tid = threadIdx.x, slot = a.row_slot[b];
+// H4 / H5 for row b; returns the sampled code, or -1 when the row produces no frame (inactive slot, step bound, EOS)
+__device__ int sample_frame(const Q3Sample& a, int b, unsigned long long* keys, float* probs) {
+    const int tid = threadIdx.x, slot = a.row_slot[b];
     Q3Slot* sl = a.slots + slot;
-    if (!sl->active) return;
+    if (!sl->active) return -1;
     if (tid < a.ncb) a.keys[(size_t)b * a.ncb + tid] = 0ull;
     const int step = sl->n_frames;
     if (step >= sl->max_steps) {  // loop bound: src/tts/engine.rs:545
         __syncthreads();
         if (tid == 0) sl->active = 0;
-        return;
+        return -1;
     }
     float* lg = a.logits + (size_t)b * a.ld;
     int code0;
@@ -436,6 +446,12 @@ __global__ __launch_bounds__(256) void k_sample(Q3Sample a) {
         if (code0 == a.eos) { sl->hit_eos = 1; sl->active = 0; }  // :558-561
         else { a.codes[((size_t)slot * a.max_steps_cap + step) * a.ncb] = code0; sl->code0 = code0; }
     }
+    return code0 == a.eos ? -1 : code0;
+}
+__global__ __launch_bounds__(256) void k_sample(Q3Sample a) {
+    __shared__ unsigned long long keys[SAMP_MAX];
+    __shared__ float probs[SAMP_MAX];
+    sample_frame(a, blockIdx.x, keys, probs);
 }
 void q3_launch_sample(const Q3Sample& a, hipStream_t s) { hipLaunchKernelGGL(k_sample, dim3(a.B), dim3(256), 0, s, a); }
 
@@ -455,11 +471,9 @@ void q3_launch_sample_rows(const float* logits, int n, int ld, int limit, float 
 // ---------------------------------------------------------------------------------------------------
 // Predictor glue (H6/H7: src/tts/engine.rs:565-631)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pred_input(Q3PredInput a) {
+__device__ void pred_input_row(const Q3PredInput& a, int b, int code0) {
     __shared__ float rinv_s;
-    const int b = blockIdx.x, tid = threadIdx.x, d = a.d;
-    const Q3Slot* sl = a.slots + a.row_slot[b];
-    if (!sl->active) return;
+    const int tid = threadIdx.x, d = a.d;
     const float* x = a.xT + (size_t)b * d;
     if (tid < 64) {
         float acc = 0.0f;
@@ -472,7 +486,6 @@ __global__ __launch_bounds__(256) void k_pred_input(Q3PredInput a) {
     }
     __syncthreads();
     const float rinv = rinv_s;
-    const int code0 = sl->code0;
     const bool ok = code0 >= 0 && code0 < a.codec0_rows;  // OOB rows embed as zeros: src/assets_manager.rs:419-437
     const float* e = a.codec0 + (size_t)(ok ? code0 : 0) * d;
     for (int i = tid; i < d; i += 256) {
@@ -488,7 +501,21 @@ __global__ __launch_bounds__(256) void k_pred_input(Q3PredInput a) {
         q3_norm_out(v, a.nw[i], a.xb + q3_atile_off(r1, i, a.dp >> 5), a.ssp + (size_t)r1 * (a.dp >> 4) + (i >> 4), (i & 15) == 0);
     }
 }
+__global__ __launch_bounds__(256) void k_pred_input(Q3PredInput a) {
+    const Q3Slot* sl = a.slots + a.row_slot[blockIdx.x];
+    if (!sl->active) return;
+    pred_input_row(a, blockIdx.x, sl->code0);
+}
 void q3_launch_pred_input(const Q3PredInput& a, hipStream_t s) { hipLaunchKernelGGL(k_pred_input, dim3(a.B), dim3(256), 0, s, a); }
+// the frame's first launch: H4/H5 (sample, EOS, bookkeeping) and, for rows that go on, the Predictor's pass-A inputs
+__global__ __launch_bounds__(256) void k_sample_input(Q3Sample a, Q3PredInput p) {
+    __shared__ unsigned long long keys[SAMP_MAX];
+    __shared__ float probs[SAMP_MAX];
+    const int code0 = sample_frame(a, blockIdx.x, keys, probs);  // (uniform over the workgroup)
+    if (code0 < 0) return;
+    pred_input_row(p, blockIdx.x, code0);
+}
+void q3_launch_sample_input(const Q3Sample& a, const Q3PredInput& p, hipStream_t s) { hipLaunchKernelGGL(k_sample_input, dim3(a.B), dim3(256), 0, s, a, p); }
 
 __global__ __launch_bounds__(256) void k_pred_next(Q3PredNext a) {
     const int b = blockIdx.x, tid = threadIdx.x, d = a.d, slot = a.row_slot[b];
