@@ -66,7 +66,73 @@ size_t type_bytes(uint32_t type, size_t nelem, uint64_t ne0, bool* ok) {
         case Q3_GGML_F32: return nelem * 4;
         case Q3_GGML_F16: case Q3_GGML_BF16: return nelem * 2;
         case Q3_GGML_Q8_0: if (ne0 % 32) { *ok = false; return 0; } return nelem / 32 * 34;
+        case Q3_GGML_Q4_K: if (ne0 % 256) { *ok = false; return 0; } return nelem / 256 * 144;
+        case Q3_GGML_Q5_K: if (ne0 % 256) { *ok = false; return 0; } return nelem / 256 * 176;
+        case Q3_GGML_Q6_K: if (ne0 % 256) { *ok = false; return 0; } return nelem / 256 * 210;
         default: *ok = false; return 0;
+    }
+}
+
+// ---- ggml's K-quants (super-blocks of 256; the gguf_q5_k_m directory of the reference, src/tts/engine.rs:91-95, holds Q5_K and Q6_K
+// tensors). The layouts are llama.cpp's (ggml-quants.c dequantize_row_q4_K / q5_K / q6_K), restated from their published definition:
+// llama.cpp is not in /root/reference, so this row is PARITY UNPINNED; tests/_gguf.py holds the independent numpy restatement. ----
+// 6-bit (scale, min) pair j of a Q4_K / Q5_K super-block (get_scale_min_k4)
+inline void scale_min_k4(int j, const uint8_t* q, uint8_t* sc, uint8_t* m) {
+    if (j < 4) { *sc = q[j] & 63; *m = q[j + 4] & 63; }
+    else { *sc = (uint8_t)((q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4)); *m = (uint8_t)((q[j + 4] >> 4) | ((q[j] >> 6) << 4)); }
+}
+// one super-block -> 256 floats
+void deq_q4_k(const uint8_t* b, float* y) {   // { f16 d, dmin; u8 scales[12]; u8 qs[128] }
+    uint16_t h; memcpy(&h, b, 2); const float d = f16_to_f32(h); memcpy(&h, b + 2, 2); const float dmin = f16_to_f32(h);
+    const uint8_t* scales = b + 4; const uint8_t* q = b + 16;
+    int is = 0;
+    for (int j = 0; j < 256; j += 64) {
+        uint8_t sc, m;
+        scale_min_k4(is + 0, scales, &sc, &m); const float d1 = d * (float)sc, m1 = dmin * (float)m;
+        scale_min_k4(is + 1, scales, &sc, &m); const float d2 = d * (float)sc, m2 = dmin * (float)m;
+        for (int l = 0; l < 32; ++l) *y++ = d1 * (float)(q[l] & 0xF) - m1;
+        for (int l = 0; l < 32; ++l) *y++ = d2 * (float)(q[l] >> 4) - m2;
+        q += 32; is += 2;
+    }
+}
+void deq_q5_k(const uint8_t* b, float* y) {   // { f16 d, dmin; u8 scales[12]; u8 qh[32]; u8 qs[128] }
+    uint16_t h; memcpy(&h, b, 2); const float d = f16_to_f32(h); memcpy(&h, b + 2, 2); const float dmin = f16_to_f32(h);
+    const uint8_t* scales = b + 4; const uint8_t* qh = b + 16; const uint8_t* ql = b + 48;
+    int is = 0; uint8_t u1 = 1, u2 = 2;
+    for (int j = 0; j < 256; j += 64) {
+        uint8_t sc, m;
+        scale_min_k4(is + 0, scales, &sc, &m); const float d1 = d * (float)sc, m1 = dmin * (float)m;
+        scale_min_k4(is + 1, scales, &sc, &m); const float d2 = d * (float)sc, m2 = dmin * (float)m;
+        for (int l = 0; l < 32; ++l) *y++ = d1 * (float)((ql[l] & 0xF) + ((qh[l] & u1) ? 16 : 0)) - m1;
+        for (int l = 0; l < 32; ++l) *y++ = d2 * (float)((ql[l] >> 4) + ((qh[l] & u2) ? 16 : 0)) - m2;
+        ql += 32; is += 2; u1 = (uint8_t)(u1 << 2); u2 = (uint8_t)(u2 << 2);
+    }
+}
+void deq_q6_k(const uint8_t* b, float* y) {   // { u8 ql[128]; u8 qh[64]; i8 scales[16]; f16 d }
+    const uint8_t* ql = b; const uint8_t* qh = b + 128; const int8_t* sc = (const int8_t*)(b + 192);
+    uint16_t h; memcpy(&h, b + 208, 2); const float d = f16_to_f32(h);
+    for (int n = 0; n < 256; n += 128) {
+        for (int l = 0; l < 32; ++l) {
+            const int is = l / 16;
+            const int q1 = (int)(int8_t)((ql[l + 0] & 0xF) | (((qh[l] >> 0) & 3) << 4)) - 32;
+            const int q2 = (int)(int8_t)((ql[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32;
+            const int q3 = (int)(int8_t)((ql[l + 0] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32;
+            const int q4 = (int)(int8_t)((ql[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32;
+            y[l + 0] = d * (float)sc[is + 0] * (float)q1;
+            y[l + 32] = d * (float)sc[is + 2] * (float)q2;
+            y[l + 64] = d * (float)sc[is + 4] * (float)q3;
+            y[l + 96] = d * (float)sc[is + 6] * (float)q4;
+        }
+        y += 128; ql += 64; qh += 32; sc += 8;
+    }
+}
+// K-quant super-block kb of tensor t -> 256 floats; false for other types
+bool deq_k_block(const Q3GgufTensor& t, size_t kb, float* y) {
+    switch (t.type) {
+        case Q3_GGML_Q4_K: deq_q4_k(t.data + kb * 144, y); return true;
+        case Q3_GGML_Q5_K: deq_q5_k(t.data + kb * 176, y); return true;
+        case Q3_GGML_Q6_K: deq_q6_k(t.data + kb * 210, y); return true;
+        default: return false;
     }
 }
 
@@ -157,8 +223,9 @@ bool Q3Gguf::meta_u64(const std::string& key, uint64_t* v) const {
 }
 
 int q3_gguf_to_f32(const Q3GgufTensor& t, float* dst, std::string& err) {
-    if (!t.data) { err = "tensor '" + t.name + "': unsupported ggml type " + std::to_string(t.type) + " (supported: F32, F16, BF16, Q8_0)"; return -1; }
+    if (!t.data) { err = "tensor '" + t.name + "': unsupported ggml type " + std::to_string(t.type) + " (supported: F32, F16, BF16, Q8_0, Q4_K, Q5_K, Q6_K)"; return -1; }
     const size_t n = t.nelem;
+    if (t.type == Q3_GGML_Q4_K || t.type == Q3_GGML_Q5_K || t.type == Q3_GGML_Q6_K) { for (size_t kb = 0; kb < n / 256; ++kb) deq_k_block(t, kb, dst + kb * 256); return 0; }
     if (t.type == Q3_GGML_F32) memcpy(dst, t.data, n * 4);
     else if (t.type == Q3_GGML_F16) { for (size_t i = 0; i < n; ++i) { uint16_t h; memcpy(&h, t.data + 2 * i, 2); dst[i] = f16_to_f32(h); } }
     else if (t.type == Q3_GGML_BF16) { for (size_t i = 0; i < n; ++i) { uint16_t h; memcpy(&h, t.data + 2 * i, 2); const uint32_t u = (uint32_t)h << 16; memcpy(&dst[i], &u, 4); } }
@@ -174,8 +241,13 @@ int q3_gguf_to_f32(const Q3GgufTensor& t, float* dst, std::string& err) {
 }
 
 int q3_gguf_to_bf16(const Q3GgufTensor& t, uint16_t* dst, std::string& err) {
-    if (!t.data) { err = "tensor '" + t.name + "': unsupported ggml type " + std::to_string(t.type) + " (supported: F32, F16, BF16, Q8_0)"; return -1; }
+    if (!t.data) { err = "tensor '" + t.name + "': unsupported ggml type " + std::to_string(t.type) + " (supported: F32, F16, BF16, Q8_0, Q4_K, Q5_K, Q6_K)"; return -1; }
     if (t.type == Q3_GGML_BF16) { memcpy(dst, t.data, t.nelem * 2); return 0; }
+    if (t.type == Q3_GGML_Q4_K || t.type == Q3_GGML_Q5_K || t.type == Q3_GGML_Q6_K) {
+        float y[256];
+        for (size_t kb = 0; kb < t.nelem / 256; ++kb) { deq_k_block(t, kb, y); for (int j = 0; j < 256; ++j) dst[kb * 256 + j] = f32_to_bf16_rne(y[j]); }
+        return 0;
+    }
     const size_t chunk = 1 << 16;
     std::vector<float> tmp(chunk);
     if (t.type == Q3_GGML_F32) {

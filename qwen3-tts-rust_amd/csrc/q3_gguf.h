@@ -5,7 +5,8 @@
 //     fallback (:267-381) — same tensor / file names, same "text_embd may be absent" rule;
 //   * llama.cpp's model loader for qwen3_tts_talker.gguf / qwen3_tts_predictor.gguf (behind LlamaModel::load,
 //     /root/reference/src/models/llama/mod.rs:360-398), for the tensor types the released quant dirs use that this engine
-//     can take: F32, F16, BF16, Q8_0 (the K-quants of gguf_q5_k_m are refused loudly).
+//     can take: F32, F16, BF16, Q8_0 and the K-quants Q4_K / Q5_K / Q6_K of the gguf_q5_k_m directory (src/tts/engine.rs:91-95);
+//     every type is de-quantised on the host and stored as bf16 (the decoder's weight format), other types are refused loudly.
 // Files are mmap'ed; tensors are converted on the host and uploaded by the engine (q3_engine.hip).
 #pragma once
 #include <cstddef>
@@ -14,7 +15,7 @@
 #include <string>
 #include <vector>
 
-enum { Q3_GGML_F32 = 0, Q3_GGML_F16 = 1, Q3_GGML_Q8_0 = 8, Q3_GGML_BF16 = 30 };
+enum { Q3_GGML_F32 = 0, Q3_GGML_F16 = 1, Q3_GGML_Q8_0 = 8, Q3_GGML_Q4_K = 12, Q3_GGML_Q5_K = 13, Q3_GGML_Q6_K = 14, Q3_GGML_BF16 = 30 };
 
 struct Q3GgufTensor {
     std::string name;
@@ -49,7 +50,7 @@ private:
     std::map<std::string, uint64_t> meta_;
 };
 
-// element conversions (ggml semantics: F16 -> f32 exact, Q8_0: f32(d) * q, BF16 -> f32 exact)
+// element conversions (ggml semantics: F16 -> f32 exact, Q8_0: f32(d) * q, BF16 -> f32 exact, K-quants: dequantize_row_q{4,5,6}_K)
 int q3_gguf_to_f32(const Q3GgufTensor& t, float* dst, std::string& err);
 // to bf16 with round-to-nearest-even from the f32 value above (BF16 sources are copied bit for bit)
 int q3_gguf_to_bf16(const Q3GgufTensor& t, uint16_t* dst, std::string& err);

@@ -7,7 +7,7 @@ import struct
 
 import numpy as np
 
-F32, F16, Q8_0, BF16 = 0, 1, 8, 30
+F32, F16, Q8_0, Q4_K, Q5_K, Q6_K, BF16 = 0, 1, 8, 12, 13, 14, 30
 ALIGN = 32
 
 
@@ -40,6 +40,120 @@ def dequantize_q8_0(raw, n):
     return (q * d[:, None]).reshape(-1)
 
 
+# ---- ggml K-quants (super-blocks of 256): an independent restatement of the published block layouts (llama.cpp ggml-quants.c:
+# block_q4_K / block_q5_K / block_q6_K and their dequantize_row_* loops). llama.cpp is not in /root/reference: PARITY UNPINNED.
+# The quantisers below are simple min/max ones (any valid block decodes deterministically; ggml's search for the best scales is
+# not restated, it does not change what a reader must do).
+def _f16(x):
+    return np.asarray(x, dtype=np.float32).astype(np.float16)
+
+
+def _pack_scales_k4(sc, mn):
+    """8 six-bit scales + 8 six-bit mins -> 12 bytes (inverse of get_scale_min_k4)."""
+    q = np.zeros(12, dtype=np.uint8)
+    for j in range(4):
+        q[j] = (sc[j] & 63) | ((sc[j + 4] >> 4) << 6)
+        q[j + 4] = (mn[j] & 63) | ((mn[j + 4] >> 4) << 6)
+        q[j + 8] = (sc[j + 4] & 0xF) | ((mn[j + 4] & 0xF) << 4)
+    return q
+
+
+def _unpack_scales_k4(q):
+    sc, mn = np.zeros(8, dtype=np.int32), np.zeros(8, dtype=np.int32)
+    for j in range(8):
+        if j < 4:
+            sc[j], mn[j] = q[j] & 63, q[j + 4] & 63
+        else:
+            sc[j] = (q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4)
+            mn[j] = (q[j + 4] >> 4) | ((q[j] >> 6) << 4)
+    return sc, mn
+
+
+def _quantize_k45(x, bits):
+    """Q4_K (bits = 4) / Q5_K (bits = 5): value = d * sc_j * q - dmin * m_j over 8 sub-blocks of 32."""
+    qmax = (1 << bits) - 1
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 8, 32)
+    out = []
+    for blk in x:
+        lo = np.minimum(blk.min(axis=1), 0.0)
+        scale = (blk.max(axis=1) - lo) / qmax
+        d = np.float32(_f16(scale.max() / 63.0)) if scale.max() > 0 else np.float32(0)
+        dmin = np.float32(_f16((-lo).max() / 63.0)) if (-lo).max() > 0 else np.float32(0)
+        sc = np.clip(np.rint(scale / d) if d > 0 else np.zeros(8), 0, 63).astype(np.int32)
+        mn = np.clip(np.rint(-lo / dmin) if dmin > 0 else np.zeros(8), 0, 63).astype(np.int32)
+        den = (d * sc.astype(np.float32))[:, None]
+        q = np.clip(np.rint((blk + (dmin * mn.astype(np.float32))[:, None]) / np.where(den > 0, den, 1.0)), 0, qmax).astype(np.uint8)
+        qs = np.zeros(128, dtype=np.uint8); qh = np.zeros(32, dtype=np.uint8)
+        for c in range(4):
+            a, b = q[2 * c], q[2 * c + 1]
+            qs[32 * c:32 * c + 32] = (a & 0xF) | ((b & 0xF) << 4)
+            if bits == 5:
+                qh |= ((a >> 4) & 1) << (2 * c)
+                qh |= ((b >> 4) & 1) << (2 * c + 1)
+        head = np.concatenate([_f16([d]).view(np.uint8), _f16([dmin]).view(np.uint8), _pack_scales_k4(sc, mn)])
+        out.append(np.concatenate([head, qh, qs]) if bits == 5 else np.concatenate([head, qs]))
+    return np.concatenate(out).astype(np.uint8)
+
+
+def _dequantize_k45(raw, n, bits):
+    bs = 176 if bits == 5 else 144
+    blk = np.frombuffer(raw, dtype=np.uint8, count=n // 256 * bs).reshape(-1, bs)
+    y = np.zeros((blk.shape[0], 256), dtype=np.float32)
+    for i, b in enumerate(blk):
+        d = np.float32(b[0:2].copy().view(np.float16)[0]); dmin = np.float32(b[2:4].copy().view(np.float16)[0])
+        sc, mn = _unpack_scales_k4(b[4:16])
+        qh = b[16:48] if bits == 5 else None
+        qs = b[48:176] if bits == 5 else b[16:144]
+        for c in range(4):
+            lo = (qs[32 * c:32 * c + 32] & 0xF).astype(np.int32); hi = (qs[32 * c:32 * c + 32] >> 4).astype(np.int32)
+            if bits == 5:
+                lo = lo + np.where(qh & (1 << (2 * c)), 16, 0); hi = hi + np.where(qh & (2 << (2 * c)), 16, 0)
+            d1 = np.float32(d * np.float32(sc[2 * c])); m1 = np.float32(dmin * np.float32(mn[2 * c]))
+            d2 = np.float32(d * np.float32(sc[2 * c + 1])); m2 = np.float32(dmin * np.float32(mn[2 * c + 1]))
+            y[i, 64 * c:64 * c + 32] = (d1 * lo.astype(np.float32)).astype(np.float32) - m1
+            y[i, 64 * c + 32:64 * c + 64] = (d2 * hi.astype(np.float32)).astype(np.float32) - m2
+    return y.reshape(-1)
+
+
+def _q6_index(e):
+    """element e of a Q6_K super-block -> (ql index, high nibble?, qh index, qh shift, scale index)"""
+    h, r = divmod(e, 128)
+    grp, l = divmod(r, 32)
+    return 64 * h + l + (32 if grp in (1, 3) else 0), grp >= 2, 32 * h + l, 2 * grp, 8 * h + l // 16 + 2 * grp
+
+
+_Q6 = np.array([_q6_index(e) for e in range(256)], dtype=np.int64)  # columns: ql index, high nibble, qh index, qh shift, scale index
+
+
+def quantize_q6_k(x):
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 256)
+    nb = x.shape[0]
+    qi, hi, hq, sh, si = _Q6.T
+    sub = np.zeros((nb, 16), dtype=np.float32)
+    np.maximum.at(sub, (np.arange(nb)[:, None], si[None, :]), np.abs(x))
+    sub /= 32.0
+    d = np.where(sub.max(axis=1) > 0, (sub.max(axis=1) / 127.0).astype(np.float16).astype(np.float32), 0).astype(np.float32)
+    sc = np.clip(np.rint(np.divide(sub, d[:, None], out=np.zeros_like(sub), where=d[:, None] > 0)), -128, 127).astype(np.int8)
+    den = d[:, None] * sc.astype(np.float32)[:, si]
+    q = (np.clip(np.rint(np.divide(x, den, out=np.zeros_like(x), where=den != 0)), -32, 31) + 32).astype(np.uint8)
+    ql = np.zeros((nb, 128), dtype=np.uint8); qh = np.zeros((nb, 64), dtype=np.uint8)
+    for e in range(256):
+        ql[:, qi[e]] |= (((q[:, e] & 0xF) << 4) if hi[e] else (q[:, e] & 0xF)).astype(np.uint8)
+        qh[:, hq[e]] |= (((q[:, e] >> 4) & 3) << int(sh[e])).astype(np.uint8)
+    return np.concatenate([ql, qh, sc.view(np.uint8), d.astype(np.float16).view(np.uint8).reshape(nb, 2)], axis=1).reshape(-1)
+
+
+def dequantize_q6_k(raw, n):
+    blk = np.frombuffer(raw, dtype=np.uint8, count=n // 256 * 210).reshape(-1, 210)
+    qi, hi, hq, sh, si = _Q6.T
+    ql, qh, sc = blk[:, :128].astype(np.int32), blk[:, 128:192].astype(np.int32), blk[:, 192:208].copy().view(np.int8).astype(np.float32)
+    d = blk[:, 208:210].copy().view(np.float16).astype(np.float32).reshape(-1)
+    nib = np.where(hi[None, :] != 0, ql[:, qi] >> 4, ql[:, qi] & 0xF)
+    q = (nib | (((qh[:, hq] >> sh[None, :]) & 3) << 4)) - 32
+    ds = (d[:, None] * sc[:, si]).astype(np.float32)
+    return (ds * q.astype(np.float32)).astype(np.float32).reshape(-1)
+
+
 def encode(arr, ty):
     a = np.ascontiguousarray(arr, dtype=np.float32)
     if ty == F32:
@@ -50,6 +164,12 @@ def encode(arr, ty):
         return f32_to_bf16_bits(a).tobytes()
     if ty == Q8_0:
         return quantize_q8_0(a).tobytes()
+    if ty == Q4_K:
+        return _quantize_k45(a, 4).tobytes()
+    if ty == Q5_K:
+        return _quantize_k45(a, 5).tobytes()
+    if ty == Q6_K:
+        return quantize_q6_k(a).tobytes()
     raise ValueError(ty)
 
 
@@ -62,6 +182,12 @@ def decode(raw, ty, n):
         return bf16_bits_to_f32(np.frombuffer(raw, dtype="<u2", count=n))
     if ty == Q8_0:
         return dequantize_q8_0(raw, n)
+    if ty == Q4_K:
+        return _dequantize_k45(raw, n, 4)
+    if ty == Q5_K:
+        return _dequantize_k45(raw, n, 5)
+    if ty == Q6_K:
+        return dequantize_q6_k(raw, n)
     raise ValueError(ty)
 
 

@@ -136,6 +136,43 @@ def test_gguf_reader_matches_numpy_restatement(tmp_path):
     assert got.shape == a.shape and np.array_equal(_bits(got), _bits(a))
 
 
+def test_gguf_k_quants_match_numpy_restatement(tmp_path):
+    """Q4_K / Q5_K / Q6_K (the tensor types of the reference's gguf_q5_k_m directory, src/tts/engine.rs:91-95): the C++ reader against
+    the independent numpy restatement of the published super-block layouts (PARITY UNPINNED: llama.cpp is not in the reference),
+    bit for bit, plus the block error bounds and hand-built blocks that exercise every bit field."""
+    import _gguf as G
+    from q3tts import native
+    rng = np.random.default_rng(9)
+    a = (rng.standard_normal((12, 512)) * 0.05).astype(np.float32)
+    a[3] = 0.0; a[4, :256] = np.abs(a[4, :256]); a[5, 256:] = -np.abs(a[5, 256:])      # all-zero block, all-positive / all-negative blocks
+    path = str(tmp_path / "k.gguf")
+    G.write(path, [("q4", a, G.Q4_K), ("q5", a, G.Q5_K), ("q6", a, G.Q6_K)])
+    ref = G.read(path)
+    for name, bound in (("q4", 1.0 / 15), ("q5", 1.0 / 31), ("q6", 1.0 / 31)):
+        got, gty = native.k_gguf_read(path, name)
+        want, ty = ref[name]
+        assert gty == ty and np.array_equal(_bits(got), _bits(want)), name
+        span = (a.reshape(-1, 32).max(axis=1) - np.minimum(a.reshape(-1, 32).min(axis=1), 0)).max()
+        assert np.abs(got - a).max() <= 1.2 * bound * max(span, np.abs(a).max()), name
+    # every bit field: random raw super-blocks (finite f16 scales) decoded by both readers
+    for ty, bs in ((G.Q4_K, 144), (G.Q5_K, 176), (G.Q6_K, 210)):
+        raw = rng.integers(0, 256, size=(6, bs), dtype=np.uint8)
+        for b in raw:   # finite f16 scale fields, everything else random
+            if ty == G.Q6_K:
+                b[208:210] = np.array([np.float16(0.37)]).view(np.uint8)
+            else:
+                b[0:4] = np.array([np.float16(0.013), np.float16(0.21)]).view(np.uint8)
+        want = G.decode(raw.tobytes(), ty, 6 * 256)
+        p2 = str(tmp_path / ("raw%d.gguf" % ty))
+        G.write(p2, [("t", np.zeros((6, 256), np.float32), ty)])
+        blob = bytearray(open(p2, "rb").read())
+        data_off = len(blob) - (raw.size + ((-raw.size) % 32))
+        blob[data_off:data_off + raw.size] = raw.tobytes()
+        open(p2, "wb").write(bytes(blob))
+        got, _ = native.k_gguf_read(p2, "t")
+        assert np.array_equal(_bits(got.reshape(-1)), _bits(want)), ty
+
+
 def test_gguf_reader_errors_are_loud(tmp_path):
     import struct
     import _gguf as G
@@ -157,10 +194,14 @@ def test_gguf_reader_errors_are_loud(tmp_path):
     (tmp_path / "cut.gguf").write_bytes(raw[:-100])
     with pytest.raises(_abi.Q3Error, match="outside the file"):
         native.k_gguf_read(str(tmp_path / "cut.gguf"), "v")
-    # a K-quant tensor (type 12 = Q4_K) is listed but refused when asked for
-    G.write(str(tmp_path / "kq.gguf"), [("v", v, G.F32)], raw_types={"v": 12})
-    with pytest.raises(_abi.Q3Error, match="unsupported ggml type 12"):
+    # a tensor type the reader does not take (10 = Q2_K) is listed but refused when asked for; a K-quant row that is not a
+    # multiple of the 256-element super-block likewise
+    G.write(str(tmp_path / "kq.gguf"), [("v", v, G.F32)], raw_types={"v": 10})
+    with pytest.raises(_abi.Q3Error, match="unsupported ggml type 10"):
         native.k_gguf_read(str(tmp_path / "kq.gguf"), "v")
+    G.write(str(tmp_path / "kq2.gguf"), [("v", v, G.F32)], raw_types={"v": 13})
+    with pytest.raises(_abi.Q3Error, match="unsupported ggml type 13"):
+        native.k_gguf_read(str(tmp_path / "kq2.gguf"), "v")
     np.save(tmp_path / "f64.npy", v.astype(np.float64))
     with pytest.raises(_abi.Q3Error, match="f32"):
         native.k_gguf_read(str(tmp_path / "f64.npy"))

@@ -434,6 +434,38 @@ def test_engine_from_model_files(oracle, tmp_path, matrix_type, assets, with_tex
         om.close()
 
 
+@pytest.mark.parametrize("matrix_type", [13, 14])
+def test_engine_from_k_quant_files(oracle, tmp_path, matrix_type):
+    """The reference's gguf_q5_k_m directory holds Q5_K / Q6_K matrices (src/tts/engine.rs:91-95). An engine created from a K-quant
+    container must behave exactly like one created from an F32 container that holds the de-quantised values (tests/_gguf.py, the
+    numpy restatement of the block layouts): same prompt rows, same greedy and sampled ids. (The K-quant layouts themselves are
+    PARITY UNPINNED: llama.cpp is not in the reference.)"""
+    import _gguf as G
+    from q3tts import _abi, native
+    cfg = _abi.tiny_config(max_batch=2, n_ctx=128, with_vocoder=0)
+    dq, df = tmp_path / "kq", tmp_path / "f32"
+    oracle.write_model_dir(str(dq), cfg.model, 0, matrix_type=matrix_type)
+    oracle.write_model_dir(str(df), cfg.model, 0, matrix_type=G.F32)
+    for fname in ("qwen3_tts_talker.gguf", "qwen3_tts_predictor.gguf"):   # the F32 twin holds what the K-quant file decodes to
+        tens = G.read(str(dq / fname))
+        assert any(ty == matrix_type for _, ty in tens.values())
+        G.write(str(df / fname), [(k, v, G.F32) for k, (v, ty) in tens.items()], meta={"general.architecture": "qwen3", "general.alignment": 32})
+    engs = []
+    try:
+        for d in (dq, df):
+            c = _abi.tiny_config(max_batch=2, n_ctx=128, with_vocoder=0)
+            c.weights_path = str(d).encode()
+            engs.append(native.NativeEngine(c))
+        desc, keep = oracle.make_prompt_desc(np.arange(900, 912), spk_emb=_spk(cfg.model.d_embed))
+        assert np.array_equal(_bits(engs[0].build_prompt(desc)), _bits(engs[1].build_prompt(desc)))
+        for kw in (dict(temperature=0.0, max_steps=6), dict(temperature=0.7, top_k=40, top_p=0.9, seed=11, max_steps=6)):
+            a, b = engs[0].generate(desc=desc, **kw), engs[1].generate(desc=desc, **kw)
+            assert a.codes.shape[0] > 0 and np.array_equal(a.codes, b.codes)
+    finally:
+        for e in engs:
+            e.close()
+
+
 def test_model_files_errors_are_loud(oracle, tmp_path):
     import _gguf as G
     from q3tts import _abi, native
