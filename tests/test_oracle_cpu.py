@@ -351,3 +351,58 @@ def test_bf16_mfma_restatement_against_hardware_vectors(oracle):
         for f in (L.q3o_mfma_bf16_dot32, L.q3o_mfma_bf16_dot32_ref):
             r = np.float32(f(ai.ctypes.data_as(C.POINTER(C.c_uint16)), bi.ctypes.data_as(C.POINTER(C.c_uint16)), float(c[i])))
             assert r.view(np.uint32) == d[i].view(np.uint32), (str(Z["set"][i]), i, float(r), float(d[i]))
+
+
+def test_sampler_expf_vs_libm_boundary_flips(oracle):
+    """the sampler evaluates exp with the spec'd q3_expf (max 2.2e-7 relative) where the reference calls libm's
+    f32 exp (src/models/llama/mod.rs:720). A literal Python restatement of :666-772 with float32 arithmetic is run twice — once with
+    the oracle's q3o_expf (and must then reproduce q3o_sample on every draw: that validates the restatement), once with libm's exp — over
+    200 logit rows x 500 draws = 1e5 draws at temperature 0.7 / top-k 40 / top-p 0.9. The flips are counted and bounded."""
+    L = oracle.lib()
+    f32 = np.float32
+    rng = np.random.default_rng(2026)
+
+    def cdf(logits, T, k, p, expf):
+        order = np.argsort(-logits, kind="stable")[:k]                      # :705-713 (stable descending, top-k)
+        v = logits[order]
+        e = np.array([expf(f32((x - v[0]) / f32(T))) for x in v], dtype=np.float32)   # :716-723
+        s = f32(0)
+        for x in e:
+            s = f32(s + x)
+        pr = np.array([f32(x / s) for x in e], dtype=np.float32)             # :726-731
+        cum, cut = f32(0), len(pr)
+        for i, x in enumerate(pr):                                           # :734-753
+            cum = f32(cum + x)
+            if cum >= f32(p):
+                cut = i + 1
+                break
+        pr = pr[:cut]
+        ns = f32(0)
+        for x in pr:
+            ns = f32(ns + x)
+        pr = np.array([f32(x / ns) for x in pr], dtype=np.float32)
+        c, out = f32(0), []
+        for x in pr:
+            c = f32(c + x)
+            out.append(c)
+        return order[:cut], np.array(out, dtype=np.float32)
+
+    def pick(order, cum, r):                                                 # :756-770: first i with r < cum[i], else the first candidate
+        i = int(np.searchsorted(cum, r, side="right"))
+        return int(order[i]) if i < len(order) else int(order[0])
+    spec = lambda x: f32(L.q3o_expf(float(x)))
+    libm = lambda x: f32(np.exp(f32(x), dtype=np.float32))
+    flips = total = 0
+    for row in range(200):
+        lg = (rng.standard_normal(2160) * 2.5).astype(np.float32)
+        o1, c1 = cdf(lg, 0.7, 40, 0.9, spec)
+        o2, c2 = cdf(lg, 0.7, 40, 0.9, libm)
+        draws = rng.random(500).astype(np.float32)
+        for j, r in enumerate(draws):
+            a = pick(o1, c1, r)
+            if j < 25:
+                assert a == L.q3o_sample(oracle.ptr(lg, oracle.f32p), 2160, 0.7, 40, 0.9, float(r)), (row, j)
+            flips += a != pick(o2, c2, r)
+            total += 1
+    print(f"sampler exp: q3_expf vs libm over {total} draws: {flips} different ids")
+    assert total == 100000 and flips <= 20   # expected ~ 2 * 40 * 2.2e-7 * 1e5 < 2
