@@ -26,7 +26,9 @@ __device__ __forceinline__ float bg_wave_sum(float v) {
     return v;
 }
 
-template <int RT, int NT, int D>
+__device__ __forceinline__ u32x4 bg_ldw(const u32x4* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+
+template <int RT, int NT, int D, bool NTW>
 __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
     extern __shared__ float part[];  // [8 waves][RT*NT*4 regs][64 lanes]
     __shared__ float srow[64];
@@ -50,14 +52,19 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
     const u32x4* wp[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) wp[j] = (const u32x4*)g.w + ((size_t)(nb0 + j) * kblocks + kb0) * 64 + lane;
+    // weights first (HBM / Infinity Cache: the long latency), then the rows (L2); D steps of both stay in flight
     u32x4 aq[D][RT], bq[D][NT];
 #pragma unroll
     for (int s = 0; s < D; ++s)
         if (s < per) {
 #pragma unroll
-            for (int i = 0; i < RT; ++i) aq[s][i] = ap[i][(size_t)s * 64];
+            for (int j = 0; j < NT; ++j) bq[s][j] = bg_ldw(wp[j] + (size_t)s * 64, NTW);
+        }
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bq[s][j] = wp[j][(size_t)s * 64];
+    for (int s = 0; s < D; ++s)
+        if (s < per) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i) aq[s][i] = ap[i][(size_t)s * 64];
         }
     // RESID: the residual operand is fetched up front instead of at the very end
     constexpr int NOUT = (TR * 64 + 511) / 512;
@@ -71,18 +78,19 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
             yres[it] = (o < TR * 64 && row < B) ? g.y[(size_t)row * g.ldy + (size_t)(nb0 + j) * 16 + (l & 15)] : 0.0f;
         }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    // row scales (norm GEMMs): wave w reduces the tile partials of rows w, w + 8, ... while the operands are in flight —
-    // lane j adds its tiles j, j + 64, ... in ascending order, then the 64-lane butterfly
+    // norm GEMMs: wave w owns the row scales of rows w, w + 8, ...; their tile partials are requested now and reduced after the main
+    // loop (lane j adds its tiles j, j + 64, ... in ascending order, then the 64-lane butterfly: DESIGN.md §4.2)
+    constexpr int NR = 2 * RT;
+    float sp0[NR], sp1[NR];
     if (g.ssp) {
-        for (int rl = wave; rl < RT * 16; rl += 8) {
-            const float* sp = g.ssp + (size_t)min(row0 + rl, B - 1) * g.ld_ssp;
-            float a = 0.0f;
-            for (int t = lane; t < g.ntiles; t += 64) a = t == lane ? sp[t] : a + sp[t];
-            a = bg_wave_sum(a);
-            if (lane == 0) srow[rl] = 1.0f / sqrtf(a / (float)g.d_norm + g.eps);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const float* sp = g.ssp + (size_t)min(row0 + wave + 8 * i, B - 1) * g.ld_ssp;
+            sp0[i] = lane < g.ntiles ? sp[lane] : 0.0f;
+            sp1[i] = lane + 64 < g.ntiles ? sp[lane + 64] : 0.0f;
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[RT][NT];
 #pragma unroll
     for (int i = 0; i < RT; ++i)
@@ -105,12 +113,33 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (s + D < per) {
 #pragma unroll
-                    for (int i = 0; i < RT; ++i) aq[d][i] = ap[i][(size_t)(s + D) * 64];
+                    for (int j = 0; j < NT; ++j) bq[d][j] = bg_ldw(wp[j] + (size_t)(s + D) * 64, NTW);
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) bq[d][j] = wp[j][(size_t)(s + D) * 64];
+                    for (int i = 0; i < RT; ++i) aq[d][i] = ap[i][(size_t)(s + D) * 64];
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
+    }
+    if (g.ssp) {  // the NR butterflies are independent chains: interleaved
+        float av[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            float a = sp0[i];
+            if (lane + 64 < g.ntiles) a = a + sp1[i];
+            if (g.ntiles > 128) {
+                const float* sp = g.ssp + (size_t)min(row0 + wave + 8 * i, B - 1) * g.ld_ssp;
+                for (int t = lane + 128; t < g.ntiles; t += 64) a = a + sp[t];
+            }
+            av[i] = a;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+            for (int i = 0; i < NR; ++i) av[i] = av[i] + __shfl_xor(av[i], m);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) srow[wave + 8 * i] = 1.0f / sqrtf(av[i] / (float)g.d_norm + g.eps);
         }
     }
 #pragma unroll
@@ -165,12 +194,20 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
 
 template <int RT, int NT>
 struct BgInst {
-    static constexpr int D = RT * NT <= 2 ? 8 : 4;
+    // steps of operands in flight per wave: as many as ~160 operand registers hold (a step = 4 (RT + NT) registers)
+    static constexpr int D = (RT + NT) <= 5 ? 8 : ((RT + NT) == 6 ? 6 : 5);
     static constexpr size_t lds = (size_t)8 * RT * NT * 4 * 64 * 4;
     static void prepare() {  // dynamic LDS above 64 KiB has to be allowed per kernel
-        if (lds > 65536) hipFuncSetAttribute((const void*)k_bgemm<RT, NT, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 65536) {
+            hipFuncSetAttribute((const void*)k_bgemm<RT, NT, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute((const void*)k_bgemm<RT, NT, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
     }
-    static void launch(const Q3BGemm& g, dim3 grid, hipStream_t s) { hipLaunchKernelGGL((k_bgemm<RT, NT, D>), grid, dim3(512), lds, s, g); }
+    static void launch(const Q3BGemm& g, dim3 grid, hipStream_t s) {
+        // once-read weight streams (the Talker at decode: every tile goes to exactly one workgroup) take non-temporal loads
+        if (g.w_once && grid.y == 1) hipLaunchKernelGGL((k_bgemm<RT, NT, D, true>), grid, dim3(512), lds, s, g);
+        else hipLaunchKernelGGL((k_bgemm<RT, NT, D, false>), grid, dim3(512), lds, s, g);
+    }
 };
 // once per process, outside any stream capture (the engine calls it before it records its graphs)
 void q3_bgemm_prepare() {

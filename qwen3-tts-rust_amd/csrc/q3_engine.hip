@@ -248,8 +248,10 @@ static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, uint16_t* xb, float*
                        hipStream_t s, bool one_row_per_slot = false, hipEvent_t* probe = nullptr) {
     const float eps = e->cfg.model.rms_eps;
     const int nt = t.d / 16;
+    const int once = &t == &e->T ? 1 : 0;  // the Talker's 2.8 GB stream once per frame step; the Predictor's weights are re-read 15 times (Infinity Cache)
     for (int l = 0; l < t.L; ++l) {
         Q3BGemm g{};
+        g.w_once = once;
         g.a = xb; g.B = rows; g.w = t.wqkv[l]; g.K = t.d; g.N = t.nqkv; g.ssp = ssp; g.ld_ssp = nt; g.ntiles = nt; g.d_norm = t.d; g.eps = eps;
         g.epi = Q3_EPI_STORE; g.y = sc.qkv; g.ldy = t.nqkv;
         q3_launch_bgemm(g, s);
@@ -262,15 +264,15 @@ static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, uint16_t* xb, float*
         at.kc = qp.kc; at.vc = qp.vc; at.n_ctx = t.n_ctx; at.row_pos = row_pos; at.row_slot = row_slot;
         at.fused = fused; at.prep = qp; at.out_bf16 = 1;
         q3_launch_attend(at, s);
-        g = Q3BGemm{}; g.a = sc.att; g.B = rows; g.w = t.wo[l]; g.K = t.nq; g.N = t.d; g.epi = Q3_EPI_RESID; g.y = x; g.ldy = t.d;
+        g = Q3BGemm{}; g.w_once = once; g.a = sc.att; g.B = rows; g.w = t.wo[l]; g.K = t.nq; g.N = t.d; g.epi = Q3_EPI_RESID; g.y = x; g.ldy = t.d;
         g.yb = xb; g.nw_next = t.ffn_norm[l]; g.ssp_out = ssp; g.ld_ssp_out = nt;
         q3_launch_bgemm(g, s);
-        g = Q3BGemm{}; g.a = xb; g.B = rows; g.w = t.wgu[l]; g.K = t.d; g.N = 2 * t.F; g.ssp = ssp; g.ld_ssp = nt; g.ntiles = nt; g.d_norm = t.d;
+        g = Q3BGemm{}; g.w_once = once; g.a = xb; g.B = rows; g.w = t.wgu[l]; g.K = t.d; g.N = 2 * t.F; g.ssp = ssp; g.ld_ssp = nt; g.ntiles = nt; g.d_norm = t.d;
         g.eps = eps; g.epi = Q3_EPI_SWIGLU; g.yb = sc.h;
         if (probe && l == 0) hipEventRecord(probe[0], s);
         q3_launch_bgemm(g, s);
         if (probe && l == 0) hipEventRecord(probe[1], s);
-        g = Q3BGemm{}; g.a = sc.h; g.B = rows; g.w = t.wd[l]; g.K = t.F; g.N = t.d; g.epi = Q3_EPI_RESID; g.y = x; g.ldy = t.d;
+        g = Q3BGemm{}; g.w_once = once; g.a = sc.h; g.B = rows; g.w = t.wd[l]; g.K = t.F; g.N = t.d; g.epi = Q3_EPI_RESID; g.y = x; g.ldy = t.d;
         g.yb = xb; g.nw_next = l + 1 < t.L ? t.attn_norm[l + 1] : t.out_norm; g.ssp_out = ssp; g.ld_ssp_out = nt;
         q3_launch_bgemm(g, s);
     }
@@ -319,7 +321,7 @@ static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
     hipEvent_t* pt = nullptr;  // probe mode 2: the Talker's layer-0 gate/up GEMM (the largest GEMM of the frame step)
     if (e->probe == 2 && B == L.nb && e->probe_i + 2 <= 8) { pt = &e->probe_ev[e->probe_i]; e->probe_i += 2; }
     run_layers(e, e->T, L.xT, L.xbT, L.sspT, B, L.row_pos_t, L.slot_id, L.sc, s, true, pt);
-    Q3BGemm g{}; g.a = L.xbT; g.B = B; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab;
+    Q3BGemm g{}; g.w_once = 1; g.a = L.xbT; g.B = B; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab;
     g.ssp = L.sspT; g.ld_ssp = m.t_d_model / 16; g.ntiles = m.t_d_model / 16; g.d_norm = m.t_d_model; g.eps = eps;
     g.epi = Q3_EPI_STORE; g.y = L.logits; g.ldy = m.t_vocab;
     q3_launch_bgemm(g, s);

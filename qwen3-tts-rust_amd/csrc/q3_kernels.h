@@ -37,6 +37,7 @@ Q3_HD size_t q3_atile_off(int row, int k, int kblocks) {
 struct Q3BGemm {
     const uint16_t* a; int a_row0; int B;       // A-tiled bf16 rows [a_row0, a_row0 + B) of a buffer with K columns
     const uint4* w; int K, N;                   // tiled bf16
+    int w_once;                                 // 1: the weights are read once per long interval (Talker decode): non-temporal loads when one workgroup owns a tile
     const float* ssp; int ld_ssp; int ntiles; int d_norm; float eps;  // row scale: s_r = 1 / sqrtf(SS(ssp[row][0..ntiles)) / d_norm + eps)
     int epi;
     float* y; int ldy;

@@ -293,6 +293,120 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
         else a.out[oi] = ov / l;
     }
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// The same attention for short caches (n_ctx <= 64: the Predictor's <= 17 keys per frame), one row per slot: ONE wave per query
+// head, the whole cache block and the first value rows requested before the q/k prep, no workgroup-wide reduction. Every
+// output follows the canonical order of k_attend bit for bit: scores = d-ascending fmaf chains, one key per
+// lane; l = the 64-lane butterfly of wave 0 (+0 +0 +0 for the three absent waves is exact); o_d: the 16 partials u = t mod 16
+// live as 4 (uu) x 4 (lane group) chains per dimension, r_uu = (o_4uu + o_4uu+1) + (o_4uu+2 + o_4uu+3) by the same two
+// shuffles, o = ((r0 + r1) + r2) + r3.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(R * 64) void k_attend_small(Q3Attend a) {
+    __shared__ __attribute__((aligned(16))) float kh[128], vh[128], ps[R][64];
+    const int g = blockIdx.x, row = blockIdx.y, hh = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pos = a.row_pos[row];
+    if (pos < 0) return;
+    const int slot = a.row_slot[row], T = pos + 1, hd = 128;
+    const Q3QkPrep& pr = a.prep;
+    const size_t hb = ((size_t)slot * a.Hkv + g) * a.n_ctx;
+    const uint16_t* kb = a.kc + hb * hd;
+    const uint16_t* vb = a.vc + hb * hd;
+    const int kg = lane >> 4, dl = lane & 15;
+    // cache operands first: independent of this row's projections (lanes beyond the cached keys read inside the slot's own block)
+    uint4 kv[16], vv0[4];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) kv[c] = ((const uint4*)kb)[c * 64 + lane];
+#pragma unroll
+    for (int uu = 0; uu < 4; ++uu) vv0[uu] = *(const uint4*)(vb + (size_t)min(4 * uu + kg, T - 1) * hd + dl * 8);
+    const float* rowp = a.qkv + (size_t)row * a.ld;
+    const int half = hd >> 1, nl = hd >> 2;
+    float qo[4], o4[4];
+    prep_head(rowp + (size_t)(g * R + hh) * hd, pr.qnw, pr.eps, pr.cs + (size_t)pos * half, pr.sn + (size_t)pos * half, hd, lane, qo);
+    __shared__ __attribute__((aligned(16))) float qh[R][128];
+    if (lane < nl) *(float4*)(qh[hh] + 4 * lane) = (float4){qo[0], qo[1], qo[2], qo[3]};
+    if (hh == 0) {  // k: norm + RoPE + append; v: append (the second wave, when there is one, takes v)
+        prep_head(rowp + (size_t)(a.Hq + g) * hd, pr.knw, pr.eps, pr.cs + (size_t)pos * half, pr.sn + (size_t)pos * half, hd, lane, o4);
+    }
+    if ((R == 1 || hh == 1) && lane < nl) {
+        const float4 v4 = ((const float4*)(rowp + (size_t)(a.Hq + a.Hkv + g) * hd))[lane];
+        *(float4*)(vh + 4 * lane) = (float4){q3_round_bf16(v4.x), q3_round_bf16(v4.y), q3_round_bf16(v4.z), q3_round_bf16(v4.w)};
+        uint2 vk;
+        vk.x = (uint32_t)q3_bf16(v4.x) | ((uint32_t)q3_bf16(v4.y) << 16); vk.y = (uint32_t)q3_bf16(v4.z) | ((uint32_t)q3_bf16(v4.w) << 16);
+        *(uint2*)(pr.vc + (hb + pos) * hd + 4 * lane) = vk;
+    }
+    if (hh == 0 && lane < nl) {
+        const int blk = pos >> 6, kl = pos & 63, c = lane >> 1, e0 = 4 * (lane & 1);
+        uint2 kk;
+        kk.x = (uint32_t)q3_bf16(o4[0]) | ((uint32_t)q3_bf16(o4[1]) << 16); kk.y = (uint32_t)q3_bf16(o4[2]) | ((uint32_t)q3_bf16(o4[3]) << 16);
+        *(uint2*)(pr.kc + hb * hd + ((size_t)(blk * (hd >> 3) + c) * 64 + kl) * 8 + e0) = kk;
+        *(float4*)(kh + 4 * lane) = (float4){q3_round_bf16(o4[0]), q3_round_bf16(o4[1]), q3_round_bf16(o4[2]), q3_round_bf16(o4[3])};
+    }
+    __syncthreads();
+    const float* q = qh[hh];
+    const float scale = 1.0f / sqrtf((float)hd);
+    float sc = 0.0f;
+    if (lane == pos) {  // newest key: from LDS, same d-ascending chain
+        for (int d = 0; d < hd; d += 4) {
+            const float4 qa = *(const float4*)(q + d), ka = *(const float4*)(kh + d);
+            sc = fmaf(qa.x, ka.x, sc); sc = fmaf(qa.y, ka.y, sc); sc = fmaf(qa.z, ka.z, sc); sc = fmaf(qa.w, ka.w, sc);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float4 qa = *(const float4*)(q + c * 8), qb = *(const float4*)(q + c * 8 + 4);
+            sc = fmaf(qa.x, q3_u2f(kv[c].x << 16), sc); sc = fmaf(qa.y, q3_u2f(kv[c].x & 0xffff0000u), sc);
+            sc = fmaf(qa.z, q3_u2f(kv[c].y << 16), sc); sc = fmaf(qa.w, q3_u2f(kv[c].y & 0xffff0000u), sc);
+            sc = fmaf(qb.x, q3_u2f(kv[c].z << 16), sc); sc = fmaf(qb.y, q3_u2f(kv[c].z & 0xffff0000u), sc);
+            sc = fmaf(qb.z, q3_u2f(kv[c].w << 16), sc); sc = fmaf(qb.w, q3_u2f(kv[c].w & 0xffff0000u), sc);
+        }
+    }
+    sc = sc * scale;
+    const float m = wave_max(lane < T ? sc : -INFINITY);
+    const float e = lane < T ? q3_expf(sc - m) : 0.0f;
+    ps[hh][lane] = e;
+    float l = wave_sum(e);
+    l = ((l + 0.0f) + 0.0f) + 0.0f;
+    float out8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out8[i] = 0.0f;
+#pragma unroll
+    for (int uu = 0; uu < 4; ++uu) {
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = 0.0f;
+        for (int t = 4 * uu + kg; t < T; t += 16) {
+            const float pt = ps[hh][t];
+            if (t == pos) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = fmaf(pt, vh[dl * 8 + i], o[i]);
+            } else {
+                const uint4 vv = t < 16 ? vv0[uu] : *(const uint4*)(vb + (size_t)t * hd + dl * 8);
+                o[0] = fmaf(pt, q3_u2f(vv.x << 16), o[0]); o[1] = fmaf(pt, q3_u2f(vv.x & 0xffff0000u), o[1]);
+                o[2] = fmaf(pt, q3_u2f(vv.y << 16), o[2]); o[3] = fmaf(pt, q3_u2f(vv.y & 0xffff0000u), o[3]);
+                o[4] = fmaf(pt, q3_u2f(vv.z << 16), o[4]); o[5] = fmaf(pt, q3_u2f(vv.z & 0xffff0000u), o[5]);
+                o[6] = fmaf(pt, q3_u2f(vv.w << 16), o[6]); o[7] = fmaf(pt, q3_u2f(vv.w & 0xffff0000u), o[7]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float r = o[i] + __shfl_xor(o[i], 16);
+            r = r + __shfl_xor(r, 32);
+            out8[i] = uu == 0 ? r : out8[i] + r;
+        }
+    }
+    if (kg == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int d = dl * 8 + i;
+            const float ov = out8[i] / l;
+            const size_t oi = (size_t)row * a.ldo + (size_t)(g * R + hh) * hd + d;
+            if (a.out_bf16) ((uint16_t*)a.out)[q3_atile_off(row, (g * R + hh) * hd + d, (a.Hq * hd) >> 5)] = q3_bf16(ov);
+            else a.out[oi] = ov;
+        }
+    }
+}
+
 void q3_launch_attend(const Q3Attend& a, hipStream_t s) {
     const int R = a.Hq / a.Hkv;
     const size_t lds = ((size_t)R * a.n_ctx + R * a.hd + R * 4 * a.hd + R * 8 + 2 * a.hd) * sizeof(float);
@@ -305,6 +419,11 @@ void q3_launch_attend(const Q3Attend& a, hipStream_t s) {
         hipFuncSetAttribute((const void*)k_attend<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute((const void*)k_attend<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = lds;
+    }
+    if (a.fused && a.n_ctx <= 64 && a.hd == 128 && (R == 1 || R == 2)) {  // short caches (the Predictor): one wave per query head
+        if (R == 2) hipLaunchKernelGGL((k_attend_small<2>), grid, dim3(128), 0, s, a);
+        else hipLaunchKernelGGL((k_attend_small<1>), grid, dim3(64), 0, s, a);
+        return;
     }
     if (a.fused) {
         if (R == 2) hipLaunchKernelGGL((k_attend<2, true>), grid, dim3(512), lds, s, a);
@@ -337,31 +456,44 @@ __device__ int sample_row(const float* logits, int limit, float temperature, int
         __syncthreads();
         return q3_argmax_idx(b);
     }
-    const bool select = top_k_i > 0 && top_k_i <= 256 && top_k_i < limit;
+    bool select = top_k_i > 0 && top_k_i <= 256 && top_k_i < limit;
     if (select) {
-        // top-k by selection: only the k largest keys are ever read below (:711-713), and the k-th round's block-wide
-        // maximum IS the k-th entry of the sorted list (keys are unique: the index is part of the key). Each thread
-        // keeps its 16 candidates in registers and their maximum cached; a round = wave max, 4-way max through LDS (double
-        // buffered: one barrier per round), and only the owner of the winner removes it and refreshes its local maximum.
-        __shared__ unsigned long long wsel[2][4];
+        // top-k without k block-wide reductions (each one is a chain of cross-lane steps: 40 rounds cost ~50 us). Only the k largest
+        // keys are ever read below (:711-713); keys are unique (the index is part of the key) except 0 = "not a candidate".
+        //  A  every thread's 16 candidates and their maximum; the k-th largest of the 256 thread maxima, T, is a lower bound of the
+        //     k-th largest key (the k thread maxima >= T are k distinct keys >= T), found by counting: rank = #{maxima > mine}
+        //  B  the candidates >= T (the top k are among them; typically ~2k of the 2160) are appended to a short list
+        //  C  the list is ranked by counting (#{larger}) — ranks are a permutation because keys are unique — and rank r < k lands in keys[r]
+        __shared__ unsigned long long lm[256];
+        __shared__ unsigned long long thr_s;
+        __shared__ int n_sel;
+        unsigned long long* sel = (unsigned long long*)probs;  // SAMP_MAX floats = SAMP_MAX / 2 keys
         unsigned long long loc[SAMP_MAX / 256];
         unsigned long long lmax = 0;
 #pragma unroll
         for (int j = 0; j < SAMP_MAX / 256; ++j) { const int i = tid + j * 256; loc[j] = i < limit ? q3_argmax_key(logits[i], (uint32_t)i) : 0ull; lmax = loc[j] > lmax ? loc[j] : lmax; }
-        for (int r = 0; r < top_k_i; ++r) {
-            unsigned long long best = lmax;
+        lm[tid] = lmax;
+        if (tid == 0) { thr_s = 0ull; n_sel = 0; }
+        __syncthreads();
+        int cnt = 0;
+        for (int j = 0; j < 256; ++j) cnt += lm[j] > lmax ? 1 : 0;
+        if (cnt == top_k_i - 1 && lmax != 0ull) thr_s = lmax;  // (stays 0 when fewer than k threads hold a candidate: then everything is listed)
+        __syncthreads();
+        const unsigned long long T = thr_s;
 #pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(best, m); best = o > best ? o : best; }
-            if ((tid & 63) == 0) wsel[r & 1][tid >> 6] = best;
+        for (int j = 0; j < SAMP_MAX / 256; ++j)
+            if (loc[j] != 0ull && loc[j] >= T) { const int pos = atomicAdd(&n_sel, 1); if (pos < SAMP_MAX / 2) sel[pos] = loc[j]; }
+        __syncthreads();
+        const int n = n_sel;
+        if (n > SAMP_MAX / 2) select = false;  // (uniform) pathological input: the list does not fit, take the full sort below
+        else {
+            for (int i = tid; i < top_k_i; i += 256) keys[i] = 0ull;
             __syncthreads();
-            unsigned long long b = wsel[r & 1][0];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) b = wsel[r & 1][w] > b ? wsel[r & 1][w] : b;
-            if (tid == 0) keys[r] = b;
-            if (lmax == b && b != 0ull) {  // (b == 0 only when fewer than top_k finite candidates remain: nothing to remove)
-                lmax = 0;
-#pragma unroll
-                for (int j = 0; j < SAMP_MAX / 256; ++j) { loc[j] = (loc[j] == b) ? 0ull : loc[j]; lmax = loc[j] > lmax ? loc[j] : lmax; }
+            for (int i = tid; i < n; i += 256) {
+                const unsigned long long mine = sel[i];
+                int rank = 0;
+                for (int j = 0; j < n; ++j) rank += sel[j] > mine ? 1 : 0;
+                if (rank < top_k_i) keys[rank] = mine;
             }
         }
         __syncthreads();

@@ -9,7 +9,7 @@ rows_want = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 which = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 rows = [r for r in csv.DictReader(open(f)) if 'voc' not in r['Kernel_Name'] and 'vgemm' not in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('k_sample(') and int(r['Grid_Size_X']) == rows_want * 256]
+idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('k_sample') and int(r['Grid_Size_X']) == rows_want * 256]
 fr = rows[idx[which]:idx[which + 1]]
 dur = lambda r: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
 print("kernels in frame:", len(fr), "span us", (int(fr[-1]['End_Timestamp']) - int(fr[0]['Start_Timestamp'])) / 1e3)
