@@ -245,7 +245,7 @@ static int alloc_scratch(q3tts_engine* e, Q3Scratch& sc, int rows, int nqkv, int
 // (+ SwiGLU), down GEMM (+ residual, + the next block's / the head's norm inputs). x: f32 residual rows; xb / ssp: their norm
 // inputs for attn_norm[0] on entry, for out_norm on exit. Restated by oracle/q3_oracle.c tfm_layers.
 static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, uint16_t* xb, float* ssp, int rows, const int* row_pos, const int* row_slot, Q3Scratch& sc,
-                       hipStream_t s, bool one_row_per_slot = false, hipEvent_t* probe = nullptr) {
+                       hipStream_t s, bool one_row_per_slot = false, hipEvent_t* probe = nullptr, int slot_mod = 0, int pos_const = 0) {
     const float eps = e->cfg.model.rms_eps;
     const int nt = t.d / 16;
     const int once = &t == &e->T ? 1 : 0;  // the Talker's 2.8 GB stream once per frame step; the Predictor's weights are re-read 15 times (Infinity Cache)
@@ -258,11 +258,12 @@ static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, uint16_t* xb, float*
         Q3QkPrep qp{}; qp.qkv = sc.qkv; qp.ld = t.nqkv; qp.rows = rows; qp.Hq = t.Hq; qp.Hkv = t.Hkv; qp.hd = t.hd;
         qp.qnw = t.qn[l]; qp.knw = t.kn[l]; qp.eps = eps; qp.cs = t.cs; qp.sn = t.sn;
         qp.kc = t.kc + l * t.layer_stride; qp.vc = t.vc + l * t.layer_stride; qp.n_ctx = t.n_ctx; qp.row_pos = row_pos; qp.row_slot = row_slot;
+        qp.slot_mod = slot_mod; qp.pos_const = pos_const;
         const bool fused = one_row_per_slot && t.Hq / t.Hkv >= 2;
         if (!fused) q3_launch_qk_prep(qp, s);
         Q3Attend at{}; at.qkv = sc.qkv; at.ld = t.nqkv; at.rows = rows; at.out = (float*)sc.att; at.ldo = t.nq; at.Hq = t.Hq; at.Hkv = t.Hkv; at.hd = t.hd;
         at.kc = qp.kc; at.vc = qp.vc; at.n_ctx = t.n_ctx; at.row_pos = row_pos; at.row_slot = row_slot;
-        at.fused = fused; at.prep = qp; at.out_bf16 = 1;
+        at.fused = fused; at.prep = qp; at.out_bf16 = 1; at.slot_mod = slot_mod; at.pos_const = pos_const;
         q3_launch_attend(at, s);
         g = Q3BGemm{}; g.w_once = once; g.a = sc.att; g.B = rows; g.w = t.wo[l]; g.K = t.nq; g.N = t.d; g.epi = Q3_EPI_RESID; g.y = x; g.ldy = t.d;
         g.yb = xb; g.nw_next = t.ffn_norm[l]; g.ssp_out = ssp; g.ld_ssp_out = nt;
@@ -310,7 +311,9 @@ static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
         if (q > 0) pred_next(q);
         hipEvent_t* pe = nullptr;
         if (e->probe == 1 && q == 1 && B == L.nb && e->probe_i + 2 <= 8) { pe = &e->probe_ev[e->probe_i]; e->probe_i += 2; }
-        run_layers(e, e->P, L.px, L.xbP, L.sspP, rows, q == 0 ? L.posA : L.pos_q + (size_t)q * L.nb, q == 0 ? L.slotA : L.slot_id, L.sc, s, q > 0, pe);
+        // the Predictor's cache lives for one frame (src/tts/engine.rs:575: cleared per frame), so it is indexed by ROW: slot = row % B,
+        // position = (q == 0 ? row / B : q + 1) — known without a load, the attention kernels request their operands at once
+        run_layers(e, e->P, L.px, L.xbP, L.sspP, rows, nullptr, nullptr, L.sc, s, q > 0, pe, B, q == 0 ? 0 : q + 1);
         // head q on the rows that carry the newest position (pass 0: rows [B, 2B)), argmax epilogue
         Q3BGemm g{}; g.a = L.xbP; g.a_row0 = q == 0 ? B : 0; g.B = B; g.w = e->P.head + head_tile_stride * q; g.K = dp; g.N = cbs;
         g.ssp = q == 0 ? L.sspP + (size_t)B * (dp / 16) : L.sspP; g.ld_ssp = dp / 16; g.ntiles = dp / 16; g.d_norm = dp; g.eps = eps;

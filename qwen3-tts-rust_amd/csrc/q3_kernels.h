@@ -59,6 +59,10 @@ struct Q3Project {
 };
 int q3_launch_project(const Q3Project& p, hipStream_t s);
 #ifdef __HIPCC__
+__device__ __forceinline__ void q3_row_map(int row, const int* row_pos, const int* row_slot, int slot_mod, int pos_const, int* pos, int* slot) {
+    if (slot_mod > 0) { *slot = row % slot_mod; *pos = pos_const + row / slot_mod; }
+    else { *pos = row_pos[row]; *slot = *pos < 0 ? 0 : row_slot[row]; }
+}
 // one element of a norm-input row: 16 consecutive lanes own one tile (all of them must be active); xb_elem = the A-tiled slot
 __device__ __forceinline__ void q3_norm_out(float v, float nwv, uint16_t* xb_elem, float* ssp_tile, bool tile_leader) {
     *xb_elem = q3_bf16(v * nwv);
@@ -88,6 +92,7 @@ struct Q3QkPrep {
     const float* cs; const float* sn;      // [n_ctx][hd/2]
     uint16_t* kc; uint16_t* vc; int n_ctx;  // layer base; per (slot, kv head): n_ctx*hd elements
     const int* row_pos; const int* row_slot;
+    int slot_mod, pos_const;  // slot_mod > 0: slot = row % slot_mod, pos = pos_const + row / slot_mod (no loads: the Predictor's per-frame cache is indexed by row)
 };
 void q3_launch_qk_prep(const Q3QkPrep& a, hipStream_t s);
 
@@ -99,6 +104,7 @@ struct Q3Attend {
     int Hq, Hkv, hd;
     const uint16_t* kc; const uint16_t* vc; int n_ctx;
     const int* row_pos; const int* row_slot;
+    int slot_mod, pos_const;  // as in Q3QkPrep
     int fused;        // 1: every slot has exactly one row in this launch -> q/k prep + KV append done in-kernel (R >= 2)
     Q3QkPrep prep;    // used when fused
 };

@@ -124,9 +124,9 @@ __device__ __forceinline__ void kv_append(uint16_t* kc, uint16_t* vc, size_t hb,
 
 __global__ __launch_bounds__(64) void k_qk_prep(Q3QkPrep a) {
     const int row = blockIdx.x, hx = blockIdx.y, lane = threadIdx.x;
-    const int pos = a.row_pos[row];
+    int pos, slot;
+    q3_row_map(row, a.row_pos, a.row_slot, a.slot_mod, a.pos_const, &pos, &slot);
     if (pos < 0) return;
-    const int slot = a.row_slot[row];
     const int hd = a.hd, half = hd >> 1, nl = hd >> 2;
     const bool isq = hx < a.Hq;
     const int g = hx - a.Hq;
@@ -156,9 +156,9 @@ template <int R, bool FUSED>
 __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int g = blockIdx.x, row = blockIdx.y;
-    const int pos = a.row_pos[row];
+    int pos, slot;
+    q3_row_map(row, a.row_pos, a.row_slot, a.slot_mod, a.pos_const, &pos, &slot);
     if (pos < 0) return;
-    const int slot = a.row_slot[row];
     const int T = pos + 1, Tcap = a.n_ctx, hd = a.hd, nch = hd >> 3;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hh = wave >> 2, sw = wave & 3;
     float* p_all = smem;                      // [R][Tcap]
@@ -305,9 +305,10 @@ template <int R>
 __global__ __launch_bounds__(R * 64) void k_attend_small(Q3Attend a) {
     __shared__ __attribute__((aligned(16))) float kh[128], vh[128], ps[R][64];
     const int g = blockIdx.x, row = blockIdx.y, hh = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int pos = a.row_pos[row];
+    int pos, slot;
+    q3_row_map(row, a.row_pos, a.row_slot, a.slot_mod, a.pos_const, &pos, &slot);
     if (pos < 0) return;
-    const int slot = a.row_slot[row], T = pos + 1, hd = 128;
+    const int T = pos + 1, hd = 128;
     const Q3QkPrep& pr = a.prep;
     const size_t hb = ((size_t)slot * a.Hkv + g) * a.n_ctx;
     const uint16_t* kb = a.kc + hb * hd;
