@@ -183,11 +183,12 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
                 sq = sq + __shfl_xor(sq, 1); sq = sq + __shfl_xor(sq, 2); sq = sq + __shfl_xor(sq, 4); sq = sq + __shfl_xor(sq, 8);
                 if (live && c == 0) g.ssp_out[(size_t)row * g.ld_ssp_out + (nb0 + j)] = sq;
             }
-        } else {  // Q3_EPI_ARGMAX: the largest key of the tile's 16 columns, one atomic per (row, tile)
+        } else {  // Q3_EPI_ARGMAX: the largest key of the tile's 16 columns goes to keys[row][column tile]; the consumer takes the maximum
+                  // over the row's N/16 entries (an atomicMax per (row, tile) on one word per row cost ~8 us of the launch)
             unsigned long long key = q3_argmax_key(g.ssp ? sc * v : v, (uint32_t)col);
 #pragma unroll
             for (int m = 1; m <= 8; m <<= 1) { const unsigned long long ok = __shfl_xor(key, m); key = ok > key ? ok : key; }
-            if (live && c == 0) atomicMax(g.keys + (size_t)row * g.key_stride, key);
+            if (live && c == 0) g.keys[(size_t)row * g.key_stride + (nb0 + j)] = key;
         }
     }
 }
@@ -221,13 +222,17 @@ void q3_bgemm_prepare() {
 // Tile choice: a launch is bound by the operand bytes a CU's load path takes in (x from L2, weights from HBM / L2), so pick the
 // (RT, NT) with the fewest bytes per workgroup-round — 32 (RT + NT) bytes per k — counted over ceil(workgroups / 256) rounds.
 // The choice never changes a result (see the header).
+// tuning hook (tools/bgemm_tune.hip): force one tile instance for every following launch; (0, 0) restores the cost model
+static int g_force_rt = 0, g_force_nt = 0;
+void q3_bgemm_force(int rt, int nt) { g_force_rt = rt; g_force_nt = nt; }
+
 int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s) {
     if (g.B < 1 || g.N % 16 || g.K % 256 || g.K < 256 || !g.a || !g.w || g.a_row0 < 0) return -1;
     if (g.yb && ((g.epi == Q3_EPI_RESID && g.N % 32) || (g.epi == Q3_EPI_SWIGLU && g.N % 64))) return -1;  // the A-tiled output has N (N/2) columns in 32-blocks
     if (g.epi == Q3_EPI_SWIGLU && (!g.yb)) return -1;
     if (g.ssp && g.ntiles < 1) return -1;
     const int tiles = g.N / 16;
-    int bestRT = 1, bestNT = 1; long bestCost = -1;
+    int bestRT = 1, bestNT = 1; long bestCost = -1, bestWgs = 0;
     for (int RT = 1; RT <= 4; ++RT)
         for (int NT = 1; NT <= 3; ++NT) {
             if (tiles % NT) continue;
@@ -236,8 +241,9 @@ int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s) {
             if (g.B <= 64 && RT > 1 && 16 * (RT - 1) * chunks >= g.B) continue;  // a smaller RT covers the rows with the same chunk count
             const long wgs = (long)(tiles / NT) * chunks, rounds = (wgs + 255) / 256;
             const long cost = rounds * (32L * (RT + NT) * g.K + 24000L);  // + a fixed cost per round (ramp, reduction)
-            if (bestCost < 0 || cost < bestCost || (cost == bestCost && NT > bestNT)) { bestCost = cost; bestRT = RT; bestNT = NT; }
+            if (bestCost < 0 || cost < bestCost || (cost == bestCost && (wgs > bestWgs || (wgs == bestWgs && NT > bestNT)))) { bestCost = cost; bestRT = RT; bestNT = NT; bestWgs = wgs; }
         }
+    if (g_force_rt > 0 && g_force_nt > 0 && tiles % g_force_nt == 0) { bestRT = g_force_rt; bestNT = g_force_nt; }
     const dim3 grid(tiles / bestNT, (g.B + 16 * bestRT - 1) / (16 * bestRT));
     q3_bgemm_prepare();
 #define L(RT_, NT_) if (bestRT == RT_ && bestNT == NT_) { BgInst<RT_, NT_>::launch(g, grid, s); return 0; }

@@ -287,7 +287,7 @@ static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
     Q3Slot* slots = e->slots;
     int* codes = e->codes;
     Q3Sample sa{}; sa.logits = L.logits; sa.ld = m.t_vocab; sa.limit = m.sample_limit; sa.eos = m.eos_code; sa.slots = slots; sa.B = B; sa.row_slot = L.slot_id;
-    sa.rng = e->rng; sa.codes = codes; sa.max_steps_cap = cap; sa.ncb = ncb; sa.keys = L.keys;
+    sa.rng = e->rng; sa.codes = codes; sa.max_steps_cap = cap; sa.ncb = ncb;
     Q3PredInput pi{}; pi.xT = L.xT; pi.out_norm = e->T.out_norm; pi.eps = eps; pi.d = de; pi.codec0 = e->codec[0]; pi.codec0_rows = m.codec0_rows;
     pi.slots = slots; pi.row_slot = L.slot_id; pi.X = L.X; pi.fb = L.fb; pi.B = B; pi.pproj0 = e->pproj[0]; pi.proj_b = e->proj_b; pi.dp = dp; pi.px = L.px;
     pi.nw = e->P.attn_norm[0]; pi.xb = L.xbP; pi.ssp = L.sspP;
@@ -299,7 +299,7 @@ static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
     }
     const size_t head_tile_stride = (size_t)(cbs / 16) * (dp / 32) * 64;  // uint4 per predictor head
     auto pred_next = [&](int q) {
-        Q3PredNext pn{}; pn.keys = L.keys; pn.q = q; pn.ncb = ncb; pn.codec_q = e->codec[q]; pn.rows_q = m.codecq_rows; pn.d = de;
+        Q3PredNext pn{}; pn.keys = L.keys; pn.n_key_parts = cbs / 16; pn.q = q; pn.ncb = ncb; pn.codec_q = e->codec[q]; pn.rows_q = m.codecq_rows; pn.d = de;
         pn.slots = slots; pn.row_slot = L.slot_id; pn.B = B; pn.codes = codes; pn.max_steps_cap = cap; pn.fb = L.fb;
         pn.tts_pad = e->tts_pad; pn.xT = L.xT; pn.row_pos_t = L.row_pos_t; pn.pproj_q = e->pproj[q]; pn.proj_b = e->proj_b; pn.dp = dp; pn.px = L.px;
         const bool last = q == ncb - 1;
@@ -317,7 +317,7 @@ static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
         // head q on the rows that carry the newest position (pass 0: rows [B, 2B)), argmax epilogue
         Q3BGemm g{}; g.a = L.xbP; g.a_row0 = q == 0 ? B : 0; g.B = B; g.w = e->P.head + head_tile_stride * q; g.K = dp; g.N = cbs;
         g.ssp = q == 0 ? L.sspP + (size_t)B * (dp / 16) : L.sspP; g.ld_ssp = dp / 16; g.ntiles = dp / 16; g.d_norm = dp; g.eps = eps;
-        g.epi = Q3_EPI_ARGMAX; g.keys = L.keys + (q + 1); g.key_stride = ncb;
+        g.epi = Q3_EPI_ARGMAX; g.keys = L.keys; g.key_stride = cbs / 16;  // per-tile maxima; k_pred_next(q + 1) reduces them
         q3_launch_bgemm(g, s);
     }
     pred_next(ncb - 1);
@@ -499,7 +499,7 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
         HIPC(hipEventCreate(&L.ev_begin)); HIPC(hipEventCreate(&L.ev_end));
         TRYC(dalloc(e, &L.xT, (size_t)nb * m.t_d_model)); TRYC(dalloc(e, &L.logits, (size_t)nb * m.t_vocab)); TRYC(dalloc(e, &L.logits_tmp, (size_t)nb * std::max(m.t_vocab, m.t_d_model)));
         TRYC(dalloc(e, &L.X, (size_t)2 * nb * m.d_embed)); TRYC(dalloc(e, &L.fb, (size_t)nb * m.d_embed));
-        TRYC(dalloc(e, &L.px, (size_t)2 * nb * m.p_d_model)); TRYC(dalloc(e, &L.keys, (size_t)nb * m.n_codebooks));
+        TRYC(dalloc(e, &L.px, (size_t)2 * nb * m.p_d_model)); TRYC(dalloc(e, &L.keys, (size_t)nb * (m.codebook_size / 16)));
         const size_t nb16 = ((size_t)nb + 15) & ~(size_t)15, nb2_16 = ((size_t)2 * nb + 15) & ~(size_t)15;  // A-tiled buffers hold whole 16-row tiles
         TRYC(dalloc(e, &L.xbT, nb16 * m.t_d_model)); TRYC(dalloc(e, &L.sspT, (size_t)nb * (m.t_d_model / 16)));
         TRYC(dalloc(e, &L.xbP, nb2_16 * m.p_d_model)); TRYC(dalloc(e, &L.sspP, (size_t)2 * nb * (m.p_d_model / 16)));
@@ -1320,7 +1320,7 @@ extern "C" int q3tts_k_bgemm(int32_t device, const uint16_t* xb, int32_t B, int3
     const size_t B16 = ((size_t)B + 15) & ~(size_t)15;
     DevBuf dx, dw, dwt, ds, dn, dy, dyb, dso, dk;
     if (dx.alloc(B16 * K * 2) || dw.alloc((size_t)N * K * 2) || dwt.alloc((size_t)N * K * 2) || ds.alloc((size_t)B * (ntiles > 0 ? ntiles : 1) * 4) ||
-        dn.alloc((size_t)N * 4) || dy.alloc((size_t)B * N * 4) || dyb.alloc(B16 * N * 2) || dso.alloc((size_t)B * (N / 16) * 4) || dk.alloc((size_t)B * 8))
+        dn.alloc((size_t)N * 4) || dy.alloc((size_t)B * N * 4) || dyb.alloc(B16 * N * 2) || dso.alloc((size_t)B * (N / 16) * 4) || dk.alloc((size_t)B * (N / 16) * 8))
         return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
     { const std::vector<uint16_t> xt = atile_host(xb, B, K); HK(hipMemcpy(dx.p, xt.data(), xt.size() * 2, hipMemcpyHostToDevice)); }
     HK(hipMemcpy(dw.p, w, (size_t)N * K * 2, hipMemcpyHostToDevice));
@@ -1335,7 +1335,7 @@ extern "C" int q3tts_k_bgemm(int32_t device, const uint16_t* xb, int32_t B, int3
     g.ssp = ssp ? (const float*)ds.p : nullptr; g.ld_ssp = ntiles; g.ntiles = ntiles; g.d_norm = d_norm; g.eps = eps; g.epi = epi;
     g.y = (float*)dy.p; g.ldy = N; g.yb = (uint16_t*)dyb.p;
     g.nw_next = nw_next ? (const float*)dn.p : nullptr; g.ssp_out = (float*)dso.p; g.ld_ssp_out = N / 16;
-    g.keys = (unsigned long long*)dk.p; g.key_stride = 1;
+    g.keys = (unsigned long long*)dk.p; g.key_stride = N / 16;
     if (q3_launch_bgemm(g, nullptr)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm: shape");
     HK(hipDeviceSynchronize());
     if (epi == Q3_EPI_STORE || epi == Q3_EPI_RESID) HK(hipMemcpy(y, dy.p, (size_t)B * N * 4, hipMemcpyDeviceToHost));
@@ -1344,7 +1344,11 @@ extern "C" int q3tts_k_bgemm(int32_t device, const uint16_t* xb, int32_t B, int3
         { std::vector<uint16_t> t(B16 * N); HK(hipMemcpy(t.data(), dyb.p, t.size() * 2, hipMemcpyDeviceToHost)); untile_host(t, B, N, yb); }
         HK(hipMemcpy(ssp_out, dso.p, (size_t)B * (N / 16) * 4, hipMemcpyDeviceToHost));
     }
-    if (epi == Q3_EPI_ARGMAX) HK(hipMemcpy(keys, dk.p, (size_t)B * 8, hipMemcpyDeviceToHost));
+    if (epi == Q3_EPI_ARGMAX) {  // the kernel leaves one maximum per (row, 16-column tile); the consumer (here: the hook) takes the row maximum
+        std::vector<uint64_t> parts((size_t)B * (N / 16));
+        HK(hipMemcpy(parts.data(), dk.p, parts.size() * 8, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b) { uint64_t m = 0; for (int t = 0; t < N / 16; ++t) m = std::max(m, parts[(size_t)b * (N / 16) + t]); keys[b] = m; }
+    }
     if (iters > 0 && mean_ms) {
         if (epi == Q3_EPI_RESID) { g.epi = Q3_EPI_STORE; g.nw_next = nullptr; }
         hipEvent_t a, b; HK(hipEventCreate(&a)); HK(hipEventCreate(&b));

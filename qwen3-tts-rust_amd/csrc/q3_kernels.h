@@ -25,7 +25,7 @@ void q3_launch_gemm(const Q3Gemm& g, hipStream_t s);
 //   STORE   y[B][N] f32 = s_r * RAW (s_r from the producer's tile partials ssp; no scale when ssp == nullptr)
 //   RESID   y[B][N] f32 += RAW; with nw_next also yb = bf16(y * nw_next) (A-tiled) and ssp_out[B][N/16] (the consumer's norm inputs)
 //   SWIGLU  yb = bf16(swiglu(s_r * RAW_gate, s_r * RAW_up)) (A-tiled, N/2 columns); each 16-column weight tile = 8 gate + 8 up columns
-//   ARGMAX  atomicMax(keys[row * key_stride], key(s_r * RAW, column))
+//   ARGMAX  keys[row * key_stride + column tile] = the largest key(s_r * RAW, column) of that 16-column tile (key_stride >= N/16)
 // bf16 activation rows live in the SAME fragment-tiled layout as the weights ("A-tiled"): tile (rt = row/16, kb = k/32) is 1 KiB,
 // lane l = (kq = l>>4, r = l&15) owns the 16 bytes holding A[rt*16 + r][kb*32 + {4kq..4kq+3, 16+4kq..16+4kq+3}], so one wave-load of
 // an A fragment is one contiguous KiB (a row-major load would touch 16 cache lines for 32 bytes each). Buffers hold
@@ -43,9 +43,10 @@ struct Q3BGemm {
     float* y; int ldy;
     uint16_t* yb;                               // A-tiled bf16 output (RESID: N columns; SWIGLU: N/2 columns), rows as y
     const float* nw_next; float* ssp_out; int ld_ssp_out;
-    unsigned long long* keys; int key_stride;
+    unsigned long long* keys; int key_stride;   // ARGMAX: per-tile maxima, [B][key_stride]
 };
 int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s);
+void q3_bgemm_force(int rt, int nt);  // tuning only: force a tile instance (0, 0: back to the cost model)
 void q3_bgemm_prepare();  // kernel attributes; call once outside stream capture
 // producer side of the split RMSNorm for plain f32 rows: xb = bf16(x * nw), ssp[row][t] = sum of squares of columns 16t..16t+15
 void q3_launch_norm_inputs(const float* x, int ldx, int rows, int d, const float* nw, uint16_t* xb, int xb_row0, float* ssp, int ld_ssp, hipStream_t s);
@@ -117,7 +118,6 @@ struct Q3Sample {
     const int* row_slot;
     const float* rng;                 // per-slot draws: rng[slot.rng_base + step]
     int* codes; int max_steps_cap; int ncb;
-    unsigned long long* keys;         // [B][ncb] argmax keys, zeroed here for the frame
 };
 void q3_launch_sample(const Q3Sample& a, hipStream_t s);
 // stand-alone sampler for the test hook: n rows, explicit draws
@@ -141,7 +141,7 @@ void q3_launch_sample_input(const Q3Sample& a, const Q3PredInput& p, hipStream_t
 // after pass q-1: code_q from the argmax key, record it, fb += codec_q[code_q]; q<ncb-1: px[b] = projected emb;
 // last: fb += tts_pad -> xT[b], row_pos_t[b] = cur_pos++, n_frames++
 struct Q3PredNext {
-    const unsigned long long* keys; int q; int ncb;
+    const unsigned long long* keys; int n_key_parts; int q; int ncb;  // keys[b][n_key_parts]: the head GEMM's per-tile maxima of pass q - 1
     const float* codec_q; int rows_q; int d;
     Q3Slot* slots; const int* row_slot; int B;
     int* codes; int max_steps_cap;

@@ -557,7 +557,6 @@ __device__ int sample_frame(const Q3Sample& a, int b, unsigned long long* keys, 
     const int tid = threadIdx.x, slot = a.row_slot[b];
     Q3Slot* sl = a.slots + slot;
     if (!sl->active) return -1;
-    if (tid < a.ncb) a.keys[(size_t)b * a.ncb + tid] = 0ull;
     const int step = sl->n_frames;
     if (step >= sl->max_steps) {  // loop bound: src/tts/engine.rs:545
         __syncthreads();
@@ -658,7 +657,18 @@ __global__ __launch_bounds__(256) void k_pred_next(Q3PredNext a) {
         if (last && tid == 0) a.row_pos_t[b] = -1;
         return;
     }
-    const int code = q3_argmax_idx(a.keys[(size_t)b * a.ncb + a.q]);
+    // code_q = argmax of the head's logits: the maximum of the per-tile keys the head GEMM left (ties -> smaller index, NaN never wins)
+    __shared__ unsigned long long kmax_s[4];
+    unsigned long long kk = tid < a.n_key_parts ? a.keys[(size_t)b * a.n_key_parts + tid] : 0ull;
+    for (int t = tid + 256; t < a.n_key_parts; t += 256) { const unsigned long long o = a.keys[(size_t)b * a.n_key_parts + t]; kk = o > kk ? o : kk; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(kk, m); kk = o > kk ? o : kk; }
+    if ((tid & 63) == 0) kmax_s[tid >> 6] = kk;
+    __syncthreads();
+    kk = kmax_s[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) kk = kmax_s[w] > kk ? kmax_s[w] : kk;
+    const int code = q3_argmax_idx(kk);
     const bool ok = code >= 0 && code < a.rows_q;
     const float* e = a.codec_q + (size_t)(ok ? code : 0) * d;
     const int frame = sl->n_frames;

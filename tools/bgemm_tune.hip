@@ -1,0 +1,75 @@
+// Tile sweep of the decoder's GEMM (csrc/q3_bgemm.hip) at the engine's shapes: every (RT, NT) instance the launcher could pick, with
+// the weights cold (rotating through copies larger than L2 + Infinity Cache: the Talker) or hot (one copy: the Predictor, whose
+// weights are re-read 15 times per frame). Prints us per launch inside a replayed hipGraph of 50 dependent launches.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I qwen3-tts-rust_amd/csrc -o tools/bgemm_tune tools/bgemm_tune.hip -L qwen3-tts-rust_amd/csrc -lq3tts -Wl,-rpath,'$ORIGIN/../qwen3-tts-rust_amd/csrc'
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "q3_kernels.h"
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+struct Shape { const char* name; int M, K, N, epi, scaled, cold; };
+
+int main(int argc, char** argv) {
+    hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    const Shape shapes[] = {
+        {"T qkv", 64, 2048, 4096, Q3_EPI_STORE, 1, 1}, {"T o", 64, 2048, 2048, Q3_EPI_RESID, 0, 1}, {"T gate/up", 64, 2048, 12288, Q3_EPI_SWIGLU, 1, 1},
+        {"T down", 64, 6144, 2048, Q3_EPI_RESID, 0, 1}, {"T head", 64, 2048, 3072, Q3_EPI_STORE, 1, 1},
+        {"T qkv", 48, 2048, 4096, Q3_EPI_STORE, 1, 1}, {"T o", 48, 2048, 2048, Q3_EPI_RESID, 0, 1}, {"T gate/up", 48, 2048, 12288, Q3_EPI_SWIGLU, 1, 1},
+        {"T down", 48, 6144, 2048, Q3_EPI_RESID, 0, 1},
+        {"T qkv", 32, 2048, 4096, Q3_EPI_STORE, 1, 1}, {"T o", 32, 2048, 2048, Q3_EPI_RESID, 0, 1}, {"T gate/up", 32, 2048, 12288, Q3_EPI_SWIGLU, 1, 1},
+        {"T down", 32, 6144, 2048, Q3_EPI_RESID, 0, 1},
+        {"T gate/up", 1, 2048, 12288, Q3_EPI_SWIGLU, 1, 1}, {"T down", 1, 6144, 2048, Q3_EPI_RESID, 0, 1},
+        {"P qkv", 64, 1024, 4096, Q3_EPI_STORE, 1, 0}, {"P o", 64, 2048, 1024, Q3_EPI_RESID, 0, 0}, {"P gate/up", 64, 1024, 6144, Q3_EPI_SWIGLU, 1, 0},
+        {"P down", 64, 3072, 1024, Q3_EPI_RESID, 0, 0}, {"P head", 64, 1024, 2048, Q3_EPI_ARGMAX, 1, 0},
+        {"P qkv", 48, 1024, 4096, Q3_EPI_STORE, 1, 0}, {"P o", 48, 2048, 1024, Q3_EPI_RESID, 0, 0}, {"P gate/up", 48, 1024, 6144, Q3_EPI_SWIGLU, 1, 0},
+        {"P down", 48, 3072, 1024, Q3_EPI_RESID, 0, 0},
+        {"P qkv", 128, 1024, 4096, Q3_EPI_STORE, 1, 0}, {"P gate/up", 128, 1024, 6144, Q3_EPI_SWIGLU, 1, 0}, {"P down", 128, 3072, 1024, Q3_EPI_RESID, 0, 0},
+    };
+    const size_t WBYTES = (size_t)2 << 30;
+    uint4* w; CK(hipMalloc(&w, WBYTES)); CK(hipMemset(w, 0x3c, WBYTES));
+    uint16_t *a, *yb; float *y, *ssp, *sso, *nw; unsigned long long* keys;
+    CK(hipMalloc(&a, 256 * 8192 * 2)); CK(hipMemset(a, 0x3c, 256 * 8192 * 2));
+    CK(hipMalloc(&yb, 256 * 16384 * 2)); CK(hipMalloc(&y, 256 * 16384 * 4)); CK(hipMemset(y, 0, 256 * 16384 * 4));
+    CK(hipMalloc(&ssp, 256 * 512 * 4)); CK(hipMemset(ssp, 0x3c, 256 * 512 * 4)); CK(hipMalloc(&sso, 256 * 1024 * 4));
+    CK(hipMalloc(&nw, 16384 * 4)); CK(hipMemset(nw, 0x3c, 16384 * 4)); CK(hipMalloc(&keys, 256 * 1024 * 8));
+    q3_bgemm_prepare();
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (const Shape& sh : shapes) {
+        const size_t wb = (size_t)sh.N * sh.K * 2;
+        const int copies = sh.cold ? (int)(WBYTES / wb) : 1;
+        printf("%-10s M=%3d K=%4d N=%5d %s:", sh.name, sh.M, sh.K, sh.N, sh.cold ? "cold" : "hot ");
+        float best = 1e9f; int brt = 0, bnt = 0; float chosen = 0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int rt = 1; rt <= 4; ++rt)
+                for (int nt = 1; nt <= 3; ++nt) {
+                    if (pass == 0 && (rt != 1 || nt != 1)) continue;  // pass 0: the launcher's own choice
+                    if (pass == 1 && (sh.N / 16) % nt) continue;
+                    q3_bgemm_force(pass == 0 ? 0 : rt, pass == 0 ? 0 : nt);
+                    hipGraph_t g; hipGraphExec_t ge;
+                    CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                    const int iters = 50;
+                    for (int i = 0; i < iters; ++i) {
+                        Q3BGemm q{}; q.a = a; q.B = sh.M; q.w = (const uint4*)((const char*)w + (size_t)(i % copies) * wb); q.K = sh.K; q.N = sh.N; q.w_once = sh.cold;
+                        if (sh.scaled) { q.ssp = ssp; q.ld_ssp = sh.K / 16; q.ntiles = sh.K / 16; q.d_norm = sh.K; q.eps = 1e-6f; }
+                        q.epi = sh.epi; q.y = y; q.ldy = sh.N; q.yb = yb; q.keys = keys; q.key_stride = sh.N / 16;
+                        if (sh.epi == Q3_EPI_RESID) { q.nw_next = nw; q.ssp_out = sso; q.ld_ssp_out = sh.N / 16; }
+                        if (q3_launch_bgemm(q, s)) { printf(" launch refused\n"); return 1; }
+                    }
+                    CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+                    CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
+                    float tot = 0;
+                    for (int rep = 0; rep < 3; ++rep) {
+                        CK(hipEventRecord(e0, s)); CK(hipGraphLaunch(ge, s)); CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+                        float ms = 0; hipEventElapsedTime(&ms, e0, e1); tot += ms;
+                    }
+                    const float us = tot * 1e3f / (3 * iters);
+                    if (pass == 0) { chosen = us; printf(" launcher %5.2f |", us); }
+                    else { printf(" (%d,%d) %5.2f", rt, nt, us); if (us < best) { best = us; brt = rt; bnt = nt; } }
+                    hipGraphExecDestroy(ge); hipGraphDestroy(g);
+                }
+        printf("  -> best (%d,%d) %.2f us (launcher %+.0f%%)\n", brt, bnt, best, 100.0f * (chosen - best) / best);
+    }
+    return 0;
+}
