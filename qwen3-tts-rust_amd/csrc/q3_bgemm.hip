@@ -193,10 +193,14 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
     }
 }
 
+// Operand steps in flight per wave (a step = 4 (RT + NT) registers; a K slice of 256 is 8 steps): 8, 5, 4, 3, 2 for RT + NT = <= 3, 4, 5, 6, 7,
+// which keeps every instance at <= ~146 registers per wave. Round 2 first ran 5-8 steps everywhere (160-230 registers): the shallow
+// depths are 3 % faster on the Talker's gate/up GEMM and 20 % on launches with more than one workgroup per CU (tools/bgemm_tune.hip), and
+// the whole job gains ~2.5 % with or without the vocoder alongside (bench.py A/B on one box: 551 -> 567 and 645 -> 661 audio-sec/s).
 template <int RT, int NT>
 struct BgInst {
-    // steps of operands in flight per wave: as many as ~160 operand registers hold (a step = 4 (RT + NT) registers)
-    static constexpr int D = (RT + NT) <= 5 ? 8 : ((RT + NT) == 6 ? 6 : 5);
+    static constexpr int S = RT + NT;
+    static constexpr int D = S <= 3 ? 8 : (S == 4 ? 5 : (S == 5 ? 4 : (S == 6 ? 3 : 2)));
     static constexpr size_t lds = (size_t)8 * RT * NT * 4 * 64 * 4;
     static void prepare() {  // dynamic LDS above 64 KiB has to be allowed per kernel
         if (lds > 65536) {
@@ -214,8 +218,9 @@ struct BgInst {
 void q3_bgemm_prepare() {
     static bool done = false;
     if (done) return;
-    BgInst<1, 1>::prepare(); BgInst<1, 2>::prepare(); BgInst<1, 3>::prepare(); BgInst<2, 1>::prepare(); BgInst<2, 2>::prepare(); BgInst<2, 3>::prepare();
-    BgInst<3, 1>::prepare(); BgInst<3, 2>::prepare(); BgInst<3, 3>::prepare(); BgInst<4, 1>::prepare(); BgInst<4, 2>::prepare(); BgInst<4, 3>::prepare();
+#define P(RT_, NT_) BgInst<RT_, NT_>::prepare();
+    P(1, 1) P(1, 2) P(1, 3) P(2, 1) P(2, 2) P(2, 3) P(3, 1) P(3, 2) P(3, 3) P(4, 1) P(4, 2) P(4, 3)
+#undef P
     done = true;
 }
 

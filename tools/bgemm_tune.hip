@@ -71,5 +71,44 @@ int main(int argc, char** argv) {
                 }
         printf("  -> best (%d,%d) %.2f us (launcher %+.0f%%)\n", brt, bnt, best, 100.0f * (chosen - best) / best);
     }
+    // Two half-batches side by side: does a chain of Predictor-layer GEMMs at 32 rows, run twice on two streams at once, finish sooner
+    // than one chain at 64 rows? (The chains are latency-bound; the question is whether two can share the CUs without slowing down.)
+    {
+        q3_bgemm_force(0, 0);
+        hipStream_t s2; CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        hipEvent_t f0, f1; CK(hipEventCreate(&f0)); CK(hipEventCreate(&f1));
+        const Shape layer[4] = {{"P qkv", 0, 1024, 4096, Q3_EPI_STORE, 1, 0}, {"P o", 0, 2048, 1024, Q3_EPI_RESID, 0, 0},
+                                {"P gate/up", 0, 1024, 6144, Q3_EPI_SWIGLU, 1, 0}, {"P down", 0, 3072, 1024, Q3_EPI_RESID, 0, 0}};
+        auto build = [&](hipStream_t st, int M, int half, hipGraphExec_t* ge) -> int {
+            hipGraph_t g;
+            CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            for (int l = 0; l < 10; ++l)
+                for (const Shape& sh : layer) {
+                    Q3BGemm q{}; q.a = a + (size_t)half * 64 * 8192; q.B = M; q.w = (const uint4*)((const char*)w + (size_t)(l * 4 + (&sh - layer)) * (16 << 20)); q.K = sh.K; q.N = sh.N;
+                    if (sh.scaled) { q.ssp = ssp + half * 64 * 512; q.ld_ssp = sh.K / 16; q.ntiles = sh.K / 16; q.d_norm = sh.K; q.eps = 1e-6f; }
+                    q.epi = sh.epi; q.y = y + (size_t)half * 64 * 16384; q.ldy = sh.N; q.yb = yb + (size_t)half * 64 * 16384;
+                    if (sh.epi == Q3_EPI_RESID) { q.nw_next = nw; q.ssp_out = sso + half * 64 * 1024; q.ld_ssp_out = sh.N / 16; }
+                    if (q3_launch_bgemm(q, st)) return 1;
+                }
+            CK(hipStreamEndCapture(st, &g)); CK(hipGraphInstantiate(ge, g, nullptr, nullptr, 0));
+            return 0;
+        };
+        for (int M : {64, 32, 16}) {
+            hipGraphExec_t ga, gb;
+            if (build(s, M, 0, &ga) || build(s2, M, 1, &gb)) { printf("dual: build failed\n"); return 1; }
+            CK(hipGraphLaunch(ga, s)); CK(hipGraphLaunch(gb, s2)); CK(hipDeviceSynchronize());
+            float one = 0, two = 0;
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipEventRecord(e0, s)); CK(hipGraphLaunch(ga, s)); CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+                float ms = 0; hipEventElapsedTime(&ms, e0, e1); one += ms;
+                CK(hipEventRecord(e0, s)); CK(hipStreamWaitEvent(s2, e0, 0));
+                CK(hipGraphLaunch(ga, s)); CK(hipGraphLaunch(gb, s2));
+                CK(hipEventRecord(f1, s2)); CK(hipStreamWaitEvent(s, f1, 0)); CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+                hipEventElapsedTime(&ms, e0, e1); two += ms;
+            }
+            printf("Predictor-layer GEMM chain (10 layers x 4 GEMMs, hot weights), %2d rows: one chain %.1f us; two chains at once on two streams %.1f us (%.2fx one)\n",
+                   M, one * 1e3f / 3, two * 1e3f / 3, two / one);
+        }
+    }
     return 0;
 }
