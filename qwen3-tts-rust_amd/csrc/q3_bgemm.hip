@@ -197,6 +197,8 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
 // which keeps every instance at <= ~146 registers per wave. Round 2 first ran 5-8 steps everywhere (160-230 registers): the shallow
 // depths are 3 % faster on the Talker's gate/up GEMM and 20 % on launches with more than one workgroup per CU (tools/bgemm_tune.hip), and
 // the whole job gains ~2.5 % with or without the vocoder alongside (bench.py A/B on one box: 551 -> 567 and 645 -> 661 audio-sec/s).
+// For RT + NT = 7 depths 1, 2 and 3 time the same (16.9 / 16.7 / 16.7 us on the Talker's gate/up): eight waves per workgroup hide the
+// latency, not the depth.
 template <int RT, int NT>
 struct BgInst {
     static constexpr int S = RT + NT;

@@ -424,15 +424,11 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
 #define HIPC(call) do { hipError_t er__ = (call); if (er__ != hipSuccess) { q3_set_err(e, Q3TTS_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(er__)); return fail(Q3TTS_ERR_DEVICE); } } while (0)
     HIPC(hipSetDevice(cfg->device));
     q3_bgemm_prepare();
-    // The frame step is a chain of ~550 short dependent launches, the vocoder a few long MFMA-bound ones: the decoder streams take the
-    // highest queue priority and the vocoder the lowest, so a frame-step kernel that becomes ready is dispatched ahead of the vocoder's
-    // waiting workgroups (Q3TTS_NO_PRIO=1: all streams at the default priority, for A/B runs)
-    int prio_least = 0, prio_greatest = 0;
-    if (!(getenv("Q3TTS_NO_PRIO") && atoi(getenv("Q3TTS_NO_PRIO")))) HIPC(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    HIPC(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_greatest));
+    HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     // Q3TTS_VOC_SERIAL=1: the vocoder shares the decoder stream (no overlap): isolates its kernels in a profile
+    // (highest / lowest stream priority for the decoder / vocoder streams was measured in both rounds: no change, left out)
     if (getenv("Q3TTS_VOC_SERIAL") && atoi(getenv("Q3TTS_VOC_SERIAL"))) e->vstream = e->stream;
-    else HIPC(hipStreamCreateWithPriority(&e->vstream, hipStreamNonBlocking, prio_least));
+    else HIPC(hipStreamCreateWithFlags(&e->vstream, hipStreamNonBlocking));
     HIPC(hipEventCreate(&e->ev0)); HIPC(hipEventCreate(&e->ev1)); HIPC(hipEventCreate(&e->ev2)); HIPC(hipEventCreate(&e->ev3));
     e->fin_ev.resize(cfg->max_batch, nullptr);
     for (auto& ev : e->fin_ev) HIPC(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -500,7 +496,7 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
         e->lanes.resize(1);
         Q3Lane& L = e->lanes[0];
         L.nb = nb;
-        HIPC(hipStreamCreateWithPriority(&L.stream, hipStreamNonBlocking, prio_greatest));
+        HIPC(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         HIPC(hipEventCreate(&L.ev_begin)); HIPC(hipEventCreate(&L.ev_end));
         TRYC(dalloc(e, &L.xT, (size_t)nb * m.t_d_model)); TRYC(dalloc(e, &L.logits, (size_t)nb * m.t_vocab)); TRYC(dalloc(e, &L.logits_tmp, (size_t)nb * std::max(m.t_vocab, m.t_d_model)));
         TRYC(dalloc(e, &L.X, (size_t)2 * nb * m.d_embed)); TRYC(dalloc(e, &L.fb, (size_t)nb * m.d_embed));
