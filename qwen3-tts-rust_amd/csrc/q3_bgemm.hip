@@ -175,7 +175,7 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
         if (epi == Q3_EPI_STORE) {
             if (live) g.y[(size_t)row * g.ldy + col] = g.ssp ? sc * v : v;
         } else if (epi == Q3_EPI_RESID) {
-            const float xv = yres[it] + v;
+            const float xv = g.col_scale ? yres[it] + g.col_scale[col] * v : yres[it] + v;
             if (live) g.y[(size_t)row * g.ldy + col] = xv;
             if (g.nw_next) {  // the consumer's norm inputs: bf16(x * nw) and the tile's sum of squares (16-lane butterfly)
                 if (live) g.yb[q3_atile_off(row, col, g.N >> 5)] = q3_bf16(xv * g.nw_next[col]);

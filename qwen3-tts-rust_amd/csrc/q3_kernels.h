@@ -23,7 +23,7 @@ void q3_launch_gemm(const Q3Gemm& g, hipStream_t s);
 // The decoder's GEMM (q3_bgemm.hip): bf16 rows x tiled bf16 weights on v_mfma_f32_16x16x32_bf16 in the canonical
 // order RAW = (((s_0 + s_1) + ...) + s_7) over 8 K-slices. K % 256 == 0, N % 16 == 0.
 //   STORE   y[B][N] f32 = s_r * RAW (s_r from the producer's tile partials ssp; no scale when ssp == nullptr)
-//   RESID   y[B][N] f32 += RAW; with nw_next also yb = bf16(y * nw_next) (A-tiled) and ssp_out[B][N/16] (the consumer's norm inputs)
+//   RESID   y[B][N] f32 += RAW (+= col_scale[column] * RAW when col_scale is given: the vocoder's LayerScale); with nw_next also yb = bf16(y * nw_next) (A-tiled) and ssp_out[B][N/16] (the consumer's norm inputs)
 //   SWIGLU  yb = bf16(swiglu(s_r * RAW_gate, s_r * RAW_up)) (A-tiled, N/2 columns); each 16-column weight tile = 8 gate + 8 up columns
 //   ARGMAX  keys[row * key_stride + column tile] = the largest key(s_r * RAW, column) of that 16-column tile (key_stride >= N/16)
 // bf16 activation rows live in the SAME fragment-tiled layout as the weights ("A-tiled"): tile (rt = row/16, kb = k/32) is 1 KiB,
@@ -43,6 +43,7 @@ struct Q3BGemm {
     float* y; int ldy;
     uint16_t* yb;                               // A-tiled bf16 output (RESID: N columns; SWIGLU: N/2 columns), rows as y
     const float* nw_next; float* ssp_out; int ld_ssp_out;
+    const float* col_scale;                     // RESID only, optional
     unsigned long long* keys; int key_stride;   // ARGMAX: per-tile maxima, [B][key_stride]
 };
 int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s);

@@ -39,6 +39,7 @@ struct VBuf { float* p = nullptr; float* hist = nullptr; int H = 0, C = 0, Tcap 
               size_t stride() const { return (size_t)(H + Tcap) * C; } };  // in elements
 
 struct VLayer { float *in_norm, *post_norm, *ls_attn, *ls_mlp; VConv q, k, v, o, gate, up, down;
+                uint4 *qkv_t = nullptr, *o_t = nullptr, *gu_t = nullptr, *down_t = nullptr;  // the four projections in the decoder GEMM's tiled layout (tfm_bg)
                 VConv qkv, gu; };  // fused launches: qkv = rows of q | k | v; gu = 16-row groups of gate and up alternating
 struct VUp { VConv ct, pw1, pw2; float *dw_w, *dw_b, *ln_w, *ln_b, *gamma; int r; VBuf dw_in; };
 struct VRes { float *ea, *ib, *ea2, *ib2; VConv c1, c2; VBuf c1_in; };
@@ -55,6 +56,8 @@ struct Q3Voc {
     std::vector<VBlk> Bk;
     float *oea = nullptr, *oib = nullptr, *out_w = nullptr, *out_b = nullptr; VBuf out_in; int out_c = 0;
     float *kring = nullptr, *vring = nullptr;  // [n_layer][B][RW][HH]
+    float* rope = nullptr; int rope_rows = 0;    // [position][hd/2][cos, sin], evaluated in double on the host like the oracle's
+    bool tfm_bg = false;                         // the transformer's projections run on k_bgemm (every K a multiple of 256)
     float *x = nullptr, *xn = nullptr, *xnb = nullptr, *qkv = nullptr, *att = nullptr, *g = nullptr;  // transformer scratch [M][.] (xnb, att, g: bf16)
     float *t1 = nullptr, *t2 = nullptr;  // generic scratch (largest stage)
     float* pcm = nullptr; size_t pcm_stride = 0;         // [B][max_steps_cap * spf]
@@ -485,6 +488,7 @@ __global__ void k_voc_hist(VCall cl, E* work, size_t stride, E* hist, int H, int
     }
 }
 
+// out_bf16: 0 f32 rows, 1 bf16 rows, 2 bf16 in the decoder GEMM's A-tiled layout (q3_atile_off)
 __global__ __launch_bounds__(64) void k_voc_rmsnorm(const float* x, const float* w, float eps, int d, float* y, int out_bf16) {
     const int r = blockIdx.x, lane = threadIdx.x;
     const float* xr = x + (size_t)r * d;
@@ -507,29 +511,33 @@ __global__ __launch_bounds__(64) void k_voc_rmsnorm(const float* x, const float*
         for (int u = 0; u < 8; ++u)
             if (i0 + u * 64 < d) {
                 const float o = (v[u] * rinv) * wv[u];
-                if (out_bf16) ((__bf16*)y)[(size_t)r * d + i0 + u * 64] = (__bf16)o; else y[(size_t)r * d + i0 + u * 64] = o;
+                if (out_bf16 == 2) ((__bf16*)y)[q3_atile_off(r, i0 + u * 64, d >> 5)] = (__bf16)o;
+                else if (out_bf16) ((__bf16*)y)[(size_t)r * d + i0 + u * 64] = (__bf16)o;
+                else y[(size_t)r * d + i0 + u * 64] = o;
             }
     }
 }
 
-// RoPE + ring append + sliding-window attention; one workgroup (64 threads) per (slot, head), tokens in order
-__global__ __launch_bounds__(64) void k_voc_attn(VCall cl, const float* qkv, float* kring, float* vring,
-                                                 int H, int hd, int RW, int W, float theta, float* att) {
-    __shared__ float sc[512];
-    __shared__ float qs[128];
-    const int s = blockIdx.y, h = blockIdx.x, lane = threadIdx.x, HH = H * hd, half = hd >> 1;
-    const int slot = cl.slot[s], T = cl.nf;
+// RoPE + ring append + sliding-window attention; one workgroup per (slot, head), one wave per new token. All tokens append their
+// K / V rows first; the ring holds W + VOC_FCAP rows, so no token of the call overwrites a row another token of the call still reads.
+// Per token the arithmetic is what the one-wave kernel of round 1 did (same chains, same order); cos / sin come from the host table.
+__global__ __launch_bounds__(64 * VOC_FCAP) void k_voc_attn(VCall cl, const float* qkv, float* kring, float* vring, const float* rope,
+                                                            int H, int hd, int RW, int W, float* att, int tiled) {
+    __shared__ float sc_s[VOC_FCAP][512];
+    __shared__ float qs_s[VOC_FCAP][128];
+    const int s = blockIdx.y, h = blockIdx.x, t = threadIdx.x >> 6, lane = threadIdx.x & 63, HH = H * hd, half = hd >> 1;
+    const int slot = cl.slot[s], T = cl.nf;  // blockDim.x = 64 * T
     float* kr = kring + (size_t)slot * RW * HH + h * hd;
     float* vr = vring + (size_t)slot * RW * HH + h * hd;
+    float* sc = sc_s[t]; float* qs = qs_s[t];
     const float scale = 1.0f / sqrtf((float)hd);
-    for (int t = 0; t < T; ++t) {
-        const int pos = cl.pos[s] + t;
-        const size_t row = ((size_t)s * T + t) * HH + h * hd;
-        const float* qp = qkv + ((size_t)s * T + t) * 3 * HH + h * hd;  // q | k | v of this row inside the fused [M][3*HH] buffer
+    const int pos = cl.pos[s] + t, m = s * T + t;
+    {
+        const float* qp = qkv + (size_t)m * 3 * HH + h * hd;  // q | k | v of this row inside the fused [M][3*HH] buffer
         const float* kp0 = qp + HH; const float* vp = qp + 2 * HH;
         if (lane < half) {
-            const double inv = pow((double)theta, -2.0 * (double)lane / (double)hd), ang = (double)pos * inv;
-            const float cs = (float)cos(ang), sn = (float)sin(ang);
+            const float2 csn = ((const float2*)rope)[(size_t)pos * half + lane];
+            const float cs = csn.x, sn = csn.y;
             float a = qp[lane], b = qp[lane + half];
             qs[lane] = a * cs - b * sn; qs[lane + half] = b * cs + a * sn;
             a = kp0[lane]; b = kp0[lane + half];
@@ -537,48 +545,49 @@ __global__ __launch_bounds__(64) void k_voc_attn(VCall cl, const float* qkv, flo
             kd[lane] = a * cs - b * sn; kd[lane + half] = b * cs + a * sn;
         }
         for (int i = lane; i < hd; i += 64) vr[(size_t)(pos % RW) * HH + i] = vp[i];
-        __syncthreads();
-        const int j0 = pos - W + 1 > 0 ? pos - W + 1 : 0, nk = pos - j0 + 1;
-        for (int j = lane; j < nk; j += 64) {
-            const float4* kp = (const float4*)(kr + (size_t)((j0 + j) % RW) * HH);
-            float a = 0.0f;
-            for (int i0 = 0; i0 < hd; i0 += 32) {  // 8 x 16 B of the key row in flight per trip, same ascending chain
-                float4 kk[8];
+    }
+    __syncthreads();
+    const int j0 = pos - W + 1 > 0 ? pos - W + 1 : 0, nk = pos - j0 + 1;
+    for (int j = lane; j < nk; j += 64) {
+        const float4* kp = (const float4*)(kr + (size_t)((j0 + j) % RW) * HH);
+        float a = 0.0f;
+        for (int i0 = 0; i0 < hd; i0 += 64) {  // 16 x 16 B of the key row in flight per trip (a 64-wide head: the whole row), same ascending chain
+            float4 kk[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) kk[u] = kp[min(i0 / 4 + u, hd / 4 - 1)];
+            for (int u = 0; u < 16; ++u) kk[u] = kp[min(i0 / 4 + u, hd / 4 - 1)];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (i0 + 4 * u < hd) {
-                        const float* qp2 = qs + i0 + 4 * u;
-                        a += qp2[0] * kk[u].x; a += qp2[1] * kk[u].y; a += qp2[2] * kk[u].z; a += qp2[3] * kk[u].w;
-                    }
-            }
-            sc[j] = a * scale;
+            for (int u = 0; u < 16; ++u)
+                if (i0 + 4 * u < hd) {
+                    const float* qp2 = qs + i0 + 4 * u;
+                    a += qp2[0] * kk[u].x; a += qp2[1] * kk[u].y; a += qp2[2] * kk[u].z; a += qp2[3] * kk[u].w;
+                }
         }
-        __syncthreads();
-        // softmax weights once per key (lane j), max and sum by wave reductions; then P.V with the weights from LDS
-        float m = -INFINITY;
-        for (int j = lane; j < nk; j += 64) m = fmaxf(m, sc[j]);
+        sc[j] = a * scale;
+    }
+    __syncthreads();
+    // softmax weights once per key (lane j), max and sum by wave reductions; then P.V with the weights from LDS
+    float mx = -INFINITY;
+    for (int j = lane; j < nk; j += 64) mx = fmaxf(mx, sc[j]);
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        float l = 0.0f;
-        for (int j = lane; j < nk; j += 64) { const float pj = expf(sc[j] - m); sc[j] = pj; l += pj; }
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float l = 0.0f;
+    for (int j = lane; j < nk; j += 64) { const float pj = expf(sc[j] - mx); sc[j] = pj; l += pj; }
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) l += __shfl_xor(l, o);
-        __syncthreads();
-        for (int i = lane; i < hd; i += 64) {
-            float o = 0.0f;
-            for (int jb = 0; jb < nk; jb += 8) {  // 8 value rows in flight per trip, same ascending chain
-                float vv[8];
+    for (int o = 32; o >= 1; o >>= 1) l += __shfl_xor(l, o);
+    __syncthreads();
+    for (int i = lane; i < hd; i += 64) {
+        float o = 0.0f;
+        for (int jb = 0; jb < nk; jb += 24) {  // 24 value rows in flight per trip (a 72-row window: three trips), same ascending chain
+            float vv[24];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) vv[u] = vr[(size_t)((j0 + min(jb + u, nk - 1)) % RW) * HH + i];
+            for (int u = 0; u < 24; ++u) vv[u] = vr[(size_t)((j0 + min(jb + u, nk - 1)) % RW) * HH + i];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (jb + u < nk) o += sc[jb + u] * vv[u];
-            }
-            ((__bf16*)att)[row + i] = (__bf16)(o / l);  // only ever the A operand of the output projection
+            for (int u = 0; u < 24; ++u)
+                if (jb + u < nk) o += sc[jb + u] * vv[u];
         }
-        __syncthreads();
+        // only ever the A operand of the output projection
+        const size_t off = tiled ? q3_atile_off(m, h * hd + i, HH >> 5) : (size_t)m * HH + h * hd + i;
+        ((__bf16*)att)[off] = (__bf16)(o / l);
     }
 }
 
@@ -755,6 +764,35 @@ int q3_voc_create(q3tts_engine* e) {
         Q3_HIP(e, hipMemcpy2DAsync(y.gu.w, (size_t)32 * d * 2, y.gate.w, (size_t)16 * d * 2, (size_t)16 * d * 2, c.d_ffn / 16, hipMemcpyDeviceToDevice, e->stream));
         Q3_HIP(e, hipMemcpy2DAsync(y.gu.w + (size_t)16 * d, (size_t)32 * d * 2, y.up.w, (size_t)16 * d * 2, (size_t)16 * d * 2, c.d_ffn / 16, hipMemcpyDeviceToDevice, e->stream));
     }
+    // every K a multiple of 256 (the shipped 1024 / 1024 / 3072): the four projections of a layer run on the decoder's k_bgemm, from
+    // copies of the same bf16 values in its tiled layout (gate | up interleaved 8 + 8 columns per tile); other shapes keep k_vgemm_small
+    v->tfm_bg = d % 256 == 0 && HH % 256 == 0 && c.d_ffn % 256 == 0 && (3 * HH) % 16 == 0 && c.d_ffn % 32 == 0;
+    if (v->tfm_bg)
+        for (int l = 0; l < c.n_layer; ++l) {
+            VLayer& y = v->L[l];
+            VTRY(valloc(e, v, &y.qkv_t, (size_t)3 * HH * d / 8)); VTRY(valloc(e, v, &y.o_t, (size_t)d * HH / 8));
+            VTRY(valloc(e, v, &y.gu_t, (size_t)2 * c.d_ffn * d / 8)); VTRY(valloc(e, v, &y.down_t, (size_t)d * c.d_ffn / 8));
+            Q3Fill f{};
+            f.mode = 0; f.row0 = 0;
+            f.dst = y.qkv_t; f.N = 3 * HH; f.K = d; f.rows = 3 * HH; f.src_a = y.qkv.w; q3_launch_fill_tiled(f, e->stream);
+            f.dst = y.o_t; f.N = d; f.K = HH; f.rows = d; f.src_a = y.o.w; q3_launch_fill_tiled(f, e->stream);
+            f.dst = y.down_t; f.N = d; f.K = c.d_ffn; f.rows = d; f.src_a = y.down.w; q3_launch_fill_tiled(f, e->stream);
+            f.mode = 1; f.dst = y.gu_t; f.N = 2 * c.d_ffn; f.K = d; f.src_a = y.gate.w; f.src_b = y.up.w; q3_launch_fill_tiled(f, e->stream);
+        }
+    {   // RoPE table: the oracle's expressions (double pow / cos / sin, rounded to f32), for every position a frame can take
+        v->rope_rows = e->cfg.max_steps_cap + VOC_FCAP;
+        const int half = c.head_dim / 2;
+        std::vector<float> tab((size_t)v->rope_rows * half * 2);
+        for (int i = 0; i < half; ++i) {
+            const double inv = pow((double)c.rope_theta, -2.0 * (double)i / (double)c.head_dim);
+            for (int p = 0; p < v->rope_rows; ++p) {
+                const double ang = (double)p * inv;
+                tab[((size_t)p * half + i) * 2] = (float)cos(ang); tab[((size_t)p * half + i) * 2 + 1] = (float)sin(ang);
+            }
+        }
+        VTRY(valloc(e, v, &v->rope, tab.size()));
+        Q3_HIP(e, hipMemcpy(v->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    }
     VTRY(gen_vec(e, v, &v->final_norm, VTID(VC_FINAL_NORM, VW_W), d, 1.0f, 0.05f));
     int rows = VOC_FCAP;  // rows per slot at the current stage
     v->spf = 1;
@@ -918,10 +956,25 @@ static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
     for (int l = 0; l < c.n_layer; ++l) {
         VLayer& L = v->L[l];
         // GEMM-only activations (normed input, attention output, SwiGLU output) are stored as the bf16 they would be rounded to
+        float* kr = v->kring + (size_t)l * v->B * v->RW * HH; float* vr = v->vring + (size_t)l * v->B * v->RW * HH;
+        if (v->tfm_bg) {  // the decoder's GEMM: A-tiled bf16 rows in, 8 K-slices per output (its tile choice never changes a result)
+            Q3BGemm g{}; g.B = M;
+            hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, L.in_norm, c.rms_eps, d, v->xnb, 2);
+            g.a = (const uint16_t*)v->xnb; g.w = L.qkv_t; g.K = d; g.N = 3 * HH; g.epi = Q3_EPI_STORE; g.y = v->qkv; g.ldy = 3 * HH;
+            if (q3_launch_bgemm(g, s)) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder: qkv GEMM shape");
+            hipLaunchKernelGGL(k_voc_attn, dim3(c.n_head, ns), dim3(64 * nf), 0, s, cl, v->qkv, kr, vr, v->rope, c.n_head, c.head_dim, v->RW, c.sliding_window, v->att, 1);
+            g.a = (const uint16_t*)v->att; g.w = L.o_t; g.K = HH; g.N = d; g.epi = Q3_EPI_RESID; g.y = v->x; g.ldy = d; g.col_scale = L.ls_attn;
+            if (q3_launch_bgemm(g, s)) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder: o GEMM shape");
+            hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, L.post_norm, c.rms_eps, d, v->xnb, 2);
+            g.a = (const uint16_t*)v->xnb; g.w = L.gu_t; g.K = d; g.N = 2 * c.d_ffn; g.epi = Q3_EPI_SWIGLU; g.y = nullptr; g.yb = (uint16_t*)v->g; g.col_scale = nullptr;
+            if (q3_launch_bgemm(g, s)) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder: gate/up GEMM shape");
+            g.a = (const uint16_t*)v->g; g.w = L.down_t; g.K = c.d_ffn; g.N = d; g.epi = Q3_EPI_RESID; g.y = v->x; g.ldy = d; g.yb = nullptr; g.col_scale = L.ls_mlp;
+            if (q3_launch_bgemm(g, s)) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder: down GEMM shape");
+            continue;
+        }
         hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, L.in_norm, c.rms_eps, d, v->xnb, 1);
         vgemm(s, L.qkv, v->xnb, 0, 0, 1, M, v->qkv, 0, 0, 0, nullptr, 1, nullptr, 1, 1);
-        hipLaunchKernelGGL(k_voc_attn, dim3(c.n_head, ns), dim3(64), 0, s, cl, v->qkv, v->kring + (size_t)l * v->B * v->RW * HH,
-                           v->vring + (size_t)l * v->B * v->RW * HH, c.n_head, c.head_dim, v->RW, c.sliding_window, c.rope_theta, v->att);
+        hipLaunchKernelGGL(k_voc_attn, dim3(c.n_head, ns), dim3(64 * nf), 0, s, cl, v->qkv, kr, vr, v->rope, c.n_head, c.head_dim, v->RW, c.sliding_window, v->att, 0);
         vgemm(s, L.o, v->att, 0, 0, 1, M, v->x, 0, 0, 1, L.ls_attn, d, nullptr, 1, 1);
         hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, L.post_norm, c.rms_eps, d, v->xnb, 1);
         vgemm(s, L.gu, v->xnb, 0, 0, 1, M, v->g, 0, 0, 4, nullptr, 1, nullptr, 1, 1, 1);  // gate | up in one launch, SwiGLU in the epilogue
