@@ -330,9 +330,13 @@ def main():
             pr = probe_leg(2)
             # The bracket also times the closing event packet. An EMPTY bracket on the same stream (empty_ms) bounds that
             # overhead from above, so the kernel's own duration lies in [kernel_ms - empty_ms, kernel_ms]; rocprofv3 puts it
-            # in between (profiles/README.md). `achieved` uses the whole bracket: a lower bound on the kernel's rate.
+            # in between (profiles/README.md), and the launch-to-launch period of the same kernel inside a replayed graph
+            # (tools/bgemm_tune.hip, 16.7 us) sits at the lower end. `achieved` uses bracket - empty bracket, both measured in
+            # this run; `achieved_lower_bound` uses the whole bracket.
             k_ms = pr["kernel_ms"]
-            k_gbs = pr["bytes"] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+            kc_ms = max(pr["kernel_ms"] - pr["empty_ms"], 1e-6)
+            k_gbs = pr["bytes"] / (kc_ms * 1e-3) / 1e9
+            k_gbs_lb = pr["bytes"] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
             traffic, traffic_src = None, None
             tpath = os.path.join(REPO, "profiles", ROUND, "pmc_traffic.json")
             if os.path.exists(tpath):
@@ -341,6 +345,7 @@ def main():
                 traffic_src = f"profiled offline (two rocprofv3 --pmc passes over `bench.py --probe-only`, profiles/{ROUND}/pmc_traffic.json), not measured in this run"
             line["roofline"] = {
                 "bound": "hbm", "achieved": round(k_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(k_gbs / HBM_PEAK_GBS, 4),
+                "achieved_lower_bound": round(k_gbs_lb, 1), "frac_lower_bound": round(k_gbs_lb / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "k_bgemm: Talker gate/up GEMM (row scale of the split RMSNorm + SwiGLU epilogue) on v_mfma_f32_16x16x32_bf16, M=%d K=%d N=%d, "
                           "28 launches per frame step, the largest GEMM of the step; bf16 ridge 2500 TF / 8 TB/s = 312 flop/B > %.0f flop/B => HBM-bound" %
@@ -348,20 +353,21 @@ def main():
                 "launch_us": round(k_ms * 1e3, 2), "empty_bracket_us": round(pr["empty_ms"] * 1e3, 2),
                 "launch_us_minus_empty_bracket": round((pr["kernel_ms"] - pr["empty_ms"]) * 1e3, 2), "launches_timed": pr["launches"],
                 "algorithmic_flops_per_launch": int(pr["flops"]), "algorithmic_bytes_per_launch": int(pr["bytes"]),
-                "tflops": round(pr["flops"] / (k_ms * 1e-3) / 1e12, 2) if k_ms > 0 else 0.0,
-                "how": "HIP events on the decode stream around every launch of this kernel in layer 0 of the Talker step, eager frame steps, "
+                "tflops": round(pr["flops"] / (kc_ms * 1e-3) / 1e12, 2),
+                "how": "achieved = algorithmic bytes / (launch_us - empty_bracket_us); HIP events on the decode stream around every launch of this kernel in layer 0 of the Talker step, eager frame steps, "
                        f"64 live utterances, codes only (q3tts_k_probe mode 2); rocprofv3 of the same leg: profiles/{ROUND}/probe_kernel_stats.csv"}
             line["frame_step_64_rows_codes_only_ms"] = round(pr["frame_step_ms"], 4)
             pb = probe_leg(1)
             b_ms = pb["kernel_ms"]
-            b_gbs = pb["bytes"] / (b_ms * 1e-3) / 1e9 if b_ms > 0 else 0.0
+            bc_ms = max(pb["kernel_ms"] - pb["empty_ms"], 1e-6)
+            b_gbs = pb["bytes"] / (bc_ms * 1e-3) / 1e9
             line["roofline_predictor_kernel"] = {
                 "bound": "hbm", "achieved": round(b_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b_gbs / HBM_PEAK_GBS, 4), "traffic": None,
                 "kernel": "k_bgemm: Predictor gate/up GEMM, M=%d K=%d N=%d (75 launches per frame step; weights re-read 15x per frame, Infinity-Cache resident)" % (pb["rows"], pb["K"], pb["N"]),
                 "launch_us": round(b_ms * 1e3, 2), "empty_bracket_us": round(pb["empty_ms"] * 1e3, 2),
                 "launch_us_minus_empty_bracket": round((pb["kernel_ms"] - pb["empty_ms"]) * 1e3, 2), "launches_timed": pb["launches"],
                 "algorithmic_flops_per_launch": int(pb["flops"]), "algorithmic_bytes_per_launch": int(pb["bytes"]),
-                "tflops": round(pb["flops"] / (b_ms * 1e-3) / 1e12, 2) if b_ms > 0 else 0.0}
+                "tflops": round(pb["flops"] / (bc_ms * 1e-3) / 1e12, 2)}
             if cfg.with_vocoder:
                 line["roofline_vocoder"] = vocoder_leg()
         else:

@@ -26,6 +26,11 @@ __device__ __forceinline__ float bg_wave_sum(float v) {
     return v;
 }
 
+__device__ __forceinline__ size_t bg_yoff(const Q3BGemm& g, int row) {
+    return g.seg_rows ? (size_t)(row / g.seg_rows) * g.seg_stride + (size_t)(row % g.seg_rows) * g.ldy : (size_t)row * g.ldy;
+}
+__device__ __forceinline__ float bg_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
 __device__ __forceinline__ u32x4 bg_ldw(const u32x4* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
 
 template <int RT, int NT, int D, bool NTW>
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
             const int o = threadIdx.x + it * 512;
             const int l = o & 63, e = (o >> 6) & 3, t = o >> 8, i = t / NT, j = t - i * NT;
             const int row = row0 + 16 * i + 4 * (l >> 4) + e;
-            yres[it] = (o < TR * 64 && row < B) ? g.y[(size_t)row * g.ldy + (size_t)(nb0 + j) * 16 + (l & 15)] : 0.0f;
+            yres[it] = (o < TR * 64 && row < B) ? g.y[bg_yoff(g, row) + (size_t)(nb0 + j) * 16 + (l & 15)] : 0.0f;
         }
     }
     // norm GEMMs: wave w owns the row scales of rows w, w + 8, ...; their tile partials are requested now and reduced after the main
@@ -172,11 +177,15 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
         float v = part[o];
 #pragma unroll
         for (int wv = 1; wv < 8; ++wv) v = v + part[(size_t)wv * (TR * 64) + o];
+        if (g.bias) v = v + g.bias[col % g.bias_n];
         if (epi == Q3_EPI_STORE) {
-            if (live) g.y[(size_t)row * g.ldy + col] = g.ssp ? sc * v : v;
+            if (live) g.y[bg_yoff(g, row) + col] = g.ssp ? sc * v : v;
+        } else if (epi == Q3_EPI_GELU) {
+            if (live) g.yb[q3_atile_off(row, col, g.N >> 5)] = q3_bf16(bg_gelu_erf(v));
         } else if (epi == Q3_EPI_RESID) {
             const float xv = g.col_scale ? yres[it] + g.col_scale[col] * v : yres[it] + v;
-            if (live) g.y[(size_t)row * g.ldy + col] = xv;
+            if (live) g.y[bg_yoff(g, row) + col] = xv;
+            if (g.yb && !g.nw_next && live) g.yb[q3_atile_off(row, col, g.N >> 5)] = q3_bf16(xv);
             if (g.nw_next) {  // the consumer's norm inputs: bf16(x * nw) and the tile's sum of squares (16-lane butterfly)
                 if (live) g.yb[q3_atile_off(row, col, g.N >> 5)] = q3_bf16(xv * g.nw_next[col]);
                 float sq = xv * xv;
@@ -235,8 +244,9 @@ void q3_bgemm_force(int rt, int nt) { g_force_rt = rt; g_force_nt = nt; }
 
 int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s) {
     if (g.B < 1 || g.N % 16 || g.K % 256 || g.K < 256 || !g.a || !g.w || g.a_row0 < 0) return -1;
-    if (g.yb && ((g.epi == Q3_EPI_RESID && g.N % 32) || (g.epi == Q3_EPI_SWIGLU && g.N % 64))) return -1;  // the A-tiled output has N (N/2) columns in 32-blocks
-    if (g.epi == Q3_EPI_SWIGLU && (!g.yb)) return -1;
+    if (g.yb && (((g.epi == Q3_EPI_RESID || g.epi == Q3_EPI_GELU) && g.N % 32) || (g.epi == Q3_EPI_SWIGLU && g.N % 64))) return -1;  // the A-tiled output has N (N/2) columns in 32-blocks
+    if ((g.epi == Q3_EPI_SWIGLU || g.epi == Q3_EPI_GELU) && (!g.yb)) return -1;
+    if (g.bias && g.bias_n < 1) return -1;
     if (g.ssp && g.ntiles < 1) return -1;
     const int tiles = g.N / 16;
     int bestRT = 1, bestNT = 1; long bestCost = -1, bestWgs = 0;

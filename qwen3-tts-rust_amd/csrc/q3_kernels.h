@@ -2,7 +2,7 @@
 #pragma once
 #include "q3_common.h"
 
-enum { Q3_EPI_STORE = 0, Q3_EPI_RESID = 1, Q3_EPI_SWIGLU = 2, Q3_EPI_ARGMAX = 3 };
+enum { Q3_EPI_STORE = 0, Q3_EPI_RESID = 1, Q3_EPI_SWIGLU = 2, Q3_EPI_ARGMAX = 3, Q3_EPI_GELU = 4 };
 
 // Exact GEMM y[B][N] = x[B][K] * W[N][K]^T in the canonical order of DESIGN.md §4.1.
 // W is bf16 in the tiled HBM layout of DESIGN.md §2.1: tile (nb = n/16, kb = k/32) is 1 KiB,
@@ -25,6 +25,7 @@ void q3_launch_gemm(const Q3Gemm& g, hipStream_t s);
 //   STORE   y[B][N] f32 = s_r * RAW (s_r from the producer's tile partials ssp; no scale when ssp == nullptr)
 //   RESID   y[B][N] f32 += RAW (+= col_scale[column] * RAW when col_scale is given: the vocoder's LayerScale); with nw_next also yb = bf16(y * nw_next) (A-tiled) and ssp_out[B][N/16] (the consumer's norm inputs)
 //   SWIGLU  yb = bf16(swiglu(s_r * RAW_gate, s_r * RAW_up)) (A-tiled, N/2 columns); each 16-column weight tile = 8 gate + 8 up columns
+//   GELU    yb = bf16(gelu_erf(RAW + bias)) (A-tiled, N columns): the vocoder's ConvNeXt pointwise pair
 //   ARGMAX  keys[row * key_stride + column tile] = the largest key(s_r * RAW, column) of that 16-column tile (key_stride >= N/16)
 // bf16 activation rows live in the SAME fragment-tiled layout as the weights ("A-tiled"): tile (rt = row/16, kb = k/32) is 1 KiB,
 // lane l = (kq = l>>4, r = l&15) owns the 16 bytes holding A[rt*16 + r][kb*32 + {4kq..4kq+3, 16+4kq..16+4kq+3}], so one wave-load of
@@ -44,6 +45,10 @@ struct Q3BGemm {
     uint16_t* yb;                               // A-tiled bf16 output (RESID: N columns; SWIGLU: N/2 columns), rows as y
     const float* nw_next; float* ssp_out; int ld_ssp_out;
     const float* col_scale;                     // RESID only, optional
+    // vocoder extras (all optional, zero = off): a bias added to RAW first (column % bias_n); f32 rows that live in per-slot segments
+    // (row m at y + (m / seg_rows) * seg_stride + (m % seg_rows) * ldy); RESID without nw_next but with yb: yb = bf16(y) (A-tiled)
+    const float* bias; int bias_n;
+    int seg_rows; size_t seg_stride;
     unsigned long long* keys; int key_stride;   // ARGMAX: per-tile maxima, [B][key_stride]
 };
 int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s);

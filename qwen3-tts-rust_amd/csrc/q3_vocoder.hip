@@ -41,7 +41,8 @@ struct VBuf { float* p = nullptr; float* hist = nullptr; int H = 0, C = 0, Tcap 
 struct VLayer { float *in_norm, *post_norm, *ls_attn, *ls_mlp; VConv q, k, v, o, gate, up, down;
                 uint4 *qkv_t = nullptr, *o_t = nullptr, *gu_t = nullptr, *down_t = nullptr;  // the four projections in the decoder GEMM's tiled layout (tfm_bg)
                 VConv qkv, gu; };  // fused launches: qkv = rows of q | k | v; gu = 16-row groups of gate and up alternating
-struct VUp { VConv ct, pw1, pw2; float *dw_w, *dw_b, *ln_w, *ln_b, *gamma; int r; VBuf dw_in; };
+struct VUp { VConv ct, pw1, pw2; float *dw_w, *dw_b, *ln_w, *ln_b, *gamma; int r; VBuf dw_in;
+             uint4 *ct_t = nullptr, *pw1_t = nullptr, *pw2_t = nullptr; };  // tiled copies for k_bgemm (up_bg)
 struct VRes { float *ea, *ib, *ea2, *ib2; VConv c1, c2; VBuf c1_in; };
 struct VBlk { float *ea, *ib; VConv ct; VRes res[3]; int r, cin, cout; VBuf ct_in; };
 
@@ -58,6 +59,7 @@ struct Q3Voc {
     float *kring = nullptr, *vring = nullptr;  // [n_layer][B][RW][HH]
     float* rope = nullptr; int rope_rows = 0;    // [position][hd/2][cos, sin], evaluated in double on the host like the oracle's
     bool tfm_bg = false;                         // the transformer's projections run on k_bgemm (every K a multiple of 256)
+    bool up_bg = false; uint16_t* upb = nullptr; // so do the up-sampling stages' ConvTranspose / pointwise GEMMs; upb: a stage's output as A-tiled bf16 for the next
     float *x = nullptr, *xn = nullptr, *xnb = nullptr, *qkv = nullptr, *att = nullptr, *g = nullptr;  // transformer scratch [M][.] (xnb, att, g: bf16)
     float *t1 = nullptr, *t2 = nullptr;  // generic scratch (largest stage)
     float* pcm = nullptr; size_t pcm_stride = 0;         // [B][max_steps_cap * spf]
@@ -202,10 +204,11 @@ __global__ __launch_bounds__(256) void k_vgemm_small(VGemm g) {
 // LDS-tiled GEMM for the big-M convolutions (the decoder blocks: thousands of rows per slot): workgroup tile
 // 128 x (NJ*32), K step 32, 2 x 2 waves of 64 x (NJ*16) (4 x NJ MFMA tiles); NJ = 3 serves the 96- and 192-channel
 // blocks without padding waste. A (f32 -> bf16) and W tiles go through registers into double-buffered LDS; the
-// registers run two K steps ahead of the LDS copy (three ahead of the MFMAs), rows are padded to 40 bf16 (80 B) so
-// that the 16 lanes of a ds_read_b128 group hit 16 distinct 4-bank slots. Conv taps are just extra K steps with a
+// registers run two K steps ahead of the LDS copy (three ahead of the MFMAs), rows are padded to 48 bf16 (96 B) so
+// that the 16 lanes of a ds_read_b128 group hit 16 distinct 4-bank slots (any row stride = 32 mod 64 bytes does). Conv taps are just extra K steps with a
 // shifted row pointer.
-#define VT_LD 40
+#define VR_SW(r) ((4 - (((r) >> 2) & 3)) & 3)  // chunk XOR of the unpadded 64-byte-row tiles (derivation: k_vgemm_ring)
+#define VT_LD 48  // 96-byte rows: conflict-free for ds_read_b128's real 16-lane groups ({0-3, 12-15, 20-27}, ...); 80-byte rows were 2-way
 template <bool ABF> struct VStage;  // one K step of staging registers (only the fields a variant uses: a union-style struct spills)
 template <> struct VStage<false> { float4 a0, a1, a2, a3; uint4 b0, b1; float live; };
 template <> struct VStage<true> { uint4 ab0, ab1; uint4 b0, b1; float live; };
@@ -313,6 +316,137 @@ __global__ __launch_bounds__(256) void k_vgemm_lds(VGemm g) {
     }
 }
 
+// The same GEMM for bf16 A operands with the operand tiles brought in by LDS-DMA (global_load_lds_dwordx4) into a ring of VR_NS stages:
+// k_vgemm_lds keeps two K steps of lookahead in registers, which left it bound by the global-load latency (~0.7 us per 32-wide K step with
+// one workgroup on a CU, 8 % MFMA issue rate on the decoder's input convolution); here three stages (48 KiB per workgroup, two workgroups
+// per CU) are in flight while one is consumed and no operand passes through registers on its way to LDS. Tile 128 x (NJ*32), 2 x 2 waves of
+// 64 x (NJ*16), one barrier per K step. A stage holds rows of 64 bytes (32 bf16) unpadded; the 16-byte chunk c of row r sits at chunk
+// position c ^ VR_SW(r), VR_SW(r) = (4 - (r >> 2)) & 3. ds_read_b128 is served in four 16-lane groups that are NOT contiguous
+// (MI355X_MICROARCH.md, LDS: {0-3, 12-15, 20-27}, ...): with lane = 16 kq + (row & 15) a group reads rows 0-3 and 12-15 at chunk kq and
+// rows 4-11 at chunk kq ^ 1, and this XOR puts those sixteen 16-byte slots on sixteen different slots of the 256-byte bank row
+// ((r >> 2) & 3 alone leaves every group 2-way conflicted). A DMA load writes lane l's 16 bytes at (wave-uniform base) + 16 l, so
+// lane l FETCHES the chunk that belongs there: row l >> 2 of its 16-row group, chunk (l & 3) ^ VR_SW(row).
+// Accumulation order per output element is unchanged (32-wide K steps ascending over taps, then channels).
+#define VR_NS 4
+template <int NJ>
+__global__ __launch_bounds__(256) void k_vgemm_ring(VGemm g) {
+    constexpr int BN = NJ * 32, LA = 2, LB = (BN / 16 + 3) / 4, L = LA + LB;
+    constexpr int STAGE = (128 + BN) * 64;  // bytes
+    extern __shared__ __attribute__((aligned(16))) char ring[];  // [VR_NS][A 128 x 64 B | B BN x 64 B]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, kq = lane >> 4;
+    // Workgroups go to the 8 XCDs round-robin by linear id. Tile t = (column tile fastest) is given to XCD t / (tiles / 8): every XCD then
+    // owns a contiguous band of row tiles with all their column tiles, so an A band is fetched into ONE L2 (not into as many as it has
+    // column tiles) and the workgroups running together on an XCD walk the same few weight tiles.
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int total = gridDim.x * gridDim.y;
+        if ((total & 7) == 0) {
+            const int id = blockIdx.x + gridDim.x * blockIdx.y, t = (id & 7) * (total >> 3) + (id >> 3);
+            bx = t % gridDim.x; by = t / gridDim.x;
+        }
+    }
+    const int m0 = by * 128, n0 = bx * BN;
+    const int cin = g.c.cin, nout = g.c.nout, kpt = cin >> 5, steps = g.c.ntap * kpt;
+    // loader role: 16-row group gA (A) / gB (B), row lrow of the group, chunk fetched = (lane & 3) ^ ((row >> 2) & 3)
+    const int lrow = lane >> 2;
+    const uint16_t* arow[LA]; int achunk[LA];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int row = (wave * LA + i) * 16 + lrow;  // row of the 128-row tile
+        int m = m0 + row; if (m >= g.M) m = g.M - 1;
+        const int s = m / g.T, t = m - s * g.T;
+        achunk[i] = ((lane & 3) ^ VR_SW(row)) * 8;
+        arow[i] = (const uint16_t*)g.x + (size_t)s * g.x_stride + g.x_off + (size_t)t * cin + achunk[i];
+    }
+    const uint16_t* brow[LB]; int bgrp[LB];
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        bgrp[i] = min(wave * LB + i, BN / 16 - 1);  // (a clamped duplicate re-writes the same bytes)
+        const int row = bgrp[i] * 16 + lrow;
+        int n = n0 + row; if (n >= nout) n = nout - 1;
+        brow[i] = g.c.w + (size_t)n * cin + ((lane & 3) ^ VR_SW(row)) * 8;
+    }
+    auto issue = [&](int step) {
+        const int tap = step / kpt, k0 = (step - tap * kpt) << 5;
+        const long sh = (long)(g.c.ntap - 1 - tap) * g.c.dil * cin - k0;
+        char* st = ring + (size_t)(step % VR_NS) * STAGE;
+#pragma unroll
+        for (int i = 0; i < LA; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(arow[i] - sh),
+                                             (__attribute__((address_space(3))) void*)(st + (wave * LA + i) * 1024), 16, 0, 0);
+        const size_t wo = (size_t)tap * nout * cin + k0;
+#pragma unroll
+        for (int i = 0; i < LB; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(brow[i] + wo),
+                                             (__attribute__((address_space(3))) void*)(st + 128 * 64 + bgrp[i] * 1024), 16, 0, 0);
+    };
+    f32x4 acc[4][NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // fragment addresses inside a stage: row R, chunk kq -> R * 64 + ((kq ^ VR_SW(R)) * 16)
+    int aoff[4], boff[NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int R = wm * 64 + i * 16 + lr; aoff[i] = R * 64 + ((kq ^ VR_SW(R)) << 4); }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { const int R = wn * NJ * 16 + j * 16 + lr; boff[j] = 128 * 64 + R * 64 + ((kq ^ VR_SW(R)) << 4); }
+#pragma unroll
+    for (int p = 0; p < VR_NS - 1; ++p)
+        if (p < steps) issue(p);
+    for (int step = 0; step < steps; ++step) {
+        // this wave's loads of stage `step` have landed when at most the later stages' loads are outstanding
+        if (step + VR_NS - 2 < steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((VR_NS - 2) * L) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // every wave's part of the stage is in LDS, and every wave is done reading stage step - 1
+        if (step + VR_NS - 1 < steps) issue(step + VR_NS - 1);  // into the buffer stage step - 1 used
+        const char* st = ring + (size_t)(step % VR_NS) * STAGE;
+        bf16x8 a_[4], b_[NJ];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_[i] = *(const bf16x8*)(st + aoff[i]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b_[j] = *(const bf16x8*)(st + boff[j]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_[i], b_[j], acc[i][j], 0, 0, 0);
+    }
+    const bool rmw = g.epi == 1 || g.epi == 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float yv[4][NJ];  // residual operands of this row tile: one batch of loads, not a round trip per element
+        if (rmw) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = min(m0 + wm * 64 + i * 16 + 4 * kq + e, g.M - 1);
+                const int s = m / g.T, t = m - s * g.T;
+                const float* yp = g.y + (size_t)s * g.y_stride + g.y_off + (size_t)t * nout;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) yv[e][j] = yp[min(n0 + wn * NJ * 16 + j * 16 + lr, nout - 1)];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = m0 + wm * 64 + i * 16 + 4 * kq + e;
+            if (m >= g.M) continue;
+            const int s = m / g.T, t = m - s * g.T;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n0 + wn * NJ * 16 + j * 16 + lr;
+                if (n < nout) vepi(g, acc[i][j][e], s, t, n, rmw ? yv[e][j] : 0.0f);
+            }
+        }
+    }
+}
+template <int NJ>
+static void launch_vgemm_ring(hipStream_t s, const VGemm& g, dim3 grid) {
+    constexpr size_t lds = (size_t)VR_NS * (128 + NJ * 32) * 64;
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute((const void*)k_vgemm_ring<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    hipLaunchKernelGGL((k_vgemm_ring<NJ>), grid, dim3(256), lds, s, g);
+}
+
 // Fused residual unit of the narrow decoder blocks (C <= 192 channels, where everything is HBM-bound):
 //   o += conv1x1(snake2(conv7_dil(xin)))  and  next_in = snake_next(o)
 // in ONE pass: the workgroup stages its R + 6*dil input rows in LDS as bf16 once (the seven taps read LDS, not HBM),
@@ -328,136 +462,189 @@ struct VResUnit {
     float* o; size_t o_stride; int store_o;
     float* y2; size_t y2_stride; int y2_off; const float *ea3, *ib3;  // snake of the consumer, written (bf16) into its work buffer
 };
+#ifdef Q3_STAMPS
+__device__ unsigned long long g_voc_stamps[4][16];  // experiment builds: s_memtime stamps of four workgroups' wave 0
+#define VR_STAMP(i_) do { if (stamp_wg >= 0 && threadIdx.x == 0) g_voc_stamps[stamp_wg][i_] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define VR_STAMP(i_) do { } while (0)
+#endif
 template <int NT, int MT>
 __global__ __launch_bounds__(256) void k_voc_resunit(VResUnit g) {
-    constexpr int C = NT * 16, KS = C / 32, R = 64 * MT, LDA = C + 8, S1 = 7 * KS, S = 8 * KS;
+#ifdef Q3_STAMPS
+    const int stamp_wg = (blockIdx.y == 5 && (blockIdx.x == 3 || blockIdx.x == 20)) ? (blockIdx.x == 3 ? 0 : 1) : ((blockIdx.y == 40 && blockIdx.x == 11) ? 2 : -1);
+#endif
+    VR_STAMP(0);
+    constexpr int C = NT * 16, KS = C / 32, R = 64 * MT, LDA = C + 16, S1 = 7 * KS, S = 8 * KS;  // row stride 2 C + 32 bytes = 32 mod 64: conflict-free fragment reads
     constexpr int BPASS = (C + 63) / 64;  // weight-chunk loader passes: 64 rows x 64 B per pass
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
     const int halo = 6 * g.dil;
     __bf16* At = lds;                                  // [R + halo][LDA]
     __bf16* Zt = lds;                                  // [R][LDA]: reuses the input tile once conv1 has consumed it
-    __bf16* Bs = At + (size_t)(R + halo) * LDA;         // [2][C][VT_LD]
+    __bf16* Bs = At + (size_t)(R + halo) * LDA;         // [2][C][32], 16-byte chunk c of row n at chunk position c ^ VR_SW(n) (see k_vgemm_ring)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
     const int sidx = blockIdx.y, t0 = blockIdx.x * R, T = g.T;
-    // weight chunk pipeline: chunk c < S1 is (tap, ks) of conv1, chunk S1 + ks is conv2
+    // weight chunk pipeline: chunk c < S1 is (tap, ks) of conv1, chunk S1 + ks is conv2. Four register sets hold the chunks k + 1 .. k + 4
+    // while step k computes from LDS: with one set (a chunk requested one step before its LDS copy) every step waited ~0.35 us for its
+    // weights to arrive from L2 and the kernel sat at 16 % of the MFMA rate whatever the LDS layout.
     const int bn = tid >> 2, bpart = tid & 3;
-    uint4 rb0, rb1, rb2;  // (named scalars: an indexed array lands in scratch here)
-    rb1 = rb2 = make_uint4(0, 0, 0, 0);
-#define VR_GLOADB(step_)                                                                                                 \
+    // (named scalars: an indexed array lands in scratch here)
+#define VR_DECL(X_) uint4 X_##0, X_##1, X_##2; X_##0 = X_##1 = X_##2 = make_uint4(0, 0, 0, 0)
+    VR_DECL(ra); VR_DECL(rb); VR_DECL(rc); VR_DECL(rd);
+#define VR_GLOADB(X_, step_)                                                                                            \
     do {                                                                                                                \
         const int st__ = min((step_), S - 1);                                                                           \
         const uint16_t* base__ = (st__ < S1 ? g.w1 + (size_t)(st__ / KS) * C * C + (st__ % KS) * 32 : g.w2 + (st__ - S1) * 32) + bpart * 8; \
-        rb0 = *(const uint4*)(base__ + (size_t)min(bn, C - 1) * C);                                                      \
-        if (BPASS > 1) rb1 = *(const uint4*)(base__ + (size_t)min(bn + 64, C - 1) * C);                                  \
-        if (BPASS > 2) rb2 = *(const uint4*)(base__ + (size_t)min(bn + 128, C - 1) * C);                                 \
+        X_##0 = *(const uint4*)(base__ + (size_t)min(bn, C - 1) * C);                                                    \
+        if (BPASS > 1) X_##1 = *(const uint4*)(base__ + (size_t)min(bn + 64, C - 1) * C);                                \
+        if (BPASS > 2) X_##2 = *(const uint4*)(base__ + (size_t)min(bn + 128, C - 1) * C);                               \
     } while (0)
-#define VR_SSTOREB(buf_)                                                                                                \
+#define VR_SSTOREB(X_, buf_)                                                                                            \
     do {                                                                                                                \
-        __bf16* d__ = &Bs[((size_t)(buf_) * C + bn) * VT_LD + bpart * 8];                                               \
-        if (bn < C) *(uint4*)d__ = rb0;                                                                                 \
-        if (BPASS > 1 && bn + 64 < C) *(uint4*)(d__ + 64 * VT_LD) = rb1;                                                \
-        if (BPASS > 2 && bn + 128 < C) *(uint4*)(d__ + 128 * VT_LD) = rb2;                                              \
+        __bf16* d__ = &Bs[((size_t)(buf_) * C + bn) * 32 + ((bpart ^ VR_SW(bn)) << 3)];  /* VR_SW(bn + 64 k) = VR_SW(bn) */     \
+        if (bn < C) *(uint4*)d__ = X_##0;                                                                               \
+        if (BPASS > 1 && bn + 64 < C) *(uint4*)(d__ + 64 * 32) = X_##1;                                                 \
+        if (BPASS > 2 && bn + 128 < C) *(uint4*)(d__ + 128 * 32) = X_##2;                                               \
     } while (0)
-    VR_GLOADB(0);
-    // stage the input rows (f32 -> bf16), rows past T are zero
+    VR_GLOADB(ra, 0);
+    VR_STAMP(1);
+    // stage the input rows (bf16 work buffer), rows past T are zero: 16 bytes per lane, up to 12 loads in flight per thread (the whole
+    // tile in one round trip; 8-byte loads 8 at a time took three and were 23 % of the workgroup's time)
     {
         const uint16_t* xp = (const uint16_t*)g.xin + (size_t)sidx * g.xin_stride + (size_t)t0 * C;  // buffer row t0 = output row t0 - halo
-        const int nrow = R + halo, c4 = C / 4, total = nrow * c4;
-        for (int base = tid; base < total; base += 8 * 256) {  // 8 loads (4 bf16 channels each) in flight per thread
-            uint2 v[8];
+        const int nrow = R + halo, c8 = C / 8, total = nrow * c8;
+        for (int base = tid; base < total; base += 12 * 256) {
+            uint4 v[12];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = min(base + u * 256, total - 1), r = i / c4, c = (i - r * c4) * 4;
-                v[u] = *(const uint2*)(xp + (size_t)min(r, T + halo - 1 - t0) * C + c);
+            for (int u = 0; u < 12; ++u) {
+                const int i = min(base + u * 256, total - 1), r = i / c8, c = (i - r * c8) * 8;
+                v[u] = *(const uint4*)(xp + (size_t)min(r, T + halo - 1 - t0) * C + c);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 12; ++u) {
                 const int i = base + u * 256;
                 if (i < total) {
-                    const int r = i / c4, c = (i - r * c4) * 4;
+                    const int r = i / c8, c = (i - r * c8) * 8;
                     const bool live = t0 + r < T + halo;
-                    *(uint2*)(At + (size_t)r * LDA + c) = live ? v[u] : make_uint2(0, 0);
+                    *(uint4*)(At + (size_t)r * LDA + c) = live ? v[u] : make_uint4(0, 0, 0, 0);
                 }
             }
         }
     }
-    VR_SSTOREB(0);
-    VR_GLOADB(1);
+    VR_SSTOREB(ra, 0);
+    // at the top of step k: LDS[k & 1] = chunk k, set (k + j) % LK = chunk k + j, j = 1..LK. LK = 4 sets, 3 for the 192-channel block whose
+    // sets are three registers wide (a fourth would push the wave past 256 registers and halve the occupancy)
+    constexpr int LK = BPASS > 2 ? 3 : 4;
+    VR_GLOADB(rb, 1); VR_GLOADB(rc, 2);
+    if (LK == 4) { VR_GLOADB(rd, 3); VR_GLOADB(ra, 4); } else { VR_GLOADB(ra, 3); }
     __syncthreads();
-    f32x4 acc[MT][NT];
+    VR_STAMP(2);
+    // wave tiling: a wave owns MTW row tiles x NTW column tiles. The wide blocks (one row tile per wave, >= 8 column tiles) split the
+    // columns over wave pairs instead — 2 row tiles x NT/2 column tiles per wave: 2 + NT/2 fragment reads per K step instead of 1 + NT
+    // for the same MFMAs (at 192 channels the LDS reads, 13 KiB per wave-step for 12 MFMAs, were what bounded the loop)
+    constexpr int WN = (MT == 1 && NT >= 8) ? 2 : 1, MTW = MT * WN, NTW = NT / WN;
+    f32x4 acc[MTW][NTW];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MTW; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int wrow0 = wave * MT * 16;
-#define VR_STEP(step_, SRC_, ROWOFF_, KOFF_)                                                                             \
+        for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wrow0 = (wave / WN) * MTW * 16, ncol0 = (wave % WN) * NTW * 16;
+    // between the convolutions: snake2(conv1 + bias) -> bf16 tile (D layout: lane holds rows 4*kq+e, column lr of every tile)
+#define VR_BETWEEN()                                                                                                    \
     do {                                                                                                                \
-        const int buf__ = (step_) & 1;                                                                                  \
-        bf16x8 a__[MT], b__[NT];                                                                                        \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                  \
-            a__[i] = *(const bf16x8*)&SRC_[(size_t)(wrow0 + i * 16 + lr + (ROWOFF_)) * LDA + (KOFF_) + kq * 8];         \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                  \
-            b__[j] = *(const bf16x8*)&Bs[((size_t)buf__ * C + j * 16 + lr) * VT_LD + kq * 8];                           \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                  \
-            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                              \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a__[i], b__[j], acc[i][j], 0, 0, 0);                \
-        VR_SSTOREB(buf__ ^ 1);                                                                                          \
-        VR_GLOADB((step_) + 2);                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                                  \
+            _Pragma("unroll") for (int j = 0; j < NTW; ++j) {                                                            \
+                const int n = ncol0 + j * 16 + lr;                                                                      \
+                const float bb = g.b1[n], ea = g.ea2[n], ib = g.ib2[n];                                                 \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                         \
+                    const float v = acc[i][j][e] + bb;                                                                  \
+                    const float sn = __sinf(v * ea);                                                                    \
+                    Zt[(size_t)(wrow0 + i * 16 + 4 * kq + e) * LDA + n] = (__bf16)(v + ib * (sn * sn));                 \
+                    acc[i][j][e] = 0.0f;                                                                                \
+                }                                                                                                       \
+            }                                                                                                           \
         __syncthreads();                                                                                                \
     } while (0)
-    for (int step = 0; step < S1; ++step) {
-        const int tap = step / KS, ks = step - tap * KS;
-        VR_STEP(step, At, tap * g.dil, ks * 32);
+#define VR_STEP(step_, X_)  /* X_ = the set holding chunk step_ + 1 */                                                  \
+    do {                                                                                                                \
+        const int sp__ = (step_), buf__ = sp__ & 1, tap__ = sp__ / KS, koff__ = (sp__ - tap__ * KS) * 32;               \
+        const int rowoff__ = sp__ < S1 ? tap__ * g.dil : 0;  /* conv2 (chunks S1..) reads the snake tile in place */    \
+        bf16x8 a__[MTW], b__[NTW];                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                                  \
+            a__[i] = *(const bf16x8*)&At[(size_t)(wrow0 + i * 16 + lr + rowoff__) * LDA + koff__ + kq * 8];             \
+        _Pragma("unroll") for (int j = 0; j < NTW; ++j)                                                                  \
+            b__[j] = *(const bf16x8*)&Bs[((size_t)buf__ * C + ncol0 + j * 16 + lr) * 32 + ((kq ^ VR_SW(lr)) << 3)];     \
+        _Pragma("unroll") for (int i = 0; i < MTW; ++i)                                                                  \
+            _Pragma("unroll") for (int j = 0; j < NTW; ++j)                                                              \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a__[i], b__[j], acc[i][j], 0, 0, 0);                \
+        VR_SSTOREB(X_, buf__ ^ 1);                                                                                      \
+        VR_GLOADB(X_, sp__ + 1 + LK);                                                                                        \
+        __syncthreads();                                                                                                \
+    } while (0)
+    static_assert(S % LK == 0, "the step loop is unrolled by the number of register sets");
+    for (int step0 = 0; step0 < S; step0 += LK) {  // S = 8 KS; S1 = 7 KS falls on sub-step S1 % LK of its trip
+#define VR_SUB(u_, X_)                                                                                                  \
+        if ((S1 % LK) == (u_) && step0 + (u_) == S1) {                                                                  \
+            VR_STAMP(3); VR_BETWEEN(); VR_STAMP(4);                                                                     \
+        }                                                                                                               \
+        VR_STEP(step0 + (u_), X_)
+        if (LK == 4) { VR_SUB(0, rb); VR_SUB(1, rc); VR_SUB(2, rd); VR_SUB(3, ra); }
+        else { VR_SUB(0, rb); VR_SUB(1, rc); VR_SUB(2, ra); }
     }
-    // the residual operand is fetched now and consumed after the second convolution (one batch of loads in flight,
-    // not one round trip per element)
-    float ov[MT][4][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int t = min(t0 + wrow0 + i * 16 + 4 * kq + e, T - 1);
-            const float* op = g.o + (size_t)sidx * g.o_stride + (size_t)t * C;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) ov[i][e][j] = op[j * 16 + lr];
-        }
-    // snake2(conv1 + bias) -> bf16 tile (D layout: lane holds rows 4*kq+e, column lr of every tile)
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = j * 16 + lr;
-            const float bb = g.b1[n], ea = g.ea2[n], ib = g.ib2[n];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = acc[i][j][e] + bb;
-                const float sn = __sinf(v * ea);
-                Zt[(size_t)(wrow0 + i * 16 + 4 * kq + e) * LDA + n] = (__bf16)(v + ib * (sn * sn));
-                acc[i][j][e] = 0.0f;
-            }
-        }
-    __syncthreads();
-    for (int step = S1; step < S; ++step) VR_STEP(step, Zt, 0, (step - S1) * 32);
+#undef VR_SUB
+#undef VR_BETWEEN
+    VR_STAMP(5);
 #undef VR_STEP
 #undef VR_GLOADB
 #undef VR_SSTOREB
+#undef VR_DECL
+    // Epilogue through LDS: conv2 + bias goes to an f32 tile [R][C + 4] (the input tile and the weight ring are dead: the last step ended
+    // with a barrier), then every thread finishes 4 consecutive channels of a row at a time: o (16-byte load) + tile -> o (16-byte store)
+    // and snake_next(o) -> bf16 x 4 (8-byte store). Straight from the D layout it was 96 four- and two-byte stores and 48 four-byte
+    // loads per thread, 64-byte runs each: 38 % of the workgroup's time went into issuing them.
+    constexpr int LDO = C + 4;
+    float* Ot = (float*)lds;
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MTW; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int t = t0 + wrow0 + i * 16 + 4 * kq + e;
-            if (t >= T) continue;
-            float* op = g.o + (size_t)sidx * g.o_stride + (size_t)t * C;
-            __bf16* yp = (__bf16*)g.y2 + (size_t)sidx * g.y2_stride + g.y2_off + (size_t)t * C;
+        for (int j = 0; j < NTW; ++j) {
+            const int n = ncol0 + j * 16 + lr;
+            const float bb = g.b2[n];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int n = j * 16 + lr;
-                const float v = ov[i][e][j] + (acc[i][j][e] + g.b2[n]);
-                if (g.store_o) op[n] = v;
-                const float sn = __sinf(v * g.ea3[n]);
-                yp[n] = (__bf16)(v + g.ib3[n] * (sn * sn));
+            for (int e = 0; e < 4; ++e) Ot[(size_t)(wrow0 + i * 16 + 4 * kq + e) * LDO + n] = acc[i][j][e] + bb;
+        }
+    __syncthreads();
+    {
+        constexpr int c4n = C / 4, total = R * c4n, PER = (total + 255) / 256;
+        float* ob = g.o + (size_t)sidx * g.o_stride;
+        __bf16* yb = (__bf16*)g.y2 + (size_t)sidx * g.y2_stride + g.y2_off;
+        constexpr int PB = PER < 12 ? PER : 12;  // residual loads in flight per thread: all of them for every instantiated shape
+        for (int p0 = 0; p0 < PER; p0 += PB) {
+            float4 ov[PB];
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int idx = min(tid + (p0 + u) * 256, total - 1), row = idx / c4n, c = (idx - row * c4n) * 4;
+                ov[u] = *(const float4*)(ob + (size_t)min(t0 + row, T - 1) * C + c);
+            }
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int idx = tid + (p0 + u) * 256;
+                if (p0 + u >= PER || idx >= total) continue;
+                const int row = idx / c4n, c = (idx - row * c4n) * 4, t = t0 + row;
+                if (t >= T) continue;
+                const float4 a = *(const float4*)&Ot[(size_t)row * LDO + c];
+                const float4 ea = *(const float4*)(g.ea3 + c), ib = *(const float4*)(g.ib3 + c);
+                float4 v; v.x = ov[u].x + a.x; v.y = ov[u].y + a.y; v.z = ov[u].z + a.z; v.w = ov[u].w + a.w;
+                if (g.store_o) *(float4*)(ob + (size_t)t * C + c) = v;
+                float sn; __bf16 h[4];
+                sn = __sinf(v.x * ea.x); h[0] = (__bf16)(v.x + ib.x * (sn * sn));
+                sn = __sinf(v.y * ea.y); h[1] = (__bf16)(v.y + ib.y * (sn * sn));
+                sn = __sinf(v.z * ea.z); h[2] = (__bf16)(v.z + ib.z * (sn * sn));
+                sn = __sinf(v.w * ea.w); h[3] = (__bf16)(v.w + ib.w * (sn * sn));
+                *(uint2*)(yb + (size_t)t * C + c) = *(const uint2*)h;
             }
         }
+    }
+    VR_STAMP(6);
 }
 
 __global__ void k_voc_embed(VCall cl, const int* codes, int max_steps_cap, int ncb_model, const float* const* cb, int ncb, int cbs, int cd,
@@ -593,7 +780,7 @@ __global__ __launch_bounds__(64 * VOC_FCAP) void k_voc_attn(VCall cl, const floa
 
 // ConvNeXt front: depthwise causal conv k7 + LayerNorm(eps 1e-6) per position; one wave per (slot, t)
 __global__ __launch_bounds__(64) void k_voc_dw_ln(const float* x, size_t x_stride, int H, int T, int C, const float* dw_w, const float* dw_b,
-                                                  const float* ln_w, const float* ln_b, float* y) {
+                                                  const float* ln_w, const float* ln_b, float* y, int tiled) {
     extern __shared__ float row[];
     const int s = blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
     const float* xp = x + (size_t)s * x_stride + (size_t)(H + t) * C;
@@ -613,7 +800,11 @@ __global__ __launch_bounds__(64) void k_voc_dw_ln(const float* x, size_t x_strid
     for (int m = 32; m >= 1; m >>= 1) var += __shfl_xor(var, m);
     const float rinv = 1.0f / sqrtf(var / (float)C + 1e-6f);
     float* yp = y + ((size_t)s * T + t) * C;
-    for (int i = lane; i < C; i += 64) yp[i] = ((row[i] - mean) * rinv) * ln_w[i] + ln_b[i];
+    for (int i = lane; i < C; i += 64) {
+        const float o = ((row[i] - mean) * rinv) * ln_w[i] + ln_b[i];
+        if (tiled) ((__bf16*)y)[q3_atile_off(s * T + t, i, C >> 5)] = (__bf16)o;  // GEMM-only: the bf16 it would be rounded to, A-tiled
+        else yp[i] = o;
+    }
 }
 
 // V6: Conv k7 C -> 1 over the snaked input (with history) + clamp -> PCM of the slot. A block produces 64 samples:
@@ -806,6 +997,14 @@ int q3_voc_create(q3tts_engine* e) {
         VTRY(gen_vec(e, v, &p.ln_w, VTID(comp, VW_LN_W), d, 1.0f, 0.05f)); VTRY(gen_vec(e, v, &p.ln_b, VTID(comp, VW_LN_B), d, 0.0f, 0.02f));
         VTRY(gen_conv(e, v, &p.pw1, comp, VW_PW1, VW_PW1_B, 1, 1, d, 4 * d, 4 * d, 1.0f));
         VTRY(gen_conv(e, v, &p.pw2, comp, VW_PW2, VW_PW2_B, 1, 1, 4 * d, d, d, 1.0f));
+        if (d % 256 == 0) {  // tiled copies for k_bgemm (K = d and 4 d, N = r d, 4 d, d: all multiples of 32)
+            v->up_bg = true;
+            VTRY(valloc(e, v, &p.ct_t, (size_t)r * d * d / 8)); VTRY(valloc(e, v, &p.pw1_t, (size_t)4 * d * d / 8)); VTRY(valloc(e, v, &p.pw2_t, (size_t)4 * d * d / 8));
+            Q3Fill f{}; f.mode = 0; f.row0 = 0;
+            f.dst = p.ct_t; f.N = r * d; f.K = d; f.rows = r * d; f.src_a = p.ct.w; q3_launch_fill_tiled(f, e->stream);
+            f.dst = p.pw1_t; f.N = 4 * d; f.K = d; f.rows = 4 * d; f.src_a = p.pw1.w; q3_launch_fill_tiled(f, e->stream);
+            f.dst = p.pw2_t; f.N = d; f.K = 4 * d; f.rows = d; f.src_a = p.pw2.w; q3_launch_fill_tiled(f, e->stream);
+        }
         VTRY(gen_vec(e, v, &p.gamma, VTID(comp, VW_GAMMA), d, 0.1f, 0.01f));
     }
     VTRY(gen_conv(e, v, &v->dec_in, VC_DEC_IN, VW_W, VW_B, 7, 1, d, c.decoder_dim, c.decoder_dim, 1.0f));
@@ -842,6 +1041,7 @@ int q3_voc_create(q3tts_engine* e) {
     VTRY(valloc(e, v, &v->att, M * HH)); VTRY(valloc(e, v, &v->g, M * c.d_ffn));
     VTRY(valloc(e, v, &v->kring, (size_t)c.n_layer * v->B * v->RW * HH)); VTRY(valloc(e, v, &v->vring, (size_t)c.n_layer * v->B * v->RW * HH));
     VTRY(valloc(e, v, &v->t1, (size_t)VOC_MAX_NS * scratch)); VTRY(valloc(e, v, &v->t2, (size_t)VOC_MAX_NS * scratch));
+    if (v->up_bg) { size_t rows_up = (size_t)VOC_MAX_NS * VOC_FCAP; for (auto& u : v->U) rows_up *= u.r; VTRY(valloc(e, v, &v->upb, rows_up * d)); }
     v->pcm_stride = (size_t)(e->cfg.max_steps_cap + VOC_FCAP) * v->spf;  // + padding frames behind a finished utterance
     VTRY(valloc(e, v, &v->pcm, (size_t)v->B * v->pcm_stride));
     v->frames_done.assign(v->B, 0); v->last_flag.assign(v->B, 0);
@@ -877,6 +1077,8 @@ struct VSnake { float* y2 = nullptr; size_t stride = 0; int off = 0; const float
 static VSnake snake_into(const VBuf& dst, const float* ea, const float* ib, int C) {
     VSnake k; k.y2 = dst.p; k.stride = dst.stride(); k.off = dst.H * dst.C; k.ea = ea; k.ib = ib; k.n = C; k.bf16 = dst.bf16; return k;
 }
+// Q3TTS_VOC_NORING=1: the register-staged kernel for bf16 A as well (A/B runs and the tests that compare the two)
+static bool voc_ring() { const char* ev = getenv("Q3TTS_VOC_NORING"); return !(ev && atoi(ev)); }
 static void vgemm(hipStream_t s, const VConv& c, const float* x, size_t x_stride, int x_off, int ns, int T, float* y, size_t y_stride, int y_off,
                   int epi = 0, const float* scale = nullptr, int scale_n = 1, const VSnake* sk = nullptr, int store = 1, int a_bf16 = 0, int y_bf16 = 0) {
     VGemm g; g.x = x; g.x_stride = x_stride; g.x_off = x_off; g.T = T; g.M = ns * T; g.c = c; g.y = y; g.y_stride = y_stride; g.y_off = y_off;
@@ -899,11 +1101,19 @@ static void vgemm(hipStream_t s, const VConv& c, const float* x, size_t x_stride
         }
     } else if (c.nout % 128 != 0 && c.nout % 96 == 0) {
         dim3 grid(c.nout / 96, (g.M + 127) / 128);
-        if (a_bf16) hipLaunchKernelGGL((k_vgemm_lds<3, true>), grid, dim3(256), 0, s, g);
+        if (a_bf16 && voc_ring()) launch_vgemm_ring<3>(s, g, grid);
+        else if (a_bf16) hipLaunchKernelGGL((k_vgemm_lds<3, true>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((k_vgemm_lds<3, false>), grid, dim3(256), 0, s, g);
+    } else if (c.nout % 64 == 0 && (long)((c.nout + 127) / 128) * ((g.M + 127) / 128) < 192) {
+        // too few 128 x 128 tiles for 256 CUs (the decoder's input convolution: 1024 rows x 1536 columns): 128 x 64 tiles, twice the workgroups
+        dim3 grid(c.nout / 64, (g.M + 127) / 128);
+        if (a_bf16 && voc_ring()) launch_vgemm_ring<2>(s, g, grid);
+        else if (a_bf16) hipLaunchKernelGGL((k_vgemm_lds<2, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((k_vgemm_lds<2, false>), grid, dim3(256), 0, s, g);
     } else {
         dim3 grid((c.nout + 127) / 128, (g.M + 127) / 128);
-        if (a_bf16) hipLaunchKernelGGL((k_vgemm_lds<4, true>), grid, dim3(256), 0, s, g);
+        if (a_bf16 && voc_ring()) launch_vgemm_ring<4>(s, g, grid);
+        else if (a_bf16) hipLaunchKernelGGL((k_vgemm_lds<4, true>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((k_vgemm_lds<4, false>), grid, dim3(256), 0, s, g);
     }
 }
@@ -914,8 +1124,8 @@ static bool resunit_ok(int C) {
 }
 template <int NT, int MT>
 static void launch_resunit_t(hipStream_t s, const VResUnit& g, int ns) {
-    constexpr int C = NT * 16, R = 64 * MT, LDA = C + 8;
-    const size_t lds = ((size_t)(R + 6 * g.dil) * LDA + (size_t)2 * C * VT_LD) * 2;
+    constexpr int C = NT * 16, R = 64 * MT, LDA = C + 16;
+    const size_t lds = std::max(((size_t)(R + 6 * g.dil) * LDA + (size_t)2 * C * 32) * 2, (size_t)R * (C + 4) * 4);  // input tile + weight ring, later the f32 output tile
     static bool attr_set = false;
     if (!attr_set) { hipFuncSetAttribute((const void*)k_voc_resunit<NT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr_set = true; }
     hipLaunchKernelGGL((k_voc_resunit<NT, MT>), dim3((g.T + R - 1) / R, ns), dim3(256), lds, s, g);
@@ -980,18 +1190,44 @@ static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
         vgemm(s, L.gu, v->xnb, 0, 0, 1, M, v->g, 0, 0, 4, nullptr, 1, nullptr, 1, 1, 1);  // gate | up in one launch, SwiGLU in the epilogue
         vgemm(s, L.down, v->g, 0, 0, 1, M, v->x, 0, 0, 1, L.ls_mlp, d, nullptr, 1, 1);
     }
-    hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, v->final_norm, c.rms_eps, d, v->xn, 0);
     // V5a upsample stages; cur = [ns][T][d] contiguous per slot (stride T*d)
     const float* cur = v->xn; int T = nf; size_t cur_stride = (size_t)nf * d; int cur_off = 0;
-    for (auto& p : v->U) {
-        hist(s, cl, p.dw_in, T * p.r, 0);
-        vgemm(s, p.ct, cur, cur_stride, cur_off, ns, T, p.dw_in.p, p.dw_in.stride(), p.dw_in.H * d);  // [T][r*d] == [T*r][d]
-        T *= p.r;
-        hipLaunchKernelGGL(k_voc_dw_ln, dim3(T, ns), dim3(64), (size_t)d * 4, s, p.dw_in.p, p.dw_in.stride(), p.dw_in.H, T, d, p.dw_w, p.dw_b, p.ln_w, p.ln_b, v->t1);
-        hist(s, cl, p.dw_in, T, 1);  // history = the raw ConvTranspose output, saved before the in-place residual below
-        vgemm(s, p.pw1, v->t1, (size_t)T * d, 0, ns, T, v->t2, (size_t)T * 4 * d, 0, 3);
-        vgemm(s, p.pw2, v->t2, (size_t)T * 4 * d, 0, ns, T, p.dw_in.p, p.dw_in.stride(), p.dw_in.H * d, 1, p.gamma, d);  // residual in place
-        cur = p.dw_in.p; cur_stride = p.dw_in.stride(); cur_off = p.dw_in.H * d;
+    if (v->up_bg) {
+        // the stages' single-tap GEMMs on the decoder's k_bgemm: A-tiled bf16 rows (row m = s * T + t) in, f32 results into the per-slot
+        // work buffers (segmented rows), bias / GELU / LayerScale-residual in the epilogue
+        hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, v->final_norm, c.rms_eps, d, v->xnb, 2);
+        const uint16_t* a_in = (const uint16_t*)v->xnb;
+        for (size_t ui = 0; ui < v->U.size(); ++ui) {
+            VUp& p = v->U[ui];
+            hist(s, cl, p.dw_in, T * p.r, 0);
+            Q3BGemm g{}; g.a = a_in; g.B = ns * T; g.w = p.ct_t; g.K = d; g.N = p.r * d; g.epi = Q3_EPI_STORE;  // [T][r*d] == [T*r][d]
+            g.bias = p.ct.b; g.bias_n = p.ct.bias_n; g.y = p.dw_in.p + (size_t)p.dw_in.H * d; g.ldy = p.r * d; g.seg_rows = T; g.seg_stride = p.dw_in.stride();
+            if (q3_launch_bgemm(g, s)) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder: upsample ConvTranspose GEMM shape");
+            T *= p.r;
+            hipLaunchKernelGGL(k_voc_dw_ln, dim3(T, ns), dim3(64), (size_t)d * 4, s, p.dw_in.p, p.dw_in.stride(), p.dw_in.H, T, d, p.dw_w, p.dw_b, p.ln_w, p.ln_b, v->t1, 1);
+            hist(s, cl, p.dw_in, T, 1);  // history = the raw ConvTranspose output, saved before the in-place residual below
+            Q3BGemm h{}; h.a = (const uint16_t*)v->t1; h.B = ns * T; h.w = p.pw1_t; h.K = d; h.N = 4 * d; h.epi = Q3_EPI_GELU;
+            h.bias = p.pw1.b; h.bias_n = p.pw1.bias_n; h.yb = (uint16_t*)v->t2;
+            if (q3_launch_bgemm(h, s)) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder: pointwise-1 GEMM shape");
+            Q3BGemm r{}; r.a = (const uint16_t*)v->t2; r.B = ns * T; r.w = p.pw2_t; r.K = 4 * d; r.N = d; r.epi = Q3_EPI_RESID;  // residual in place
+            r.bias = p.pw2.b; r.bias_n = p.pw2.bias_n; r.col_scale = p.gamma; r.y = p.dw_in.p + (size_t)p.dw_in.H * d; r.ldy = d; r.seg_rows = T; r.seg_stride = p.dw_in.stride();
+            if (ui + 1 < v->U.size()) r.yb = v->upb;  // the next stage's GEMM input
+            if (q3_launch_bgemm(r, s)) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder: pointwise-2 GEMM shape");
+            a_in = v->upb;
+            cur = p.dw_in.p; cur_stride = p.dw_in.stride(); cur_off = p.dw_in.H * d;
+        }
+    } else {
+        hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, v->final_norm, c.rms_eps, d, v->xn, 0);
+        for (auto& p : v->U) {
+            hist(s, cl, p.dw_in, T * p.r, 0);
+            vgemm(s, p.ct, cur, cur_stride, cur_off, ns, T, p.dw_in.p, p.dw_in.stride(), p.dw_in.H * d);  // [T][r*d] == [T*r][d]
+            T *= p.r;
+            hipLaunchKernelGGL(k_voc_dw_ln, dim3(T, ns), dim3(64), (size_t)d * 4, s, p.dw_in.p, p.dw_in.stride(), p.dw_in.H, T, d, p.dw_w, p.dw_b, p.ln_w, p.ln_b, v->t1, 0);
+            hist(s, cl, p.dw_in, T, 1);  // history = the raw ConvTranspose output, saved before the in-place residual below
+            vgemm(s, p.pw1, v->t1, (size_t)T * d, 0, ns, T, v->t2, (size_t)T * 4 * d, 0, 3);
+            vgemm(s, p.pw2, v->t2, (size_t)T * 4 * d, 0, ns, T, p.dw_in.p, p.dw_in.stride(), p.dw_in.H * d, 1, p.gamma, d);  // residual in place
+            cur = p.dw_in.p; cur_stride = p.dw_in.stride(); cur_off = p.dw_in.H * d;
+        }
     }
     // V5b decoder
     hist(s, cl, v->dec_in_in, T, 0);
@@ -1110,6 +1346,15 @@ extern "C" int q3tts_k_vocoder(q3tts_engine* e, const int32_t* codes, int32_t n_
 // Measurement hook (bench.py's roofline_vocoder): the batched vocoder alone — n_slots slots x 4-frame chunks, `chunks` calls on the
 // engine's stream with nothing else on the GPU, HIP events around them. Codes are seeded pseudo-random. *ms_per_chunk = the mean
 // duration of one batched 4-frame call (n_slots x 4 frames of PCM).
+#ifdef Q3_STAMPS
+static void voc_print_stamps() {
+    unsigned long long st[4][16];
+    if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_voc_stamps), sizeof(st)) != hipSuccess) return;
+    for (int w = 0; w < 3; ++w)
+        fprintf(stderr, "resunit stamps wg %d (100 MHz ticks from entry): first weights requested %llu | input staged + barrier %llu | conv1 done %llu | snake tile done %llu | conv2 done %llu | stores issued %llu\n",
+                w, st[w][1] - st[w][0], st[w][2] - st[w][0], st[w][3] - st[w][0], st[w][4] - st[w][0], st[w][5] - st[w][0], st[w][6] - st[w][0]);
+}
+#endif
 extern "C" int q3tts_k_vocoder_bench(q3tts_engine* e, int32_t n_slots, int32_t chunks, float* ms_per_chunk) {
     if (!e || !ms_per_chunk || n_slots <= 0 || chunks <= 0) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder bench: bad argument");
     if (!e->voc) return q3_set_err(e, Q3TTS_ERR_STATE, "engine created with with_vocoder = 0");
@@ -1132,6 +1377,9 @@ extern "C" int q3tts_k_vocoder_bench(q3tts_engine* e, int32_t n_slots, int32_t c
     float ms = 0.0f;
     Q3_HIP(e, hipEventElapsedTime(&ms, e->ev0, e->ev2));
     *ms_per_chunk = ms / (float)chunks;
+#ifdef Q3_STAMPS
+    voc_print_stamps();
+#endif
     for (int i = 0; i < n_slots; ++i) VTRY(q3_voc_reset(e, i));
     return Q3TTS_OK;
 }

@@ -323,6 +323,11 @@ def test_vocoder_narrow_block_kernels(oracle):
             assert np.array_equal(eng.vocoder(codes), one)
         finally:
             del os.environ["Q3TTS_VOC_NOFUSE"]
+        os.environ["Q3TTS_VOC_NORING"] = "1"   # the register-staged GEMM instead of the LDS-DMA ring: same K-step order, same bits
+        try:
+            assert np.array_equal(eng.vocoder(codes), one)
+        finally:
+            del os.environ["Q3TTS_VOC_NORING"]
     finally:
         eng.close()
         L.q3o_vocoder_destroy(v)
@@ -774,6 +779,11 @@ def test_full_shape_vocoder_pcm_vs_oracle(oracle, n_frames):
               f"bf16-input oracle vs f32 oracle {e(ref, ref32):.2e}; signal RMS {float(np.sqrt(np.mean(ref32 ** 2))):.2f}")
         assert one.shape == ref.shape == (n_frames * 1920,) and e(one, ref) <= PCM_RMS_TOL_FULL and e(one, ref32) <= PCM_RMS_TOL_FULL
         assert np.array_equal(eng.vocoder(codes, chunk_frames=4), one)
+        os.environ["Q3TTS_VOC_NORING"] = "1"   # big convolutions on the register-staged GEMM: same bits as the LDS-DMA ring
+        try:
+            assert np.array_equal(eng.vocoder(codes), one)
+        finally:
+            del os.environ["Q3TTS_VOC_NORING"]
     finally:
         eng.close()
         L.q3o_vocoder_destroy(v)
