@@ -412,36 +412,70 @@ __global__ __launch_bounds__(256) void k_vgemm_ring(VGemm g) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_[i], b_[j], acc[i][j], 0, 0, 0);
     }
+    // Epilogue through LDS: the accumulators go to an f32 tile [128][BN + 4] (the ring is idle; the launch sizes the LDS for the larger
+    // of the two), then every thread finishes 4 consecutive columns of a row per trip with 16-byte loads / stores of y (and 8-byte stores
+    // of the bf16 snake output). The D layout itself gives 64-byte runs of 4-byte stores: on the memory-bound layers (1x1 convolutions,
+    // the transposed convolutions) issuing those was a large part of the kernel. Per element the arithmetic is vepi's.
+    constexpr int LDO = BN + 4, C4 = BN / 4, PER = 128 * C4 / 256;
+    float* Ot = (float*)ring;
     const bool rmw = g.epi == 1 || g.epi == 2;
+    __syncthreads();  // every wave is done with the last stage
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float yv[4][NJ];  // residual operands of this row tile: one batch of loads, not a round trip per element
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Ot[(size_t)(wm * 64 + i * 16 + 4 * kq + e) * LDO + wn * NJ * 16 + j * 16 + lr] = acc[i][j][e];
+    __syncthreads();
+    constexpr int PB = 8;  // items in flight per batch
+    for (int u0 = 0; u0 < PER; u0 += PB) {
+        float4 yo[PB];
         if (rmw) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int m = min(m0 + wm * 64 + i * 16 + 4 * kq + e, g.M - 1);
-                const int s = m / g.T, t = m - s * g.T;
-                const float* yp = g.y + (size_t)s * g.y_stride + g.y_off + (size_t)t * nout;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) yv[e][j] = yp[min(n0 + wn * NJ * 16 + j * 16 + lr, nout - 1)];
+            for (int u = 0; u < PB; ++u) {
+                const int idx = tid + (u0 + u) * 256, row = min(idx / C4, 127), cc = (idx - (idx / C4) * C4) * 4;
+                const int m = min(m0 + row, g.M - 1), n = min(n0 + cc, nout - 4);
+                const int sl = m / g.T, t = m - sl * g.T;
+                yo[u] = *(const float4*)(g.y + (size_t)sl * g.y_stride + g.y_off + (size_t)t * nout + n);
             }
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int m = m0 + wm * 64 + i * 16 + 4 * kq + e;
-            if (m >= g.M) continue;
-            const int s = m / g.T, t = m - s * g.T;
+        for (int u = 0; u < PB; ++u) {
+            const int idx = tid + (u0 + u) * 256, row = idx / C4, cc = (idx - row * C4) * 4;
+            const int m = m0 + row, n = n0 + cc;
+            if (u0 + u >= PER || m >= g.M || n >= nout) continue;  // (nout is a multiple of 4: checked by the launcher)
+            const int sl = m / g.T, t = m - sl * g.T;
+            const float4 a4 = *(const float4*)&Ot[(size_t)row * LDO + cc];
+            float v[4] = {a4.x, a4.y, a4.z, a4.w};
+            const float yv[4] = {rmw ? yo[u].x : 0.f, rmw ? yo[u].y : 0.f, rmw ? yo[u].z : 0.f, rmw ? yo[u].w : 0.f};
+            float sv[4];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = n0 + wn * NJ * 16 + j * 16 + lr;
-                if (n < nout) vepi(g, acc[i][j][e], s, t, n, rmw ? yv[e][j] : 0.0f);
+            for (int q = 0; q < 4; ++q) {
+                const int nn = n + q;
+                if (g.c.b) v[q] += g.c.b[nn % g.c.bias_n];
+                if (g.epi == 1) v[q] = yv[q] + g.scale[nn % g.scale_n] * v[q];
+                else if (g.epi == 2) v[q] = yv[q] + v[q];
+                else if (g.epi == 3) v[q] = gelu_erf(v[q]);
+                if (g.y2) {
+                    const int c = nn % g.snake_n;
+                    const float sn = __sinf(v[q] * g.ea[c]);
+                    sv[q] = v[q] + g.ib[c] * (sn * sn);
+                }
+            }
+            if (g.store) *(float4*)(g.y + (size_t)sl * g.y_stride + g.y_off + (size_t)t * nout + n) = make_float4(v[0], v[1], v[2], v[3]);
+            if (g.y2) {
+                const size_t o2 = (size_t)sl * g.y2_stride + g.y2_off + (size_t)t * nout + n;
+                if (g.y2_bf16) {
+                    __bf16 hh[4] = {(__bf16)sv[0], (__bf16)sv[1], (__bf16)sv[2], (__bf16)sv[3]};
+                    *(uint2*)((__bf16*)g.y2 + o2) = *(const uint2*)hh;
+                } else *(float4*)(g.y2 + o2) = make_float4(sv[0], sv[1], sv[2], sv[3]);
             }
         }
     }
 }
 template <int NJ>
 static void launch_vgemm_ring(hipStream_t s, const VGemm& g, dim3 grid) {
-    constexpr size_t lds = (size_t)VR_NS * (128 + NJ * 32) * 64;
+    constexpr size_t lds_ring = (size_t)VR_NS * (128 + NJ * 32) * 64, lds_out = (size_t)128 * (NJ * 32 + 4) * 4, lds = lds_ring > lds_out ? lds_ring : lds_out;
     static bool attr_set = false;
     if (!attr_set) { hipFuncSetAttribute((const void*)k_vgemm_ring<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
     hipLaunchKernelGGL((k_vgemm_ring<NJ>), grid, dim3(256), lds, s, g);
@@ -661,6 +695,15 @@ __global__ void k_voc_embed(VCall cl, const int* codes, int max_steps_cap, int n
         }
         out[(size_t)s * out_stride + out_off + (size_t)t * cd + i] = acc;
     }
+}
+
+// f32 rows of a slot -> the bf16 they would be rounded to by the consuming GEMM, into its work buffer (n a multiple of 4)
+__global__ void k_voc_rows_bf16(const float* src, size_t src_stride, uint16_t* dst, size_t dst_stride, int n) {
+    const int s = blockIdx.y, i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float4 v = *(const float4*)(src + (size_t)s * src_stride + i);
+    __bf16 h[4] = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    *(uint2*)(dst + (size_t)s * dst_stride + i) = *(const uint2*)h;
 }
 
 // history rows: work[s][0:H] <- hist[slot]  (load)   /   hist[slot] <- work[s][T : T+H]  (save)
@@ -1008,7 +1051,7 @@ int q3_voc_create(q3tts_engine* e) {
         VTRY(gen_vec(e, v, &p.gamma, VTID(comp, VW_GAMMA), d, 0.1f, 0.01f));
     }
     VTRY(gen_conv(e, v, &v->dec_in, VC_DEC_IN, VW_W, VW_B, 7, 1, d, c.decoder_dim, c.decoder_dim, 1.0f));
-    VTRY(mk_buf(e, v, &v->dec_in_in, 6, d, rows));
+    VTRY(mk_buf(e, v, &v->dec_in_in, 6, d, rows, 1));  // bf16: it only ever feeds the decoder's input convolution
     size_t scratch = (size_t)rows * std::max(4 * d, c.decoder_dim);
     v->Bk.resize(c.n_dec_blocks);
     int ch = c.decoder_dim;
@@ -1079,6 +1122,8 @@ static VSnake snake_into(const VBuf& dst, const float* ea, const float* ib, int 
 }
 // Q3TTS_VOC_NORING=1: the register-staged kernel for bf16 A as well (A/B runs and the tests that compare the two)
 static bool voc_ring() { const char* ev = getenv("Q3TTS_VOC_NORING"); return !(ev && atoi(ev)); }
+// (its epilogue moves 4 columns at a time: nout and every row start are multiples of 4 elements for all convolutions of the vocoder)
+static bool voc_ring_ok(const VGemm& g) { return voc_ring() && g.c.nout % 4 == 0 && g.y_off % 4 == 0 && g.y_stride % 4 == 0 && g.y2_off % 4 == 0 && g.y2_stride % 4 == 0; }
 static void vgemm(hipStream_t s, const VConv& c, const float* x, size_t x_stride, int x_off, int ns, int T, float* y, size_t y_stride, int y_off,
                   int epi = 0, const float* scale = nullptr, int scale_n = 1, const VSnake* sk = nullptr, int store = 1, int a_bf16 = 0, int y_bf16 = 0) {
     VGemm g; g.x = x; g.x_stride = x_stride; g.x_off = x_off; g.T = T; g.M = ns * T; g.c = c; g.y = y; g.y_stride = y_stride; g.y_off = y_off;
@@ -1101,18 +1146,18 @@ static void vgemm(hipStream_t s, const VConv& c, const float* x, size_t x_stride
         }
     } else if (c.nout % 128 != 0 && c.nout % 96 == 0) {
         dim3 grid(c.nout / 96, (g.M + 127) / 128);
-        if (a_bf16 && voc_ring()) launch_vgemm_ring<3>(s, g, grid);
+        if (a_bf16 && voc_ring_ok(g)) launch_vgemm_ring<3>(s, g, grid);
         else if (a_bf16) hipLaunchKernelGGL((k_vgemm_lds<3, true>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((k_vgemm_lds<3, false>), grid, dim3(256), 0, s, g);
     } else if (c.nout % 64 == 0 && (long)((c.nout + 127) / 128) * ((g.M + 127) / 128) < 192) {
         // too few 128 x 128 tiles for 256 CUs (the decoder's input convolution: 1024 rows x 1536 columns): 128 x 64 tiles, twice the workgroups
         dim3 grid(c.nout / 64, (g.M + 127) / 128);
-        if (a_bf16 && voc_ring()) launch_vgemm_ring<2>(s, g, grid);
+        if (a_bf16 && voc_ring_ok(g)) launch_vgemm_ring<2>(s, g, grid);
         else if (a_bf16) hipLaunchKernelGGL((k_vgemm_lds<2, true>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((k_vgemm_lds<2, false>), grid, dim3(256), 0, s, g);
     } else {
         dim3 grid((c.nout + 127) / 128, (g.M + 127) / 128);
-        if (a_bf16 && voc_ring()) launch_vgemm_ring<4>(s, g, grid);
+        if (a_bf16 && voc_ring_ok(g)) launch_vgemm_ring<4>(s, g, grid);
         else if (a_bf16) hipLaunchKernelGGL((k_vgemm_lds<4, true>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((k_vgemm_lds<4, false>), grid, dim3(256), 0, s, g);
     }
@@ -1231,8 +1276,8 @@ static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
     }
     // V5b decoder
     hist(s, cl, v->dec_in_in, T, 0);
-    hipMemcpy2DAsync(v->dec_in_in.p + (size_t)v->dec_in_in.H * d, v->dec_in_in.stride() * 4, cur + cur_off, cur_stride * 4, (size_t)T * d * 4, ns,
-                     hipMemcpyDeviceToDevice, s);
+    hipLaunchKernelGGL(k_voc_rows_bf16, dim3((unsigned)(((size_t)T * d / 4 + 255) / 256), ns), dim3(256), 0, s, cur + cur_off, cur_stride,
+                       (uint16_t*)v->dec_in_in.p + (size_t)v->dec_in_in.H * d, v->dec_in_in.stride(), T * d);
     int ch = c.decoder_dim;
     // Every SnakeBeta runs in the epilogue of the convolution that produces its input and lands directly in the
     // work buffer of the convolution that consumes it: dec_in -> blk0.ct_in; ct -> res0.c1_in; c1 -> (snake2) -> c2's
@@ -1240,7 +1285,7 @@ static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
     hist(s, cl, v->Bk[0].ct_in, T, 0);
     {
         const VSnake sk = snake_into(v->Bk[0].ct_in, v->Bk[0].ea, v->Bk[0].ib, ch);
-        vgemm(s, v->dec_in, v->dec_in_in.p, v->dec_in_in.stride(), v->dec_in_in.H * d, ns, T, v->t1, (size_t)T * ch, 0, 0, nullptr, 1, &sk, 0);
+        vgemm(s, v->dec_in, v->dec_in_in.p, v->dec_in_in.stride(), v->dec_in_in.H * d, ns, T, v->t1, (size_t)T * ch, 0, 0, nullptr, 1, &sk, 0, 1);
     }
     hist(s, cl, v->dec_in_in, T, 1);
     float* z = v->t1; float* o = v->t2;
