@@ -1,0 +1,26 @@
+# Collects the round's profile summaries on the GPU box into gpurun_out/prof_final/ (copy what is to be judged into profiles/rNN/).
+#   bash tools/collect_profiles.sh
+# Every rocprofv3 call runs the program itself after "--"; counters (--pmc) in their own passes; graph replay is traceable with
+# DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (profiles/README.md).
+set -o pipefail
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_final; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
+stats() {  # name, env assignment or "-", bench args...
+  name=$1; shift; envv=$1; shift
+  rm -rf /tmp/prof_$name
+  if [ "$envv" = "-" ]; then rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 $R/bench.py "$@" > $OUT/$name.log 2>&1
+  else export $envv; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 $R/bench.py "$@" > $OUT/$name.log 2>&1; unset ${envv%%=*}; fi
+  f=$(find /tmp/prof_$name -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && cp "$f" $OUT/${name}_kernel_stats.csv && echo "$name: $(wc -l < $OUT/${name}_kernel_stats.csv) kernels"
+}
+stats probe - --probe-only && \
+stats vocoder_only - --probe-only vocoder && \
+stats bench_b64_graph - --steps 1 --warmup 0 --no-single --no-cpu-baseline --no-probe && \
+stats bench_b64_eager Q3TTS_NO_GRAPH=1 --steps 1 --warmup 0 --no-single --no-cpu-baseline --no-probe
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$c
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 $R/bench.py --probe-only > $OUT/pmc_$c.log 2>&1
+  cp "$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)" $OUT/pmc_$c.csv
+done
+python3 $R/tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv "k_bgemm<4, 3, 2, true>" 131072 $OUT/pmc_traffic.json
+cd $R && python bench.py > $OUT/bench_b64_n1.json 2> $OUT/bench_b64_n1.err; tail -c 600 $OUT/bench_b64_n1.json
