@@ -202,6 +202,168 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same GEMM for MANY rows (prefill: thousands of prompt rows in one pass): k_bgemm re-reads its weights for every 64-row chunk and
+// runs ~12 MFMAs per wave between memory waits, which is right for decode (weights are the traffic) and leaves a 3 000-row prefill at
+// ~240 TFLOP/s. Here a workgroup (4 waves, 2 x 2) owns a 128 x 128 tile, each wave a 64 x 64 part over the WHOLE K, and the operand
+// tiles arrive by LDS-DMA in a 4-stage ring (one 32-wide K step per stage: 8 A tiles + 8 B tiles of 1 KiB, both already stored in
+// fragment order, so a DMA instruction moves one fragment and a fragment read is lane-linear: no swizzle, no bank conflicts).
+// The canonical order is kept by construction: a wave runs the MFMA chain of K-slice w from zero accumulators, then
+// total = (w == 0) ? chain : total + chain (plain f32 adds, slices ascending) — the bits k_bgemm produces from its 8 waves.
+// Tile t = (row tile fastest) goes to XCD t / (tiles / 8): an XCD owns a band of column tiles with all their row tiles, so a weight
+// tile is fetched into one L2 while the (smaller) row operand streams through.
+// Epilogues STORE / RESID / SWIGLU straight from the D layout (lane (kq, c): rows 4 kq + e, column c of a tile).
+// ---------------------------------------------------------------------------------------------------------------------
+#define BB_NS 4
+__global__ __launch_bounds__(256) void k_bgemm_big(Q3BGemm g) {
+    extern __shared__ __attribute__((aligned(16))) char bb_ring[];  // [BB_NS][A: 8 row tiles x 1 KiB | B: 8 column tiles x 1 KiB]
+    __shared__ float srow[128];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1, kq = lane >> 4, c = lane & 15;
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int total = gridDim.x * gridDim.y;
+        if ((total & 7) == 0) {
+            const int id = blockIdx.x + gridDim.x * blockIdx.y, t = (id & 7) * (total >> 3) + (id >> 3);
+            by = t % gridDim.y; bx = t / gridDim.y;
+        }
+    }
+    const int B = g.B, kblocks = g.K >> 5, per = g.K >> 8;  // per = steps per K-slice
+    const int rt0 = (g.a_row0 >> 4) + by * 8, rt_last = (g.a_row0 + B - 1) >> 4, nb0 = bx * 8;
+    // loader: wave w brings A tiles 2w, 2w+1 and B tiles 2w, 2w+1 of every stage
+    const u32x4* asrc[2]; const u32x4* bsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        asrc[i] = (const u32x4*)g.a + (size_t)min(rt0 + wave * 2 + i, rt_last) * kblocks * 64 + lane;
+        bsrc[i] = (const u32x4*)g.w + (size_t)(nb0 + wave * 2 + i) * kblocks * 64 + lane;
+    }
+    auto issue = [&](int step) {
+        char* st = bb_ring + (size_t)(step % BB_NS) * 16384;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (size_t)step * 64),
+                                             (__attribute__((address_space(3))) void*)(st + (wave * 2 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + (size_t)step * 64),
+                                             (__attribute__((address_space(3))) void*)(st + 8192 + (wave * 2 + i) * 1024), 16, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < BB_NS - 1; ++p) issue(p);  // (K >= 256: at least 8 steps)
+    // row scales of the split RMSNorm: wave w owns rows w, w + 4, ... of the tile (lane j adds its tiles j, j + 64, ... ascending, then
+    // the 64-lane butterfly: DESIGN.md §4.2)
+    if (g.ssp) {  // 16 rows per trip: their partials are requested together (one round trip, not one per row)
+        for (int i0 = 0; i0 < 32; i0 += 16) {
+            float a0[16], a1[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float* sp = g.ssp + (size_t)min(by * 128 + wave + 4 * (i0 + i), B - 1) * g.ld_ssp;
+                a0[i] = lane < g.ntiles ? sp[lane] : 0.0f;
+                a1[i] = lane + 64 < g.ntiles ? sp[lane + 64] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float a = a0[i];
+                if (lane + 64 < g.ntiles) a = a + a1[i];
+                if (g.ntiles > 128) {
+                    const float* sp = g.ssp + (size_t)min(by * 128 + wave + 4 * (i0 + i), B - 1) * g.ld_ssp;
+                    for (int t = lane + 128; t < g.ntiles; t += 64) a = a + sp[t];
+                }
+                a0[i] = a;
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) a0[i] = a0[i] + __shfl_xor(a0[i], m);
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) srow[wave + 4 * (i0 + i)] = 1.0f / sqrtf(a0[i] / (float)g.d_norm + g.eps);
+            }
+        }
+    }
+    f32x4 acc[4][4], tot[4][4];
+    const int nsteps = kblocks;
+    int in_slice = 0, slice = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int step = 0; step < nsteps; ++step) {
+        if (step + BB_NS - 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((BB_NS - 2) * 4) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (step + BB_NS - 1 < nsteps) issue(step + BB_NS - 1);
+        const char* st = bb_ring + (size_t)(step % BB_NS) * 16384;
+        bf16x8 a_[4], b_[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_[i] = *(const bf16x8*)(st + (wm * 4 + i) * 1024 + lane * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b_[j] = *(const bf16x8*)(st + 8192 + (wn * 4 + j) * 1024 + lane * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_[i], b_[j], acc[i][j], 0, 0, 0);
+        if (++in_slice == per) {  // the slice's chain is complete: RAW = ((s_0 + s_1) + ...) + s_7
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (slice == 0) tot[i][j] = acc[i][j];
+                    else { tot[i][j][0] = tot[i][j][0] + acc[i][j][0]; tot[i][j][1] = tot[i][j][1] + acc[i][j][1]; tot[i][j][2] = tot[i][j][2] + acc[i][j][2]; tot[i][j][3] = tot[i][j][3] + acc[i][j][3]; }
+                    acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            in_slice = 0; ++slice;
+        }
+    }
+    __syncthreads();  // srow
+    const int epi = g.epi;
+    if (epi == Q3_EPI_RESID) {  // the residual operands of the whole 64 x 64 part in one batch of loads (the chain accumulators are free now)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = min(by * 128 + wm * 64 + i * 16 + 4 * kq + e, B - 1);
+                    acc[i][j][e] = g.y[(size_t)row * g.ldy + (nb0 + wn * 4 + j) * 16 + c];
+                }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int rl = wm * 64 + i * 16 + 4 * kq + e, row = by * 128 + rl;
+            const bool live = row < B;
+            const float sc = g.ssp ? srow[rl] : 1.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int tile = nb0 + wn * 4 + j, col = tile * 16 + c;
+                const float v = tot[i][j][e];
+                if (epi == Q3_EPI_SWIGLU) {  // gate = columns 0-7 of a tile, up = the same row 8 columns further (lane + 8)
+                    const float up = __shfl(v, (lane + 8) & 63);
+                    if (live && c < 8) g.yb[q3_atile_off(row, tile * 8 + c, g.N >> 6)] = q3_bf16(q3_swiglu(sc * v, sc * up));
+                } else if (epi == Q3_EPI_STORE) {
+                    if (live) g.y[(size_t)row * g.ldy + col] = g.ssp ? sc * v : v;
+                } else {  // Q3_EPI_RESID
+                    const float xv = acc[i][j][e] + v;
+                    if (live) g.y[(size_t)row * g.ldy + col] = xv;
+                    if (g.nw_next) {
+                        if (live) g.yb[q3_atile_off(row, col, g.N >> 5)] = q3_bf16(xv * g.nw_next[col]);
+                        float sq = xv * xv;
+                        sq = sq + __shfl_xor(sq, 1); sq = sq + __shfl_xor(sq, 2); sq = sq + __shfl_xor(sq, 4); sq = sq + __shfl_xor(sq, 8);
+                        if (live && c == 0) g.ssp_out[(size_t)row * g.ld_ssp_out + tile] = sq;
+                    }
+                }
+            }
+        }
+}
+static bool bg_big_ok(const Q3BGemm& g) {
+    return g.B >= 256 && (g.epi == Q3_EPI_STORE || g.epi == Q3_EPI_RESID || g.epi == Q3_EPI_SWIGLU) && g.N % 128 == 0 && g.a_row0 % 16 == 0 &&
+           !g.bias && !g.col_scale && !g.seg_rows && !(g.epi == Q3_EPI_RESID && g.yb && !g.nw_next);
+}
+static void bg_launch_big(const Q3BGemm& g, hipStream_t s) {
+    const dim3 grid(g.N / 128, (g.B + 127) / 128);
+    hipLaunchKernelGGL(k_bgemm_big, grid, dim3(256), BB_NS * 16384, s, g);
+}
+
 // Operand steps in flight per wave (a step = 4 (RT + NT) registers; a K slice of 256 is 8 steps): 8, 5, 4, 3, 2 for RT + NT = <= 3, 4, 5, 6, 7,
 // which keeps every instance at <= ~146 registers per wave. Round 2 first ran 5-8 steps everywhere (160-230 registers): the shallow
 // depths are 3 % faster on the Talker's gate/up GEMM and 20 % on launches with more than one workgroup per CU (tools/bgemm_tune.hip), and
@@ -225,10 +387,13 @@ struct BgInst {
         else hipLaunchKernelGGL((k_bgemm<RT, NT, D, false>), grid, dim3(512), lds, s, g);
     }
 };
+static int g_big = 1;  // Q3TTS_BG_NOBIG=1: many-row launches stay on k_bgemm (A/B runs; the results are the same bits)
 // once per process, outside any stream capture (the engine calls it before it records its graphs)
 void q3_bgemm_prepare() {
     static bool done = false;
     if (done) return;
+    { const char* ev = getenv("Q3TTS_BG_NOBIG"); g_big = !(ev && atoi(ev)); }
+    hipFuncSetAttribute((const void*)k_bgemm_big, hipFuncAttributeMaxDynamicSharedMemorySize, BB_NS * 16384);
 #define P(RT_, NT_) BgInst<RT_, NT_>::prepare();
     P(1, 1) P(1, 2) P(1, 3) P(2, 1) P(2, 2) P(2, 3) P(3, 1) P(3, 2) P(3, 3) P(4, 1) P(4, 2) P(4, 3)
 #undef P
@@ -248,6 +413,8 @@ int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s) {
     if ((g.epi == Q3_EPI_SWIGLU || g.epi == Q3_EPI_GELU) && (!g.yb)) return -1;
     if (g.bias && g.bias_n < 1) return -1;
     if (g.ssp && g.ntiles < 1) return -1;
+    q3_bgemm_prepare();
+    if (g_big && g_force_rt == 0 && bg_big_ok(g)) { bg_launch_big(g, s); return 0; }
     const int tiles = g.N / 16;
     int bestRT = 1, bestNT = 1; long bestCost = -1, bestWgs = 0;
     for (int RT = 1; RT <= 4; ++RT)

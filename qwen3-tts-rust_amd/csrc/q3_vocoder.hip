@@ -58,6 +58,8 @@ struct Q3Voc {
     float *oea = nullptr, *oib = nullptr, *out_w = nullptr, *out_b = nullptr; VBuf out_in; int out_c = 0;
     float *kring = nullptr, *vring = nullptr;  // [n_layer][B][RW][HH]
     float* rope = nullptr; int rope_rows = 0;    // [position][hd/2][cos, sin], evaluated in double on the host like the oracle's
+    struct ZeroEnt { char* base; unsigned long long bytes; };  // per-slot history blocks: base + slot * bytes
+    ZeroEnt* zero_tab = nullptr; int n_zero = 0;  // q3_voc_reset: one launch instead of one memset per buffer
     bool tfm_bg = false;                         // the transformer's projections run on k_bgemm (every K a multiple of 256)
     bool up_bg = false; uint16_t* upb = nullptr; // so do the up-sampling stages' ConvTranspose / pointwise GEMMs; upb: a stage's output as A-tiled bf16 for the next
     float *x = nullptr, *xn = nullptr, *xnb = nullptr, *qkv = nullptr, *att = nullptr, *g = nullptr;  // transformer scratch [M][.] (xnb, att, g: bf16)
@@ -1104,14 +1106,29 @@ static void zero_hist(q3tts_engine* e, VBuf& b, int slot) {
     const size_t es = b.bf16 ? 2 : 4;
     if (b.H > 0) hipMemsetAsync((char*)b.hist + (size_t)slot * b.H * b.C * es, 0, (size_t)b.H * b.C * es, e->stream);
 }
+// zeroes every history block of a slot: grid (entries, 4)
+__global__ void k_voc_zero(const Q3Voc::ZeroEnt* tab, int slot) {
+    const Q3Voc::ZeroEnt z = tab[blockIdx.x];
+    uint32_t* p = (uint32_t*)(z.base + (size_t)slot * z.bytes);
+    const size_t n = z.bytes / 4;  // (bf16 / f32 blocks of H x C elements, C even: whole dwords)
+    for (size_t i = (size_t)blockIdx.y * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.y * blockDim.x) p[i] = 0u;
+}
 int q3_voc_reset(q3tts_engine* e, int slot) {
     Q3Voc* v = e->voc;
     if (!v) return Q3TTS_OK;
-    zero_hist(e, v->pre_in, slot);
-    for (auto& u : v->U) zero_hist(e, u.dw_in, slot);
-    zero_hist(e, v->dec_in_in, slot);
-    for (auto& b : v->Bk) { zero_hist(e, b.ct_in, slot); for (auto& r : b.res) zero_hist(e, r.c1_in, slot); }
-    zero_hist(e, v->out_in, slot);
+    if (!v->zero_tab) {  // built at the first reset: the work buffers exist by then
+        std::vector<Q3Voc::ZeroEnt> tab;
+        auto add = [&](const VBuf& b) { if (b.H > 0) tab.push_back({(char*)b.hist, (unsigned long long)b.H * b.C * (b.bf16 ? 2 : 4)}); };
+        add(v->pre_in);
+        for (auto& u : v->U) add(u.dw_in);
+        add(v->dec_in_in);
+        for (auto& b : v->Bk) { add(b.ct_in); for (auto& r : b.res) add(r.c1_in); }
+        add(v->out_in);
+        v->n_zero = (int)tab.size();
+        VTRY(valloc(e, v, &v->zero_tab, tab.size()));
+        Q3_HIP(e, hipMemcpy(v->zero_tab, tab.data(), tab.size() * sizeof(Q3Voc::ZeroEnt), hipMemcpyHostToDevice));
+    }
+    if (v->n_zero) hipLaunchKernelGGL(k_voc_zero, dim3(v->n_zero, 4), dim3(256), 0, e->stream, v->zero_tab, slot);
     v->frames_done[slot] = 0; v->last_flag[slot] = 0;
     return Q3TTS_OK;
 }

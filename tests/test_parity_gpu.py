@@ -616,6 +616,22 @@ def test_bgemm_swiglu_matches_oracle(oracle, native, B, K, N):
     assert np.count_nonzero(got["yb"] & 0x7fff) > got["yb"].size // 2
 
 
+@pytest.mark.parametrize("B,K,N,epi", [(256, 2048, 4096, 0), (300, 2048, 4096, 0), (1000, 1024, 256, 0), (513, 256, 128, 0), (257, 2048, 2048, 1), (640, 6144, 2048, 1),
+                                       (300, 512, 128, 1), (256, 2048, 12288, 2), (391, 1024, 6144, 2), (1984, 2048, 4096, 0)])
+def test_bgemm_many_rows_kernel_matches_oracle(oracle, native, B, K, N, epi):
+    """Prefill-sized launches (>= 256 rows, N % 128 == 0) run k_bgemm_big: 128 x 128 tiles, the whole K in one wave, the 8 K-slices summed
+    in the canonical order inside the wave. Same bits as the oracle (and therefore as k_bgemm), ragged last row tiles included."""
+    ref, got, _, _ = _bgemm_case(oracle, native, B, K, N, epi, epi != 1, 900 + B + N + epi)
+    if epi == 0:
+        assert np.array_equal(_bits(got["y"]), _bits(ref["y"]))
+    elif epi == 1:
+        assert np.array_equal(_bits(got["y"]), _bits(ref["y"]))
+        assert np.array_equal(got["yb"], ref["yb"])
+        assert np.array_equal(_bits(got["ssp_out"]), _bits(ref["ssp_out"]))
+    else:
+        assert np.array_equal(got["yb"], ref["yb"])
+
+
 @pytest.mark.parametrize("B,K,N", [(64, 1024, 2048), (2, 1024, 2048), (33, 512, 64), (64, 2048, 3072)])
 def test_bgemm_argmax_matches_oracle(oracle, native, B, K, N):
     ref, got, _, _ = _bgemm_case(oracle, native, B, K, N, 3, True, 7 + B + N)
