@@ -1102,10 +1102,6 @@ void q3_voc_destroy(q3tts_engine* e) {
     e->voc = nullptr;
 }
 
-static void zero_hist(q3tts_engine* e, VBuf& b, int slot) {
-    const size_t es = b.bf16 ? 2 : 4;
-    if (b.H > 0) hipMemsetAsync((char*)b.hist + (size_t)slot * b.H * b.C * es, 0, (size_t)b.H * b.C * es, e->stream);
-}
 // zeroes every history block of a slot: grid (entries, 4)
 __global__ void k_voc_zero(const Q3Voc::ZeroEnt* tab, int slot) {
     const Q3Voc::ZeroEnt z = tab[blockIdx.x];
