@@ -1027,7 +1027,9 @@ int q3_voc_create(q3tts_engine* e) {
             }
         }
         VTRY(valloc(e, v, &v->rope, tab.size()));
-        Q3_HIP(e, hipMemcpy(v->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+        // (valloc zero-fills asynchronously on e->stream: the copy is ordered on that stream, or the fill could land on top of it)
+        Q3_HIP(e, hipMemcpyAsync(v->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, e->stream));
+        Q3_HIP(e, hipStreamSynchronize(e->stream));
     }
     VTRY(gen_vec(e, v, &v->final_norm, VTID(VC_FINAL_NORM, VW_W), d, 1.0f, 0.05f));
     int rows = VOC_FCAP;  // rows per slot at the current stage
@@ -1122,7 +1124,9 @@ int q3_voc_reset(q3tts_engine* e, int slot) {
         add(v->out_in);
         v->n_zero = (int)tab.size();
         VTRY(valloc(e, v, &v->zero_tab, tab.size()));
-        Q3_HIP(e, hipMemcpy(v->zero_tab, tab.data(), tab.size() * sizeof(Q3Voc::ZeroEnt), hipMemcpyHostToDevice));
+        // (valloc zero-fills asynchronously on e->stream: the copy has to be ordered on that stream, or the fill lands on top of it)
+        Q3_HIP(e, hipMemcpyAsync(v->zero_tab, tab.data(), tab.size() * sizeof(Q3Voc::ZeroEnt), hipMemcpyHostToDevice, e->stream));
+        Q3_HIP(e, hipStreamSynchronize(e->stream));
     }
     if (v->n_zero) hipLaunchKernelGGL(k_voc_zero, dim3(v->n_zero, 4), dim3(256), 0, e->stream, v->zero_tab, slot);
     v->frames_done[slot] = 0; v->last_flag[slot] = 0;

@@ -333,6 +333,27 @@ def test_vocoder_narrow_block_kernels(oracle):
         L.q3o_vocoder_destroy(v)
 
 
+def test_slot_reuse_starts_from_a_clean_vocoder_state(oracle, tiny_voc):
+    """The same request on the same slot, before and after a different utterance used that slot: identical PCM. (The vocoder's conv
+    histories are zeroed by one kernel at admission; a reset that does nothing shows up here as a different first chunk.)"""
+    cfg, eng, v = tiny_voc
+    om = oracle.OracleModel(cfg.model, seed=0, n_ctx=256, n_threads=4)
+
+    def req(seed, n_ids, frames):
+        desc, keep = oracle.make_prompt_desc(np.arange(3, 3 + n_ids), spk_emb=_spk(cfg.model.d_embed))
+        return dict(embd=om.build_prompt(desc), want_pcm=1, temperature=0.7, top_k=40, top_p=0.9, seed=seed, max_steps=frames, min_frames=frames, force_eos_at=frames)
+
+    a, b = req(11, 6, 9), req(12, 9, 14)
+    first = eng.generate_batch([a])[0]
+    other = eng.generate_batch([b])[0]
+    again = eng.generate_batch([a])[0]
+    assert first.status == other.status == again.status == 0
+    assert np.array_equal(first.codes, again.codes) and np.array_equal(first.pcm, again.pcm)
+    ref = _oracle_pcm(oracle, v, np.clip(first.codes, 0, cfg.vocoder.codebook_size - 1).astype(np.int32))
+    assert float(np.sqrt(np.mean((again.pcm - ref) ** 2))) <= PCM_RMS_TOL
+    om.close()
+
+
 def test_batch_with_pcm_crosses_row_buckets(oracle, tiny_voc):
     """Mixed lengths on 4 slots with the vocoder on: rows are re-packed 4 -> 2 -> 1 mid-utterance, slots are re-used."""
     cfg, eng, v = tiny_voc
