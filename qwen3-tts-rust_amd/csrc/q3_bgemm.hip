@@ -387,12 +387,10 @@ struct BgInst {
         else hipLaunchKernelGGL((k_bgemm<RT, NT, D, false>), grid, dim3(512), lds, s, g);
     }
 };
-static int g_big = 1;  // Q3TTS_BG_NOBIG=1: many-row launches stay on k_bgemm (A/B runs; the results are the same bits)
 // once per process, outside any stream capture (the engine calls it before it records its graphs)
 void q3_bgemm_prepare() {
     static bool done = false;
     if (done) return;
-    { const char* ev = getenv("Q3TTS_BG_NOBIG"); g_big = !(ev && atoi(ev)); }
     hipFuncSetAttribute((const void*)k_bgemm_big, hipFuncAttributeMaxDynamicSharedMemorySize, BB_NS * 16384);
 #define P(RT_, NT_) BgInst<RT_, NT_>::prepare();
     P(1, 1) P(1, 2) P(1, 3) P(2, 1) P(2, 2) P(2, 3) P(3, 1) P(3, 2) P(3, 3) P(4, 1) P(4, 2) P(4, 3)
@@ -414,7 +412,14 @@ int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s) {
     if (g.bias && g.bias_n < 1) return -1;
     if (g.ssp && g.ntiles < 1) return -1;
     q3_bgemm_prepare();
-    if (g_big && g_force_rt == 0 && bg_big_ok(g)) { bg_launch_big(g, s); return 0; }
+    if (g.B >= 256 && g_force_rt == 0 && bg_big_ok(g)) {
+        // Q3TTS_BG_BIG: 1 = the many-row kernel whenever it is eligible, -1 = never (A/B runs and the tests: the results are the same bits);
+        // default: when it fills the chip — at least one 128 x 128 tile per CU (prefill; the vocoder's 256-row GEMMs stay on k_bgemm)
+        const char* ev = getenv("Q3TTS_BG_BIG");
+        const int policy = ev ? atoi(ev) : 0;
+        const long wgs = (long)(g.N / 128) * ((g.B + 127) / 128);
+        if (policy > 0 || (policy == 0 && wgs >= 256)) { bg_launch_big(g, s); return 0; }
+    }
     const int tiles = g.N / 16;
     int bestRT = 1, bestNT = 1; long bestCost = -1, bestWgs = 0;
     for (int RT = 1; RT <= 4; ++RT)

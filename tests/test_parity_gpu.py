@@ -4,6 +4,7 @@ Every comparison here is `==` on raw bits: the device kernels and the oracle fol
 summation orders, so there is no tolerance to state.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -642,7 +643,11 @@ def test_bgemm_swiglu_matches_oracle(oracle, native, B, K, N):
 def test_bgemm_many_rows_kernel_matches_oracle(oracle, native, B, K, N, epi):
     """Prefill-sized launches (>= 256 rows, N % 128 == 0) run k_bgemm_big: 128 x 128 tiles, the whole K in one wave, the 8 K-slices summed
     in the canonical order inside the wave. Same bits as the oracle (and therefore as k_bgemm), ragged last row tiles included."""
-    ref, got, _, _ = _bgemm_case(oracle, native, B, K, N, epi, epi != 1, 900 + B + N + epi)
+    os.environ["Q3TTS_BG_BIG"] = "1"   # (the launcher's own rule wants >= 256 tiles: the oracle would take minutes at such sizes)
+    try:
+        ref, got, _, _ = _bgemm_case(oracle, native, B, K, N, epi, epi != 1, 900 + B + N + epi)
+    finally:
+        del os.environ["Q3TTS_BG_BIG"]
     if epi == 0:
         assert np.array_equal(_bits(got["y"]), _bits(ref["y"]))
     elif epi == 1:
