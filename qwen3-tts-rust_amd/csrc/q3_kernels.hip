@@ -650,7 +650,10 @@ __global__ __launch_bounds__(256) void k_sample_input(Q3Sample a, Q3PredInput p)
 void q3_launch_sample_input(const Q3Sample& a, const Q3PredInput& p, hipStream_t s) { hipLaunchKernelGGL(k_sample_input, dim3(a.B), dim3(256), 0, s, a, p); }
 
 __global__ __launch_bounds__(256) void k_pred_next(Q3PredNext a) {
-    const int b = blockIdx.x, tid = threadIdx.x, d = a.d, slot = a.row_slot[b];
+    const int b = blockIdx.x, tid = threadIdx.x, d = a.d;
+    // the per-tile keys do not depend on the slot: requested before the slot state is looked at (one round trip less on the chain)
+    unsigned long long kk = tid < a.n_key_parts ? a.keys[(size_t)b * a.n_key_parts + tid] : 0ull;
+    const int slot = a.row_slot[b];
     Q3Slot* sl = a.slots + slot;
     const bool last = a.q == a.ncb - 1;
     if (!sl->active) {
@@ -659,7 +662,6 @@ __global__ __launch_bounds__(256) void k_pred_next(Q3PredNext a) {
     }
     // code_q = argmax of the head's logits: the maximum of the per-tile keys the head GEMM left (ties -> smaller index, NaN never wins)
     __shared__ unsigned long long kmax_s[4];
-    unsigned long long kk = tid < a.n_key_parts ? a.keys[(size_t)b * a.n_key_parts + tid] : 0ull;
     for (int t = tid + 256; t < a.n_key_parts; t += 256) { const unsigned long long o = a.keys[(size_t)b * a.n_key_parts + t]; kk = o > kk ? o : kk; }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(kk, m); kk = o > kk ? o : kk; }
