@@ -528,19 +528,28 @@ __device__ int sample_row(const float* logits, int limit, float temperature, int
         for (int i = tid; i < n_all; i += 256) probs[i] = q3_expf((q3_key_value(keys[i]) - max_logit) / temperature);
     }
     __syncthreads();
-    if (tid == 0) {
-        int n = n_all;
-        float sum = 0.0f;
-        for (int i = 0; i < n; ++i) sum += probs[i];
-        if (sum > 0.0f) for (int i = 0; i < n; ++i) probs[i] /= sum;     // :726-731
-        if (top_p < 1.0f) {                                              // :734-753
+    // :726-764. The reference's sums are sequential f32 adds and stay so (thread 0, in order); the divisions between them are
+    // element-wise and run on all threads — one thread doing everything spent ~15 us of this kernel walking LDS five times.
+    __shared__ float bc_s; __shared__ int cut_s;
+    int n = n_all;
+    if (tid == 0) { float sum = 0.0f; for (int i = 0; i < n; ++i) sum += probs[i]; bc_s = sum; }
+    __syncthreads();
+    { const float sum = bc_s; if (sum > 0.0f) for (int i = tid; i < n; i += 256) probs[i] /= sum; }     // :726-731
+    __syncthreads();
+    if (top_p < 1.0f) {                                                  // :734-753
+        if (tid == 0) {
             float cum = 0.0f; int cutoff = n;
             for (int i = 0; i < n; ++i) { cum += probs[i]; if (cum >= top_p) { cutoff = i + 1; break; } }
-            n = cutoff;
             float ns = 0.0f;
-            for (int i = 0; i < n; ++i) ns += probs[i];
-            if (ns > 0.0f) for (int i = 0; i < n; ++i) probs[i] /= ns;
+            for (int i = 0; i < cutoff; ++i) ns += probs[i];
+            cut_s = cutoff; bc_s = ns;
         }
+        __syncthreads();
+        n = cut_s;
+        { const float ns = bc_s; if (ns > 0.0f) for (int i = tid; i < n; i += 256) probs[i] /= ns; }
+        __syncthreads();
+    }
+    if (tid == 0) {
         float cum = 0.0f; int res = -1;                                  // :756-764
         for (int i = 0; i < n; ++i) { cum += probs[i]; if (r < cum) { res = q3_argmax_idx(keys[i]); break; } }
         if (res < 0) res = n > 0 ? q3_argmax_idx(keys[0]) : 0;           // :767-770
@@ -620,17 +629,36 @@ __device__ void pred_input_row(const Q3PredInput& a, int b, int code0) {
     const float rinv = rinv_s;
     const bool ok = code0 >= 0 && code0 < a.codec0_rows;  // OOB rows embed as zeros: src/assets_manager.rs:419-437
     const float* e = a.codec0 + (size_t)(ok ? code0 : 0) * d;
-    for (int i = tid; i < d; i += 256) {
-        a.X[(size_t)b * d + i] = (x[i] * rinv) * a.out_norm[i];
-        const float ev = ok ? e[i] : 0.0f;
-        a.fb[(size_t)b * d + i] = 0.0f + ev;
-    }
     const float* pr = ok ? a.pproj0 + (size_t)code0 * a.dp : a.proj_b;  // proj(0) = bias
+    // every operand of the row is requested before anything is stored (a loop of load, store, load, store ... paid one memory round
+    // trip per 256 elements: 12 in a row, ~10 us of this kernel)
+    constexpr int NI = 8, NP = 4;  // d <= 8 * 256, dp <= 4 * 256 (checked at engine creation for the shipped shapes; larger: extra trips)
+    for (int i0 = 0; i0 < d; i0 += NI * 256) {
+        float xv[NI], nv[NI], ev[NI];
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = min(i0 + tid + u * 256, d - 1);
+            xv[u] = x[i]; nv[u] = a.out_norm[i]; ev[u] = ok ? e[i] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = i0 + tid + u * 256;
+            if (i < d) { a.X[(size_t)b * d + i] = (xv[u] * rinv) * nv[u]; a.fb[(size_t)b * d + i] = 0.0f + ev[u]; }
+        }
+    }
     const int r1 = a.B + b;  // pass A rows: [0, B) the projected hidden rows, [B, 2B) the code rows
-    for (int i = tid; i < a.dp; i += 256) {  // (dp % 256 == 0: whole waves, 16 consecutive lanes per norm tile)
-        const float v = pr[i];
-        a.px[(size_t)r1 * a.dp + i] = v;
-        q3_norm_out(v, a.nw[i], a.xb + q3_atile_off(r1, i, a.dp >> 5), a.ssp + (size_t)r1 * (a.dp >> 4) + (i >> 4), (i & 15) == 0);
+    for (int i0 = 0; i0 < a.dp; i0 += NP * 256) {  // (dp % 256 == 0: whole waves, 16 consecutive lanes per norm tile)
+        float pv[NP], wv[NP];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) { const int i = min(i0 + tid + u * 256, a.dp - 1); pv[u] = pr[i]; wv[u] = a.nw[i]; }
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int i = i0 + tid + u * 256;
+            if (i < a.dp) {  // (uniform per wave: dp % 256 == 0)
+                a.px[(size_t)r1 * a.dp + i] = pv[u];
+                q3_norm_out(pv[u], wv[u], a.xb + q3_atile_off(r1, i, a.dp >> 5), a.ssp + (size_t)r1 * (a.dp >> 4) + (i >> 4), (i & 15) == 0);
+            }
+        }
     }
 }
 __global__ __launch_bounds__(256) void k_pred_input(Q3PredInput a) {
@@ -675,18 +703,44 @@ __global__ __launch_bounds__(256) void k_pred_next(Q3PredNext a) {
     const float* e = a.codec_q + (size_t)(ok ? code : 0) * d;
     const int frame = sl->n_frames;
     if (tid == 0) a.codes[((size_t)slot * a.max_steps_cap + frame) * a.ncb + a.q] = code;
-    for (int i = tid; i < d; i += 256) {
-        const float ev = ok ? e[i] : 0.0f;
-        float f = a.fb[(size_t)b * d + i] + ev;
-        if (!last) a.fb[(size_t)b * d + i] = f;
-        else {  // the Talker's next input row and its norm inputs for layer 0
-            f = f + a.tts_pad[i]; a.xT[(size_t)b * d + i] = f;
-            q3_norm_out(f, a.nw[i], a.xb + q3_atile_off(b, i, d >> 5), a.ssp + (size_t)b * (d >> 4) + (i >> 4), (i & 15) == 0);
+    // operands of the whole row first, stores after (see pred_input_row): the table rows and the running feedback sum in one round trip
+    constexpr int NI = 8, NP = 4;
+    const float* pr = ok ? a.pproj_q + (size_t)code * a.dp : a.proj_b;
+    float pv[NP], wv[NP];
+    if (!last) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) { const int i = min(tid + u * 256, a.dp - 1); pv[u] = pr[i]; wv[u] = a.nw[i]; }
+    }
+    for (int i0 = 0; i0 < d; i0 += NI * 256) {
+        float ev[NI], fv[NI], tp[NI], nv[NI];
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = min(i0 + tid + u * 256, d - 1);
+            ev[u] = ok ? e[i] : 0.0f; fv[u] = a.fb[(size_t)b * d + i];
+            if (last) { tp[u] = a.tts_pad[i]; nv[u] = a.nw[i]; }
+        }
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = i0 + tid + u * 256;
+            if (i >= d) continue;  // (uniform per wave: d % 256 == 0)
+            float f = fv[u] + ev[u];
+            if (!last) a.fb[(size_t)b * d + i] = f;
+            else {  // the Talker's next input row and its norm inputs for layer 0
+                f = f + tp[u]; a.xT[(size_t)b * d + i] = f;
+                q3_norm_out(f, nv[u], a.xb + q3_atile_off(b, i, d >> 5), a.ssp + (size_t)b * (d >> 4) + (i >> 4), (i & 15) == 0);
+            }
         }
     }
     if (!last) {
-        const float* pr = ok ? a.pproj_q + (size_t)code * a.dp : a.proj_b;
-        for (int i = tid; i < a.dp; i += 256) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int i = tid + u * 256;
+            if (i < a.dp) {
+                a.px[(size_t)b * a.dp + i] = pv[u];
+                q3_norm_out(pv[u], wv[u], a.xb + q3_atile_off(b, i, a.dp >> 5), a.ssp + (size_t)b * (a.dp >> 4) + (i >> 4), (i & 15) == 0);
+            }
+        }
+        for (int i = tid + NP * 256; i < a.dp; i += 256) {  // (dp > 1024: not a shipped shape)
             const float v = pr[i];
             a.px[(size_t)b * a.dp + i] = v;
             q3_norm_out(v, a.nw[i], a.xb + q3_atile_off(b, i, a.dp >> 5), a.ssp + (size_t)b * (a.dp >> 4) + (i >> 4), (i & 15) == 0);
