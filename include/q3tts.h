@@ -301,6 +301,12 @@ int q3tts_k_mfma_bf16(int32_t device, const uint16_t* a, const uint16_t* b, cons
 int q3tts_k_bgemm(int32_t device, const uint16_t* xb, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, const float* ssp, int32_t ntiles,
                   int32_t d_norm, float eps, int32_t epilogue, const float* nw_next, float* y, uint16_t* yb, float* ssp_out, uint64_t* keys,
                   int32_t iters, float* mean_kernel_ms);
+/* The same GEMM with the epilogue extras only the vocoder uses (nothing in the reference: its vocoder is an ONNX graph, src/models/onnx.rs:342-459):
+ * bias[col % bias_n] added to RAW first; epilogue 0: y = RAW + bias; 1: y += col_scale[col] * (RAW + bias), optionally yb = bf16(y);
+ * 4: yb = bf16(gelu_erf(RAW + bias)). seg_rows > 0: the f32 rows live in B / seg_rows segments separated by gap_rows rows the kernel
+ * must not touch (checked by the hook). y / yb are dense [B][N] on the host side. */
+int q3tts_k_bgemm_voc(int32_t device, const uint16_t* xb, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, int32_t epilogue, const float* bias,
+                      int32_t bias_n, const float* col_scale, int32_t seg_rows, int32_t gap_rows, float* y, uint16_t* yb, int32_t want_yb);
 /* H6 — Assets::project (src/assets_manager.rs:383-399) in the reference's own f32 sequence: y[r][o] = bias[o]; y += x[r][i] * w[o][i]
  * for i ascending (w f32 row-major [n_out][n_in]). nw != NULL: also the rows' norm inputs xb = bf16(y * nw), ssp [rows][n_out/16]. */
 int q3tts_k_project(int32_t device, const float* x, int32_t rows, int32_t n_in, const float* w, const float* bias, int32_t n_out, const float* nw,

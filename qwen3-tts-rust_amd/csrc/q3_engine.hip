@@ -1364,6 +1364,53 @@ extern "C" int q3tts_k_bgemm(int32_t device, const uint16_t* xb, int32_t B, int3
 }
 
 // H6 through the projection kernel: y[rows][n_out] = bias + sum x * w (reference order); nw != NULL: the rows' norm inputs too
+// The vocoder's extras of the decoder GEMM (bias, GELU -> bf16, LayerScale column scale, per-slot row segments, a bf16 copy of the
+// residual result) through one hook: epi 0 (store) / 1 (residual) / 4 (GELU). y0 / y are dense [B][N]; with seg_rows > 0 the kernel
+// works on a buffer of B / seg_rows segments, each preceded by gap_rows sentinel rows that must come back untouched.
+extern "C" int q3tts_k_bgemm_voc(int32_t device, const uint16_t* xb, int32_t B, int32_t K, const uint16_t* w, int32_t N, int32_t epi, const float* bias,
+                                 int32_t bias_n, const float* col_scale, int32_t seg_rows, int32_t gap_rows, float* y, uint16_t* yb, int32_t want_yb) {
+    if (!xb || !w || B <= 0 || K % 256 || K < 256 || N % 32 || (epi != Q3_EPI_STORE && epi != Q3_EPI_RESID && epi != Q3_EPI_GELU))
+        return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm_voc hook: K % 256 == 0, N % 32 == 0, epilogue 0 / 1 / 4");
+    if ((epi != Q3_EPI_GELU && !y) || ((epi == Q3_EPI_GELU || want_yb) && !yb)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm_voc hook: output missing");
+    if (seg_rows < 0 || gap_rows < 0 || (seg_rows > 0 && B % seg_rows) || (bias && bias_n < 1)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm_voc hook: segments / bias");
+    HK(hipSetDevice(device));
+    const size_t B16 = ((size_t)B + 15) & ~(size_t)15;
+    const int T = seg_rows > 0 ? seg_rows : B, S = B / T, P = T + (seg_rows > 0 ? gap_rows : 0);
+    DevBuf dx, dw, dwt, db, dc, dy, dyb;
+    if (dx.alloc(B16 * K * 2) || dw.alloc((size_t)N * K * 2) || dwt.alloc((size_t)N * K * 2) || db.alloc((size_t)(bias ? bias_n : 1) * 4) || dc.alloc((size_t)N * 4) ||
+        dy.alloc((size_t)S * P * N * 4) || dyb.alloc(B16 * N * 2))
+        return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
+    { const std::vector<uint16_t> xt = atile_host(xb, B, K); HK(hipMemcpy(dx.p, xt.data(), xt.size() * 2, hipMemcpyHostToDevice)); }
+    HK(hipMemcpy(dw.p, w, (size_t)N * K * 2, hipMemcpyHostToDevice));
+    if (bias) HK(hipMemcpy(db.p, bias, (size_t)bias_n * 4, hipMemcpyHostToDevice));
+    if (col_scale) HK(hipMemcpy(dc.p, col_scale, (size_t)N * 4, hipMemcpyHostToDevice));
+    std::vector<float> seg((size_t)S * P * N, -12345.5f);  // sentinel in the gap rows
+    if (epi != Q3_EPI_GELU)
+        for (int sidx = 0; sidx < S; ++sidx)
+            for (int t = 0; t < T; ++t) memcpy(&seg[((size_t)sidx * P + (P - T) + t) * N], y + ((size_t)sidx * T + t) * N, (size_t)N * 4);
+    HK(hipMemcpy(dy.p, seg.data(), seg.size() * 4, hipMemcpyHostToDevice));
+    Q3Fill f{}; f.dst = (uint4*)dwt.p; f.N = N; f.K = K; f.mode = 0; f.row0 = 0; f.rows = N; f.src_a = (const uint16_t*)dw.p;
+    q3_launch_fill_tiled(f, nullptr);
+    Q3BGemm g{}; g.a = (const uint16_t*)dx.p; g.B = B; g.w = (const uint4*)dwt.p; g.K = K; g.N = N; g.epi = epi;
+    g.y = (float*)dy.p + (size_t)(P - T) * N; g.ldy = N;
+    if (seg_rows > 0) { g.seg_rows = T; g.seg_stride = (size_t)P * N; }
+    g.bias = bias ? (const float*)db.p : nullptr; g.bias_n = bias_n; g.col_scale = col_scale ? (const float*)dc.p : nullptr;
+    if (epi == Q3_EPI_GELU || want_yb) g.yb = (uint16_t*)dyb.p;
+    if (q3_launch_bgemm(g, nullptr)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm_voc: shape");
+    HK(hipDeviceSynchronize());
+    if (epi != Q3_EPI_GELU) {
+        HK(hipMemcpy(seg.data(), dy.p, seg.size() * 4, hipMemcpyDeviceToHost));
+        for (int sidx = 0; sidx < S; ++sidx) {
+            for (int t = 0; t < P - T; ++t)
+                for (int c = 0; c < N; ++c)
+                    if (seg[((size_t)sidx * P + t) * N + c] != -12345.5f) return q3_set_err(nullptr, Q3TTS_ERR_DEVICE, "bgemm_voc: a gap row was written");
+            for (int t = 0; t < T; ++t) memcpy(y + ((size_t)sidx * T + t) * N, &seg[((size_t)sidx * P + (P - T) + t) * N], (size_t)N * 4);
+        }
+    }
+    if (epi == Q3_EPI_GELU || want_yb) { std::vector<uint16_t> t(B16 * N); HK(hipMemcpy(t.data(), dyb.p, t.size() * 2, hipMemcpyDeviceToHost)); untile_host(t, B, N, yb); }
+    return Q3TTS_OK;
+}
+
 extern "C" int q3tts_k_project(int32_t device, const float* x, int32_t rows, int32_t n_in, const float* w, const float* bias, int32_t n_out, const float* nw,
                                float* y, uint16_t* xb, float* ssp) {
     if (!x || !w || !bias || !y || rows <= 0 || n_in % 64 || n_out % 16 || (nw && (!xb || !ssp))) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "project hook: n_in % 64 == 0, n_out % 16 == 0");

@@ -286,6 +286,24 @@ def k_bgemm(xb, wb, ssp, d_norm, eps, epi, nw_next=None, y0=None, device=0, iter
     return dict(y=y, yb=yb, ssp_out=sso, keys=keys, ms=ms.value)
 
 
+def k_bgemm_voc(xb, wb, epi, bias=None, col_scale=None, seg_rows=0, gap_rows=0, y0=None, want_yb=False, device=0):
+    """The decoder's GEMM with the vocoder's epilogue extras (q3tts_k_bgemm_voc): returns dict(y=[B][N] f32 or None, yb=[B][N] bf16 bits or None)."""
+    lib = _abi.load_library()
+    xb = np.ascontiguousarray(xb, dtype=np.uint16); wb = np.ascontiguousarray(wb, dtype=np.uint16)
+    B, K = xb.shape
+    N = wb.shape[0]
+    y = None if epi == 4 else (np.zeros((B, N), dtype=np.float32) if y0 is None else np.ascontiguousarray(y0, dtype=np.float32).copy())
+    yb = np.zeros((B, N), dtype=np.uint16) if (epi == 4 or want_yb) else None
+    b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+    cs = None if col_scale is None else np.ascontiguousarray(col_scale, dtype=np.float32)
+    rc = lib.q3tts_k_bgemm_voc(device, xb.ctypes.data, B, K, wb.ctypes.data, N, epi, None if b is None else b.ctypes.data, 0 if b is None else b.size,
+                               None if cs is None else cs.ctypes.data, seg_rows, gap_rows, None if y is None else y.ctypes.data,
+                               None if yb is None else yb.ctypes.data, 1 if want_yb else 0)
+    if rc != 0:
+        raise _abi.Q3Error(f"q3tts_k_bgemm_voc failed ({rc}): {lib.q3tts_last_error(None).decode()}")
+    return dict(y=y, yb=yb)
+
+
 def k_project(x, w, bias, nw=None, device=0):
     lib = _abi.load_library()
     x = np.ascontiguousarray(x, dtype=np.float32); w = np.ascontiguousarray(w, dtype=np.float32); b = np.ascontiguousarray(bias, dtype=np.float32)

@@ -658,6 +658,47 @@ def test_bgemm_many_rows_kernel_matches_oracle(oracle, native, B, K, N, epi):
         assert np.array_equal(got["yb"], ref["yb"])
 
 
+def _bf16_round_bits(a):
+    """RNE to bf16 of finite f32 values, as bits."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+@pytest.mark.parametrize("B,K,N,seg,gap", [(64, 1024, 2048, 0, 0), (48, 1024, 1024, 8, 6), (512, 1024, 4096, 16, 6), (40, 4096, 1024, 8, 3), (7, 256, 96, 0, 0)])
+def test_bgemm_vocoder_epilogue_extras(oracle, native, B, K, N, seg, gap):
+    """bias, LayerScale column scale, GELU, per-slot row segments and the bf16 copy of the residual result (what the vocoder's transformer and
+    up-sampling stages ask of k_bgemm): RAW comes from the oracle-checked store epilogue, the rest is element-wise f32 arithmetic restated
+    here in numpy (no fused multiply-add on either side: the library is built with -ffp-contract=off)."""
+    from scipy.special import erf
+    rng = np.random.default_rng(B + K + N)
+    xb, wb = _bf16_bits(_rand(rng, (B, K), 1.0)), _bf16_bits(_rand(rng, (N, K), 0.03))
+    raw = native.k_bgemm(xb, wb, None, K, 1e-6, 0)["y"]
+    ref = oracle.bgemm(xb, wb, None, K, 1e-6, 0, None, None)["y"]
+    assert np.array_equal(_bits(raw), _bits(ref))
+    bias_n = N // 2 if N % 2 == 0 and N >= 64 else N            # (the ConvTranspose bias repeats every d of its r * d outputs)
+    bias = _rand(rng, (bias_n,), 0.05)
+    cs = (0.01 + np.abs(_rand(rng, (N,), 0.01))).astype(np.float32)
+    y0 = _rand(rng, (B, N), 1.0)
+    bcol = bias[np.arange(N) % bias_n][None, :]
+    v = (raw + bcol).astype(np.float32)
+    # store + bias, into row segments with untouched gap rows in between
+    got = native.k_bgemm_voc(xb, wb, 0, bias=bias, seg_rows=seg, gap_rows=gap)
+    assert np.array_equal(_bits(got["y"]), _bits(v))
+    # residual with column scale + bias, and the bf16 copy the next stage's GEMM reads
+    got = native.k_bgemm_voc(xb, wb, 1, bias=bias, col_scale=cs, seg_rows=seg, gap_rows=gap, y0=y0, want_yb=True)
+    exp = (y0 + (cs[None, :] * v).astype(np.float32)).astype(np.float32)
+    assert np.array_equal(_bits(got["y"]), _bits(exp))
+    assert np.array_equal(got["yb"], _bf16_round_bits(exp))
+    # GELU -> bf16, the device's expression in f32: (0.5 x) * (1 + erff(x / sqrt 2)). erff and scipy's f32 erf may differ in the last
+    # place, which 1 + erf amplifies for negative x: absolute slack 2^-20 |x| on top of half a bf16 step
+    got = native.k_bgemm_voc(xb, wb, 4, bias=bias)
+    e32 = erf((v * np.float32(0.70710678118654752)).astype(np.float32)).astype(np.float32)
+    g32 = ((np.float32(0.5) * v).astype(np.float32) * (np.float32(1.0) + e32).astype(np.float32)).astype(np.float32)
+    dev = (got["yb"].astype(np.uint32) << 16).view(np.float32)
+    assert np.all(np.abs(dev.astype(np.float64) - g32.astype(np.float64)) <= np.abs(g32) * 2.0 ** -8 + np.abs(v) * 2.0 ** -20)
+    assert np.count_nonzero(got["yb"] != _bf16_round_bits(g32)) <= max(4, got["yb"].size // 200)
+
+
 @pytest.mark.parametrize("B,K,N", [(64, 1024, 2048), (2, 1024, 2048), (33, 512, 64), (64, 2048, 3072)])
 def test_bgemm_argmax_matches_oracle(oracle, native, B, K, N):
     ref, got, _, _ = _bgemm_case(oracle, native, B, K, N, 3, True, 7 + B + N)
