@@ -720,6 +720,23 @@ __global__ void k_voc_hist(VCall cl, E* work, size_t stride, E* hist, int H, int
     }
 }
 
+// All history loads of a call in ONE launch at its start (work[s][0:H] <- hist[slot]) and all saves in ONE at its end
+// (hist[slot] <- work[s][T : T+H]): 42 launches of ~5 us per batched call became 4. grid (chunks, ns, entries); blocks are dwords.
+struct VHistTab {
+    int n;
+    struct Ent { char* work; char* hist; unsigned long long stride_b, block_b, tail_b; } e[24];  // bytes: per-slot stride, H*C block, offset T*C
+};
+__global__ void k_voc_hist_all(VCall cl, VHistTab tab, int save) {
+    const VHistTab::Ent z = tab.e[blockIdx.z];
+    const int s = blockIdx.y, slot = cl.slot[s];
+    uint32_t* w = (uint32_t*)(z.work + (size_t)s * z.stride_b + (save ? z.tail_b : 0));
+    uint32_t* h = (uint32_t*)(z.hist + (size_t)slot * z.block_b);
+    const size_t n = z.block_b / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (save) h[i] = w[i]; else w[i] = h[i];
+    }
+}
+
 // out_bf16: 0 f32 rows, 1 bf16 rows, 2 bf16 in the decoder GEMM's A-tiled layout (q3_atile_off)
 __global__ __launch_bounds__(64) void k_voc_rmsnorm(const float* x, const float* w, float eps, int d, float* y, int out_bf16) {
     const int r = blockIdx.x, lane = threadIdx.x;
@@ -1213,17 +1230,33 @@ static void hist(hipStream_t s, const VCall& cl, VBuf& b, int T, int save) {
     if (b.bf16) hipLaunchKernelGGL((k_voc_hist<uint16_t>), grid, dim3(256), 0, s, cl, (uint16_t*)b.p, b.stride(), (uint16_t*)b.hist, b.H, b.C, T, save);
     else hipLaunchKernelGGL((k_voc_hist<float>), grid, dim3(256), 0, s, cl, b.p, b.stride(), b.hist, b.H, b.C, T, save);
 }
+// every history-bearing buffer with the rows it receives in a call of nf frames, in pipeline order; the ConvNeXt buffers (dw_in) are
+// loaded with the others but saved by their own launch (their rows are modified in place right after the depthwise convolution)
+static void hist_all(hipStream_t s, const VCall& cl, Q3Voc* v, int nf, int save) {
+    VHistTab tab; tab.n = 0;
+    auto add = [&](const VBuf& b, int T, bool with_save) {
+        if (b.H == 0 || (save && !with_save) || tab.n >= 24) return;
+        const size_t es = b.bf16 ? 2 : 4;
+        tab.e[tab.n++] = {(char*)b.p, (char*)b.hist, (unsigned long long)(b.stride() * es), (unsigned long long)((size_t)b.H * b.C * es), (unsigned long long)((size_t)T * b.C * es)};
+    };
+    int T = nf;
+    add(v->pre_in, T, true);
+    for (auto& p : v->U) { T *= p.r; add(p.dw_in, T, false); }
+    add(v->dec_in_in, T, true);
+    for (auto& k : v->Bk) { add(k.ct_in, T, true); T *= k.r; for (auto& r : k.res) add(r.c1_in, T, true); }
+    add(v->out_in, T, true);
+    if (tab.n) hipLaunchKernelGGL(k_voc_hist_all, dim3(16, cl.ns, tab.n), dim3(256), 0, s, cl, tab, save);
+}
 // one batched streaming call: ns slots x nf new frames each (uniform nf <= VOC_FCAP)
 static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
     Q3Voc* v = e->voc;
     const q3tts_vocoder_config& c = v->c;
     const int ns = cl.ns, nf = cl.nf, d = c.latent_dim, HH = c.n_head * c.head_dim, M = ns * nf;
+    hist_all(s, cl, v, nf, 0);
     // V1 + V2
-    hist(s, cl, v->pre_in, nf, 0);
     hipLaunchKernelGGL(k_voc_embed, dim3(nf, ns), dim3(128), 0, s, cl, e->codes, e->cfg.max_steps_cap, e->cfg.model.n_codebooks, v->cb_dev,
                        c.n_codebooks, c.codebook_size, c.codebook_dim, v->pre_in.p, v->pre_in.stride(), v->pre_in.H * v->pre_in.C);
     vgemm(s, v->pre, v->pre_in.p, v->pre_in.stride(), v->pre_in.H * v->pre_in.C, ns, nf, v->x, (size_t)nf * d, 0);
-    hist(s, cl, v->pre_in, nf, 1);
     // V3 transformer (rows m = s*nf + t)
     for (int l = 0; l < c.n_layer; ++l) {
         VLayer& L = v->L[l];
@@ -1261,7 +1294,6 @@ static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
         const uint16_t* a_in = (const uint16_t*)v->xnb;
         for (size_t ui = 0; ui < v->U.size(); ++ui) {
             VUp& p = v->U[ui];
-            hist(s, cl, p.dw_in, T * p.r, 0);
             Q3BGemm g{}; g.a = a_in; g.B = ns * T; g.w = p.ct_t; g.K = d; g.N = p.r * d; g.epi = Q3_EPI_STORE;  // [T][r*d] == [T*r][d]
             g.bias = p.ct.b; g.bias_n = p.ct.bias_n; g.y = p.dw_in.p + (size_t)p.dw_in.H * d; g.ldy = p.r * d; g.seg_rows = T; g.seg_stride = p.dw_in.stride();
             if (q3_launch_bgemm(g, s)) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder: upsample ConvTranspose GEMM shape");
@@ -1281,7 +1313,6 @@ static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
     } else {
         hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, v->final_norm, c.rms_eps, d, v->xn, 0);
         for (auto& p : v->U) {
-            hist(s, cl, p.dw_in, T * p.r, 0);
             vgemm(s, p.ct, cur, cur_stride, cur_off, ns, T, p.dw_in.p, p.dw_in.stride(), p.dw_in.H * d);  // [T][r*d] == [T*r][d]
             T *= p.r;
             hipLaunchKernelGGL(k_voc_dw_ln, dim3(T, ns), dim3(64), (size_t)d * 4, s, p.dw_in.p, p.dw_in.stride(), p.dw_in.H, T, d, p.dw_w, p.dw_b, p.ln_w, p.ln_b, v->t1, 0);
@@ -1292,56 +1323,49 @@ static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
         }
     }
     // V5b decoder
-    hist(s, cl, v->dec_in_in, T, 0);
     hipLaunchKernelGGL(k_voc_rows_bf16, dim3((unsigned)(((size_t)T * d / 4 + 255) / 256), ns), dim3(256), 0, s, cur + cur_off, cur_stride,
                        (uint16_t*)v->dec_in_in.p + (size_t)v->dec_in_in.H * d, v->dec_in_in.stride(), T * d);
     int ch = c.decoder_dim;
     // Every SnakeBeta runs in the epilogue of the convolution that produces its input and lands directly in the
     // work buffer of the convolution that consumes it: dec_in -> blk0.ct_in; ct -> res0.c1_in; c1 -> (snake2) -> c2's
     // input; c2 -> next unit's c1_in / next block's ct_in / the final conv's window.
-    hist(s, cl, v->Bk[0].ct_in, T, 0);
     {
         const VSnake sk = snake_into(v->Bk[0].ct_in, v->Bk[0].ea, v->Bk[0].ib, ch);
         vgemm(s, v->dec_in, v->dec_in_in.p, v->dec_in_in.stride(), v->dec_in_in.H * d, ns, T, v->t1, (size_t)T * ch, 0, 0, nullptr, 1, &sk, 0, 1);
     }
-    hist(s, cl, v->dec_in_in, T, 1);
     float* z = v->t1; float* o = v->t2;
     for (size_t bi = 0; bi < v->Bk.size(); ++bi) {
         VBlk& k = v->Bk[bi];
-        hist(s, cl, k.res[0].c1_in, T * k.r, 0);
         {
             const VSnake sk = snake_into(k.res[0].c1_in, k.res[0].ea, k.res[0].ib, k.cout);
             vgemm(s, k.ct, k.ct_in.p, k.ct_in.stride(), k.ct_in.H * k.cin, ns, T, o, (size_t)T * k.r * k.cout, 0, 0, nullptr, 1, &sk, 1, 1);
         }
-        hist(s, cl, k.ct_in, T, 1);
         T *= k.r; ch = k.cout;
         for (int u = 0; u < 3; ++u) {
             VRes& r = k.res[u];
             if (resunit_ok(ch)) {  // narrow blocks: the whole residual unit in one pass over HBM
                 VSnake sk;
-                if (u < 2) { hist(s, cl, k.res[u + 1].c1_in, T, 0); sk = snake_into(k.res[u + 1].c1_in, k.res[u + 1].ea, k.res[u + 1].ib, ch); }
-                else if (bi + 1 < v->Bk.size()) { VBlk& nx = v->Bk[bi + 1]; hist(s, cl, nx.ct_in, T, 0); sk = snake_into(nx.ct_in, nx.ea, nx.ib, ch); }
-                else { hist(s, cl, v->out_in, T, 0); sk = snake_into(v->out_in, v->oea, v->oib, ch); }
+                if (u < 2) { sk = snake_into(k.res[u + 1].c1_in, k.res[u + 1].ea, k.res[u + 1].ib, ch); }
+                else if (bi + 1 < v->Bk.size()) { VBlk& nx = v->Bk[bi + 1]; sk = snake_into(nx.ct_in, nx.ea, nx.ib, ch); }
+                else { sk = snake_into(v->out_in, v->oea, v->oib, ch); }
                 launch_resunit(s, r, ns, T, ch, o, u < 2 ? 1 : 0, sk);
-                hist(s, cl, r.c1_in, T, 1);
                 continue;
             }
             {
                 VSnake sk; sk.y2 = z; sk.stride = (size_t)T * ch; sk.off = 0; sk.ea = r.ea2; sk.ib = r.ib2; sk.n = ch; sk.bf16 = 1;  // snake2 -> z (bf16)
                 vgemm(s, r.c1, r.c1_in.p, r.c1_in.stride(), r.c1_in.H * ch, ns, T, z, (size_t)T * ch, 0, 0, nullptr, 1, &sk, 0, 1);
             }
-            hist(s, cl, r.c1_in, T, 1);
             VSnake sk;
-            if (u < 2) { hist(s, cl, k.res[u + 1].c1_in, T, 0); sk = snake_into(k.res[u + 1].c1_in, k.res[u + 1].ea, k.res[u + 1].ib, ch); }
-            else if (bi + 1 < v->Bk.size()) { VBlk& nx = v->Bk[bi + 1]; hist(s, cl, nx.ct_in, T, 0); sk = snake_into(nx.ct_in, nx.ea, nx.ib, ch); }
-            else { hist(s, cl, v->out_in, T, 0); sk = snake_into(v->out_in, v->oea, v->oib, ch); }
+            if (u < 2) { sk = snake_into(k.res[u + 1].c1_in, k.res[u + 1].ea, k.res[u + 1].ib, ch); }
+            else if (bi + 1 < v->Bk.size()) { VBlk& nx = v->Bk[bi + 1]; sk = snake_into(nx.ct_in, nx.ea, nx.ib, ch); }
+            else { sk = snake_into(v->out_in, v->oea, v->oib, ch); }
             vgemm(s, r.c2, z, (size_t)T * ch, 0, ns, T, o, (size_t)T * ch, 0, 2, nullptr, 1, &sk, u < 2 ? 1 : 0, 1);  // o += conv k1
         }
     }
     // V6
     hipLaunchKernelGGL(k_voc_out, dim3((T + 63) / 64, ns), dim3(256), (size_t)(70 * (ch + 1) + 7 * ch) * 4, s, cl, v->out_in.p, v->out_in.stride(), v->out_in.H, T, ch, v->out_w, v->out_b,
                        v->pcm, v->pcm_stride, v->spf);
-    hist(s, cl, v->out_in, T, 1);
+    hist_all(s, cl, v, nf, 1);
     Q3_HIP(e, hipGetLastError());
     return Q3TTS_OK;
 }
