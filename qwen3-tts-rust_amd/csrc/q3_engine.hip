@@ -260,10 +260,12 @@ static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, uint16_t* xb, float*
         qp.kc = t.kc + l * t.layer_stride; qp.vc = t.vc + l * t.layer_stride; qp.n_ctx = t.n_ctx; qp.row_pos = row_pos; qp.row_slot = row_slot;
         qp.slot_mod = slot_mod; qp.pos_const = pos_const;
         const bool fused = one_row_per_slot && t.Hq / t.Hkv >= 2;
-        if (!fused) q3_launch_qk_prep(qp, s);
+        // the Predictor's pass A: rows [0, B) at position 0 and [B, 2B) at position 1 of an empty per-frame cache: one fused launch
+        const bool pair = !one_row_per_slot && slot_mod > 0 && rows == 2 * slot_mod && pos_const == 0 && t.Hq / t.Hkv == 2 && t.hd == 128;
+        if (!fused && !pair) q3_launch_qk_prep(qp, s);
         Q3Attend at{}; at.qkv = sc.qkv; at.ld = t.nqkv; at.rows = rows; at.out = (float*)sc.att; at.ldo = t.nq; at.Hq = t.Hq; at.Hkv = t.Hkv; at.hd = t.hd;
         at.kc = qp.kc; at.vc = qp.vc; at.n_ctx = t.n_ctx; at.row_pos = row_pos; at.row_slot = row_slot;
-        at.fused = fused; at.prep = qp; at.out_bf16 = 1; at.slot_mod = slot_mod; at.pos_const = pos_const;
+        at.fused = pair ? 2 : (fused ? 1 : 0); at.prep = qp; at.out_bf16 = 1; at.slot_mod = slot_mod; at.pos_const = pos_const;
         q3_launch_attend(at, s);
         g = Q3BGemm{}; g.w_once = once; g.a = sc.att; g.B = rows; g.w = t.wo[l]; g.K = t.nq; g.N = t.d; g.epi = Q3_EPI_RESID; g.y = x; g.ldy = t.d;
         g.yb = xb; g.nw_next = t.ffn_norm[l]; g.ssp_out = ssp; g.ld_ssp_out = nt;

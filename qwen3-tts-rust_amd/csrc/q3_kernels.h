@@ -113,6 +113,7 @@ struct Q3Attend {
     const int* row_pos; const int* row_slot;
     int slot_mod, pos_const;  // as in Q3QkPrep
     int fused;        // 1: every slot has exactly one row in this launch -> q/k prep + KV append done in-kernel (R >= 2)
+                      // 2: rows b (position 0) and slot_mod + b (position 1) of every slot, nothing cached yet (R == 2, hd == 128): k_attend_pair
     Q3QkPrep prep;    // used when fused
 };
 void q3_launch_attend(const Q3Attend& a, hipStream_t s);

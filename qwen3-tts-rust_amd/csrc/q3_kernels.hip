@@ -408,6 +408,91 @@ __global__ __launch_bounds__(R * 64) void k_attend_small(Q3Attend a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Pass A of the Predictor: TWO rows per slot in one launch — row b at position 0 (the projected hidden row), row slot_mod + b at
+// position 1 (the first code row) — and nothing cached yet. One workgroup per (KV group, slot): its four waves are (row, query head);
+// k / v of both rows are prepared into LDS (and appended to the cache for the later passes), so no wave reads the cache and the
+// separate k_qk_prep launch is not needed. Scores, softmax and PV follow k_attend_small's expressions term by term with every key
+// served from LDS (the bf16-rounded values the cache holds): same chains, same order, same bits.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_attend_pair(Q3Attend a) {
+    __shared__ __attribute__((aligned(16))) float kh[2][128], vh[2][128], qh[2][2][128], ps[2][2][64];
+    const int g = blockIdx.x, b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rr = wave >> 1, hh = wave & 1, R = 2, hd = 128;
+    const int row = rr * a.slot_mod + b, slot = b, pos = rr;
+    const Q3QkPrep& pr = a.prep;
+    const size_t hb = ((size_t)slot * a.Hkv + g) * a.n_ctx;
+    const float* rowp = a.qkv + (size_t)row * a.ld;
+    const int half = hd >> 1, nl = hd >> 2;
+    float qo[4], o4[4];
+    prep_head(rowp + (size_t)(g * R + hh) * hd, pr.qnw, pr.eps, pr.cs + (size_t)pos * half, pr.sn + (size_t)pos * half, hd, lane, qo);
+    if (lane < nl) *(float4*)(qh[rr][hh] + 4 * lane) = (float4){qo[0], qo[1], qo[2], qo[3]};
+    if (hh == 0) {  // k of this row: norm + RoPE + append
+        prep_head(rowp + (size_t)(a.Hq + g) * hd, pr.knw, pr.eps, pr.cs + (size_t)pos * half, pr.sn + (size_t)pos * half, hd, lane, o4);
+        if (lane < nl) {
+            const int blk = pos >> 6, kl = pos & 63, c = lane >> 1, e0 = 4 * (lane & 1);
+            uint2 kk;
+            kk.x = (uint32_t)q3_bf16(o4[0]) | ((uint32_t)q3_bf16(o4[1]) << 16); kk.y = (uint32_t)q3_bf16(o4[2]) | ((uint32_t)q3_bf16(o4[3]) << 16);
+            *(uint2*)(pr.kc + hb * hd + ((size_t)(blk * (hd >> 3) + c) * 64 + kl) * 8 + e0) = kk;
+            *(float4*)(kh[rr] + 4 * lane) = (float4){q3_round_bf16(o4[0]), q3_round_bf16(o4[1]), q3_round_bf16(o4[2]), q3_round_bf16(o4[3])};
+        }
+    } else if (lane < nl) {  // v of this row: append
+        const float4 v4 = ((const float4*)(rowp + (size_t)(a.Hq + a.Hkv + g) * hd))[lane];
+        *(float4*)(vh[rr] + 4 * lane) = (float4){q3_round_bf16(v4.x), q3_round_bf16(v4.y), q3_round_bf16(v4.z), q3_round_bf16(v4.w)};
+        uint2 vk;
+        vk.x = (uint32_t)q3_bf16(v4.x) | ((uint32_t)q3_bf16(v4.y) << 16); vk.y = (uint32_t)q3_bf16(v4.z) | ((uint32_t)q3_bf16(v4.w) << 16);
+        *(uint2*)(pr.vc + (hb + pos) * hd + 4 * lane) = vk;
+    }
+    __syncthreads();
+    const int T = pos + 1;
+    const float* q = qh[rr][hh];
+    const float scale = 1.0f / sqrtf((float)hd);
+    float sc = 0.0f;
+    if (lane < T) {  // key `lane`: the d-ascending chain
+        const float* kk = kh[lane];
+        for (int d = 0; d < hd; d += 4) {
+            const float4 qa = *(const float4*)(q + d), ka = *(const float4*)(kk + d);
+            sc = fmaf(qa.x, ka.x, sc); sc = fmaf(qa.y, ka.y, sc); sc = fmaf(qa.z, ka.z, sc); sc = fmaf(qa.w, ka.w, sc);
+        }
+    }
+    sc = sc * scale;
+    const float m = wave_max(lane < T ? sc : -INFINITY);
+    const float e = lane < T ? q3_expf(sc - m) : 0.0f;
+    ps[rr][hh][lane] = e;
+    float l = wave_sum(e);
+    l = ((l + 0.0f) + 0.0f) + 0.0f;
+    const int kg = lane >> 4, dl = lane & 15;
+    float out8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out8[i] = 0.0f;
+#pragma unroll
+    for (int uu = 0; uu < 4; ++uu) {
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = 0.0f;
+        for (int t = 4 * uu + kg; t < T; t += 16) {
+            const float pt = ps[rr][hh][t];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = fmaf(pt, vh[t][dl * 8 + i], o[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float r = o[i] + __shfl_xor(o[i], 16);
+            r = r + __shfl_xor(r, 32);
+            out8[i] = uu == 0 ? r : out8[i] + r;
+        }
+    }
+    if (kg == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int d = dl * 8 + i;
+            const float ov = out8[i] / l;
+            if (a.out_bf16) ((uint16_t*)a.out)[q3_atile_off(row, (g * R + hh) * hd + d, (a.Hq * hd) >> 5)] = q3_bf16(ov);
+            else a.out[(size_t)row * a.ldo + (size_t)(g * R + hh) * hd + d] = ov;
+        }
+    }
+}
+
 void q3_launch_attend(const Q3Attend& a, hipStream_t s) {
     const int R = a.Hq / a.Hkv;
     const size_t lds = ((size_t)R * a.n_ctx + R * a.hd + R * 4 * a.hd + R * 8 + 2 * a.hd) * sizeof(float);
@@ -420,6 +505,10 @@ void q3_launch_attend(const Q3Attend& a, hipStream_t s) {
         hipFuncSetAttribute((const void*)k_attend<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute((const void*)k_attend<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = lds;
+    }
+    if (a.fused == 2) {  // two rows per slot, empty cache (the Predictor's pass A): see k_attend_pair
+        hipLaunchKernelGGL(k_attend_pair, dim3(a.Hkv, a.slot_mod), dim3(256), 0, s, a);
+        return;
     }
     if (a.fused && a.n_ctx <= 64 && a.hd == 128 && (R == 1 || R == 2)) {  // short caches (the Predictor): one wave per query head
         if (R == 2) hipLaunchKernelGGL((k_attend_small<2>), grid, dim3(128), 0, s, a);
