@@ -317,7 +317,7 @@ __global__ __launch_bounds__(R * 64) void k_attend_small(Q3Attend a) {
     // cache operands first: independent of this row's projections (lanes beyond the cached keys read inside the slot's own block)
     uint4 kv[16], vv0[4];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) kv[c] = ((const uint4*)kb)[c * 64 + lane];
+    for (int c = 0; c < 16; ++c) kv[c] = lane < pos ? ((const uint4*)kb)[c * 64 + lane] : make_uint4(0, 0, 0, 0);  // (only cached keys: <= 16 of the block's 64 lanes)
 #pragma unroll
     for (int uu = 0; uu < 4; ++uu) vv0[uu] = *(const uint4*)(vb + (size_t)min(4 * uu + kg, T - 1) * hd + dl * 8);
     const float* rowp = a.qkv + (size_t)row * a.ld;
