@@ -9,6 +9,14 @@
 #include "q3_kernels.h"
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
+// touches a weight matrix once (16 bytes per lane, results folded into a value that is never stored): after it the matrix sits in
+// the memory-side Infinity Cache (and partly in the L2s) — the experiment at the end asks what a GEMM gains from that
+__global__ __launch_bounds__(256) void k_touch(const uint4* w, size_t n16, unsigned* sink) {
+    unsigned acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) { const uint4 v = w[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x9e3779b9u) sink[0] = acc;
+}
+
 struct Shape { const char* name; int M, K, N, epi, scaled, cold; };
 
 int main(int argc, char** argv) {
@@ -70,6 +78,40 @@ int main(int argc, char** argv) {
                     hipGraphExecDestroy(ge); hipGraphDestroy(g);
                 }
         printf("  -> best (%d,%d) %.2f us (launcher %+.0f%%)\n", brt, bnt, best, 100.0f * (chosen - best) / best);
+    }
+    // Does a GEMM run faster when its (otherwise cold) weights were read once just before — i.e. are in the Infinity Cache?
+    {
+        q3_bgemm_force(0, 0);
+        unsigned* sink; CK(hipMalloc(&sink, 64));
+        const Shape tsh[2] = {{"T gate/up", 64, 2048, 12288, Q3_EPI_SWIGLU, 1, 1}, {"T down", 64, 6144, 2048, Q3_EPI_RESID, 0, 1}};
+        for (const Shape& sh : tsh) {
+            const size_t wb = (size_t)sh.N * sh.K * 2;
+            const int copies = (int)(WBYTES / wb);
+            for (int pre = 0; pre < 2; ++pre) {
+                hipGraph_t g; hipGraphExec_t ge;
+                CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                const int iters = 30;
+                for (int i = 0; i < iters; ++i) {
+                    const uint4* wi = (const uint4*)((const char*)w + (size_t)(i % copies) * wb);
+                    if (pre) hipLaunchKernelGGL(k_touch, dim3(1024), dim3(256), 0, s, wi, wb / 16, sink);
+                    Q3BGemm q{}; q.a = a; q.B = sh.M; q.w = wi; q.K = sh.K; q.N = sh.N; q.w_once = 1;
+                    if (sh.scaled) { q.ssp = ssp; q.ld_ssp = sh.K / 16; q.ntiles = sh.K / 16; q.d_norm = sh.K; q.eps = 1e-6f; }
+                    q.epi = sh.epi; q.y = y; q.ldy = sh.N; q.yb = yb;
+                    if (sh.epi == Q3_EPI_RESID) { q.nw_next = nw; q.ssp_out = sso; q.ld_ssp_out = sh.N / 16; }
+                    if (q3_launch_bgemm(q, s)) return 1;
+                }
+                CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+                CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
+                float tot = 0;
+                for (int rep = 0; rep < 3; ++rep) {
+                    CK(hipEventRecord(e0, s)); CK(hipGraphLaunch(ge, s)); CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+                    float ms = 0; hipEventElapsedTime(&ms, e0, e1); tot += ms;
+                }
+                printf("%-10s M=64, cold weights%s: %.2f us per %s\n", sh.name, pre ? ", each touched by a streaming kernel right before" : "",
+                       tot * 1e3f / (3 * iters), pre ? "(touch + GEMM) pair" : "GEMM");
+                hipGraphExecDestroy(ge); hipGraphDestroy(g);
+            }
+        }
     }
     // Two half-batches side by side: does a chain of Predictor-layer GEMMs at 32 rows, run twice on two streams at once, finish sooner
     // than one chain at 64 rows? (The chains are latency-bound; the question is whether two can share the CUs without slowing down.)
