@@ -42,6 +42,7 @@ def make_workload(n_per_gpu, rank, world, spk, keepalive, want_pcm):
     from q3tts import dist as qd
     from q3tts.native import make_prompt_desc
     reqs, frames = [], []
+    meta = []  # (global index, prompt ids, target frames, sampler seed): what the oracle needs to replay an utterance
     for gi in qd.shard_indices(n_per_gpu * world, rank, world):
         r = np.random.default_rng(977 * gi + 1)
         n_text = int(r.integers(8, 65))
@@ -52,6 +53,8 @@ def make_workload(n_per_gpu, rank, world, spk, keepalive, want_pcm):
         reqs.append(dict(desc=desc, temperature=0.7, top_k=40, top_p=0.9, seed=qd.global_seed(1000, gi), max_steps=256,
                          min_frames=target, force_eos_at=target, want_pcm=want_pcm))
         frames.append(target)
+        meta.append((gi, ids, target, qd.global_seed(1000, gi)))
+    make_workload.meta = meta
     return reqs, frames
 
 
@@ -134,22 +137,90 @@ def cpu_baseline(cfg, spk, with_voc, gpu_codes, gpu_pcm):
     return main_leg, parity
 
 
+def batch_parity(cfg, spk, meta, outs, picks, n_frames=8):
+    """Value check of the TIMED batch leg (BASELINE configs[2], sampled, 64 slots, row buckets, batched vocoder): the first `n_frames`
+    frames of a few of its utterances against the oracle replaying the same prompt ids, sampler seed and controls. ids must be equal;
+    the PCM of those frames (the vocoder is causal) within the full-shape tolerance. /root/reference/src/tts/engine.rs:545-642."""
+    import ctypes as C
+    import _oracle as O
+    L = O.lib()
+    thr = min(os.cpu_count() or 1, 64)
+    om = O.OracleModel(cfg.model, seed=cfg.synth_seed, n_ctx=512, n_threads=thr)
+    v = L.q3o_vocoder_create(C.byref(cfg.vocoder), cfg.synth_seed, thr) if cfg.with_vocoder else None
+    rep = {"what": f"timed batch leg vs the oracle: first {n_frames} sampled frames of utterances {picks} (prompt ids, seed 1000 + index, temperature 0.7 / top-k 40 / top-p 0.9)",
+           "ids_equal": True, "utterances": []}
+    t0 = time.time()
+    try:
+        for i in picks:
+            gi, ids, target, seed = meta[i]
+            nf = min(n_frames, target)
+            desc, keep = O.make_prompt_desc(ids, spk_emb=spk)
+            pe = om.build_prompt(desc)
+            ref, _ = om.generate(pe, temperature=0.7, top_k=40, top_p=0.9, seed=seed, max_steps=nf, min_frames=target, force_eos_at=target)
+            got = outs[i].codes[:nf]
+            eq = bool(ref.shape == got.shape and np.array_equal(ref, got))
+            ent = {"index": int(gi), "prompt_rows": int(pe.shape[0]), "frames": int(nf), "ids_equal": eq}
+            if v is not None and outs[i].pcm is not None and eq:
+                cc = np.clip(ref, 0, cfg.vocoder.codebook_size - 1).astype(np.int32)
+                pcm = np.zeros(cc.shape[0] * 1920 + 64, dtype=np.float32)
+                L.q3o_vocoder_reset(v)
+                n = L.q3o_vocoder_decode(v, O.ptr(cc, O.i32p), cc.shape[0], 1, O.ptr(pcm, O.f32p), pcm.size)
+                ent["pcm_rms_error"] = float(np.sqrt(np.mean((outs[i].pcm[:n] - pcm[:n]) ** 2)))
+                ent["pcm_signal_rms"] = float(np.sqrt(np.mean(pcm[:n] ** 2)))
+            rep["utterances"].append(ent)
+            rep["ids_equal"] = rep["ids_equal"] and eq
+    finally:
+        if v is not None:
+            L.q3o_vocoder_destroy(v)
+        om.close()
+    rep["oracle_seconds"] = round(time.time() - t0, 1)
+    assert rep["ids_equal"], f"codec ids of the timed batch leg differ from the CPU oracle: {rep['utterances']}"
+    worst = max([u.get("pcm_rms_error", 0.0) for u in rep["utterances"]] or [0.0])
+    assert worst <= 5e-3, f"PCM of the timed batch leg is off the CPU oracle: RMS error {worst}"
+    return rep
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (this parent never initialises a GPU) and
-    relay rank 0's JSON line."""
+    relay rank 0's JSON line. Every child is polled: if one exits non-zero (bad device, out of memory) the others — which would sit in
+    the RCCL rendezvous until its timeout — are terminated and the bench fails at once. Children are always fresh processes."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = []
+    out_path = os.path.join(REPO, "gpurun_out", f"bench_rank0_{os.getpid()}.out") if os.path.isdir(os.path.join(REPO, "gpurun_out")) else f"/tmp/bench_rank0_{os.getpid()}.out"
+    out_f = open(out_path, "w+")
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = max(rc, p.wait())
-    sys.stdout.write(out)
+                                      stdout=out_f if r == 0 else subprocess.DEVNULL, text=True))
+    rc = 0
+    live = list(range(n))
+    while live:
+        time.sleep(0.2)
+        for r in list(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.remove(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write(f"bench.py: rank {r} exited with {code}; stopping the other ranks\n")
+                for o in live:
+                    procs[o].terminate()
+    if rc != 0:
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    out_f.seek(0)
+    sys.stdout.write(out_f.read())
     sys.stdout.flush()
+    out_f.close()
+    try:
+        os.remove(out_path)
+    except OSError:
+        pass
     return rc
 
 
@@ -166,12 +237,15 @@ def main():
     ap.add_argument("--no-probe", action="store_true", help="skip the in-situ dominant-kernel measurement (roofline.achieved falls back to the whole frame step)")
     ap.add_argument("--probe-only", nargs="?", const="talker", default=None, choices=["talker", "predictor", "vocoder"],
                     help=f"run only one probe leg (the commands profiled for profiles/{ROUND}/*): the Talker's gate/up (default), the Predictor's, or the vocoder alone")
+    ap.add_argument("--tiny", action="store_true", help="tests only: the small shape of the parity tests instead of the 1.7B shape (the JSON line is marked invalid)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("Q3TTS_BENCH_FAIL_RANK", "") == str(rank):  # tests/test_host_cpu.py: a rank that dies at start-up
+        sys.exit(3)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
@@ -180,7 +254,13 @@ def main():
     backend = os.environ.get("Q3TTS_DIST_BACKEND", "nccl")
     if os.environ.get("Q3TTS_ONE_GPU", "0") not in ("", "0"):
         local_rank = 0
-    if world > 1:
+    # tests/test_dist_gpu.py: Q3TTS_FORCE_DIST=1 runs the N > 1 code (process group, device-side i16 gather) at WORLD_SIZE = 1 — RCCL
+    # accepts a single rank, so a 1-GPU box executes every line of the collective path; Q3TTS_BENCH_CHECK_GATHER=1 keeps the host PCM
+    # as well and compares what the gather delivered with it; Q3TTS_BENCH_DUMP=<prefix> writes every rank's codec ids by global index
+    use_dist = world > 1 or os.environ.get("Q3TTS_FORCE_DIST", "0") not in ("", "0")
+    check_gather = os.environ.get("Q3TTS_BENCH_CHECK_GATHER", "0") not in ("", "0")
+    dump_prefix = os.environ.get("Q3TTS_BENCH_DUMP", "")
+    if use_dist:
         import torch
         import torch.distributed as dist
         if backend == "nccl":
@@ -191,16 +271,16 @@ def main():
 
     from q3tts import _abi, native
     from q3tts import dist as qd
-    cfg = _abi.full_config_py()
-    cfg.device, cfg.max_batch, cfg.n_ctx, cfg.max_steps_cap = local_rank, min(64, args.batch), args.n_ctx, 512
+    cfg = _abi.tiny_config(max_batch=min(64, args.batch), n_ctx=512) if args.tiny else _abi.full_config_py()
+    cfg.device, cfg.max_batch, cfg.n_ctx, cfg.max_steps_cap = local_rank, min(64, args.batch), (512 if args.tiny else args.n_ctx), 512
     cfg.with_vocoder = 0 if args.no_vocoder else 1
     eng = native.NativeEngine(cfg)
-    spk = vivian()
+    spk = vivian()[:cfg.model.d_embed]
     keepalive = []
-    dev_gather = world > 1 and cfg.with_vocoder
+    dev_gather = bool(use_dist and cfg.with_vocoder)
     if dev_gather:
         eng.set_device_pcm(True)   # the gather reads the PCM where the vocoder wrote it; no per-rank host copy
-    reqs, frames = make_workload(args.batch, rank, world, spk, keepalive, 0 if args.no_vocoder else (2 if dev_gather else 1))
+    reqs, frames = make_workload(args.batch, rank, world, spk, keepalive, 0 if args.no_vocoder else (2 if dev_gather and not check_gather else 1))
 
     def sync_all():
         if dist is not None:
@@ -221,7 +301,8 @@ def main():
             rows = rows.cpu()
         g = qd.gather_pcm_device(dist, rows, [o.n_samples for o in outs], rank, world, as_i16=True)
         if rank == 0:
-            host = [t.cpu() for t in g[0]]  # noqa: F841  (rank 0 ends with every utterance's PCM in host memory)
+            host = [t.cpu() for t in g[0]]  # (rank 0 ends with every utterance's PCM in host memory)
+            gather_pcm.last = (host, g[1].cpu())
         elif backend == "nccl":
             torch.cuda.synchronize()
         return time.perf_counter() - t0
@@ -284,6 +365,23 @@ def main():
     elapsed = time.perf_counter() - t0
     assert all(o.status == 0 for o in outs)
     assert [o.n_frames for o in outs] == frames, "forced lengths not honoured"
+    timed_outs = outs  # the last timed step's results: value-checked against the oracle below (batch_parity)
+    gather_check = None
+    if check_gather and dev_gather and rank == 0:
+        # what the collective delivered for rank 0's own utterances == the reference's i16 conversion (src/utils/audio.rs:35-37) of the
+        # host PCM of the same run
+        host, lens = gather_pcm.last
+        assert int(lens[0, 0]) == len(outs)
+        bad = 0
+        for j, o in enumerate(outs):
+            want = np.trunc(np.clip(o.pcm.astype(np.float32) * np.float32(32767.0), -32768.0, 32767.0)).astype(np.int16)
+            got = host[0][j, :int(lens[0, 1 + j])].numpy()
+            assert int(lens[0, 1 + j]) == want.size == o.n_samples, (j, int(lens[0, 1 + j]), want.size)
+            bad += int(np.count_nonzero(got != want))
+        gather_check = {"backend": backend, "world": world, "utterances": len(outs), "samples": int(sum(o.n_samples for o in outs)), "mismatching_samples": bad}
+        assert bad == 0, gather_check
+    if dump_prefix:
+        np.savez(f"{dump_prefix}.rank{rank}.npz", **{f"g{make_workload.meta[j][0]}": o.codes for j, o in enumerate(outs)})
     if dist is not None:
         import torch
         tdev = "cuda" if backend == "nccl" else "cpu"
@@ -310,7 +408,8 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]: batch=%d mixed-length prompts per GPU (n_text~U{8..64}, n_frames~U{25..250} "
                                    "EOS-forced), temperature=0.7 top-k=40 top-p=0.9, prompt ids -> codec ids -> 24 kHz PCM%s" %
-                                   (3 if world > 1 else 2, args.batch, " on %d GPUs, utterances sharded by global index, one RCCL gather of the i16 PCM to rank 0" % world if world > 1 else ""),
+                                   (3 if world > 1 else 2, args.batch, " on %d GPUs, utterances sharded by global index, one %s gather of the i16 PCM to rank 0" %
+                                   (world, "RCCL" if backend == "nccl" else backend + " (host rehearsal, NOT RCCL)") if world > 1 else ""),
                        "shape": "Qwen3-TTS-12Hz-1.7B (28x2048 Talker, 5x1024 Predictor, 8-layer codec vocoder), seeded synthetic bf16 weights",
                        "utterances_per_gpu": args.batch, "n_ctx": args.n_ctx, "with_vocoder": not args.no_vocoder},
             "rtf_per_utterance": round(frame_step_ms / 80.0, 5),
@@ -325,9 +424,13 @@ def main():
                 "algorithmic_flops": int(flops_step), "algorithmic_bytes": int(bytes_step),
                 "tflops": round(mfma_tf, 2), "hbm_GBs": round(hbm_gbs, 1), "frac_of_8TBs": round(hbm_gbs / HBM_PEAK_GBS, 4)},
         }
-        if world > 1:
+        if use_dist:
             line["value_without_gather"] = round(audio_sec / elapsed_nog, 2)
             line["gather_ms_per_step"] = round(t_gather / args.steps * 1e3, 3)
+        if gather_check:
+            line["gather_check"] = gather_check
+        if args.tiny:
+            line["invalid"] = "test run on the tiny shape"
         if not args.no_probe:
             pr = probe_leg(2)
             # The bracket also times the closing event packet. An EMPTY bracket on the same stream (empty_ms) bounds that
@@ -431,10 +534,13 @@ def main():
             "front_end_ms_p50": round(float(np.median(fe)), 2), "first_chunk_ms_p50": round(float(np.median(cf)), 2),
             "first_chunk_incl_front_end_ms_p50": round(float(np.median(np.asarray(fe) + np.asarray(cf))), 2)}
         e1.close()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:  # (rank 0 only, after the timed region and its barrier; the other ranks wait at the last barrier)
         line["cpu_baseline"], parity = cpu_baseline(cfg, spk, cfg.with_vocoder, gpu_codes, gpu_pcm)
         if parity:
             line["parity_in_this_run"] = parity
+        # (N > 1: the PCM stays on the device for the gather, so the batch leg is checked on ids only there)
+        picks = sorted({0, len(timed_outs) // 2, len(timed_outs) - 1})
+        line["parity_batch_leg"] = batch_parity(cfg, spk, make_workload.meta, timed_outs, picks)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

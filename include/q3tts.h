@@ -95,7 +95,8 @@ typedef struct q3tts_engine_config {
     uint64_t synth_seed;   /* seeded synthetic weights when weights_path == NULL */
     const char* weights_path; /* NULL -> synthetic. Else the reference's quant directory (src/tts/engine.rs:91-131):
                                * qwen3_tts_talker.gguf + qwen3_tts_predictor.gguf (llama.cpp qwen3 tensor names; F32, F16,
-                               * BF16 or Q8_0, converted to bf16 at load) and qwen3_assets.gguf or its NPY fallback
+                               * BF16, Q8_0 or the K-quants Q4_K / Q5_K / Q6_K of the gguf_q5_k_m directory, converted to
+                               * bf16 at load) and qwen3_assets.gguf or its NPY fallback
                                * (src/assets_manager.rs:14-26). Shapes must match `model`; the table row counts
                                * (text_vocab, codec0_rows, codecq_rows) are taken from the files. The vocoder stays
                                * synthetic: the reference ships it as ONNX only. */
@@ -183,7 +184,7 @@ int q3tts_stream_end(q3tts_stream* s, q3tts_result* out_codes_optional);
 typedef struct q3tts_timings {
     float prefill_ms, decode_ms, vocoder_ms, total_ms;
     float frame_step_ms;      /* mean device time of one frame-step graph replay */
-    float probe_kernel_ms;    /* q3tts_k_probe: mean in-situ device time of the probed kernel (Predictor gate/up GEMM, full batch) */
+    float probe_kernel_ms;    /* q3tts_k_probe: mean in-situ device time of the probed kernel (mode 2: the Talker's layer-0 gate/up GEMM; mode 1: the Predictor's), full batch */
     int64_t frame_steps;      /* graph replays timed */
     int64_t algo_bytes_per_step; /* SURVEY.md §8(d) algorithmic bytes of one frame step at the batch run */
     int64_t algo_flops_per_step; /* 2 * (W_T + 15 W_P + 15 h + pj) * mean live utterances per step (decoder GEMMs) */
@@ -301,6 +302,9 @@ int q3tts_k_mfma_bf16(int32_t device, const uint16_t* a, const uint16_t* b, cons
 int q3tts_k_bgemm(int32_t device, const uint16_t* xb, int32_t B, int32_t K, const uint16_t* w_bf16, int32_t N, const float* ssp, int32_t ntiles,
                   int32_t d_norm, float eps, int32_t epilogue, const float* nw_next, float* y, uint16_t* yb, float* ssp_out, uint64_t* keys,
                   int32_t iters, float* mean_kernel_ms);
+/* Which kernel serves launches of >= 256 rows: 1 = the many-row kernel (k_bgemm_big) whenever eligible, -1 = never, 0 = when it fills the
+ * chip (default; the environment variable Q3TTS_BG_BIG sets the initial value once per process). The results are the same bits. */
+int q3tts_k_bgemm_policy(int32_t big);
 /* The same GEMM with the epilogue extras only the vocoder uses (nothing in the reference: its vocoder is an ONNX graph, src/models/onnx.rs:342-459):
  * bias[col % bias_n] added to RAW first; epilogue 0: y = RAW + bias; 1: y += col_scale[col] * (RAW + bias), optionally yb = bf16(y);
  * 4: yb = bf16(gelu_erf(RAW + bias)). seg_rows > 0: the f32 rows live in B / seg_rows segments separated by gap_rows rows the kernel
@@ -313,6 +317,9 @@ int q3tts_k_project(int32_t device, const float* x, int32_t rows, int32_t n_in, 
                     float* y, uint16_t* xb, float* ssp);
 /* producer side of the split RMSNorm for plain f32 rows: xb = bf16(x * nw), ssp[r][t] = sum of squares of tile t */
 int q3tts_k_norm_inputs(int32_t device, const float* x, int32_t rows, int32_t d, const float* nw, uint16_t* xb, float* ssp);
+/* Allocator contract: device memory is handed out with its zero fill COMPLETED. Allocates `bytes` through the engine's allocator,
+ * uploads a pattern into the first and last 4 KiB on the null stream at once, and reports the bytes that read back wrong (0 expected). */
+int q3tts_k_alloc_upload(q3tts_engine* e, int64_t bytes, int64_t* mismatches);
 /* rand 0.8 StdRng (ChaCha12) stream: seed_from_u64(seed) then n x gen::<f32>() */
 int q3tts_k_rng_f32(uint64_t seed, int32_t n, float* out);
 

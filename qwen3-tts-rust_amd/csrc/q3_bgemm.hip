@@ -388,9 +388,11 @@ struct BgInst {
     }
 };
 // once per process, outside any stream capture (the engine calls it before it records its graphs)
+static int g_big_policy = 0;  // Q3TTS_BG_BIG, read once: 1 = the many-row kernel whenever it is eligible, -1 = never, 0 = when it fills the chip
 void q3_bgemm_prepare() {
     static bool done = false;
     if (done) return;
+    { const char* ev = getenv("Q3TTS_BG_BIG"); g_big_policy = ev ? atoi(ev) : 0; }
     hipFuncSetAttribute((const void*)k_bgemm_big, hipFuncAttributeMaxDynamicSharedMemorySize, BB_NS * 16384);
 #define P(RT_, NT_) BgInst<RT_, NT_>::prepare();
     P(1, 1) P(1, 2) P(1, 3) P(2, 1) P(2, 2) P(2, 3) P(3, 1) P(3, 2) P(3, 3) P(4, 1) P(4, 2) P(4, 3)
@@ -404,6 +406,8 @@ void q3_bgemm_prepare() {
 // tuning hook (tools/bgemm_tune.hip): force one tile instance for every following launch; (0, 0) restores the cost model
 static int g_force_rt = 0, g_force_nt = 0;
 void q3_bgemm_force(int rt, int nt) { g_force_rt = rt; g_force_nt = nt; }
+// test hook (q3tts_k_bgemm_policy): the many-row kernel always (1) / never (-1) / by the fill rule (0), overriding Q3TTS_BG_BIG
+void q3_bgemm_big_policy(int policy) { q3_bgemm_prepare(); g_big_policy = policy; }
 
 int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s) {
     if (g.B < 1 || g.N % 16 || g.K % 256 || g.K < 256 || !g.a || !g.w || g.a_row0 < 0) return -1;
@@ -415,8 +419,7 @@ int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s) {
     if (g.B >= 256 && g_force_rt == 0 && bg_big_ok(g)) {
         // Q3TTS_BG_BIG: 1 = the many-row kernel whenever it is eligible, -1 = never (A/B runs and the tests: the results are the same bits);
         // default: when it fills the chip — at least one 128 x 128 tile per CU (prefill; the vocoder's 256-row GEMMs stay on k_bgemm)
-        const char* ev = getenv("Q3TTS_BG_BIG");
-        const int policy = ev ? atoi(ev) : 0;
+        const int policy = g_big_policy;
         const long wgs = (long)(g.N / 128) * ((g.B + 127) / 128);
         if (policy > 0 || (policy == 0 && wgs >= 256)) { bg_launch_big(g, s); return 0; }
     }

@@ -108,6 +108,9 @@ int q3_set_err(q3tts_engine* e, int code, const std::string& msg);
             return q3_set_err((e), Q3TTS_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(err__));     \
     } while (0)
 
+// zero-filled device memory whose fill has completed on return (the one allocator of engine, vocoder, mel and clone state)
+int q3_dev_alloc_zeroed(q3tts_engine* e, void** p, size_t bytes);
+
 // host ChaCha12 StdRng (q3_rng.cpp)
 void q3_stdrng_f32(uint64_t seed, int n, float* out);
 

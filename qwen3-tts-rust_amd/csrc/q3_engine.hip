@@ -72,13 +72,24 @@ static int validate(const q3tts_engine_config& c, std::string& why) {
     return Q3TTS_OK;
 }
 
+// Zero-filled device memory. The fill has COMPLETED when the pointer is handed out: an upload on any stream (the null stream, the
+// vocoder stream, a caller's) can never be overtaken by it. (Rounds 1 and 2 filled asynchronously on e->stream, a non-blocking stream,
+// and patched three call sites whose uploads were zeroed again; the allocator is the one place to close that race.)
+int q3_dev_alloc_zeroed(q3tts_engine* e, void** p, size_t bytes) {
+    void* q = nullptr;
+    hipError_t err = hipMalloc(&q, bytes);
+    if (err != hipSuccess) return q3_set_err(e, Q3TTS_ERR_OOM, std::string("hipMalloc: ") + hipGetErrorString(err));
+    err = hipMemsetAsync(q, 0, bytes, e->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    if (err != hipSuccess) { hipFree(q); return q3_set_err(e, Q3TTS_ERR_DEVICE, std::string("hipMemset: ") + hipGetErrorString(err)); }
+    *p = q;
+    return Q3TTS_OK;
+}
 template <class T>
 static int dalloc(q3tts_engine* e, T** p, size_t n) {
     void* q = nullptr;
-    hipError_t err = hipMalloc(&q, n * sizeof(T) + 64);
-    if (err != hipSuccess) return q3_set_err(e, Q3TTS_ERR_OOM, std::string("hipMalloc: ") + hipGetErrorString(err));
-    err = hipMemsetAsync(q, 0, n * sizeof(T) + 64, e->stream);
-    if (err != hipSuccess) return q3_set_err(e, Q3TTS_ERR_DEVICE, std::string("hipMemset: ") + hipGetErrorString(err));
+    const int rc = q3_dev_alloc_zeroed(e, &q, n * sizeof(T) + 64);
+    if (rc != Q3TTS_OK) return rc;
     *p = (T*)q;
     return Q3TTS_OK;
 }
@@ -123,8 +134,7 @@ struct GgSrc {
         if (!t) return rc;
         std::vector<float> h(n); std::string err;
         if (q3_gguf_to_f32(*t, h.data(), err)) return fail(err);
-        Q3_HIP(e, hipMemcpyAsync(dst, h.data(), n * 4, hipMemcpyHostToDevice, e->stream));  // ordered after dalloc's zero fill
-        Q3_HIP(e, hipStreamSynchronize(e->stream));
+        Q3_HIP(e, hipMemcpy(dst, h.data(), n * 4, hipMemcpyHostToDevice));  // (h is a local: synchronous copy)
         return Q3TTS_OK;
     }
     // [N][K] matrix -> bf16 row-major staging buffer `which` on the device
@@ -244,9 +254,11 @@ static int alloc_scratch(q3tts_engine* e, Q3Scratch& sc, int rows, int nqkv, int
 // attention (q/k norm + RoPE + KV append fused for decode rows), O GEMM (+ residual, + the FFN norm inputs), gate/up GEMM
 // (+ SwiGLU), down GEMM (+ residual, + the next block's / the head's norm inputs). x: f32 residual rows; xb / ssp: their norm
 // inputs for attn_norm[0] on entry, for out_norm on exit. Restated by oracle/q3_oracle.c tfm_layers.
-static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, uint16_t* xb, float* ssp, int rows, const int* row_pos, const int* row_slot, Q3Scratch& sc,
+// Returns the number of launches the GEMM launcher refused (a shape it cannot run: stale activations would follow silently).
+static int run_layers(q3tts_engine* e, Q3Tfm& t, float* x, uint16_t* xb, float* ssp, int rows, const int* row_pos, const int* row_slot, Q3Scratch& sc,
                        hipStream_t s, bool one_row_per_slot = false, hipEvent_t* probe = nullptr, int slot_mod = 0, int pos_const = 0) {
     const float eps = e->cfg.model.rms_eps;
+    int bad = 0;
     const int nt = t.d / 16;
     const int once = &t == &e->T ? 1 : 0;  // the Talker's 2.8 GB stream once per frame step; the Predictor's weights are re-read 15 times (Infinity Cache)
     for (int l = 0; l < t.L; ++l) {
@@ -254,7 +266,7 @@ static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, uint16_t* xb, float*
         g.w_once = once;
         g.a = xb; g.B = rows; g.w = t.wqkv[l]; g.K = t.d; g.N = t.nqkv; g.ssp = ssp; g.ld_ssp = nt; g.ntiles = nt; g.d_norm = t.d; g.eps = eps;
         g.epi = Q3_EPI_STORE; g.y = sc.qkv; g.ldy = t.nqkv;
-        q3_launch_bgemm(g, s);
+        bad += q3_launch_bgemm(g, s) != 0;
         Q3QkPrep qp{}; qp.qkv = sc.qkv; qp.ld = t.nqkv; qp.rows = rows; qp.Hq = t.Hq; qp.Hkv = t.Hkv; qp.hd = t.hd;
         qp.qnw = t.qn[l]; qp.knw = t.kn[l]; qp.eps = eps; qp.cs = t.cs; qp.sn = t.sn;
         qp.kc = t.kc + l * t.layer_stride; qp.vc = t.vc + l * t.layer_stride; qp.n_ctx = t.n_ctx; qp.row_pos = row_pos; qp.row_slot = row_slot;
@@ -269,20 +281,23 @@ static void run_layers(q3tts_engine* e, Q3Tfm& t, float* x, uint16_t* xb, float*
         q3_launch_attend(at, s);
         g = Q3BGemm{}; g.w_once = once; g.a = sc.att; g.B = rows; g.w = t.wo[l]; g.K = t.nq; g.N = t.d; g.epi = Q3_EPI_RESID; g.y = x; g.ldy = t.d;
         g.yb = xb; g.nw_next = t.ffn_norm[l]; g.ssp_out = ssp; g.ld_ssp_out = nt;
-        q3_launch_bgemm(g, s);
+        bad += q3_launch_bgemm(g, s) != 0;
         g = Q3BGemm{}; g.w_once = once; g.a = xb; g.B = rows; g.w = t.wgu[l]; g.K = t.d; g.N = 2 * t.F; g.ssp = ssp; g.ld_ssp = nt; g.ntiles = nt; g.d_norm = t.d;
         g.eps = eps; g.epi = Q3_EPI_SWIGLU; g.yb = sc.h;
         if (probe && l == 0) hipEventRecord(probe[0], s);
-        q3_launch_bgemm(g, s);
+        bad += q3_launch_bgemm(g, s) != 0;
         if (probe && l == 0) hipEventRecord(probe[1], s);
         g = Q3BGemm{}; g.w_once = once; g.a = sc.h; g.B = rows; g.w = t.wd[l]; g.K = t.F; g.N = t.d; g.epi = Q3_EPI_RESID; g.y = x; g.ldy = t.d;
         g.yb = xb; g.nw_next = l + 1 < t.L ? t.attn_norm[l + 1] : t.out_norm; g.ssp_out = ssp; g.ld_ssp_out = nt;
-        q3_launch_bgemm(g, s);
+        bad += q3_launch_bgemm(g, s) != 0;
     }
+    return bad;
 }
 
 // one frame: src/tts/engine.rs:545-642 for the slots [b0, b0 + nb) of one lane
-static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
+// Returns the number of refused launches (0 = the frame was issued completely).
+static int record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
+    int bad = 0;
     const q3tts_model_config& m = e->cfg.model;
     const int ncb = m.n_codebooks, cbs = m.codebook_size, dp = m.p_d_model, de = m.d_embed, cap = e->cfg.max_steps_cap;
     const float eps = m.rms_eps;
@@ -297,7 +312,7 @@ static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
     {   // H6 (src/assets_manager.rs:383-399) for the hidden rows only: every code embedding arrives pre-projected
         Q3Project pj{}; pj.x = L.X; pj.ldx = de; pj.rows = B; pj.w = e->proj_w; pj.bias = e->proj_b; pj.n_in = de; pj.n_out = dp; pj.y = L.px; pj.ldy = dp;
         pj.nw = e->P.attn_norm[0]; pj.xb = L.xbP; pj.ssp = L.sspP; pj.ld_ssp = dp / 16;  // rows [0, B) of pass A
-        q3_launch_project(pj, s);
+        bad += q3_launch_project(pj, s) != 0;
     }
     const size_t head_tile_stride = (size_t)(cbs / 16) * (dp / 32) * 64;  // uint4 per predictor head
     auto pred_next = [&](int q) {
@@ -315,21 +330,22 @@ static void record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
         if (e->probe == 1 && q == 1 && B == L.nb && e->probe_i + 2 <= 8) { pe = &e->probe_ev[e->probe_i]; e->probe_i += 2; }
         // the Predictor's cache lives for one frame (src/tts/engine.rs:575: cleared per frame), so it is indexed by ROW: slot = row % B,
         // position = (q == 0 ? row / B : q + 1) — known without a load, the attention kernels request their operands at once
-        run_layers(e, e->P, L.px, L.xbP, L.sspP, rows, nullptr, nullptr, L.sc, s, q > 0, pe, B, q == 0 ? 0 : q + 1);
+        bad += run_layers(e, e->P, L.px, L.xbP, L.sspP, rows, nullptr, nullptr, L.sc, s, q > 0, pe, B, q == 0 ? 0 : q + 1);
         // head q on the rows that carry the newest position (pass 0: rows [B, 2B)), argmax epilogue
         Q3BGemm g{}; g.a = L.xbP; g.a_row0 = q == 0 ? B : 0; g.B = B; g.w = e->P.head + head_tile_stride * q; g.K = dp; g.N = cbs;
         g.ssp = q == 0 ? L.sspP + (size_t)B * (dp / 16) : L.sspP; g.ld_ssp = dp / 16; g.ntiles = dp / 16; g.d_norm = dp; g.eps = eps;
         g.epi = Q3_EPI_ARGMAX; g.keys = L.keys; g.key_stride = cbs / 16;  // per-tile maxima; k_pred_next(q + 1) reduces them
-        q3_launch_bgemm(g, s);
+        bad += q3_launch_bgemm(g, s) != 0;
     }
     pred_next(ncb - 1);
     hipEvent_t* pt = nullptr;  // probe mode 2: the Talker's layer-0 gate/up GEMM (the largest GEMM of the frame step)
     if (e->probe == 2 && B == L.nb && e->probe_i + 2 <= 8) { pt = &e->probe_ev[e->probe_i]; e->probe_i += 2; }
-    run_layers(e, e->T, L.xT, L.xbT, L.sspT, B, L.row_pos_t, L.slot_id, L.sc, s, true, pt);
+    bad += run_layers(e, e->T, L.xT, L.xbT, L.sspT, B, L.row_pos_t, L.slot_id, L.sc, s, true, pt);
     Q3BGemm g{}; g.w_once = 1; g.a = L.xbT; g.B = B; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab;
     g.ssp = L.sspT; g.ld_ssp = m.t_d_model / 16; g.ntiles = m.t_d_model / 16; g.d_norm = m.t_d_model; g.eps = eps;
     g.epi = Q3_EPI_STORE; g.y = L.logits; g.ldy = m.t_vocab;
-    q3_launch_bgemm(g, s);
+    bad += q3_launch_bgemm(g, s) != 0;
+    return bad;
 }
 
 static bool file_exists(const std::string& p) { FILE* f = fopen(p.c_str(), "rb"); if (f) fclose(f); return f != nullptr; }
@@ -340,10 +356,7 @@ static uint16_t host_bf16(float f) {
 }
 static int upload_table(q3tts_engine* e, float** dst, const float* host, size_t n) {
     TRY(dalloc(e, dst, n));
-    // dalloc zero-fills asynchronously on e->stream, a non-blocking stream: the copy has to be ordered on that stream too
-    // (a plain hipMemcpy runs on the null stream and could be overtaken by the fill, zeroing rows of the table)
-    Q3_HIP(e, hipMemcpyAsync(*dst, host, n * 4, hipMemcpyHostToDevice, e->stream));
-    Q3_HIP(e, hipStreamSynchronize(e->stream));  // `host` may be a temporary of the caller
+    Q3_HIP(e, hipMemcpy(*dst, host, n * 4, hipMemcpyHostToDevice));  // `host` may be a temporary of the caller: synchronous copy
     return Q3TTS_OK;
 }
 static int upload_proj(q3tts_engine* e, const float* w, const float* b) {  // proj.weight stays f32 (src/assets_manager.rs:212-241, :383-399)
@@ -557,8 +570,9 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
         L.graphs.resize(e->buckets.size(), nullptr); L.execs.resize(e->buckets.size(), nullptr);
         for (size_t bi = 0; bi < e->buckets.size(); ++bi) {
             HIPC(hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal));
-            record_frame(e, L, L.stream, e->buckets[bi]);
+            const int refused = record_frame(e, L, L.stream, e->buckets[bi]);
             HIPC(hipStreamEndCapture(L.stream, &L.graphs[bi]));
+            if (refused) { q3_set_err(e, Q3TTS_ERR_INVALID, "frame step: " + std::to_string(refused) + " kernel launch(es) refused for this model shape"); return fail(Q3TTS_ERR_INVALID); }
             HIPC(hipGraphInstantiate(&L.execs[bi], L.graphs[bi], nullptr, nullptr, 0));
             HIPC(hipStreamSynchronize(L.stream));
         }
@@ -755,7 +769,10 @@ static int run_chunk(q3tts_engine* e, int CH, float* dev_ms) {
     if (e->probe) { hipEventRecord(e->probe_ev[8], L.stream); hipEventRecord(e->probe_ev[9], L.stream); }  // empty bracket
     for (int i = 0; i < CH; ++i) {
         if (!L.execs.empty() && !e->probe) { Q3_HIP(e, hipGraphLaunch(L.execs[e->cur_bucket], L.stream)); }
-        else { record_frame(e, L, L.stream, e->buckets[e->cur_bucket]); Q3_HIP(e, hipGetLastError()); }
+        else {
+            if (record_frame(e, L, L.stream, e->buckets[e->cur_bucket])) return q3_set_err(e, Q3TTS_ERR_INVALID, "frame step: a kernel launch was refused for this model shape");
+            Q3_HIP(e, hipGetLastError());
+        }
     }
     e->row_steps += (long long)CH * e->buckets[e->cur_bucket];
     Q3_HIP(e, hipEventRecord(L.ev_end, L.stream));
@@ -794,7 +811,8 @@ static int admit_group(q3tts_engine* e, std::vector<Adm>& grp, int total) {
     Q3_HIP(e, hipMemcpyAsync(e->pf_slot, slot.data(), (size_t)total * 4, hipMemcpyHostToDevice, s));
     Q3_HIP(e, hipStreamSynchronize(s));  // pos/slot are locals
     q3_launch_norm_inputs(e->xp, m.t_d_model, total, m.t_d_model, e->T.attn_norm[0], e->xbp, 0, e->sspp, m.t_d_model / 16, s);
-    run_layers(e, e->T, e->xp, e->xbp, e->sspp, total, e->pf_pos, e->pf_slot, e->sc_pre, s);
+    if (run_layers(e, e->T, e->xp, e->xbp, e->sspp, total, e->pf_pos, e->pf_slot, e->sc_pre, s))
+        return q3_set_err(e, Q3TTS_ERR_INVALID, "prefill: a kernel launch was refused for this model shape");
     Q3_HIP(e, hipGetLastError());
     for (const Adm& a : grp) {
         const q3tts_request* r = a.r;
@@ -806,7 +824,7 @@ static int admit_group(q3tts_engine* e, std::vector<Adm>& grp, int total) {
         Q3BGemm g{}; g.a = e->xbp; g.a_row0 = (int)lastr; g.B = 1; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab;
         g.ssp = e->sspp + lastr * (m.t_d_model / 16); g.ld_ssp = m.t_d_model / 16; g.ntiles = m.t_d_model / 16; g.d_norm = m.t_d_model; g.eps = m.rms_eps;
         g.epi = Q3_EPI_STORE; g.y = L.logits + (size_t)row * m.t_vocab; g.ldy = m.t_vocab;
-        q3_launch_bgemm(g, s);
+        if (q3_launch_bgemm(g, s)) return q3_set_err(e, Q3TTS_ERR_INVALID, "prefill head: launch refused for this model shape");
         // sampler stream (src/tts/engine.rs:473-485)
         float temperature = e->temperature, top_p = e->top_p; int top_k = e->top_k, has_seed = e->has_seed; uint64_t seed = e->seed;
         if (!r->use_engine_sampler) { temperature = r->temperature; top_k = r->top_k; top_p = r->top_p; has_seed = r->has_seed; seed = r->seed; }
@@ -1514,6 +1532,36 @@ extern "C" int q3tts_k_probe(q3tts_engine* e, int32_t enable) {
         for (auto& ev : e->probe_ev) Q3_HIP(e, hipEventCreate(&ev));
     }
     e->probe = enable == 2 ? 2 : (enable ? 1 : 0);
+    return Q3TTS_OK;
+}
+
+// The allocator's contract (q3_dev_alloc_zeroed): the zero fill has completed when the pointer is handed out. The hook allocates
+// `bytes` through it, uploads a pattern into the first and last 4 KiB on the NULL stream at once (the stream an unsuspecting call
+// site would use), and counts the bytes that do not read back as written / as zero. An asynchronous fill on e->stream — the state
+// of rounds 1 and 2 — loses this race on large buffers.
+extern "C" int q3tts_k_alloc_upload(q3tts_engine* e, int64_t bytes, int64_t* mismatches) {
+    if (!e || !mismatches || bytes < 16384) return q3_set_err(e, Q3TTS_ERR_INVALID, "alloc hook: bytes >= 16384");
+    Q3_HIP(e, hipSetDevice(e->cfg.device));
+    void* q = nullptr;
+    TRY(q3_dev_alloc_zeroed(e, &q, (size_t)bytes));
+    std::vector<uint8_t> pat(4096), back(12288);
+    for (int i = 0; i < 4096; ++i) pat[i] = (uint8_t)(1 + i % 251);
+    hipError_t er = hipMemcpyAsync(q, pat.data(), 4096, hipMemcpyHostToDevice, nullptr);
+    if (er == hipSuccess) er = hipMemcpyAsync((char*)q + bytes - 4096, pat.data(), 4096, hipMemcpyHostToDevice, nullptr);
+    if (er == hipSuccess) er = hipDeviceSynchronize();
+    if (er == hipSuccess) er = hipMemcpy(back.data(), q, 8192, hipMemcpyDeviceToHost);
+    if (er == hipSuccess) er = hipMemcpy(back.data() + 8192, (char*)q + bytes - 4096, 4096, hipMemcpyDeviceToHost);
+    hipFree(q);
+    if (er != hipSuccess) return q3_set_err(e, Q3TTS_ERR_DEVICE, hipGetErrorString(er));
+    int64_t bad = 0;
+    for (int i = 0; i < 4096; ++i) bad += (back[i] != pat[i]) + (back[4096 + i] != 0) + (back[8192 + i] != pat[i]);
+    *mismatches = bad;
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_k_bgemm_policy(int32_t big) {
+    if (big < -1 || big > 1) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm policy: -1, 0 or 1");
+    q3_bgemm_big_policy(big);
     return Q3TTS_OK;
 }
 

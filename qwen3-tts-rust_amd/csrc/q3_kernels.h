@@ -53,7 +53,8 @@ struct Q3BGemm {
 };
 int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s);
 void q3_bgemm_force(int rt, int nt);  // tuning only: force a tile instance (0, 0: back to the cost model)
-void q3_bgemm_prepare();  // kernel attributes; call once outside stream capture
+void q3_bgemm_prepare();  // kernel attributes + the Q3TTS_BG_BIG policy (read once); call once outside stream capture
+void q3_bgemm_big_policy(int policy);  // 1 / -1 / 0: k_bgemm_big always / never / when it fills the chip (tests, A/B runs)
 // producer side of the split RMSNorm for plain f32 rows: xb = bf16(x * nw), ssp[row][t] = sum of squares of columns 16t..16t+15
 void q3_launch_norm_inputs(const float* x, int ldx, int rows, int d, const float* nw, uint16_t* xb, int xb_row0, float* ssp, int ld_ssp, hipStream_t s);
 // H6 (src/assets_manager.rs:383-399) in the reference's own f32 sequence: y[row][o] = bias[o]; for i: y += x[row][i] * w[o][i].

@@ -916,8 +916,8 @@ __global__ __launch_bounds__(256) void k_voc_out(VCall cl, const float* x, size_
 template <class T>
 static int valloc(q3tts_engine* e, Q3Voc* v, T** p, size_t n) {
     void* q = nullptr;
-    if (hipMalloc(&q, n * sizeof(T) + 256) != hipSuccess) return q3_set_err(e, Q3TTS_ERR_OOM, "hipMalloc (vocoder)");
-    hipMemsetAsync(q, 0, n * sizeof(T) + 256, e->stream);
+    const int rc = q3_dev_alloc_zeroed(e, &q, n * sizeof(T) + 256);  // the zero fill has completed on return (q3_engine.hip)
+    if (rc != Q3TTS_OK) return rc;
     v->allocs.push_back(q);
     *p = (T*)q;
     return Q3TTS_OK;
@@ -953,10 +953,8 @@ static int gen_snake(q3tts_engine* e, Q3Voc* v, uint32_t ta, uint32_t tb, int C,
         a[i] = (float)exp((double)al); b[i] = (float)(1.0 / (exp((double)be) + 1e-9));
     }
     VTRY(valloc(e, v, ea, (size_t)C)); VTRY(valloc(e, v, ib, (size_t)C));
-    // same stream as valloc's zero-fill (a null-stream copy could be overtaken by that memset), synced: a/b are locals
-    Q3_HIP(e, hipMemcpyAsync(*ea, a.data(), (size_t)C * 4, hipMemcpyHostToDevice, e->stream));
-    Q3_HIP(e, hipMemcpyAsync(*ib, b.data(), (size_t)C * 4, hipMemcpyHostToDevice, e->stream));
-    Q3_HIP(e, hipStreamSynchronize(e->stream));
+    Q3_HIP(e, hipMemcpy(*ea, a.data(), (size_t)C * 4, hipMemcpyHostToDevice));  // (a / b are locals: synchronous copies)
+    Q3_HIP(e, hipMemcpy(*ib, b.data(), (size_t)C * 4, hipMemcpyHostToDevice));
     return Q3TTS_OK;
 }
 static int mk_buf(q3tts_engine* e, Q3Voc* v, VBuf* b, int H, int C, int Tcap, int bf16 = 0) {
@@ -991,8 +989,7 @@ int q3_voc_create(q3tts_engine* e) {
                            (1.0f / sqrtf(16.0f)) / Q3_IH4_STD, 1, e->stream);
     }
     { float** cd = nullptr; VTRY(valloc(e, v, &cd, (size_t)16)); v->cb_dev = (const float**)cd;
-      Q3_HIP(e, hipMemcpyAsync((void*)cd, v->cb.data(), sizeof(float*) * c.n_codebooks, hipMemcpyHostToDevice, e->stream));
-      Q3_HIP(e, hipStreamSynchronize(e->stream)); }
+      Q3_HIP(e, hipMemcpy((void*)cd, v->cb.data(), sizeof(float*) * c.n_codebooks, hipMemcpyHostToDevice)); }
     VTRY(gen_conv(e, v, &v->pre, VC_PRE, VW_W, VW_B, c.pre_conv_kernel, 1, c.codebook_dim, d, d, 1.0f));
     VTRY(mk_buf(e, v, &v->pre_in, c.pre_conv_kernel - 1, c.codebook_dim, VOC_FCAP));
     v->L.resize(c.n_layer);
@@ -1044,9 +1041,7 @@ int q3_voc_create(q3tts_engine* e) {
             }
         }
         VTRY(valloc(e, v, &v->rope, tab.size()));
-        // (valloc zero-fills asynchronously on e->stream: the copy is ordered on that stream, or the fill could land on top of it)
-        Q3_HIP(e, hipMemcpyAsync(v->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, e->stream));
-        Q3_HIP(e, hipStreamSynchronize(e->stream));
+        Q3_HIP(e, hipMemcpy(v->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
     }
     VTRY(gen_vec(e, v, &v->final_norm, VTID(VC_FINAL_NORM, VW_W), d, 1.0f, 0.05f));
     int rows = VOC_FCAP;  // rows per slot at the current stage
@@ -1141,9 +1136,7 @@ int q3_voc_reset(q3tts_engine* e, int slot) {
         add(v->out_in);
         v->n_zero = (int)tab.size();
         VTRY(valloc(e, v, &v->zero_tab, tab.size()));
-        // (valloc zero-fills asynchronously on e->stream: the copy has to be ordered on that stream, or the fill lands on top of it)
-        Q3_HIP(e, hipMemcpyAsync(v->zero_tab, tab.data(), tab.size() * sizeof(Q3Voc::ZeroEnt), hipMemcpyHostToDevice, e->stream));
-        Q3_HIP(e, hipStreamSynchronize(e->stream));
+        Q3_HIP(e, hipMemcpy(v->zero_tab, tab.data(), tab.size() * sizeof(Q3Voc::ZeroEnt), hipMemcpyHostToDevice));
     }
     if (v->n_zero) hipLaunchKernelGGL(k_voc_zero, dim3(v->n_zero, 4), dim3(256), 0, e->stream, v->zero_tab, slot);
     v->frames_done[slot] = 0; v->last_flag[slot] = 0;

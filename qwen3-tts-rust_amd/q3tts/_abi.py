@@ -118,7 +118,7 @@ SYMBOLS = [
     "q3tts_k_vocoder", "q3tts_k_vocoder_bench", "q3tts_set_device_pcm", "q3tts_get_device_pcm", "q3tts_k_rng_f32", "q3tts_k_probe", "q3tts_k_gguf_read", "q3tts_mel_frames", "q3tts_mel",
     "q3tts_clone_default_config", "q3tts_clone_init", "q3tts_clone_audio_frames", "q3tts_clone_audio_encode",
     "q3tts_clone_speaker_encode", "q3tts_k_speaker_from_mel", "q3tts_k_audio_latent",
-    "q3tts_k_mfma_bf16", "q3tts_k_bgemm", "q3tts_k_bgemm_voc", "q3tts_k_project", "q3tts_k_norm_inputs", "q3tts_tokenizer_load", "q3tts_tokenizer_free", "q3tts_tokenizer_vocab_size", "q3tts_tokenizer_encode", "q3tts_tokenizer_decode",
+    "q3tts_k_alloc_upload", "q3tts_k_bgemm_policy", "q3tts_k_mfma_bf16", "q3tts_k_bgemm", "q3tts_k_bgemm_voc", "q3tts_k_project", "q3tts_k_norm_inputs", "q3tts_tokenizer_load", "q3tts_tokenizer_free", "q3tts_tokenizer_vocab_size", "q3tts_tokenizer_encode", "q3tts_tokenizer_decode",
 ]
 
 
@@ -195,6 +195,8 @@ def load_library(path=None):
     lib.q3tts_k_norm_inputs.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.q3tts_k_bgemm_voc.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                       C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+    lib.q3tts_k_bgemm_policy.argtypes = [C.c_int32]
+    lib.q3tts_k_alloc_upload.argtypes = [vp, C.c_int64, C.POINTER(C.c_int64)]
     lib.q3tts_tokenizer_load.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_int32]
     lib.q3tts_tokenizer_free.argtypes = [vp]
     lib.q3tts_tokenizer_free.restype = None

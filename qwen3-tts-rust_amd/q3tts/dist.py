@@ -72,8 +72,8 @@ def device_pcm_tensor(engine, device):
 
 def gather_pcm_device(dist, pcm_rows, n_samples, rank, world, as_i16=True):
     """The path's ONE collective, straight from device memory: pcm_rows [n][stride] f32 on the device (row i =
-    utterance i of this rank), n_samples[i] valid samples each. Lengths travel in one all_gather, the PCM (i16 as the reference
-    saves it, src/utils/audio.rs:30-46, or f32) in one padded gather to rank 0. Returns on rank 0 (list of per-rank tensors
+    utterance i of this rank), n_samples[i] valid samples each. Lengths travel in one all_gather, the PCM (i16 by the reference's own
+    conversion, src/utils/audio.rs:35-37: scale, clamp to [-32768, 32767], truncate; or f32) in one padded gather to rank 0. Returns on rank 0 (list of per-rank tensors
     [max_n][max_len], lengths [world][max_n]); elsewhere None. Works over gloo as well (CPU tensors)."""
     import torch
     dev = pcm_rows.device
@@ -93,7 +93,9 @@ def gather_pcm_device(dist, pcm_rows, n_samples, rank, world, as_i16=True):
         blk = pcm_rows[:n_local, :max_len]
         mask = torch.arange(max_len, device=dev)[None, :] < lens[1:, None]
         blk = torch.where(mask, blk, torch.zeros((), dtype=blk.dtype, device=dev))
-        buf[:n_local] = (blk.clamp(-1.0, 1.0) * 32767.0).round().to(torch.int16) if as_i16 else blk
+        # f32 -> i16 exactly as the reference saves audio (src/utils/audio.rs:35-37): (x * 32767).clamp(-32768, 32767) as i16,
+        # i.e. truncation toward zero — the same expression as q3tts/api.py's save_wav
+        buf[:n_local] = torch.trunc((blk * 32767.0).clamp(-32768.0, 32767.0)).to(torch.int16) if as_i16 else blk
     wire = buf.view(torch.uint8)  # neither RCCL nor gloo has a 16-bit integer type: the i16 samples travel as bytes
     gathered = [torch.zeros_like(wire) for _ in range(world)] if rank == 0 else None
     dist.gather(wire, gathered, dst=0)

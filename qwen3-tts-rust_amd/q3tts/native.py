@@ -220,6 +220,12 @@ class NativeEngine:
         mode = 2 if enable is True else int(enable)
         self._check(self.lib.q3tts_k_probe(self.h, mode), "q3tts_k_probe")
 
+    def alloc_upload_mismatches(self, nbytes):
+        """Allocator contract hook (q3tts_k_alloc_upload): bytes that read back wrong after a null-stream upload right behind the allocation."""
+        bad = C.c_int64(-1)
+        self._check(self.lib.q3tts_k_alloc_upload(self.h, int(nbytes), C.byref(bad)), "q3tts_k_alloc_upload")
+        return int(bad.value)
+
     def talker_prefill(self, embd):
         e = np.ascontiguousarray(embd, dtype=np.float32)
         hid = np.zeros(self.cfg.model.t_d_model, dtype=np.float32)

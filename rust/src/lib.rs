@@ -46,6 +46,7 @@ pub struct q3tts_result {
     pub n_samples: i32, pub sample_rate: i32, pub first_chunk_ms: c_float, pub total_ms: c_float,
 }
 pub enum q3tts_engine {}
+pub enum q3tts_stream {}
 
 #[link(name = "q3tts")]
 extern "C" {
@@ -58,6 +59,10 @@ extern "C" {
     pub fn q3tts_generate(e: *mut q3tts_engine, req: *const q3tts_request, out: *mut q3tts_result) -> c_int;
     pub fn q3tts_generate_batch(e: *mut q3tts_engine, reqs: *const q3tts_request, n: i32, outs: *mut q3tts_result) -> c_int;
     pub fn q3tts_result_free(r: *mut q3tts_result);
+    // streaming: 4-frame (64-code) chunks as the reference's vocoder thread produces them (src/tts/engine.rs:507-541)
+    pub fn q3tts_stream_begin(e: *mut q3tts_engine, req: *const q3tts_request, out: *mut *mut q3tts_stream) -> c_int;
+    pub fn q3tts_stream_poll(s: *mut q3tts_stream, chunk: *mut *const c_float, n_samples: *mut i32, is_final: *mut i32) -> c_int;
+    pub fn q3tts_stream_end(s: *mut q3tts_stream, out_codes_optional: *mut q3tts_result) -> c_int;
     // voice-clone encoders (replace AudioEncoder / SpeakerEncoder, src/models/onnx.rs:82-160)
     pub fn q3tts_clone_default_config(cfg: *mut q3tts_clone_config);
     pub fn q3tts_clone_init(e: *mut q3tts_engine, cfg: *const q3tts_clone_config) -> c_int;
@@ -133,6 +138,47 @@ impl TtsEngine {
             let samples = std::slice::from_raw_parts(out.pcm, out.n_samples as usize).to_vec();
             q3tts_result_free(&mut out);
             Ok(AudioSample { samples, sample_rate: 24000, channels: 1 })
+        }
+    }
+}
+impl TtsEngine {
+    /// run_inference_stream with `stream_tx = Some(..)` — src/tts/engine.rs:444-448,520-526: every decoded 4-frame chunk is sent
+    /// down the channel as soon as its PCM is on the host (`stx.send(samples.clone())`, send errors ignored as there), and the whole
+    /// utterance is returned at the end. The reference threads `stream_tx` through privately (:438-443 pass None); this is the
+    /// same hook made callable. Chunks come from q3tts_stream_poll; the engine overlaps the vocoder with the next frames itself.
+    pub fn generate_with_voice_stream(&mut self, text_ids: &[u32], voice: &VoiceFile, instruct_ids: Option<&[u32]>,
+                                      stream_tx: Option<std::sync::mpsc::Sender<Vec<f32>>>) -> Result<AudioSample, String> {
+        let codes32: Vec<i32> = voice.audio_codes.iter().map(|&c| c as i32).collect();
+        let desc = q3tts_prompt_desc {
+            text_ids: text_ids.as_ptr(), n_text: text_ids.len() as i32,
+            instruct_ids: instruct_ids.map_or(std::ptr::null(), |s| s.as_ptr()), n_instruct: instruct_ids.map_or(0, |s| s.len() as i32),
+            lang_id: 2055, spk_id: -1, spk_emb: voice.speaker_embedding.as_ptr(),
+            ref_codes: if codes32.is_empty() { std::ptr::null() } else { codes32.as_ptr() }, n_ref_frames: (codes32.len() / 16) as i32,
+            ref_text_ids: std::ptr::null(), n_ref_text: 0,
+        };
+        let req = q3tts_request {
+            prompt_embd: std::ptr::null(), n_tok: 0, prompt: &desc, use_engine_sampler: 0,
+            temperature: self.sampler.temperature, top_k: self.sampler.top_k, top_p: self.sampler.top_p,
+            has_seed: self.sampler.seed.is_some() as i32, seed: self.sampler.seed.unwrap_or(0),
+            max_steps: self.max_steps as i32, min_frames: 0, force_eos_at: -1, want_pcm: 1,
+        };
+        unsafe {
+            let err = |e: *mut q3tts_engine| CStr::from_ptr(q3tts_last_error(e)).to_string_lossy().into_owned();
+            let mut st: *mut q3tts_stream = std::ptr::null_mut();
+            if q3tts_stream_begin(self.raw, &req, &mut st) != 0 { return Err(err(self.raw)); }
+            let mut full_audio: Vec<f32> = Vec::new();
+            loop {
+                let (mut chunk, mut n, mut fin) = (std::ptr::null::<c_float>(), 0i32, 0i32);
+                if q3tts_stream_poll(st, &mut chunk, &mut n, &mut fin) != 0 { q3tts_stream_end(st, std::ptr::null_mut()); return Err(err(self.raw)); }
+                if n > 0 {
+                    let samples = std::slice::from_raw_parts(chunk, n as usize).to_vec();  // the chunk is only valid until the next poll
+                    if let Some(ref stx) = stream_tx { let _ = stx.send(samples.clone()); }
+                    full_audio.extend(samples);
+                }
+                if fin != 0 { break; }
+            }
+            if q3tts_stream_end(st, std::ptr::null_mut()) != 0 { return Err(err(self.raw)); }
+            Ok(AudioSample { samples: full_audio, sample_rate: 24000, channels: 1 })
         }
     }
 }

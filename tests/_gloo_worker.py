@@ -32,7 +32,8 @@ if rank == 0:
         idx = qd.shard_indices(n_total, r, world)
         assert int(lens[r, 0]) == len(idx)
         for j, gi in enumerate(idx):
-            want = np.round(np.clip(fake_pcm(gi) * 0.01, -1, 1) * 32767.0).astype(np.int16)
+            # the reference's conversion (src/utils/audio.rs:35-37), as tests/test_host_cpu.py states it for save_wav
+            want = np.trunc(np.clip((fake_pcm(gi) * 0.01).astype(np.float32) * np.float32(32767.0), -32768.0, 32767.0)).astype(np.int16)
             assert int(lens[r, 1 + j]) == want.size and np.array_equal(tens[r][j, :want.size].numpy(), want), (r, j)
 else:
     assert gd is None

@@ -1,0 +1,65 @@
+"""The N > 1 code of bench.py executed on the 1-GPU box (VERDICT r02, next #1c/d).
+
+* backend nccl (RCCL) at WORLD_SIZE = 1: process group on the device, zero-copy view of the engine's packed device PCM, device-side i16
+  conversion, uint8 all_gather / gather — every line of `gather_pcm_device` runs, and what it delivers must equal the reference's i16
+  conversion (src/utils/audio.rs:35-37) of the host PCM of the same run.
+* two ranks over gloo, both engines on GPU 0: per-utterance codec ids equal the one-rank run's for the same GLOBAL indices (sharding and
+  global-index seeds: results do not depend on the number of ranks). This run also goes through `spawn_ranks`.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(REPO, "bench.py")
+COMMON = ["--tiny", "--steps", "1", "--warmup", "0", "--no-single", "--no-probe", "--no-cpu-baseline"]
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _run(args, env_extra, timeout=600):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        if k not in env_extra:
+            env.pop(k, None)
+    p = subprocess.run([sys.executable, BENCH] + args + COMMON, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_dist_branch_with_rccl_at_world_size_1():
+    line = _run(["--gpus", "1", "--batch", "6"],
+                {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()),
+                 "Q3TTS_FORCE_DIST": "1", "Q3TTS_BENCH_CHECK_GATHER": "1"})
+    gc = line["gather_check"]
+    print("RCCL world-1 gather:", gc, "gather ms/step", line["gather_ms_per_step"])
+    assert gc["backend"] == "nccl" and gc["utterances"] == 6 and gc["samples"] > 6 * 25 * 1920 - 1 and gc["mismatching_samples"] == 0
+    assert line["value_without_gather"] >= line["value"] > 0
+
+
+def test_two_ranks_give_the_ids_of_one_rank_for_the_same_global_indices(tmp_path):
+    a, b = str(tmp_path / "two"), str(tmp_path / "one")
+    _run(["--gpus", "2", "--batch", "3"], {"Q3TTS_DIST_BACKEND": "gloo", "Q3TTS_ONE_GPU": "1", "Q3TTS_BENCH_DUMP": a})   # via spawn_ranks
+    _run(["--gpus", "1", "--batch", "6"], {"Q3TTS_BENCH_DUMP": b})
+    one = np.load(b + ".rank0.npz")
+    assert sorted(one.files) == [f"g{i}" for i in range(6)]
+    seen = set()
+    for r in range(2):
+        two = np.load(f"{a}.rank{r}.npz")
+        assert sorted(two.files) == [f"g{i}" for i in range(r, 6, 2)]   # rank r owns {i : i mod 2 == r}
+        for k in two.files:
+            assert two[k].shape == one[k].shape and two[k].shape[0] >= 25 and np.array_equal(two[k], one[k]), k
+            seen.add(k)
+    assert len(seen) == 6

@@ -205,3 +205,20 @@ def test_gguf_reader_errors_are_loud(tmp_path):
     np.save(tmp_path / "f64.npy", v.astype(np.float64))
     with pytest.raises(_abi.Q3Error, match="f32"):
         native.k_gguf_read(str(tmp_path / "f64.npy"))
+
+
+def test_bench_spawn_ranks_fails_fast_when_a_rank_dies():
+    """bench.py --gpus 2 without a launcher: rank 1 exits at start-up; rank 0 would wait in the rendezvous until its timeout. The
+    parent polls every child, terminates the survivor and returns non-zero within seconds (no GPU is touched before the rendezvous)."""
+    import subprocess
+    import sys
+    import time
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, Q3TTS_DIST_BACKEND="gloo", Q3TTS_BENCH_FAIL_RANK="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--tiny", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert p.returncode != 0 and "rank 1 exited with 3" in p.stderr, (p.returncode, p.stderr[-500:])
+    assert time.time() - t0 < 120

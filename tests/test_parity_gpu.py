@@ -643,11 +643,12 @@ def test_bgemm_swiglu_matches_oracle(oracle, native, B, K, N):
 def test_bgemm_many_rows_kernel_matches_oracle(oracle, native, B, K, N, epi):
     """Prefill-sized launches (>= 256 rows, N % 128 == 0) run k_bgemm_big: 128 x 128 tiles, the whole K in one wave, the 8 K-slices summed
     in the canonical order inside the wave. Same bits as the oracle (and therefore as k_bgemm), ragged last row tiles included."""
-    os.environ["Q3TTS_BG_BIG"] = "1"   # (the launcher's own rule wants >= 256 tiles: the oracle would take minutes at such sizes)
+    lib = native._abi.load_library()
+    assert lib.q3tts_k_bgemm_policy(1) == 0   # (the launcher's own rule wants >= 256 tiles: the oracle would take minutes at such sizes)
     try:
         ref, got, _, _ = _bgemm_case(oracle, native, B, K, N, epi, epi != 1, 900 + B + N + epi)
     finally:
-        del os.environ["Q3TTS_BG_BIG"]
+        assert lib.q3tts_k_bgemm_policy(0) == 0
     if epi == 0:
         assert np.array_equal(_bits(got["y"]), _bits(ref["y"]))
     elif epi == 1:
@@ -832,6 +833,73 @@ def test_64_slots_mixed_lengths_sampled_ids_and_pcm(oracle):
         eng.close()
         om.close()
         L.q3o_vocoder_destroy(v)
+
+
+def test_full_shape_64_slots_sampled_mixed_lengths_ids_and_pcm(oracle):
+    """configs[2] at the BENCHMARKED shape and batch (VERDICT r02, next #1a): the full 1.7B shape, max_batch = 64, 72 sampled requests of
+    mixed prompt and target lengths with the vocoder on. The first 64 start together on 64 rows; targets of 4 / 8 / 12 frames drain the
+    batch through the row buckets 64 -> 48 -> 32 -> 16 (k_gather_rows moves the surviving rows' logits / hidden state); requests 64..71
+    wait and take re-used slots (stale KV, vocoder state reset); every result is handed over deferred. The oracle (one utterance at a
+    time, ~1 s per frame) replays five of them: the first, a long one that outlives every bucket change, one from the middle, and two
+    on re-used slots including the last — ids equal, PCM within the full-shape tolerance. /root/reference/src/tts/engine.rs:545-642."""
+    import json
+    import time
+    from q3tts import _abi, native
+    cfg = _abi.full_config_py()
+    cfg.max_batch, cfg.n_ctx, cfg.max_steps_cap = 64, 128, 32
+    threads = min(16, os.cpu_count() or 4)
+    eng = native.NativeEngine(cfg)
+    om = oracle.OracleModel(cfg.model, seed=0, n_ctx=128, n_threads=threads)
+    L = oracle.lib()
+    v = L.q3o_vocoder_create(C.byref(cfg.vocoder), 0, threads)
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "speakers", "vivian.json")) as f:
+            spk = np.asarray(json.load(f)["spk_emb"], dtype=np.float32)
+        rng = np.random.default_rng(6464)
+        reqs, metas, keep_all = [], [], []
+        for i in range(72):
+            n_text = int(rng.integers(2, 9))
+            target = (4, 8, 12)[i % 3] if i < 64 else 4 + (i % 2)
+            ids = rng.integers(0, 151643, size=n_text)
+            desc, keep = oracle.make_prompt_desc(ids, spk_emb=spk)
+            keep_all.append((desc, keep))
+            kw = dict(temperature=0.7, top_k=40, top_p=0.9, seed=1000 + i, max_steps=16, min_frames=target, force_eos_at=target)
+            reqs.append(dict(desc=desc, want_pcm=1, **kw)); metas.append((desc, kw, target))
+        outs = eng.generate_batch(reqs)
+        tm = eng.timings()
+        assert all(o.status == 0 for o in outs) and [o.n_frames for o in outs] == [m[2] for m in metas]
+        assert tm.mean_rows < 60.0 and tm.mean_live_slots > 16.0   # the batch did drain through smaller row buckets
+        t0 = time.time()
+        worst = 0.0
+        for i in (0, 2, 37, 64, 71):
+            desc, kw, target = metas[i]
+            pe = om.build_prompt(desc)
+            ref, _ = om.generate(pe, **kw)
+            assert ref.shape == (target, 16) and np.array_equal(outs[i].codes, ref), i
+            ref_pcm = _oracle_pcm(oracle, v, np.clip(ref, 0, cfg.vocoder.codebook_size - 1).astype(np.int32))
+            assert outs[i].pcm.shape == ref_pcm.shape == (target * 1920,), i
+            worst = max(worst, float(np.sqrt(np.mean((outs[i].pcm - ref_pcm) ** 2))))
+        print(f"full shape, 64 slots, 72 sampled requests: ids of 5 replayed utterances equal; worst PCM RMS {worst:.2e} (tolerance {PCM_RMS_TOL_FULL:.0e}); "
+              f"mean live {tm.mean_live_slots:.1f}, mean rows {tm.mean_rows:.1f}, frame step {tm.frame_step_ms:.2f} ms; oracle {time.time() - t0:.0f} s on {threads} threads")
+        assert worst <= PCM_RMS_TOL_FULL
+    finally:
+        eng.close()
+        om.close()
+        L.q3o_vocoder_destroy(v)
+
+
+def test_allocator_hands_out_memory_with_the_zero_fill_completed():
+    """Rounds 1 and 2 zero-filled asynchronously on a non-blocking stream and fixed three call sites whose uploads were overwritten by
+    the fill. The allocator now returns after the fill: a null-stream upload right behind a LARGE allocation (the fill of 1 GiB takes
+    ~0.2 ms, the upload is issued microseconds after the allocation returns) must read back intact, and the rest must read zero."""
+    from q3tts import _abi, native
+    cfg = _abi.tiny_config(max_batch=1, n_ctx=64, with_vocoder=1)
+    eng = native.NativeEngine(cfg)
+    try:
+        for nbytes in (1 << 30, 16384, 256 << 20, 1 << 30):
+            assert eng.alloc_upload_mismatches(nbytes) == 0, nbytes
+    finally:
+        eng.close()
 
 
 @pytest.mark.parametrize("n_frames", [4, 7])
