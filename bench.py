@@ -271,8 +271,8 @@ def main():
 
     from q3tts import _abi, native
     from q3tts import dist as qd
-    cfg = _abi.tiny_config(max_batch=min(64, args.batch), n_ctx=512) if args.tiny else _abi.full_config_py()
-    cfg.device, cfg.max_batch, cfg.n_ctx, cfg.max_steps_cap = local_rank, min(64, args.batch), (512 if args.tiny else args.n_ctx), 512
+    cfg = _abi.tiny_config(max_batch=min(64, args.batch), n_ctx=1024) if args.tiny else _abi.full_config_py()
+    cfg.device, cfg.max_batch, cfg.n_ctx, cfg.max_steps_cap = local_rank, min(64, args.batch), (1024 if args.tiny else args.n_ctx), 512
     cfg.with_vocoder = 0 if args.no_vocoder else 1
     eng = native.NativeEngine(cfg)
     spk = vivian()[:cfg.model.d_embed]
