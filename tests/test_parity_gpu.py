@@ -893,7 +893,7 @@ def test_allocator_hands_out_memory_with_the_zero_fill_completed():
     the fill. The allocator now returns after the fill: a null-stream upload right behind a LARGE allocation (the fill of 1 GiB takes
     ~0.2 ms, the upload is issued microseconds after the allocation returns) must read back intact, and the rest must read zero."""
     from q3tts import _abi, native
-    cfg = _abi.tiny_config(max_batch=1, n_ctx=64, with_vocoder=1)
+    cfg = _abi.tiny_config(max_batch=1, n_ctx=128, with_vocoder=1)
     eng = native.NativeEngine(cfg)
     try:
         for nbytes in (1 << 30, 16384, 256 << 20, 1 << 30):
