@@ -37,6 +37,7 @@ template <int RT, int NT, int D, bool NTW>
 __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
     extern __shared__ float part[];  // [8 waves][RT*NT*4 regs][64 lanes]
     __shared__ float srow[64];
+    Q3_STAMP(g, 0);
     constexpr int TR = RT * NT * 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kq = lane >> 4, r = lane & 15;
     // workgroups are dealt round-robin to the 8 XCDs in linear-id order: the row chunks of one column group get ids 8 apart
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    Q3_STAMP(g, 1);
     f32x4 acc[RT][NT];
 #pragma unroll
     for (int i = 0; i < RT; ++i)
@@ -116,6 +118,9 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef Q3_STAMPS
+                if (s == 0) { asm volatile("" :: "v"(acc[0][0][0])); Q3_STAMP(g, 2); }
+#endif
                 if (s + D < per) {
 #pragma unroll
                     for (int j = 0; j < NT; ++j) bq[d][j] = bg_ldw(wp[j] + (size_t)(s + D) * 64, NTW);
@@ -126,6 +131,9 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
             }
         }
     }
+#ifdef Q3_STAMPS
+    asm volatile("" :: "v"(acc[0][0][0])); Q3_STAMP(g, 3);
+#endif
     if (g.ssp) {  // the NR butterflies are independent chains: interleaved
         float av[NR];
 #pragma unroll
@@ -154,6 +162,7 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) part[((size_t)wave * TR + (i * NT + j) * 4 + e) * 64 + lane] = acc[i][j][e];
     __syncthreads();
+    Q3_STAMP(g, 4);
     // slice partials combined in slice order; element (tile t, reg e, lane l) -> row 16 i + 4 (l >> 4) + e, col 16 j + (l & 15)
     const int epi = g.epi;
 #pragma unroll
@@ -200,6 +209,11 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
             if (live && c == 0) g.keys[(size_t)row * g.key_stride + (nb0 + j)] = key;
         }
     }
+#ifdef Q3_STAMPS
+    Q3_STAMP(g, 5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    Q3_STAMP(g, 6);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -4,6 +4,16 @@
 
 enum { Q3_EPI_STORE = 0, Q3_EPI_RESID = 1, Q3_EPI_SWIGLU = 2, Q3_EPI_ARGMAX = 3, Q3_EPI_GELU = 4 };
 
+// Experiment builds (-DQ3_STAMPS, tools/chain_stamps.hip): every workgroup's first thread records up to 8 constant-rate (100 MHz)
+// timestamps at dbg[(linear workgroup id) * 8 + i]. Compiled out of the product library.
+#ifdef Q3_STAMPS
+#define Q3_STAMP_FIELD unsigned long long* dbg;
+#define Q3_STAMP(p, i) do { if ((p).dbg && threadIdx.x == 0) (p).dbg[((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define Q3_STAMP_FIELD
+#define Q3_STAMP(p, i) do { } while (0)
+#endif
+
 // Exact GEMM y[B][N] = x[B][K] * W[N][K]^T in the canonical order of DESIGN.md §4.1.
 // W is bf16 in the tiled HBM layout of DESIGN.md §2.1: tile (nb = n/16, kb = k/32) is 1 KiB,
 // lane l = (kq = l>>4, n = l&15) owns the 8 weights W[nb*16+n][kb*32+kq*8 .. +8].
@@ -50,6 +60,7 @@ struct Q3BGemm {
     const float* bias; int bias_n;
     int seg_rows; size_t seg_stride;
     unsigned long long* keys; int key_stride;   // ARGMAX: per-tile maxima, [B][key_stride]
+    Q3_STAMP_FIELD
 };
 int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s);
 void q3_bgemm_force(int rt, int nt);  // tuning only: force a tile instance (0, 0: back to the cost model)
@@ -116,6 +127,7 @@ struct Q3Attend {
     int fused;        // 1: every slot has exactly one row in this launch -> q/k prep + KV append done in-kernel (R >= 2)
                       // 2: rows b (position 0) and slot_mod + b (position 1) of every slot, nothing cached yet (R == 2, hd == 128): k_attend_pair
     Q3QkPrep prep;    // used when fused
+    Q3_STAMP_FIELD
 };
 void q3_launch_attend(const Q3Attend& a, hipStream_t s);
 
@@ -156,6 +168,7 @@ struct Q3PredNext {
     float* fb; const float* tts_pad; float* xT; int* row_pos_t;
     const float* pproj_q; const float* proj_b; int dp; float* px;  // q < ncb-1: px[b] = proj(codec_q[code]) from the table
     const float* nw; uint16_t* xb; float* ssp;  // norm inputs of the row just written: px[b] (Predictor layer 0) or, last, xT[b] (Talker layer 0)
+    Q3_STAMP_FIELD
 };
 void q3_launch_pred_next(const Q3PredNext& a, hipStream_t s);
 

@@ -156,6 +156,7 @@ template <int R, bool FUSED>
 __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int g = blockIdx.x, row = blockIdx.y;
+    Q3_STAMP(a, 0);
     int pos, slot;
     q3_row_map(row, a.row_pos, a.row_slot, a.slot_mod, a.pos_const, &pos, &slot);
     if (pos < 0) return;
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
         for (int i = tid; i < R * hd; i += R * 256) qh[i] = a.qkv[(size_t)row * a.ld + (size_t)g * R * hd + i];
     }
     __syncthreads();
+    Q3_STAMP(a, 1);
     const uint16_t* kb = a.kc + hb * hd;
     const uint16_t* vb = a.vc + hb * hd;
     const float scale = 1.0f / sqrtf((float)hd);
@@ -245,6 +247,7 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
     lsum = wave_sum(lsum);
     if (lane == 0) lw[hh * 4 + sw] = lsum;
     __syncthreads();
+    Q3_STAMP(a, 2);
     const int kg = lane >> 4, dl = lane & 15;
     float o[8];
 #pragma unroll
@@ -282,6 +285,7 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
         for (int e = 0; e < 8; ++e) ow[(hh * 4 + sw) * hd + dl * 8 + e] = o[e];
     }
     __syncthreads();
+    Q3_STAMP(a, 3);
     for (int i = tid; i < R * hd; i += R * 256) {
         const int h2 = i / hd, d = i - h2 * hd;
         const float r0 = ow[(h2 * 4 + 0) * hd + d], r1 = ow[(h2 * 4 + 1) * hd + d], r2 = ow[(h2 * 4 + 2) * hd + d],
@@ -292,120 +296,167 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
         if (a.out_bf16) ((uint16_t*)a.out)[q3_atile_off(row, (g * R + h2) * hd + d, (a.Hq * hd) >> 5)] = q3_bf16(ov / l);  // the O projection's A-tiled operand
         else a.out[oi] = ov / l;
     }
+#ifdef Q3_STAMPS
+    Q3_STAMP(a, 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    Q3_STAMP(a, 5);
+#endif
 }
 // ---------------------------------------------------------------------------------------------------------------------
-// The same attention for short caches (n_ctx <= 64: the Predictor's <= 17 keys per frame), one row per slot: ONE wave per query
-// head, the whole cache block and the first value rows requested before the q/k prep, no workgroup-wide reduction. Every
-// output follows the canonical order of k_attend bit for bit: scores = d-ascending fmaf chains, one key per
-// lane; l = the 64-lane butterfly of wave 0 (+0 +0 +0 for the three absent waves is exact); o_d: the 16 partials u = t mod 16
-// live as 4 (uu) x 4 (lane group) chains per dimension, r_uu = (o_4uu + o_4uu+1) + (o_4uu+2 + o_4uu+3) by the same two
-// shuffles, o = ((r0 + r1) + r2) + r3.
+// The same attention for short caches (n_ctx <= 64: the Predictor's <= 17 keys per frame), one row per slot. Every output follows the
+// canonical order of k_attend bit for bit. Built around the kernel's dependent chain, measured with in-kernel timestamps
+// (tools/chain_stamps.hip: the round-2 kernel spent 3.2 us before its first barrier on three dependent load round trips, 2.0 us on two
+// divergent LDS-fed score chains and 1.7 us on the value pass with 64 cross-lane shuffles):
+//  * workgroup = R query-head waves + ONE wave for k (lanes 0-31: RMSNorm + RoPE + append) and v (lanes 32-63: append); every global
+//    operand of a wave — row segments, norm weights, RoPE entries, the cached keys (one key per lane, 16 chunks) and the first 16 cached
+//    value rows (2 dims per lane) — is requested before anything is computed: one round trip
+//  * the newest key reaches lane `pos` of the query waves through LDS in the cache's own packed layout, so cached and newest keys run the
+//    SAME d-ascending fmaf chain (one code path); q is read back from LDS as broadcast 16-byte reads
+//  * value pass without shuffles: a lane owns 2 output dims and keeps all 16 key partials u = t mod 16 of them in registers; p_t comes
+//    from v_readlane (a scalar); r_w = (o_4w + o_4w+1) + (o_4w+2 + o_4w+3), o = ((r0 + r1) + r2) + r3 are plain adds in the lane
+//  * l = the 64-lane butterfly of wave 0 of k_attend (+0 +0 +0 for the three absent waves is exact)
 // ---------------------------------------------------------------------------------------------------------------------
 template <int R>
-__global__ __launch_bounds__(R * 64) void k_attend_small(Q3Attend a) {
-    __shared__ __attribute__((aligned(16))) float kh[128], vh[128], ps[R][64];
-    const int g = blockIdx.x, row = blockIdx.y, hh = threadIdx.x >> 6, lane = threadIdx.x & 63;
+__global__ __launch_bounds__((R + 1) * 64) void k_attend_small(Q3Attend a) {
+    __shared__ __attribute__((aligned(16))) float qh[R][128];      // q after norm + RoPE (f32)
+    __shared__ __attribute__((aligned(16))) uint32_t knew[64];     // newest key, bf16 pairs in the cache's chunk order: chunk c = 16 bytes at knew + 4 c
+    __shared__ __attribute__((aligned(16))) uint32_t vnew[64];     // newest value, bf16 pairs: dims 2 i, 2 i + 1 in word i
+    const int g = blockIdx.x, row = blockIdx.y, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    Q3_STAMP(a, 0);
     int pos, slot;
     q3_row_map(row, a.row_pos, a.row_slot, a.slot_mod, a.pos_const, &pos, &slot);
     if (pos < 0) return;
-    const int T = pos + 1, hd = 128;
+    const int T = pos + 1, hd = 128, half = 64, nl = 32;
     const Q3QkPrep& pr = a.prep;
     const size_t hb = ((size_t)slot * a.Hkv + g) * a.n_ctx;
     const uint16_t* kb = a.kc + hb * hd;
     const uint16_t* vb = a.vc + hb * hd;
-    const int kg = lane >> 4, dl = lane & 15;
-    // cache operands first: independent of this row's projections (lanes beyond the cached keys read inside the slot's own block)
-    uint4 kv[16], vv0[4];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) kv[c] = lane < pos ? ((const uint4*)kb)[c * 64 + lane] : make_uint4(0, 0, 0, 0);  // (only cached keys: <= 16 of the block's 64 lanes)
-#pragma unroll
-    for (int uu = 0; uu < 4; ++uu) vv0[uu] = *(const uint4*)(vb + (size_t)min(4 * uu + kg, T - 1) * hd + dl * 8);
     const float* rowp = a.qkv + (size_t)row * a.ld;
-    const int half = hd >> 1, nl = hd >> 2;
-    float qo[4], o4[4];
-    prep_head(rowp + (size_t)(g * R + hh) * hd, pr.qnw, pr.eps, pr.cs + (size_t)pos * half, pr.sn + (size_t)pos * half, hd, lane, qo);
-    __shared__ __attribute__((aligned(16))) float qh[R][128];
-    if (lane < nl) *(float4*)(qh[hh] + 4 * lane) = (float4){qo[0], qo[1], qo[2], qo[3]};
-    if (hh == 0) {  // k: norm + RoPE + append; v: append (the second wave, when there is one, takes v)
-        prep_head(rowp + (size_t)(a.Hq + g) * hd, pr.knw, pr.eps, pr.cs + (size_t)pos * half, pr.sn + (size_t)pos * half, hd, lane, o4);
-    }
-    if ((R == 1 || hh == 1) && lane < nl) {
-        const float4 v4 = ((const float4*)(rowp + (size_t)(a.Hq + a.Hkv + g) * hd))[lane];
-        *(float4*)(vh + 4 * lane) = (float4){q3_round_bf16(v4.x), q3_round_bf16(v4.y), q3_round_bf16(v4.z), q3_round_bf16(v4.w)};
-        uint2 vk;
-        vk.x = (uint32_t)q3_bf16(v4.x) | ((uint32_t)q3_bf16(v4.y) << 16); vk.y = (uint32_t)q3_bf16(v4.z) | ((uint32_t)q3_bf16(v4.w) << 16);
-        *(uint2*)(pr.vc + (hb + pos) * hd + 4 * lane) = vk;
-    }
-    if (hh == 0 && lane < nl) {
-        const int blk = pos >> 6, kl = pos & 63, c = lane >> 1, e0 = 4 * (lane & 1);
-        uint2 kk;
-        kk.x = (uint32_t)q3_bf16(o4[0]) | ((uint32_t)q3_bf16(o4[1]) << 16); kk.y = (uint32_t)q3_bf16(o4[2]) | ((uint32_t)q3_bf16(o4[3]) << 16);
-        *(uint2*)(pr.kc + hb * hd + ((size_t)(blk * (hd >> 3) + c) * 64 + kl) * 8 + e0) = kk;
-        *(float4*)(kh + 4 * lane) = (float4){q3_round_bf16(o4[0]), q3_round_bf16(o4[1]), q3_round_bf16(o4[2]), q3_round_bf16(o4[3])};
-    }
-    __syncthreads();
-    const float* q = qh[hh];
-    const float scale = 1.0f / sqrtf((float)hd);
-    float sc = 0.0f;
-    if (lane == pos) {  // newest key: from LDS, same d-ascending chain
-        for (int d = 0; d < hd; d += 4) {
-            const float4 qa = *(const float4*)(q + d), ka = *(const float4*)(kh + d);
-            sc = fmaf(qa.x, ka.x, sc); sc = fmaf(qa.y, ka.y, sc); sc = fmaf(qa.z, ka.z, sc); sc = fmaf(qa.w, ka.w, sc);
-        }
-    } else {
+    const float* csp = pr.cs + (size_t)pos * half + 4 * (lane & 15);
+    const float* snp = pr.sn + (size_t)pos * half + 4 * (lane & 15);
+    if (wv == R) {
+        // ---- k (lanes 0..31) and v (lanes 32..63) of this row: norm + RoPE, bf16, append, and the LDS copies the query waves read
+        const bool isk = lane < nl;
+        const float4 x4 = isk ? ((const float4*)(rowp + (size_t)(a.Hq + g) * hd))[lane] : ((const float4*)(rowp + (size_t)(a.Hq + a.Hkv + g) * hd))[lane - nl];
+        float4 w4 = (float4){0.f, 0.f, 0.f, 0.f}, c4 = (float4){1.f, 1.f, 1.f, 1.f}, s4 = (float4){0.f, 0.f, 0.f, 0.f};
+        if (isk) { w4 = ((const float4*)pr.knw)[lane]; c4 = *(const float4*)csp; s4 = *(const float4*)snp; }
+        // prep_head's arithmetic, with the operands above (lanes >= 32 contribute +0 to the sum of squares, as there)
+        const float4 v = isk ? x4 : (float4){0.f, 0.f, 0.f, 0.f};
+        float acc = 0.0f;
+        acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+        acc = wave_sum(acc);
+        const float rinv = 1.0f / sqrtf(acc / (float)hd + pr.eps);
+        const float y[4] = {(v.x * rinv) * w4.x, (v.y * rinv) * w4.y, (v.z * rinv) * w4.z, (v.w * rinv) * w4.w};
+        const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+        float o[4];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const float4 qa = *(const float4*)(q + c * 8), qb = *(const float4*)(q + c * 8 + 4);
-            sc = fmaf(qa.x, q3_u2f(kv[c].x << 16), sc); sc = fmaf(qa.y, q3_u2f(kv[c].x & 0xffff0000u), sc);
-            sc = fmaf(qa.z, q3_u2f(kv[c].y << 16), sc); sc = fmaf(qa.w, q3_u2f(kv[c].y & 0xffff0000u), sc);
-            sc = fmaf(qb.x, q3_u2f(kv[c].z << 16), sc); sc = fmaf(qb.y, q3_u2f(kv[c].z & 0xffff0000u), sc);
-            sc = fmaf(qb.z, q3_u2f(kv[c].w << 16), sc); sc = fmaf(qb.w, q3_u2f(kv[c].w & 0xffff0000u), sc);
+        for (int e = 0; e < 4; ++e) {
+            const float other = __shfl_xor(y[e], 16);
+            o[e] = (lane < 16) ? fmaf(-other, ss[e], y[e] * cc[e]) : fmaf(other, ss[e], y[e] * cc[e]);
         }
+        if (isk) {
+            uint2 kk;
+            kk.x = (uint32_t)q3_bf16(o[0]) | ((uint32_t)q3_bf16(o[1]) << 16); kk.y = (uint32_t)q3_bf16(o[2]) | ((uint32_t)q3_bf16(o[3]) << 16);
+            const int blk = pos >> 6, kl = pos & 63, c = lane >> 1, e0 = 4 * (lane & 1);
+            *(uint2*)(pr.kc + hb * hd + ((size_t)(blk * (hd >> 3) + c) * 64 + kl) * 8 + e0) = kk;
+            *(uint2*)(knew + 2 * lane) = kk;   // elements 4 lane .. 4 lane + 3 = chunk lane / 2, half lane & 1
+        } else {
+            const int j = lane - nl;
+            uint2 vk;
+            vk.x = (uint32_t)q3_bf16(x4.x) | ((uint32_t)q3_bf16(x4.y) << 16); vk.y = (uint32_t)q3_bf16(x4.z) | ((uint32_t)q3_bf16(x4.w) << 16);
+            *(uint2*)(pr.vc + (hb + pos) * hd + 4 * j) = vk;
+            *(uint2*)(vnew + 2 * j) = vk;
+        }
+        Q3_STAMP(a, 1);
+        __syncthreads();
+        return;
     }
-    sc = sc * scale;
+    // ---- query head wv: operands first
+    const int hq = g * R + wv;
+    uint4 kv[16];
+    uint32_t vv[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) kv[c] = lane < pos ? ((const uint4*)kb)[c * 64 + lane] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) vv[u] = u < pos ? *(const uint32_t*)(vb + (size_t)u * hd + 2 * lane) : 0u;
+    float4 x4 = (float4){0.f, 0.f, 0.f, 0.f}, w4 = x4, c4 = (float4){1.f, 1.f, 1.f, 1.f}, s4 = x4;
+    if (lane < nl) { x4 = ((const float4*)(rowp + (size_t)hq * hd))[lane]; w4 = ((const float4*)pr.qnw)[lane]; c4 = *(const float4*)csp; s4 = *(const float4*)snp; }
+    {
+        float acc = 0.0f;
+        acc = fmaf(x4.x, x4.x, acc); acc = fmaf(x4.y, x4.y, acc); acc = fmaf(x4.z, x4.z, acc); acc = fmaf(x4.w, x4.w, acc);
+        acc = wave_sum(acc);
+        const float rinv = 1.0f / sqrtf(acc / (float)hd + pr.eps);
+        const float y[4] = {(x4.x * rinv) * w4.x, (x4.y * rinv) * w4.y, (x4.z * rinv) * w4.z, (x4.w * rinv) * w4.w};
+        const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float other = __shfl_xor(y[e], 16);
+            o[e] = (lane < 16) ? fmaf(-other, ss[e], y[e] * cc[e]) : fmaf(other, ss[e], y[e] * cc[e]);
+        }
+        if (lane < nl) *(float4*)(qh[wv] + 4 * lane) = (float4){o[0], o[1], o[2], o[3]};
+    }
+    Q3_STAMP(a, 1);
+    __syncthreads();
+    Q3_STAMP(a, 2);
+    if (lane == pos) {  // the newest key, in the packed form the cached keys arrive in
+#pragma unroll
+        for (int c = 0; c < 16; ++c) kv[c] = *(const uint4*)(knew + 4 * c);
+    }
+    const float* q = qh[wv];
+    float sc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const float4 qa = *(const float4*)(q + c * 8), qb = *(const float4*)(q + c * 8 + 4);
+        sc = fmaf(qa.x, q3_u2f(kv[c].x << 16), sc); sc = fmaf(qa.y, q3_u2f(kv[c].x & 0xffff0000u), sc);
+        sc = fmaf(qa.z, q3_u2f(kv[c].y << 16), sc); sc = fmaf(qa.w, q3_u2f(kv[c].y & 0xffff0000u), sc);
+        sc = fmaf(qb.x, q3_u2f(kv[c].z << 16), sc); sc = fmaf(qb.y, q3_u2f(kv[c].z & 0xffff0000u), sc);
+        sc = fmaf(qb.z, q3_u2f(kv[c].w << 16), sc); sc = fmaf(qb.w, q3_u2f(kv[c].w & 0xffff0000u), sc);
+    }
+    sc = sc * (1.0f / sqrtf((float)hd));
     const float m = wave_max(lane < T ? sc : -INFINITY);
     const float e = lane < T ? q3_expf(sc - m) : 0.0f;
-    ps[hh][lane] = e;
     float l = wave_sum(e);
     l = ((l + 0.0f) + 0.0f) + 0.0f;
-    float out8[8];
+#ifdef Q3_STAMPS
+    asm volatile("" :: "v"(l)); Q3_STAMP(a, 3);
+#endif
+    // value pass: this lane's dims d0 = 2 lane, d0 + 1; partial u holds the keys t = u, u + 16, ... in ascending order
+    float o0[16], o1[16];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) out8[i] = 0.0f;
+    for (int u = 0; u < 16; ++u) { o0[u] = 0.0f; o1[u] = 0.0f; }
+    const uint32_t vn = vnew[lane];
 #pragma unroll
-    for (int uu = 0; uu < 4; ++uu) {
-        float o[8];
+    for (int c = 0; c < 4; ++c) {
+        if (16 * c >= T) break;  // (uniform)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = 0.0f;
-        for (int t = 4 * uu + kg; t < T; t += 16) {
-            const float pt = ps[hh][t];
-            if (t == pos) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] = fmaf(pt, vh[dl * 8 + i], o[i]);
-            } else {
-                const uint4 vv = t < 16 ? vv0[uu] : *(const uint4*)(vb + (size_t)t * hd + dl * 8);
-                o[0] = fmaf(pt, q3_u2f(vv.x << 16), o[0]); o[1] = fmaf(pt, q3_u2f(vv.x & 0xffff0000u), o[1]);
-                o[2] = fmaf(pt, q3_u2f(vv.y << 16), o[2]); o[3] = fmaf(pt, q3_u2f(vv.y & 0xffff0000u), o[3]);
-                o[4] = fmaf(pt, q3_u2f(vv.z << 16), o[4]); o[5] = fmaf(pt, q3_u2f(vv.z & 0xffff0000u), o[5]);
-                o[6] = fmaf(pt, q3_u2f(vv.w << 16), o[6]); o[7] = fmaf(pt, q3_u2f(vv.w & 0xffff0000u), o[7]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float r = o[i] + __shfl_xor(o[i], 16);
-            r = r + __shfl_xor(r, 32);
-            out8[i] = uu == 0 ? r : out8[i] + r;
+        for (int u = 0; u < 16; ++u) {
+            const int t = 16 * c + u;
+            if (t >= T) break;  // (uniform)
+            uint32_t w;
+            if (t == pos) w = vn;
+            else if (c == 0) w = vv[u];
+            else w = *(const uint32_t*)(vb + (size_t)t * hd + 2 * lane);  // (caches beyond 16 keys: not the shipped Predictor)
+            const float pt = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e), t));  // (t is uniform: a scalar broadcast, no LDS)
+            o0[u] = fmaf(pt, q3_u2f(w << 16), o0[u]);
+            o1[u] = fmaf(pt, q3_u2f(w & 0xffff0000u), o1[u]);
         }
     }
-    if (kg == 0) {
+    float r0[4], r1[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int d = dl * 8 + i;
-            const float ov = out8[i] / l;
-            const size_t oi = (size_t)row * a.ldo + (size_t)(g * R + hh) * hd + d;
-            if (a.out_bf16) ((uint16_t*)a.out)[q3_atile_off(row, (g * R + hh) * hd + d, (a.Hq * hd) >> 5)] = q3_bf16(ov);
-            else a.out[oi] = ov;
-        }
+    for (int w = 0; w < 4; ++w) {
+        r0[w] = (o0[4 * w] + o0[4 * w + 1]) + (o0[4 * w + 2] + o0[4 * w + 3]);
+        r1[w] = (o1[4 * w] + o1[4 * w + 1]) + (o1[4 * w + 2] + o1[4 * w + 3]);
     }
+    const float ov0 = (((r0[0] + r0[1]) + r0[2]) + r0[3]) / l, ov1 = (((r1[0] + r1[1]) + r1[2]) + r1[3]) / l;
+    const int d0 = 2 * lane;
+    if (a.out_bf16) *(uint32_t*)((uint16_t*)a.out + q3_atile_off(row, hq * hd + d0, (a.Hq * hd) >> 5)) = (uint32_t)q3_bf16(ov0) | ((uint32_t)q3_bf16(ov1) << 16);
+    else *(float2*)(a.out + (size_t)row * a.ldo + (size_t)hq * hd + d0) = make_float2(ov0, ov1);
+#ifdef Q3_STAMPS
+    Q3_STAMP(a, 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    Q3_STAMP(a, 5);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -511,8 +562,8 @@ void q3_launch_attend(const Q3Attend& a, hipStream_t s) {
         return;
     }
     if (a.fused && a.n_ctx <= 64 && a.hd == 128 && (R == 1 || R == 2)) {  // short caches (the Predictor): one wave per query head
-        if (R == 2) hipLaunchKernelGGL((k_attend_small<2>), grid, dim3(128), 0, s, a);
-        else hipLaunchKernelGGL((k_attend_small<1>), grid, dim3(64), 0, s, a);
+        if (R == 2) hipLaunchKernelGGL((k_attend_small<2>), grid, dim3(192), 0, s, a);
+        else hipLaunchKernelGGL((k_attend_small<1>), grid, dim3(128), 0, s, a);
         return;
     }
     if (a.fused) {
