@@ -58,34 +58,13 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
     const u32x4* wp[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) wp[j] = (const u32x4*)g.w + ((size_t)(nb0 + j) * kblocks + kb0) * 64 + lane;
-    // weights first (HBM / Infinity Cache: the long latency), then the rows (L2); D steps of both stay in flight
-    u32x4 aq[D][RT], bq[D][NT];
-#pragma unroll
-    for (int s = 0; s < D; ++s)
-        if (s < per) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) bq[s][j] = bg_ldw(wp[j] + (size_t)s * 64, NTW);
-        }
-#pragma unroll
-    for (int s = 0; s < D; ++s)
-        if (s < per) {
-#pragma unroll
-            for (int i = 0; i < RT; ++i) aq[s][i] = ap[i][(size_t)s * 64];
-        }
-    // RESID: the residual operand is fetched up front instead of at the very end
-    constexpr int NOUT = (TR * 64 + 511) / 512;
-    float yres[NOUT];
-    if (g.epi == Q3_EPI_RESID) {
-#pragma unroll
-        for (int it = 0; it < NOUT; ++it) {
-            const int o = threadIdx.x + it * 512;
-            const int l = o & 63, e = (o >> 6) & 3, t = o >> 8, i = t / NT, j = t - i * NT;
-            const int row = row0 + 16 * i + 4 * (l >> 4) + e;
-            yres[it] = (o < TR * 64 && row < B) ? g.y[bg_yoff(g, row) + (size_t)(nb0 + j) * 16 + (l & 15)] : 0.0f;
-        }
-    }
-    // norm GEMMs: wave w owns the row scales of rows w, w + 8, ...; their tile partials are requested now and reduced after the main
-    // loop (lane j adds its tiles j, j + 64, ... in ascending order, then the 64-lane butterfly: DESIGN.md §4.2)
+    // Load order = the order the results are needed in (vmcnt retires in order): first the norm GEMMs' tile partials (a few hundred
+    // bytes per wave from L2), whose reduction to the row scales then runs WHILE the operands are in flight (in-kernel timestamps,
+    // tools/chain_stamps.hip: done after the main loop it cost ~1 us of every norm GEMM); then the weights (HBM / Infinity Cache: the
+    // long latency) and the rows (L2), D steps of both; last what only the epilogue reads (residual, next norm weight, bias, scale).
+    // Every load below is unconditional (out-of-range steps re-read step per - 1): straight-line code, so the counted waits are exact.
+    // norm GEMMs: wave w owns the row scales of rows w, w + 8, ...: lane j adds its tiles j, j + 64, ... in ascending order, then the
+    // 64-lane butterfly
     constexpr int NR = 2 * RT;
     float sp0[NR], sp1[NR];
     if (g.ssp) {
@@ -96,8 +75,69 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
             sp1[i] = lane + 64 < g.ntiles ? sp[lane + 64] : 0.0f;
         }
     }
+    u32x4 aq[D][RT], bq[D][NT];
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+        const size_t so = (size_t)min(s, per - 1) * 64;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bq[s][j] = bg_ldw(wp[j] + so, NTW);
+    }
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+        const size_t so = (size_t)min(s, per - 1) * 64;
+#pragma unroll
+        for (int i = 0; i < RT; ++i) aq[s][i] = ap[i][so];
+    }
+    // epilogue operands, fetched up front instead of at the very end (each was a dependent round trip behind the slice reduction)
+    constexpr int NOUT = (TR * 64 + 511) / 512;
+    float yres[NOUT], nwv[NOUT], bsv[NOUT], csv[NOUT];
+#pragma unroll
+    for (int it = 0; it < NOUT; ++it) { yres[it] = 0.0f; nwv[it] = 0.0f; bsv[it] = 0.0f; csv[it] = 1.0f; }
+    if (g.epi == Q3_EPI_RESID) {
+#pragma unroll
+        for (int it = 0; it < NOUT; ++it) {
+            const int o = threadIdx.x + it * 512;
+            const int l = o & 63, e = (o >> 6) & 3, t = o >> 8, i = t / NT, j = t - i * NT;
+            const int row = row0 + 16 * i + 4 * (l >> 4) + e, col = (nb0 + min(j, NT - 1)) * 16 + (l & 15);
+            const bool in = o < TR * 64;
+            yres[it] = (in && row < B) ? g.y[bg_yoff(g, row) + col] : 0.0f;
+            if (g.nw_next) nwv[it] = in ? g.nw_next[col] : 0.0f;
+            if (g.col_scale) csv[it] = in ? g.col_scale[col] : 1.0f;
+        }
+    }
+    if (g.bias && g.epi != Q3_EPI_SWIGLU) {
+#pragma unroll
+        for (int it = 0; it < NOUT; ++it) {
+            const int o = threadIdx.x + it * 512;
+            const int l = o & 63, t = o >> 8, i = t / NT, j = t - i * NT;
+            const int col = (nb0 + min(j, NT - 1)) * 16 + (l & 15);
+            bsv[it] = o < TR * 64 ? g.bias[col % g.bias_n] : 0.0f;
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
     Q3_STAMP(g, 1);
+    if (g.ssp) {  // the NR butterflies are independent chains: interleaved; they wait for the partials only (the first loads issued)
+        float av[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            float a = sp0[i];
+            if (lane + 64 < g.ntiles) a = a + sp1[i];
+            if (g.ntiles > 128) {
+                const float* sp = g.ssp + (size_t)min(row0 + wave + 8 * i, B - 1) * g.ld_ssp;
+                for (int t = lane + 128; t < g.ntiles; t += 64) a = a + sp[t];
+            }
+            av[i] = a;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+            for (int i = 0; i < NR; ++i) av[i] = av[i] + __shfl_xor(av[i], m);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) srow[wave + 8 * i] = 1.0f / sqrtf(av[i] / (float)g.d_norm + g.eps);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[RT][NT];
 #pragma unroll
     for (int i = 0; i < RT; ++i)
@@ -134,27 +174,6 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
 #ifdef Q3_STAMPS
     asm volatile("" :: "v"(acc[0][0][0])); Q3_STAMP(g, 3);
 #endif
-    if (g.ssp) {  // the NR butterflies are independent chains: interleaved
-        float av[NR];
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            float a = sp0[i];
-            if (lane + 64 < g.ntiles) a = a + sp1[i];
-            if (g.ntiles > 128) {
-                const float* sp = g.ssp + (size_t)min(row0 + wave + 8 * i, B - 1) * g.ld_ssp;
-                for (int t = lane + 128; t < g.ntiles; t += 64) a = a + sp[t];
-            }
-            av[i] = a;
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1)
-#pragma unroll
-            for (int i = 0; i < NR; ++i) av[i] = av[i] + __shfl_xor(av[i], m);
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < NR; ++i) srow[wave + 8 * i] = 1.0f / sqrtf(av[i] / (float)g.d_norm + g.eps);
-        }
-    }
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -165,6 +184,31 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
     Q3_STAMP(g, 4);
     // slice partials combined in slice order; element (tile t, reg e, lane l) -> row 16 i + 4 (l >> 4) + e, col 16 j + (l & 15)
     const int epi = g.epi;
+    if (epi == Q3_EPI_SWIGLU) {
+        // one thread per (gate, up) pair: pair p of the 32 in a (tile, register) block of 64 lanes sits in lanes l = 16 (p / 8) + p % 8 (gate,
+        // column c = p % 8 < 8 of the tile) and l + 8 (up, the same row 8 columns further); every thread has work (a loop over all
+        // TR * 64 elements left the up lanes idle: half of the epilogue's issue slots)
+        constexpr int NP = (TR * 32 + 511) / 512;
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            const int p = threadIdx.x + it * 512;
+            if (p >= TR * 32) break;  // (TR * 32 is a multiple of 128: whole waves leave together)
+            const int q = p & 31, l = ((q >> 3) << 4) + (q & 7), o = ((p >> 5) << 6) + l;
+            const int e = (o >> 6) & 3, t = o >> 8, i = t / NT, j = t - i * NT;
+            const int rl = 16 * i + 4 * (l >> 4) + e, row = row0 + rl, c = l & 15;
+            const float sc = g.ssp ? srow[rl] : 1.0f;
+            float gt = part[o], up = part[o + 8];
+#pragma unroll
+            for (int wv = 1; wv < 8; ++wv) { gt = gt + part[(size_t)wv * (TR * 64) + o]; up = up + part[(size_t)wv * (TR * 64) + o + 8]; }
+            if (row < B) g.yb[q3_atile_off(row, (nb0 + j) * 8 + c, g.N >> 6)] = q3_bf16(q3_swiglu(sc * gt, sc * up));
+        }
+#ifdef Q3_STAMPS
+        Q3_STAMP(g, 5);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        Q3_STAMP(g, 6);
+#endif
+        return;
+    }
 #pragma unroll
     for (int it = 0; it < NOUT; ++it) {
         const int o = threadIdx.x + it * 512;
@@ -174,29 +218,20 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
         const int col = (nb0 + j) * 16 + c;
         const bool live = row < B;
         const float sc = g.ssp ? srow[rl] : 1.0f;
-        if (epi == Q3_EPI_SWIGLU) {
-            // gate lanes (column < 8 of a tile) finish one output each: swiglu(s * gate, s * up), up = the same row 8 columns further
-            if (c >= 8) continue;
-            float gt = part[o], up = part[o + 8];
-#pragma unroll
-            for (int wv = 1; wv < 8; ++wv) { gt = gt + part[(size_t)wv * (TR * 64) + o]; up = up + part[(size_t)wv * (TR * 64) + o + 8]; }
-            if (live) g.yb[q3_atile_off(row, (nb0 + j) * 8 + c, g.N >> 6)] = q3_bf16(q3_swiglu(sc * gt, sc * up));
-            continue;
-        }
         float v = part[o];
 #pragma unroll
         for (int wv = 1; wv < 8; ++wv) v = v + part[(size_t)wv * (TR * 64) + o];
-        if (g.bias) v = v + g.bias[col % g.bias_n];
+        if (g.bias) v = v + bsv[it];
         if (epi == Q3_EPI_STORE) {
             if (live) g.y[bg_yoff(g, row) + col] = g.ssp ? sc * v : v;
         } else if (epi == Q3_EPI_GELU) {
             if (live) g.yb[q3_atile_off(row, col, g.N >> 5)] = q3_bf16(bg_gelu_erf(v));
         } else if (epi == Q3_EPI_RESID) {
-            const float xv = g.col_scale ? yres[it] + g.col_scale[col] * v : yres[it] + v;
+            const float xv = g.col_scale ? yres[it] + csv[it] * v : yres[it] + v;
             if (live) g.y[bg_yoff(g, row) + col] = xv;
             if (g.yb && !g.nw_next && live) g.yb[q3_atile_off(row, col, g.N >> 5)] = q3_bf16(xv);
             if (g.nw_next) {  // the consumer's norm inputs: bf16(x * nw) and the tile's sum of squares (16-lane butterfly)
-                if (live) g.yb[q3_atile_off(row, col, g.N >> 5)] = q3_bf16(xv * g.nw_next[col]);
+                if (live) g.yb[q3_atile_off(row, col, g.N >> 5)] = q3_bf16(xv * nwv[it]);
                 float sq = xv * xv;
                 sq = sq + __shfl_xor(sq, 1); sq = sq + __shfl_xor(sq, 2); sq = sq + __shfl_xor(sq, 4); sq = sq + __shfl_xor(sq, 8);
                 if (live && c == 0) g.ssp_out[(size_t)row * g.ld_ssp_out + (nb0 + j)] = sq;

@@ -184,7 +184,11 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
             if (lane < nl) {
                 const float4 vv = ((const float4*)(rowp + (size_t)(a.Hq + a.Hkv + g) * hd))[lane];
                 kv_append(pr.kc, pr.vc, hb, hd, pos, lane, o, vv);
-                *(float4*)(kh + 4 * lane) = (float4){q3_round_bf16(o[0]), q3_round_bf16(o[1]), q3_round_bf16(o[2]), q3_round_bf16(o[3])};
+                // the newest key in the cache's own packed form (bf16 pairs, chunk c = 16 bytes at kh + 4 c words): the lane that owns it
+                // then runs the same chain as every cached key (an LDS-fed float chain of its own cost ~1.5 us of this kernel)
+                uint2 kk;
+                kk.x = (uint32_t)q3_bf16(o[0]) | ((uint32_t)q3_bf16(o[1]) << 16); kk.y = (uint32_t)q3_bf16(o[2]) | ((uint32_t)q3_bf16(o[3]) << 16);
+                *(uint2*)((uint32_t*)kh + 2 * lane) = kk;
                 *(float4*)(vh + 4 * lane) = (float4){q3_round_bf16(vv.x), q3_round_bf16(vv.y), q3_round_bf16(vv.z), q3_round_bf16(vv.w)};
             }
         }
@@ -208,6 +212,10 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
             uint4 kv[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) kv[c] = kp[c * 64];
+            if (FUSED && t == pos) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) kv[c] = *(const uint4*)((const uint32_t*)kh + 4 * c);
+            }
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 const float4 qa = *(const float4*)(q + c * 8), qb = *(const float4*)(q + c * 8 + 4);
@@ -218,19 +226,12 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
             }
         } else
         for (int c = 0; c < nch; ++c) {
-            const uint4 kv = kp[c * 64];
+            const uint4 kv = (FUSED && t == pos) ? *(const uint4*)((const uint32_t*)kh + 4 * c) : kp[c * 64];
             const float* qc = q + c * 8;
             s = fmaf(qc[0], q3_u2f(kv.x << 16), s); s = fmaf(qc[1], q3_u2f(kv.x & 0xffff0000u), s);
             s = fmaf(qc[2], q3_u2f(kv.y << 16), s); s = fmaf(qc[3], q3_u2f(kv.y & 0xffff0000u), s);
             s = fmaf(qc[4], q3_u2f(kv.z << 16), s); s = fmaf(qc[5], q3_u2f(kv.z & 0xffff0000u), s);
             s = fmaf(qc[6], q3_u2f(kv.w << 16), s); s = fmaf(qc[7], q3_u2f(kv.w & 0xffff0000u), s);
-        }
-        if (FUSED && t == pos) {  // newest key: from LDS, same d-ascending chain (float4 reads)
-            s = 0.0f;
-            for (int d = 0; d < hd; d += 4) {
-                const float4 qa = *(const float4*)(q + d), ka = *(const float4*)(kh + d);
-                s = fmaf(qa.x, ka.x, s); s = fmaf(qa.y, ka.y, s); s = fmaf(qa.z, ka.z, s); s = fmaf(qa.w, ka.w, s);
-            }
         }
         s = s * scale;
         if (t < T) { p[t] = s; mloc = fmaxf(mloc, s); }
