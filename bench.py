@@ -180,6 +180,45 @@ def batch_parity(cfg, spk, meta, outs, picks, n_frames=8):
     return rep
 
 
+def node_main(args):
+    """`python bench.py --gpus N --node`: the same workload (N x batch utterances, the global list of make_workload) through the
+    library's own multi-GPU entry points (q3tts_node_*, include/q3tts.h): ONE process, one engine + one host thread per GPU, requests
+    sharded by index (i mod N), the i16 PCM gathered to GPU 0 with RCCL over xGMI. The driver's N > 1 runs use one process per GPU
+    (torch.distributed); this leg measures the path a Rust host would call."""
+    from q3tts import _abi, native
+    n = args.gpus
+    cfg = _abi.tiny_config(max_batch=min(64, args.batch), n_ctx=1024) if args.tiny else _abi.full_config_py()
+    cfg.max_batch, cfg.n_ctx, cfg.max_steps_cap = min(64, args.batch), (1024 if args.tiny else args.n_ctx), 512
+    cfg.with_vocoder = 1
+    spk = vivian()[:cfg.model.d_embed]
+    keepalive = []
+    reqs, frames = make_workload(args.batch * n, 0, 1, spk, keepalive, 1)
+    node = native.NativeNode(cfg, list(range(n)))
+    for _ in range(args.warmup):
+        node.generate_batch(reqs, gather_i16=True)
+    t0 = time.perf_counter()
+    gather_ms = gen_ms = 0.0
+    for _ in range(args.steps):
+        outs = node.generate_batch(reqs, gather_i16=True)
+        tm = node.timings()
+        gather_ms += tm.gather_ms; gen_ms += tm.generate_ms
+    elapsed = time.perf_counter() - t0
+    assert all(o.status == 0 for o in outs) and [o.n_frames for o in outs] == frames
+    assert all(o.pcm_i16 is not None and o.pcm_i16.size == o.n_frames * 1920 for o in outs)
+    audio = sum(frames) * FRAME_SEC * args.steps
+    line = {"metric": "audio_sec_per_s", "value": round(audio / elapsed, 2), "unit": "audio-sec/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[%d] through q3tts_node_* (one process, one engine + host thread per GPU): %d x %d mixed-length prompts sharded by index, "
+                                   "temperature=0.7 top-k=40 top-p=0.9, prompt ids -> codec ids -> 24 kHz PCM -> i16 gathered to GPU 0 (RCCL) -> host" % (3 if n > 1 else 2, n, args.batch),
+                       "utterances_per_gpu": args.batch, "n_ctx": cfg.n_ctx, "with_vocoder": True},
+            "node": {"generate_ms_per_step": round(gen_ms / args.steps, 2), "gather_ms_per_step": round(gather_ms / args.steps, 3), "gathered_bytes_per_step": int(tm.gathered_bytes)},
+            "value_without_gather": round(audio / max(elapsed - gather_ms * 1e-3, 1e-9), 2)}
+    if args.tiny:
+        line["invalid"] = "test run on the tiny shape"
+    node.close()
+    print(json.dumps(line), flush=True)
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (this parent never initialises a GPU) and
     relay rank 0's JSON line. Every child is polled: if one exits non-zero (bad device, out of memory) the others — which would sit in
@@ -238,8 +277,11 @@ def main():
     ap.add_argument("--probe-only", nargs="?", const="talker", default=None, choices=["talker", "predictor", "vocoder"],
                     help=f"run only one probe leg (the commands profiled for profiles/{ROUND}/*): the Talker's gate/up (default), the Predictor's, or the vocoder alone")
     ap.add_argument("--tiny", action="store_true", help="tests only: the small shape of the parity tests instead of the 1.7B shape (the JSON line is marked invalid)")
+    ap.add_argument("--node", action="store_true", help="one process: the library's q3tts_node_* entry points drive all --gpus devices (instead of one rank process per GPU)")
     args = ap.parse_args()
 
+    if args.node:
+        return node_main(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 

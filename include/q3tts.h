@@ -180,6 +180,37 @@ int q3tts_stream_begin(q3tts_engine* e, const q3tts_request* req, q3tts_stream**
 int q3tts_stream_poll(q3tts_stream* s, const float** chunk, int32_t* n_samples, int32_t* is_final);
 int q3tts_stream_end(q3tts_stream* s, q3tts_result* out_codes_optional);
 
+/* ---- one node, several GPUs ----------------------------------------------------------------------
+ * The reference is one utterance at a time on one device (n_seq_max = 1, src/models/llama/mod.rs:413; `&mut self`,
+ * src/tts/engine.rs:390). Utterances share nothing but read-only weights, so a batch shards over independent units:
+ * q3tts_node_create builds one engine (full weight replica) and one host thread per listed device; request i of a
+ * q3tts_node_generate_batch call runs on device i mod n_devices (order preserved, results independent of n_devices: the
+ * sampler stream is a function of req->seed only). There is no data-path collective. With pcm_i16 != NULL the finished
+ * PCM stays on the devices, is converted there to 16-bit samples exactly as the reference saves audio
+ * (src/utils/audio.rs:35-37: (x * 32767).clamp(-32768, 32767) as i16) and gathered to the FIRST listed device with RCCL
+ * over xGMI — one ncclAllGather of the per-utterance sample counts, one group of ncclSend / ncclRecv — then copied to the
+ * host once: pcm_i16[i] = malloc'd [outs[i].n_samples] samples of request i (release with q3tts_free; outs[i].pcm stays
+ * NULL). With pcm_i16 == NULL requests behave as in q3tts_generate_batch (want_pcm = 1: f32 PCM in host memory) and RCCL
+ * is never loaded. RCCL is resolved at run time (librccl.so.1); a node handle is not re-entrant. */
+typedef struct q3tts_node q3tts_node;
+typedef struct q3tts_node_timings {
+    float generate_ms;      /* slowest device: its q3tts_generate_batch wall time */
+    float gather_ms;        /* pack + collectives + copy to the host (0 without pcm_i16) */
+    float total_ms;
+    int64_t gathered_bytes; /* i16 PCM bytes that reached the host through device 0 */
+    int32_t n_devices;
+} q3tts_node_timings;
+int q3tts_node_create(const q3tts_engine_config* cfg /* .device is ignored */, const int32_t* devices, int32_t n_devices, q3tts_node** out);
+void q3tts_node_destroy(q3tts_node* n);
+int q3tts_node_generate_batch(q3tts_node* n, const q3tts_request* reqs, int32_t n_reqs, q3tts_result* outs, int16_t** pcm_i16 /* [n_reqs] or NULL */);
+int q3tts_node_get_timings(const q3tts_node* n, q3tts_node_timings* out);
+const char* q3tts_node_last_error(const q3tts_node* n);
+int32_t q3tts_node_size(const q3tts_node* n);
+q3tts_engine* q3tts_node_engine(q3tts_node* n, int32_t rank);  /* the engine of device `rank` (sampler defaults, timings); owned by the node */
+/* Host only: the global request indices device `rank` of `world` owns, in order ({i : i mod world == rank}); returns the count
+ * (idx may be NULL to query it), -1 on bad arguments. */
+int32_t q3tts_node_shard(int32_t n_total, int32_t world, int32_t rank, int32_t* idx, int32_t cap);
+
 /* Per-stage device timings of the last generate call (hipEvent), ms. */
 typedef struct q3tts_timings {
     float prefill_ms, decode_ms, vocoder_ms, total_ms;

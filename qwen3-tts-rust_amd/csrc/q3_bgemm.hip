@@ -438,15 +438,16 @@ struct BgInst {
 };
 // once per process, outside any stream capture (the engine calls it before it records its graphs)
 static int g_big_policy = 0;  // Q3TTS_BG_BIG, read once: 1 = the many-row kernel whenever it is eligible, -1 = never, 0 = when it fills the chip
-void q3_bgemm_prepare() {
-    static bool done = false;
-    if (done) return;
-    { const char* ev = getenv("Q3TTS_BG_BIG"); g_big_policy = ev ? atoi(ev) : 0; }
-    hipFuncSetAttribute((const void*)k_bgemm_big, hipFuncAttributeMaxDynamicSharedMemorySize, BB_NS * 16384);
+void q3_bgemm_prepare() {  // once per DEVICE (function attributes are per device: q3tts_node_* drives several from one process)
+    static Q3PerDevice pd;
+    static std::once_flag env_once;
+    std::call_once(env_once, []() { const char* ev = getenv("Q3TTS_BG_BIG"); g_big_policy = ev ? atoi(ev) : 0; });
+    pd.ensure(1, []() {
+        hipFuncSetAttribute((const void*)k_bgemm_big, hipFuncAttributeMaxDynamicSharedMemorySize, BB_NS * 16384);
 #define P(RT_, NT_) BgInst<RT_, NT_>::prepare();
-    P(1, 1) P(1, 2) P(1, 3) P(2, 1) P(2, 2) P(2, 3) P(3, 1) P(3, 2) P(3, 3) P(4, 1) P(4, 2) P(4, 3)
+        P(1, 1) P(1, 2) P(1, 3) P(2, 1) P(2, 2) P(2, 3) P(3, 1) P(3, 2) P(3, 3) P(4, 1) P(4, 2) P(4, 3)
 #undef P
-    done = true;
+    });
 }
 
 // Tile choice: a launch is bound by the operand bytes a CU's load path takes in (x from L2, weights from HBM / L2), so pick the

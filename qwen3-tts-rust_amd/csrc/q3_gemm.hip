@@ -571,12 +571,11 @@ template <int RT, int NT>
 static void launch_fat(const Q3Gemm& g, dim3 grid, hipStream_t s) {
     const bool norm = g.norm_w != nullptr;
     const size_t lds = ((size_t)8 * RT * 16 * (NT * 16 + 1) + (size_t)RT * 16 * NT * 16 + (norm ? (size_t)g.K : 0)) * 4;
-    static size_t attr = 0;  // dynamic LDS above 64 KiB has to be allowed per kernel (K <= 8192 bounds it)
-    if (lds > attr) {
+    static Q3PerDevice pd;  // dynamic LDS above 64 KiB has to be allowed per kernel and per device (K <= 8192 bounds it)
+    pd.ensure(lds, [&]() {
         hipFuncSetAttribute((const void*)k_gemm_fat<RT, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute((const void*)k_gemm_fat<RT, NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = lds;
-    }
+    });
     if (norm) hipLaunchKernelGGL((k_gemm_fat<RT, NT, true>), grid, dim3(256), lds, s, g);
     else hipLaunchKernelGGL((k_gemm_fat<RT, NT, false>), grid, dim3(256), lds, s, g);
 }

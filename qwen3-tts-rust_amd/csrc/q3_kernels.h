@@ -14,6 +14,19 @@ enum { Q3_EPI_STORE = 0, Q3_EPI_RESID = 1, Q3_EPI_SWIGLU = 2, Q3_EPI_ARGMAX = 3,
 #define Q3_STAMP(p, i) do { } while (0)
 #endif
 
+// Kernel attributes (dynamic LDS above 64 KiB) belong to a function ON A DEVICE: a process that drives several GPUs (q3tts_node_*)
+// has to set them once per device, not once per process. need(dev_value) returns true when the current device has not yet been given
+// a value >= dev_value; the caller then sets the attribute and calls done(dev_value). One lock per launch site, uncontended.
+#include <mutex>
+struct Q3PerDevice {
+    std::mutex mu; size_t have[64] = {0};
+    template <class F> void ensure(size_t want, F set_attr) {
+        int dev = 0; if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        std::lock_guard<std::mutex> lk(mu);
+        if (have[dev & 63] < want) { set_attr(); have[dev & 63] = want; }
+    }
+};
+
 // Exact GEMM y[B][N] = x[B][K] * W[N][K]^T in the canonical order of DESIGN.md §4.1.
 // W is bf16 in the tiled HBM layout of DESIGN.md §2.1: tile (nb = n/16, kb = k/32) is 1 KiB,
 // lane l = (kq = l>>4, n = l&15) owns the 8 weights W[nb*16+n][kb*32+kq*8 .. +8].

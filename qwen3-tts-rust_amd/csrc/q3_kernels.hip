@@ -549,15 +549,15 @@ void q3_launch_attend(const Q3Attend& a, hipStream_t s) {
     const int R = a.Hq / a.Hkv;
     const size_t lds = ((size_t)R * a.n_ctx + R * a.hd + R * 4 * a.hd + R * 8 + 2 * a.hd) * sizeof(float);
     dim3 grid(a.Hkv, a.rows);
-    static size_t attr = 0;  // the score buffer is R * n_ctx floats: above 64 KiB the dynamic LDS size has to be allowed per kernel
-    if (lds > 65536 && lds > attr) {
-        hipFuncSetAttribute((const void*)k_attend<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)k_attend<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)k_attend<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)k_attend<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)k_attend<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = lds;
-    }
+    static Q3PerDevice pd;  // the score buffer is R * n_ctx floats: above 64 KiB the dynamic LDS size has to be allowed per kernel (and per device)
+    if (lds > 65536)
+        pd.ensure(lds, [&]() {
+            hipFuncSetAttribute((const void*)k_attend<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute((const void*)k_attend<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute((const void*)k_attend<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute((const void*)k_attend<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute((const void*)k_attend<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        });
     if (a.fused == 2) {  // two rows per slot, empty cache (the Predictor's pass A): see k_attend_pair
         hipLaunchKernelGGL(k_attend_pair, dim3(a.Hkv, a.slot_mod), dim3(256), 0, s, a);
         return;

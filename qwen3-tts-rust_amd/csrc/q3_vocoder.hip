@@ -478,8 +478,8 @@ __global__ __launch_bounds__(256) void k_vgemm_ring(VGemm g) {
 template <int NJ>
 static void launch_vgemm_ring(hipStream_t s, const VGemm& g, dim3 grid) {
     constexpr size_t lds_ring = (size_t)VR_NS * (128 + NJ * 32) * 64, lds_out = (size_t)128 * (NJ * 32 + 4) * 4, lds = lds_ring > lds_out ? lds_ring : lds_out;
-    static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute((const void*)k_vgemm_ring<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    static Q3PerDevice pd;
+    pd.ensure(lds, [&]() { hipFuncSetAttribute((const void*)k_vgemm_ring<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
     hipLaunchKernelGGL((k_vgemm_ring<NJ>), grid, dim3(256), lds, s, g);
 }
 
@@ -1198,8 +1198,8 @@ template <int NT, int MT>
 static void launch_resunit_t(hipStream_t s, const VResUnit& g, int ns) {
     constexpr int C = NT * 16, R = 64 * MT, LDA = C + 16;
     const size_t lds = std::max(((size_t)(R + 6 * g.dil) * LDA + (size_t)2 * C * 32) * 2, (size_t)R * (C + 4) * 4);  // input tile + weight ring, later the f32 output tile
-    static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute((const void*)k_voc_resunit<NT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr_set = true; }
+    static Q3PerDevice pd;
+    pd.ensure(1, []() { hipFuncSetAttribute((const void*)k_voc_resunit<NT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); });
     hipLaunchKernelGGL((k_voc_resunit<NT, MT>), dim3((g.T + R - 1) / R, ns), dim3(256), lds, s, g);
 }
 static void launch_resunit(hipStream_t s, const VRes& r, int ns, int T, int C, float* o, int store_o, const VSnake& sk) {

@@ -94,6 +94,10 @@ class Timings(C.Structure):
     ]
 
 
+class NodeTimings(C.Structure):
+    _fields_ = [("generate_ms", C.c_float), ("gather_ms", C.c_float), ("total_ms", C.c_float), ("gathered_bytes", C.c_int64), ("n_devices", C.c_int32)]
+
+
 class CloneConfig(C.Structure):
     """q3tts_clone_config: the two encoders of the voice-clone front-end (include/q3tts.h)."""
     _fields_ = [
@@ -118,7 +122,7 @@ SYMBOLS = [
     "q3tts_k_vocoder", "q3tts_k_vocoder_bench", "q3tts_set_device_pcm", "q3tts_get_device_pcm", "q3tts_k_rng_f32", "q3tts_k_probe", "q3tts_k_gguf_read", "q3tts_mel_frames", "q3tts_mel",
     "q3tts_clone_default_config", "q3tts_clone_init", "q3tts_clone_audio_frames", "q3tts_clone_audio_encode",
     "q3tts_clone_speaker_encode", "q3tts_k_speaker_from_mel", "q3tts_k_audio_latent",
-    "q3tts_k_alloc_upload", "q3tts_k_bgemm_policy", "q3tts_k_mfma_bf16", "q3tts_k_bgemm", "q3tts_k_bgemm_voc", "q3tts_k_project", "q3tts_k_norm_inputs", "q3tts_tokenizer_load", "q3tts_tokenizer_free", "q3tts_tokenizer_vocab_size", "q3tts_tokenizer_encode", "q3tts_tokenizer_decode",
+    "q3tts_node_create", "q3tts_node_destroy", "q3tts_node_generate_batch", "q3tts_node_get_timings", "q3tts_node_last_error", "q3tts_node_size", "q3tts_node_engine", "q3tts_node_shard", "q3tts_k_alloc_upload", "q3tts_k_bgemm_policy", "q3tts_k_mfma_bf16", "q3tts_k_bgemm", "q3tts_k_bgemm_voc", "q3tts_k_project", "q3tts_k_norm_inputs", "q3tts_tokenizer_load", "q3tts_tokenizer_free", "q3tts_tokenizer_vocab_size", "q3tts_tokenizer_encode", "q3tts_tokenizer_decode",
 ]
 
 
@@ -195,6 +199,19 @@ def load_library(path=None):
     lib.q3tts_k_norm_inputs.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.q3tts_k_bgemm_voc.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                       C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+    lib.q3tts_node_create.argtypes = [C.POINTER(EngineConfig), i32p, C.c_int32, C.POINTER(vp)]
+    lib.q3tts_node_destroy.argtypes = [vp]
+    lib.q3tts_node_destroy.restype = None
+    lib.q3tts_node_generate_batch.argtypes = [vp, C.POINTER(Request), C.c_int32, C.POINTER(Result), C.POINTER(C.POINTER(C.c_int16))]
+    lib.q3tts_node_get_timings.argtypes = [vp, C.POINTER(NodeTimings)]
+    lib.q3tts_node_last_error.argtypes = [vp]
+    lib.q3tts_node_last_error.restype = C.c_char_p
+    lib.q3tts_node_size.argtypes = [vp]
+    lib.q3tts_node_size.restype = C.c_int32
+    lib.q3tts_node_engine.argtypes = [vp, C.c_int32]
+    lib.q3tts_node_engine.restype = vp
+    lib.q3tts_node_shard.argtypes = [C.c_int32, C.c_int32, C.c_int32, i32p, C.c_int32]
+    lib.q3tts_node_shard.restype = C.c_int32
     lib.q3tts_k_bgemm_policy.argtypes = [C.c_int32]
     lib.q3tts_k_alloc_upload.argtypes = [vp, C.c_int64, C.POINTER(C.c_int64)]
     lib.q3tts_tokenizer_load.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_int32]

@@ -251,6 +251,76 @@ class NativeEngine:
 
 # ---- kernel-level hooks (host arrays in / out) -------------------------------------------------
 
+class NativeNode:
+    """q3tts_node_*: one engine + one host thread per listed GPU inside the library, requests sharded by index (i mod G), the PCM of a
+    batch optionally gathered to the first device as i16 over RCCL (include/q3tts.h)."""
+
+    def __init__(self, cfg, devices):
+        self.lib = _abi.load_library()
+        self.cfg = cfg
+        self.devices = [int(d) for d in devices]
+        arr = (C.c_int32 * len(self.devices))(*self.devices)
+        self.h = C.c_void_p()
+        rc = self.lib.q3tts_node_create(C.byref(cfg), arr, len(self.devices), C.byref(self.h))
+        if rc != 0:
+            raise _abi.Q3Error(f"q3tts_node_create failed ({rc}): {self.lib.q3tts_node_last_error(None).decode()}")
+
+    def close(self):
+        if self.h:
+            self.lib.q3tts_node_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        self.close()
+
+    def generate_batch(self, requests, gather_i16=False):
+        """requests: kwargs dicts for NativeEngine.make_request. Returns GenResult list; with gather_i16 every result carries .pcm_i16
+        (np.int16, gathered through device 0) instead of .pcm."""
+        n = len(requests)
+        arr = (_abi.Request * n)()
+        keep = []
+        for i, kw in enumerate(requests):
+            r, k = NativeEngine.make_request(**kw)
+            arr[i] = r
+            keep.append(k)
+        res = (_abi.Result * n)()
+        i16 = (C.POINTER(C.c_int16) * n)() if gather_i16 else None
+        rc = self.lib.q3tts_node_generate_batch(self.h, arr, n, res, i16)
+        if rc != 0:
+            raise _abi.Q3Error(f"q3tts_node_generate_batch failed ({rc}): {self.lib.q3tts_node_last_error(self.h).decode()}")
+        ncb = self.cfg.model.n_codebooks
+        outs = []
+        for i in range(n):
+            r = res[i]
+            codes = np.ctypeslib.as_array(r.codes, shape=(r.n_frames, ncb)).copy() if r.n_frames > 0 else np.zeros((0, ncb), dtype=np.int32)
+            pcm = np.ctypeslib.as_array(r.pcm, shape=(r.n_samples,)).copy() if (r.pcm and r.n_samples > 0) else None
+            o = GenResult(r.status, codes, pcm, bool(r.hit_eos), r.first_chunk_ms, r.total_ms, r.sample_rate)
+            o.n_samples = int(r.n_samples)
+            o.pcm_i16 = None
+            if gather_i16 and i16[i]:
+                o.pcm_i16 = np.ctypeslib.as_array(i16[i], shape=(r.n_samples,)).copy()
+                self.lib.q3tts_free(C.cast(i16[i], C.c_void_p))
+            self.lib.q3tts_result_free(C.byref(r))
+            outs.append(o)
+        return outs
+
+    def timings(self):
+        t = _abi.NodeTimings()
+        self.lib.q3tts_node_get_timings(self.h, C.byref(t))
+        return t
+
+
+def node_shard(n_total, world, rank):
+    """q3tts_node_shard (host only): the global request indices device `rank` of `world` owns, in order."""
+    lib = _abi.load_library()
+    k = lib.q3tts_node_shard(n_total, world, rank, None, 0)
+    if k < 0:
+        raise ValueError("bad shard arguments")
+    idx = np.zeros(max(k, 1), dtype=np.int32)
+    lib.q3tts_node_shard(n_total, world, rank, _ptr(idx, i32p), k)
+    return idx[:k].tolist()
+
+
 def k_gemm_exact(x, w_bf16, norm_w=None, eps=1e-6, bias=None, epilogue=0, y_in=None, device=0, iters=0):
     lib = _abi.load_library()
     x = np.ascontiguousarray(x, dtype=np.float32)

@@ -63,3 +63,52 @@ def test_two_ranks_give_the_ids_of_one_rank_for_the_same_global_indices(tmp_path
             assert two[k].shape == one[k].shape and two[k].shape[0] >= 25 and np.array_equal(two[k], one[k]), k
             seen.add(k)
     assert len(seen) == 6
+
+
+def test_node_api_one_device_gathers_the_reference_i16_pcm():
+    """Multi-GPU behind the C ABI (q3tts_node_*) with the one device of this box: the same code path an 8-GPU node runs — engine
+    thread, device-side i16 packing, ncclCommInitAll, the all-gather of the sample counts, the (here empty) send / receive group, one
+    copy to the host. ids equal a plain engine's for the same requests; the gathered i16 equals the reference's conversion
+    (src/utils/audio.rs:35-37) of that engine's f32 PCM; without the gather the node hands back the f32 PCM itself."""
+    sys.path.insert(0, os.path.join(REPO, "qwen3-tts-rust_amd")); sys.path.insert(0, os.path.join(REPO, "tests"))
+    import _oracle as O
+    from q3tts import _abi, native
+    cfg = _abi.tiny_config(max_batch=4, n_ctx=256, with_vocoder=1)
+    rng = np.random.default_rng(77)
+    reqs, keep = [], []
+    for i in range(7):   # more requests than slots: slot re-use inside the node's engine
+        spk = ((np.arange(cfg.model.d_embed) % 13 - 6) * 0.03125).astype(np.float32)
+        desc, k = O.make_prompt_desc(rng.integers(0, 151643, size=int(rng.integers(3, 12))), spk_emb=spk)
+        keep.append((desc, k))
+        t = int(rng.integers(3, 14))
+        reqs.append(dict(desc=desc, temperature=0.7, top_k=40, top_p=0.9, seed=500 + i, max_steps=20, min_frames=t, force_eos_at=t, want_pcm=1))
+    eng = native.NativeEngine(cfg)
+    try:
+        plain = eng.generate_batch(reqs)
+    finally:
+        eng.close()
+    node = native.NativeNode(cfg, [0])
+    try:
+        got = node.generate_batch(reqs, gather_i16=True)
+        tm = node.timings()
+        again = node.generate_batch(reqs, gather_i16=False)
+    finally:
+        node.close()
+    assert tm.n_devices == 1 and tm.gathered_bytes == 2 * sum(o.n_samples for o in plain) and tm.gather_ms > 0
+    for a, b, c in zip(plain, got, again):
+        assert b.status == 0 and np.array_equal(a.codes, b.codes) and np.array_equal(a.codes, c.codes)
+        want = np.trunc(np.clip(a.pcm.astype(np.float32) * np.float32(32767.0), -32768.0, 32767.0)).astype(np.int16)
+        assert b.pcm is None and b.pcm_i16 is not None and np.array_equal(b.pcm_i16, want)
+        assert c.pcm is not None and np.array_equal(c.pcm, a.pcm)
+    print(f"node API, 1 device: 7 utterances, {tm.gathered_bytes} bytes gathered in {tm.gather_ms:.2f} ms (generate {tm.generate_ms:.1f} ms)")
+
+
+def test_bench_node_mode_one_gpu():
+    """bench.py --node (the q3tts_node_* leg) on the one GPU of this box."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--node", "--tiny", "--batch", "5", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["node"]["gathered_bytes_per_step"] > 5 * 25 * 1920 * 2 - 1

@@ -222,3 +222,18 @@ def test_bench_spawn_ranks_fails_fast_when_a_rank_dies():
                        capture_output=True, text=True, timeout=240)
     assert p.returncode != 0 and "rank 1 exited with 3" in p.stderr, (p.returncode, p.stderr[-500:])
     assert time.time() - t0 < 120
+
+
+def test_node_shard_order_matches_the_python_sharding():
+    """q3tts_node_shard (host only, no GPU): device r of G owns {i : i mod G == r} in order — the partition q3tts/dist.py and bench.py
+    use across processes; sharding followed by reassembly is the identity for every (n, G), empty shards included."""
+    from q3tts import dist as qd
+    from q3tts import native
+    for n in (0, 1, 7, 64, 65, 512):
+        for G in (1, 2, 3, 8):
+            parts = [native.node_shard(n, G, r) for r in range(G)]
+            assert parts == [qd.shard_indices(n, r, G) for r in range(G)]
+            assert sorted(i for p in parts for i in p) == list(range(n))
+            assert qd.reassemble([[f"u{i}" for i in p] for p in parts], n, G) == [f"u{i}" for i in range(n)]
+    with pytest.raises(ValueError):
+        native.node_shard(4, 2, 2)
