@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 FRAME_SEC = 0.08  # 1 frame = 16 codes = 1920 samples @ 24 kHz (reference: src/tts/engine.rs:509-512,653)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
-ROUND = "r02"
+ROUND = "r03"
 
 
 def vivian():
@@ -276,6 +276,7 @@ def main():
     ap.add_argument("--no-probe", action="store_true", help="skip the in-situ dominant-kernel measurement (roofline.achieved falls back to the whole frame step)")
     ap.add_argument("--probe-only", nargs="?", const="talker", default=None, choices=["talker", "predictor", "vocoder"],
                     help=f"run only one probe leg (the commands profiled for profiles/{ROUND}/*): the Talker's gate/up (default), the Predictor's, or the vocoder alone")
+    ap.add_argument("--probe-kind", type=int, default=0, help="with --probe-only talker / predictor: 0 gate/up GEMM (default), 1 QKV GEMM, 2 attention, 3 O projection, 4 down projection")
     ap.add_argument("--tiny", action="store_true", help="tests only: the small shape of the parity tests instead of the 1.7B shape (the JSON line is marked invalid)")
     ap.add_argument("--node", action="store_true", help="one process: the library's q3tts_node_* entry points drive all --gpus devices (instead of one rank process per GPU)")
     args = ap.parse_args()
@@ -349,12 +350,15 @@ def main():
             torch.cuda.synchronize()
         return time.perf_counter() - t0
 
-    def probe_leg(mode=2):
-        """One GEMM, in situ: the same batch of 64 utterances for 24 forced frames (codes only, so nothing else shares the GPU),
-        frame steps launched eagerly with HIP events on the decode stream around it. mode 2: the Talker's layer-0 gate/up GEMM
-        (k_bgemm, M = 64, K = 2048, N = 12288 — the largest GEMM of the frame step); mode 1: the Predictor's pass-1 / layer-0 gate/up
-        (k_bgemm, M = 64, K = 1024, N = 6144)."""
-        eng.probe(mode)
+    KINDS = {0: "gate/up GEMM", 1: "QKV GEMM", 2: "attention", 3: "O projection", 4: "down projection"}
+
+    def probe_leg(mode=2, kind=0):
+        """One launch, in situ: the same batch of 64 utterances for 24 forced frames (codes only, so nothing else shares the GPU), frame
+        steps launched eagerly with HIP events on the decode stream around ONE launch per frame — block 0 of the Talker step (mode 2)
+        or of the Predictor's pass 1 (mode 1); kind 0 gate/up GEMM, 1 QKV GEMM, 2 attention, 3 O projection, 4 down projection.
+        Algorithmic bytes per launch follow SURVEY.md §8(d)'s accounting (weights streamed once per launch + the operand / result rows
+        + for attention the K / V bytes of the live context), stated per kind below."""
+        eng.probe(mode + 16 * kind)
         preqs = [dict(r, min_frames=24, force_eos_at=24, max_steps=32, want_pcm=0) for r in reqs]
         for _ in range(2):
             pouts = eng.generate_batch(preqs)
@@ -362,12 +366,27 @@ def main():
         eng.probe(0)
         assert all(o.status == 0 and o.n_frames == 24 for o in pouts)
         m = cfg.model
-        rows = len(preqs)
-        K, N = (m.t_d_model, 2 * m.t_d_ffn) if mode == 2 else (m.p_d_model, 2 * m.p_d_ffn)
-        flops = 2.0 * rows * K * N
-        nbytes = 2.0 * N * K + 2.0 * rows * K + 4.0 * rows * (K // 16) + 2.0 * rows * (N // 2)  # weights + bf16 rows + tile partials + bf16 SwiGLU rows
-        return {"kernel_ms": ptm.probe_kernel_ms, "empty_ms": ptm.probe_empty_ms, "launches": int(ptm.probe_count), "rows": rows, "K": K, "N": N,
-                "flops": flops, "bytes": nbytes, "frame_step_ms": ptm.frame_step_ms}
+        M = len(preqs)
+        if mode == 2:
+            d, F, nq, nkv, hd, L, T_ctx = m.t_d_model, m.t_d_ffn, m.t_n_head * m.t_head_dim, m.t_n_kv_head * m.t_head_dim, m.t_head_dim, m.t_n_layer, ptm.mean_ctx_tokens
+        else:
+            d, F, nq, nkv, hd, L = m.p_d_model, m.p_d_ffn, m.p_n_head * m.p_head_dim, m.p_n_kv_head * m.p_head_dim, m.p_head_dim, m.p_n_layer
+            T_ctx = 3.0 * M  # pass 1: 3 keys per utterance in the per-frame cache
+        nqkv = nq + 2 * nkv
+        if kind == 0:
+            K, N = d, 2 * F; nbytes = 2.0 * N * K + 2.0 * M * K + 4.0 * M * (K // 16) + 2.0 * M * (N // 2)   # weights + bf16 rows + tile partials + bf16 SwiGLU rows
+        elif kind == 1:
+            K, N = d, nqkv; nbytes = 2.0 * N * K + 2.0 * M * K + 4.0 * M * (K // 16) + 4.0 * M * N            # ... + f32 q/k/v rows
+        elif kind == 3:
+            K, N = nq, d; nbytes = 2.0 * N * K + 2.0 * M * K + 8.0 * M * N + 2.0 * M * N + 4.0 * M * (N // 16)  # weights + bf16 rows + residual read/write + next norm inputs
+        elif kind == 4:
+            K, N = F, d; nbytes = 2.0 * N * K + 2.0 * M * K + 8.0 * M * N + 2.0 * M * N + 4.0 * M * (N // 16)
+        else:
+            K, N = hd, nq; nbytes = 2.0 * 2.0 * nkv * T_ctx + 4.0 * M * nqkv + 2.0 * 2.0 * M * nkv + 2.0 * M * nq   # K + V of the context, f32 q/k/v rows, bf16 K/V append, bf16 out rows
+        flops = 2.0 * M * K * N if kind != 2 else 2.0 * 2.0 * nq * T_ctx
+        per_step = L * (1 if mode == 2 else (m.n_codebooks - 1))   # launches of this kind per frame step (pass A of the Predictor runs 2 M rows; its attention is k_attend_pair)
+        return {"model": "Talker" if mode == 2 else "Predictor", "kind": KINDS[kind], "kernel_ms": ptm.probe_kernel_ms, "empty_ms": ptm.probe_empty_ms, "launches": int(ptm.probe_count),
+                "rows": M, "K": K, "N": N, "flops": flops, "bytes": nbytes, "frame_step_ms": ptm.frame_step_ms, "per_step": per_step, "mean_ctx_tokens": ptm.mean_ctx_tokens}
 
     def vocoder_leg():
         ms = eng.vocoder_bench(min(64, cfg.max_batch), 8)
@@ -380,7 +399,7 @@ def main():
                 "how": "HIP events on the stream around 8 batched calls (q3tts_k_vocoder_bench); FLOPs from the loaded vocoder configuration"}
 
     if args.probe_only:
-        pr = vocoder_leg() if args.probe_only == "vocoder" else probe_leg(2 if args.probe_only == "talker" else 1)
+        pr = vocoder_leg() if args.probe_only == "vocoder" else probe_leg(2 if args.probe_only == "talker" else 1, args.probe_kind)
         if rank == 0:
             print(json.dumps({"probe": pr}), flush=True)
         eng.close()
@@ -474,47 +493,52 @@ def main():
         if args.tiny:
             line["invalid"] = "test run on the tiny shape"
         if not args.no_probe:
-            pr = probe_leg(2)
-            # The bracket also times the closing event packet. An EMPTY bracket on the same stream (empty_ms) bounds that
-            # overhead from above, so the kernel's own duration lies in [kernel_ms - empty_ms, kernel_ms]; rocprofv3 puts it
-            # in between (profiles/README.md), and the launch-to-launch period of the same kernel inside a replayed graph
-            # (tools/bgemm_tune.hip, 16.7 us) sits at the lower end. `achieved` uses bracket - empty bracket, both measured in
-            # this run; `achieved_lower_bound` uses the whole bracket.
-            k_ms = pr["kernel_ms"]
-            kc_ms = max(pr["kernel_ms"] - pr["empty_ms"], 1e-6)
-            k_gbs = pr["bytes"] / (kc_ms * 1e-3) / 1e9
-            k_gbs_lb = pr["bytes"] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-            traffic, traffic_src = None, None
+            # Every kernel kind of a decoder block, measured in situ (q3tts_k_probe): the bracket also times the closing event packet; an
+            # EMPTY bracket on the same stream (empty_ms) bounds that overhead from above, so a launch's own period lies in
+            # [kernel_ms - empty_ms, kernel_ms]; rocprofv3 and the in-kernel timestamps of tools/chain_stamps.hip put it at the lower end
+            # (profiles/README.md). `achieved` uses bracket - empty bracket, both measured in this run.
+            legs = [probe_leg(mode, kind) for mode in (2, 1) for kind in (0, 1, 2, 3, 4)]
+            step_us = float(np.mean([p["frame_step_ms"] for p in legs])) * 1e3   # the probe legs' own (eager, codes-only, 64 rows) frame step
+            by_kernel = []
+            for p in legs:
+                us = max(p["kernel_ms"] - p["empty_ms"], 1e-6) * 1e3
+                gbs = p["bytes"] / (us * 1e-6) / 1e9
+                by_kernel.append({"kernel": "%s %s" % (p["model"], p["kind"]), "launches_per_frame_step": p["per_step"], "us_per_launch": round(us, 2),
+                                  "us_per_launch_whole_bracket": round(p["kernel_ms"] * 1e3, 2), "launches_timed": p["launches"],
+                                  "algorithmic_bytes_per_launch": int(p["bytes"]), "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                  "share_of_step": round(p["per_step"] * us / step_us, 4), "M": p["rows"], "K": p["K"], "N": p["N"]})
+            by_kernel.sort(key=lambda k: -k["share_of_step"])
+            top = by_kernel[0]
+            tl = [p for p in legs if "%s %s" % (p["model"], p["kind"]) == top["kernel"]][0]
+            traffic = traffic_src = step_traffic = None
             tpath = os.path.join(REPO, "profiles", ROUND, "pmc_traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
-                traffic_src = f"profiled offline (two rocprofv3 --pmc passes over `bench.py --probe-only`, profiles/{ROUND}/pmc_traffic.json), not measured in this run"
+                    tj = json.load(f)
+                ent = tj.get("by_kernel", {}).get(top["kernel"])
+                traffic = ent.get("hbm_bytes_per_launch") if ent else None
+                step_traffic = tj.get("frame_step")
+                traffic_src = f"profiled offline (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --probe-only`, profiles/{ROUND}/pmc_traffic.json), not measured in this run"
             line["roofline"] = {
-                "bound": "hbm", "achieved": round(k_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(k_gbs / HBM_PEAK_GBS, 4),
-                "achieved_lower_bound": round(k_gbs_lb, 1), "frac_lower_bound": round(k_gbs_lb / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "k_bgemm: Talker gate/up GEMM (row scale of the split RMSNorm + SwiGLU epilogue) on v_mfma_f32_16x16x32_bf16, M=%d K=%d N=%d, "
-                          "28 launches per frame step, the largest GEMM of the step; bf16 ridge 2500 TF / 8 TB/s = 312 flop/B > %.0f flop/B => HBM-bound" %
-                          (pr["rows"], pr["K"], pr["N"], pr["flops"] / pr["bytes"]),
-                "launch_us": round(k_ms * 1e3, 2), "empty_bracket_us": round(pr["empty_ms"] * 1e3, 2),
-                "launch_us_minus_empty_bracket": round((pr["kernel_ms"] - pr["empty_ms"]) * 1e3, 2), "launches_timed": pr["launches"],
-                "algorithmic_flops_per_launch": int(pr["flops"]), "algorithmic_bytes_per_launch": int(pr["bytes"]),
-                "tflops": round(pr["flops"] / (kc_ms * 1e-3) / 1e12, 2),
-                "how": "achieved = algorithmic bytes / (launch_us - empty_bracket_us); HIP events on the decode stream around every launch of this kernel in layer 0 of the Talker step, eager frame steps, "
-                       f"64 live utterances, codes only (q3tts_k_probe mode 2); rocprofv3 of the same leg: profiles/{ROUND}/probe_kernel_stats.csv"}
-            line["frame_step_64_rows_codes_only_ms"] = round(pr["frame_step_ms"], 4)
-            pb = probe_leg(1)
-            b_ms = pb["kernel_ms"]
-            bc_ms = max(pb["kernel_ms"] - pb["empty_ms"], 1e-6)
-            b_gbs = pb["bytes"] / (bc_ms * 1e-3) / 1e9
-            line["roofline_predictor_kernel"] = {
-                "bound": "hbm", "achieved": round(b_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b_gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "k_bgemm: Predictor gate/up GEMM, M=%d K=%d N=%d (75 launches per frame step; weights re-read 15x per frame, Infinity-Cache resident)" % (pb["rows"], pb["K"], pb["N"]),
-                "launch_us": round(b_ms * 1e3, 2), "empty_bracket_us": round(pb["empty_ms"] * 1e3, 2),
-                "launch_us_minus_empty_bracket": round((pb["kernel_ms"] - pb["empty_ms"]) * 1e3, 2), "launches_timed": pb["launches"],
-                "algorithmic_flops_per_launch": int(pb["flops"]), "algorithmic_bytes_per_launch": int(pb["bytes"]),
-                "tflops": round(pb["flops"] / (bc_ms * 1e-3) / 1e12, 2)}
+                "bound": "hbm", "achieved": top["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac"],
+                "traffic": traffic, "traffic_source": traffic_src, "share_of_step": top["share_of_step"],
+                "kernel": "%s (k_bgemm / attention kernel of csrc/), M=%d K=%d N=%d, %d launches per frame step: the kernel kind with the largest share of the frame step's time "
+                          "(launches x period); bf16 ridge 2500 TF / 8 TB/s = 312 flop/B > %.0f flop/B => HBM-bound by SURVEY.md §8(d)'s streaming accounting "
+                          "(the Predictor's 157 MB of weights are re-read 15 x per frame and stay Infinity-Cache resident, so its launches are latency-, not bandwidth-limited)" %
+                          (top["kernel"], top["M"], top["K"], top["N"], top["launches_per_frame_step"], tl["flops"] / tl["bytes"]),
+                "launch_us": top["us_per_launch_whole_bracket"], "empty_bracket_us": round(tl["empty_ms"] * 1e3, 2), "launch_us_minus_empty_bracket": top["us_per_launch"],
+                "launches_timed": top["launches_timed"], "algorithmic_bytes_per_launch": top["algorithmic_bytes_per_launch"],
+                "how": "achieved = algorithmic bytes / (launch_us - empty_bracket_us); HIP events on the decode stream around this launch in block 0 of every frame step, eager frame steps, "
+                       f"64 live utterances, codes only (q3tts_k_probe); rocprofv3 of the same leg: profiles/{ROUND}/probe_kernel_stats.csv"}
+            line["roofline_by_kernel"] = by_kernel
+            line["roofline_by_kernel_what"] = ("every kernel kind of a decoder block, sorted by share of the frame step (launches_per_frame_step x us_per_launch / the probe legs' frame step of "
+                                               "%.0f us); not listed: heads, sampler, projection, k_pred_next, pass-A attention (%.0f %% of the step together)" %
+                                               (step_us, 100.0 * (1.0 - sum(k["share_of_step"] for k in by_kernel))))
+            line["roofline_frame_step"] = {"bound": "hbm", "achieved": round(bytes_step / (step_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": round(bytes_step / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": step_traffic,
+                                           "what": "the whole frame step at 64 rows, codes only: SURVEY.md §8(d) algorithmic bytes of one step / its duration; traffic = memory-side bytes of all its kernels (PMC, offline)",
+                                           "us": round(step_us, 1), "algorithmic_bytes": int(bytes_step)}
+            line["frame_step_64_rows_codes_only_ms"] = round(step_us * 1e-3, 4)
             if cfg.with_vocoder:
                 line["roofline_vocoder"] = vocoder_leg()
         else:

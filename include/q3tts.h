@@ -223,6 +223,7 @@ typedef struct q3tts_timings {
     float mean_rows;             /* decode rows per frame step (row bucket), averaged over the timed frame steps */
     int64_t probe_count;         /* launches behind probe_kernel_ms */
     float probe_empty_ms;        /* mean elapsed time of an EMPTY event bracket on the same stream (event overhead) */
+    float mean_ctx_tokens;       /* sum over the live utterances of their Talker context length, averaged over the timed frame steps */
 } q3tts_timings;
 int q3tts_get_timings(const q3tts_engine* e, q3tts_timings* out);
 
@@ -315,10 +316,11 @@ int q3tts_k_vocoder_bench(q3tts_engine* e, int32_t n_slots, int32_t chunks, floa
  * reader the engine uses for weights_path. out may be NULL to query nelem / dims (ggml order: dims4[0] is the row length)
  * / ggml type (0 F32, 1 F16, 8 Q8_0, 30 BF16). Needs no GPU. */
 int q3tts_k_gguf_read(const char* path, const char* tensor, float* out, int64_t cap, int64_t* nelem, int64_t* dims4, int32_t* ggml_type);
-/* Measurement mode for bench.py: frame steps are launched eagerly (no graph replay) and one GEMM of every frame is bracketed
- * by HIP events on its own stream — enable = 2: the Talker's layer-0 gate/up GEMM (k_bgemm, the largest GEMM of the frame
- * step); enable = 1: the Predictor's pass-1 / layer-0 gate/up GEMM. q3tts_timings
- * .probe_kernel_ms / probe_count report it for the frame steps that ran at the full row count. enable = 0 restores graph replay. */
+/* Measurement mode for bench.py: frame steps are launched eagerly (no graph replay) and ONE launch of every frame is bracketed
+ * by HIP events on its own stream. enable = model + 16 * kind; model 2: block 0 of the Talker step, model 1: block 0 of the
+ * Predictor's pass 1; kind 0: the gate/up GEMM (so enable = 2 / 1 are the Talker's / Predictor's gate/up as before), 1: QKV GEMM,
+ * 2: attention kernel, 3: O projection, 4: down projection. q3tts_timings.probe_kernel_ms / probe_count report it for the frame
+ * steps that ran at the full row count. enable = 0 restores graph replay. */
 int q3tts_k_probe(q3tts_engine* e, int32_t enable);
 /* n_cases independent chains of `chain` v_mfma_f32_16x16x32_bf16 into one accumulator tile: a [n][chain][16][32] bf16 bits,
  * b [n][chain][32][16], c / d [n][16][16] f32. Pins the instruction's accumulation arithmetic. */

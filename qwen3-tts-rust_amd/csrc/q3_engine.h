@@ -90,7 +90,7 @@ struct q3tts_engine {
     Q3Mel* mel = nullptr;               // created on first use
     Q3Clone* clone = nullptr;           // q3tts_clone_init
     // q3tts_k_probe: eager frame steps, events around the Predictor gate/up GEMM (pass 1, layer 0) of every frame
-    int probe = 0;
+    int probe = 0, probe_kind = 0;      // probe: 0 off, 1 Predictor (pass 1, block 0), 2 Talker (block 0); kind: 0 gate/up, 1 QKV, 2 attention, 3 O, 4 down
     std::vector<hipEvent_t> probe_ev;   // 2 per frame of a chunk
     int probe_i = 0;
     double probe_ms = 0, probe_empty_ms = 0; long long probe_cnt = 0, probe_empty_cnt = 0, row_steps = 0;

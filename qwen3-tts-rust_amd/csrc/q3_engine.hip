@@ -266,7 +266,10 @@ static int run_layers(q3tts_engine* e, Q3Tfm& t, float* x, uint16_t* xb, float* 
         g.w_once = once;
         g.a = xb; g.B = rows; g.w = t.wqkv[l]; g.K = t.d; g.N = t.nqkv; g.ssp = ssp; g.ld_ssp = nt; g.ntiles = nt; g.d_norm = t.d; g.eps = eps;
         g.epi = Q3_EPI_STORE; g.y = sc.qkv; g.ldy = t.nqkv;
+        const int pk = (probe && l == 0) ? e->probe_kind : -1;  // which launch of block 0 the probe events bracket (q3tts_k_probe)
+        if (pk == 1) hipEventRecord(probe[0], s);
         bad += q3_launch_bgemm(g, s) != 0;
+        if (pk == 1) hipEventRecord(probe[1], s);
         Q3QkPrep qp{}; qp.qkv = sc.qkv; qp.ld = t.nqkv; qp.rows = rows; qp.Hq = t.Hq; qp.Hkv = t.Hkv; qp.hd = t.hd;
         qp.qnw = t.qn[l]; qp.knw = t.kn[l]; qp.eps = eps; qp.cs = t.cs; qp.sn = t.sn;
         qp.kc = t.kc + l * t.layer_stride; qp.vc = t.vc + l * t.layer_stride; qp.n_ctx = t.n_ctx; qp.row_pos = row_pos; qp.row_slot = row_slot;
@@ -278,18 +281,24 @@ static int run_layers(q3tts_engine* e, Q3Tfm& t, float* x, uint16_t* xb, float* 
         Q3Attend at{}; at.qkv = sc.qkv; at.ld = t.nqkv; at.rows = rows; at.out = (float*)sc.att; at.ldo = t.nq; at.Hq = t.Hq; at.Hkv = t.Hkv; at.hd = t.hd;
         at.kc = qp.kc; at.vc = qp.vc; at.n_ctx = t.n_ctx; at.row_pos = row_pos; at.row_slot = row_slot;
         at.fused = pair ? 2 : (fused ? 1 : 0); at.prep = qp; at.out_bf16 = 1; at.slot_mod = slot_mod; at.pos_const = pos_const;
+        if (pk == 2) hipEventRecord(probe[0], s);
         q3_launch_attend(at, s);
+        if (pk == 2) hipEventRecord(probe[1], s);
         g = Q3BGemm{}; g.w_once = once; g.a = sc.att; g.B = rows; g.w = t.wo[l]; g.K = t.nq; g.N = t.d; g.epi = Q3_EPI_RESID; g.y = x; g.ldy = t.d;
         g.yb = xb; g.nw_next = t.ffn_norm[l]; g.ssp_out = ssp; g.ld_ssp_out = nt;
+        if (pk == 3) hipEventRecord(probe[0], s);
         bad += q3_launch_bgemm(g, s) != 0;
+        if (pk == 3) hipEventRecord(probe[1], s);
         g = Q3BGemm{}; g.w_once = once; g.a = xb; g.B = rows; g.w = t.wgu[l]; g.K = t.d; g.N = 2 * t.F; g.ssp = ssp; g.ld_ssp = nt; g.ntiles = nt; g.d_norm = t.d;
         g.eps = eps; g.epi = Q3_EPI_SWIGLU; g.yb = sc.h;
-        if (probe && l == 0) hipEventRecord(probe[0], s);
+        if (pk == 0) hipEventRecord(probe[0], s);
         bad += q3_launch_bgemm(g, s) != 0;
-        if (probe && l == 0) hipEventRecord(probe[1], s);
+        if (pk == 0) hipEventRecord(probe[1], s);
         g = Q3BGemm{}; g.w_once = once; g.a = sc.h; g.B = rows; g.w = t.wd[l]; g.K = t.F; g.N = t.d; g.epi = Q3_EPI_RESID; g.y = x; g.ldy = t.d;
         g.yb = xb; g.nw_next = l + 1 < t.L ? t.attn_norm[l + 1] : t.out_norm; g.ssp_out = ssp; g.ld_ssp_out = nt;
+        if (pk == 4) hipEventRecord(probe[0], s);
         bad += q3_launch_bgemm(g, s) != 0;
+        if (pk == 4) hipEventRecord(probe[1], s);
     }
     return bad;
 }
@@ -1102,6 +1111,7 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
         e->tm.mean_live_slots = steps ? (float)((double)live_slot_steps / (double)steps) : 0.0f;
         e->tm.algo_flops_per_step = (long long)((double)fixed * (double)e->tm.mean_live_slots);  // 2 flop per bf16 weight (2 bytes) per live row
         e->tm.mean_rows = steps ? (float)((double)e->row_steps / (double)steps) : 0.0f;
+        e->tm.mean_ctx_tokens = steps ? (float)((double)ctx_tokens / (double)steps) : 0.0f;
         e->tm.probe_kernel_ms = e->probe_cnt ? (float)(e->probe_ms / (double)e->probe_cnt) : 0.0f;
         e->tm.probe_count = e->probe_cnt;
         e->tm.probe_empty_ms = e->probe_empty_cnt ? (float)(e->probe_empty_ms / (double)e->probe_empty_cnt) : 0.0f;
@@ -1531,7 +1541,9 @@ extern "C" int q3tts_k_probe(q3tts_engine* e, int32_t enable) {
         e->probe_ev.resize(10, nullptr);  // 4 frames x 2 + one empty bracket per chunk (event overhead calibration)
         for (auto& ev : e->probe_ev) Q3_HIP(e, hipEventCreate(&ev));
     }
-    e->probe = enable == 2 ? 2 : (enable ? 1 : 0);
+    const int model = enable & 15, kind = enable >> 4;
+    if (model > 2 || kind < 0 || kind > 4) return q3_set_err(e, Q3TTS_ERR_INVALID, "probe: model 0..2, kind 0..4");
+    e->probe = model; e->probe_kind = kind;
     return Q3TTS_OK;
 }
 

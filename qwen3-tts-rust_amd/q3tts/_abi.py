@@ -91,6 +91,7 @@ class Timings(C.Structure):
         ("frame_step_ms", C.c_float), ("probe_kernel_ms", C.c_float),
         ("frame_steps", C.c_int64), ("algo_bytes_per_step", C.c_int64), ("algo_flops_per_step", C.c_int64),
         ("mean_live_slots", C.c_float), ("mean_rows", C.c_float), ("probe_count", C.c_int64), ("probe_empty_ms", C.c_float),
+        ("mean_ctx_tokens", C.c_float),
     ]
 
 

@@ -22,5 +22,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 $R/bench.py --probe-only > $OUT/pmc_$c.log 2>&1
   cp "$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)" $OUT/pmc_$c.csv
 done
-python3 $R/tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv "k_bgemm<4, 3, 2, true>" 131072 $OUT/pmc_traffic.json
+python3 $R/tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv $OUT/pmc_traffic.json > $OUT/pmc_traffic.log 2>&1
 cd $R && python bench.py > $OUT/bench_b64_n1.json 2> $OUT/bench_b64_n1.err; tail -c 600 $OUT/bench_b64_n1.json
