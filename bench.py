@@ -506,6 +506,7 @@ def main():
                 by_kernel.append({"kernel": "%s %s" % (p["model"], p["kind"]), "launches_per_frame_step": p["per_step"], "us_per_launch": round(us, 2),
                                   "us_per_launch_whole_bracket": round(p["kernel_ms"] * 1e3, 2), "launches_timed": p["launches"],
                                   "algorithmic_bytes_per_launch": int(p["bytes"]), "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                  "frac_lower_bound": round(p["bytes"] / max(p["kernel_ms"] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
                                   "share_of_step": round(p["per_step"] * us / step_us, 4), "M": p["rows"], "K": p["K"], "N": p["N"]})
             by_kernel.sort(key=lambda k: -k["share_of_step"])
             top = by_kernel[0]
@@ -521,6 +522,7 @@ def main():
                 traffic_src = f"profiled offline (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --probe-only`, profiles/{ROUND}/pmc_traffic.json), not measured in this run"
             line["roofline"] = {
                 "bound": "hbm", "achieved": top["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac"],
+                "achieved_lower_bound": round(top["frac_lower_bound"] * HBM_PEAK_GBS, 1), "frac_lower_bound": top["frac_lower_bound"],
                 "traffic": traffic, "traffic_source": traffic_src, "share_of_step": top["share_of_step"],
                 "kernel": "%s (k_bgemm / attention kernel of csrc/), M=%d K=%d N=%d, %d launches per frame step: the kernel kind with the largest share of the frame step's time "
                           "(launches x period); bf16 ridge 2500 TF / 8 TB/s = 312 flop/B > %.0f flop/B => HBM-bound by SURVEY.md §8(d)'s streaming accounting "
@@ -532,7 +534,9 @@ def main():
                        f"64 live utterances, codes only (q3tts_k_probe); rocprofv3 of the same leg: profiles/{ROUND}/probe_kernel_stats.csv"}
             line["roofline_by_kernel"] = by_kernel
             line["roofline_by_kernel_what"] = ("every kernel kind of a decoder block, sorted by share of the frame step (launches_per_frame_step x us_per_launch / the probe legs' frame step of "
-                                               "%.0f us); not listed: heads, sampler, projection, k_pred_next, pass-A attention (%.0f %% of the step together)" %
+                                               "%.0f us); us_per_launch = event bracket - empty bracket (the lower end of a launch's period: the in-kernel timestamps of "
+                                               "tools/chain_stamps.hip, profiles/r03, put the periods 1-2 us higher), frac_lower_bound uses the whole bracket; the shares leave %.0f %% "
+                                               "for that difference and for the kernels not listed (heads, sampler, projection, k_pred_next, pass-A attention: ~7 %%)" %
                                                (step_us, 100.0 * (1.0 - sum(k["share_of_step"] for k in by_kernel))))
             line["roofline_frame_step"] = {"bound": "hbm", "achieved": round(bytes_step / (step_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": round(bytes_step / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": step_traffic,
