@@ -304,6 +304,226 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
 #endif
 }
 // ---------------------------------------------------------------------------------------------------------------------
+// Decode attention of a GQA PAIR (two query heads per KV head, hd = 128, one row per slot: every Talker step). Same canonical order as
+// k_attend<2, true>, bit for bit, with the work laid out around what the in-kernel timestamps showed (tools/chain_stamps.hip: scores
+// 5.2 us and value pass 3.4 us of a 12 us kernel at 150 cached keys, against ~6.3 us for its K / V bytes at the HBM rate):
+//  * FOUR waves per (slot, KV head) instead of eight: wave sw owns the key blocks sw, sw + 4, ... for BOTH heads — a key block (and a
+//    value row) is loaded once and used twice; the two heads' d-ascending fmaf chains are independent and interleave in the pipeline
+//  * every wave requests its first key block and its first four value rows before the q / k / v preparation (waves 0, 1: the two query
+//    heads; wave 2: k; wave 3: v), so the preparation runs under the memory latency instead of in front of it
+//  * the newest key / value reach their lane through LDS in the cache's packed form: one code path for cached and newest keys
+// ---------------------------------------------------------------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only. __syncthreads() also fences global memory, and on gfx9-family parts loads and stores
+// share one counter: with the key / value prefetch in flight it became s_waitcnt vmcnt(0) — every barrier of this kernel waited for the
+// slowest HBM load of the wave (in-kernel timestamps: first barrier passed 4.9 us after the start). Nothing read after these barriers was
+// written to GLOBAL memory by another wave of the workgroup (the K / V append is only read by later launches).
+#define Q3_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+__global__ __launch_bounds__(256, 2) void k_attend_gqa2(Q3Attend a) {  // (<= 256 registers: two workgroups per CU; unconstrained the compiler took 405)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int g = blockIdx.x, row = blockIdx.y;
+    Q3_STAMP(a, 0);
+    int pos, slot;
+    q3_row_map(row, a.row_pos, a.row_slot, a.slot_mod, a.pos_const, &pos, &slot);
+    if (pos < 0) return;
+    const int T = pos + 1, Tcap = a.n_ctx, hd = 128, half = 64, nl = 32;
+    const int tid = threadIdx.x, sw = tid >> 6, lane = tid & 63, kg = lane >> 4, dl = lane & 15;
+    float* p0 = smem;                          // [Tcap] scores / probabilities of head 0
+    float* p1 = p0 + Tcap;                     // [Tcap] head 1
+    float* qh = p1 + Tcap;                     // [2][hd]
+    float* ow = qh + 2 * hd;                   // [2][4][hd]
+    float* lw = ow + 2 * 4 * hd;               // [2][4]
+    float* mw = lw + 8;                        // [2][4]
+    uint32_t* knew = (uint32_t*)(mw + 8);      // [64] newest key, bf16 pairs, chunk c = 16 bytes at knew + 4 c
+    uint32_t* vnew = knew + 64;                // [64] newest value, bf16 pairs
+    const Q3QkPrep& pr = a.prep;
+    const size_t hb = ((size_t)slot * a.Hkv + g) * a.n_ctx;
+    const uint16_t* kb = a.kc + hb * hd;
+    const uint16_t* vb = a.vc + hb * hd;
+    // Load order = the order of use (vmcnt retires in order): the row's own operands (L2, short latency) first, then the wave's first
+    // key block (one key per lane, 16 KiB) and the value rows of its first FOUR trips (8 dims per lane; every cached key of a context of
+    // <= 256) — all from HBM, all in flight while the preparation runs. (Cache loads first made the preparation wait ~5 us for them.)
+    const float* rowp = a.qkv + (size_t)row * a.ld;
+    const float* src = rowp + (size_t)(sw < 2 ? g * 2 + sw : (sw == 2 ? a.Hq + g : a.Hq + a.Hkv + g)) * hd;
+    float4 x4 = (float4){0.f, 0.f, 0.f, 0.f}, w4 = x4, c4 = (float4){1.f, 1.f, 1.f, 1.f}, s4 = x4;
+    if (lane < nl) {
+        x4 = ((const float4*)src)[lane];
+        if (sw < 3) {
+            w4 = ((const float4*)(sw < 2 ? pr.qnw : pr.knw))[lane];
+            c4 = *(const float4*)(pr.cs + (size_t)pos * half + 4 * (lane & 15)); s4 = *(const float4*)(pr.sn + (size_t)pos * half + 4 * (lane & 15));
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {   // preparation of this row: q heads (waves 0, 1), k (wave 2: norm + RoPE + append), v (wave 3: append)
+        if (sw < 3) {  // prep_head's arithmetic
+            float acc = 0.0f;
+            acc = fmaf(x4.x, x4.x, acc); acc = fmaf(x4.y, x4.y, acc); acc = fmaf(x4.z, x4.z, acc); acc = fmaf(x4.w, x4.w, acc);
+            acc = wave_sum(acc);
+            const float rinv = 1.0f / sqrtf(acc / (float)hd + pr.eps);
+            const float y[4] = {(x4.x * rinv) * w4.x, (x4.y * rinv) * w4.y, (x4.z * rinv) * w4.z, (x4.w * rinv) * w4.w};
+            const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float other = __shfl_xor(y[e], 16);
+                o[e] = (lane < 16) ? fmaf(-other, ss[e], y[e] * cc[e]) : fmaf(other, ss[e], y[e] * cc[e]);
+            }
+            if (lane < nl) {
+                if (sw < 2) *(float4*)(qh + sw * hd + 4 * lane) = (float4){o[0], o[1], o[2], o[3]};
+                else {
+                    uint2 kk;
+                    kk.x = (uint32_t)q3_bf16(o[0]) | ((uint32_t)q3_bf16(o[1]) << 16); kk.y = (uint32_t)q3_bf16(o[2]) | ((uint32_t)q3_bf16(o[3]) << 16);
+                    const int blk = pos >> 6, kl = pos & 63, c = lane >> 1, e0 = 4 * (lane & 1);
+                    *(uint2*)(pr.kc + hb * hd + ((size_t)(blk * (hd >> 3) + c) * 64 + kl) * 8 + e0) = kk;
+                    *(uint2*)(knew + 2 * lane) = kk;
+                }
+            }
+        } else if (lane < nl) {
+            uint2 vk;
+            vk.x = (uint32_t)q3_bf16(x4.x) | ((uint32_t)q3_bf16(x4.y) << 16); vk.y = (uint32_t)q3_bf16(x4.z) | ((uint32_t)q3_bf16(x4.w) << 16);
+            *(uint2*)(pr.vc + (hb + pos) * hd + 4 * lane) = vk;
+            *(uint2*)(vnew + 2 * lane) = vk;
+        }
+    }
+    // The cache operands are requested only now: the vector L1 returns loads in issue order across the waves of a CU, so HBM misses issued
+    // ahead of the preparation's (L2-hit) operands held every wave's preparation back by the HBM latency (first barrier at 4.9 us instead of 1.9).
+    // vv[0..1]: value rows of the first two trips; vv[2..3] (keys 128..255) follow once the key block's registers are free, under the softmax phases
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 kv[16], vv[4][4];
+    {
+        const uint4* kp = (const uint4*)(kb + (size_t)min(sw, (T - 1) >> 6) * 64 * hd) + lane;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) kv[c] = kp[c * 64];
+#pragma unroll
+        for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) vv[tr][u] = *(const uint4*)(vb + (size_t)min(64 * tr + 4 * sw + kg + 16 * u, T - 1) * hd + dl * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    Q3_LDS_BARRIER();
+    Q3_STAMP(a, 1);
+    const float scale = 1.0f / sqrtf((float)hd);
+    float ml0 = -INFINITY, ml1 = -INFINITY;
+    for (int blk = sw; blk * 64 < T; blk += 4) {
+        const int t = blk * 64 + lane;
+        if (blk != sw) {  // (contexts beyond 256 keys: the following blocks of this wave)
+            const uint4* kp = (const uint4*)(kb + (size_t)blk * 64 * hd) + lane;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) kv[c] = kp[c * 64];
+        }
+        if (t == pos) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) kv[c] = *(const uint4*)(knew + 4 * c);
+        }
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float4 qa = *(const float4*)(qh + c * 8), qb = *(const float4*)(qh + c * 8 + 4);
+            const float4 ra = *(const float4*)(qh + hd + c * 8), rb = *(const float4*)(qh + hd + c * 8 + 4);
+            const float k0 = q3_u2f(kv[c].x << 16), k1 = q3_u2f(kv[c].x & 0xffff0000u), k2 = q3_u2f(kv[c].y << 16), k3 = q3_u2f(kv[c].y & 0xffff0000u);
+            const float k4 = q3_u2f(kv[c].z << 16), k5 = q3_u2f(kv[c].z & 0xffff0000u), k6 = q3_u2f(kv[c].w << 16), k7 = q3_u2f(kv[c].w & 0xffff0000u);
+            s0 = fmaf(qa.x, k0, s0); s1 = fmaf(ra.x, k0, s1); s0 = fmaf(qa.y, k1, s0); s1 = fmaf(ra.y, k1, s1);
+            s0 = fmaf(qa.z, k2, s0); s1 = fmaf(ra.z, k2, s1); s0 = fmaf(qa.w, k3, s0); s1 = fmaf(ra.w, k3, s1);
+            s0 = fmaf(qb.x, k4, s0); s1 = fmaf(rb.x, k4, s1); s0 = fmaf(qb.y, k5, s0); s1 = fmaf(rb.y, k5, s1);
+            s0 = fmaf(qb.z, k6, s0); s1 = fmaf(rb.z, k6, s1); s0 = fmaf(qb.w, k7, s0); s1 = fmaf(rb.w, k7, s1);
+        }
+        s0 = s0 * scale; s1 = s1 * scale;
+        if (t < T) { p0[t] = s0; p1[t] = s1; ml0 = fmaxf(ml0, s0); ml1 = fmaxf(ml1, s1); }
+    }
+#pragma unroll
+    for (int tr = 2; tr < 4; ++tr)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vv[tr][u] = *(const uint4*)(vb + (size_t)min(64 * tr + 4 * sw + kg + 16 * u, T - 1) * hd + dl * 8);
+    ml0 = wave_max(ml0); ml1 = wave_max(ml1);
+    if (lane == 0) { mw[sw] = ml0; mw[4 + sw] = ml1; }
+    Q3_LDS_BARRIER();
+    const float m0 = fmaxf(fmaxf(mw[0], mw[1]), fmaxf(mw[2], mw[3])), m1 = fmaxf(fmaxf(mw[4], mw[5]), fmaxf(mw[6], mw[7]));
+    float ls0 = 0.0f, ls1 = 0.0f;
+    for (int blk = sw; blk * 64 < T; blk += 4) {
+        const int t = blk * 64 + lane;
+        if (t < T) {
+            const float e0 = q3_expf(p0[t] - m0), e1 = q3_expf(p1[t] - m1);
+            p0[t] = e0; p1[t] = e1; ls0 += e0; ls1 += e1;
+        }
+    }
+    ls0 = wave_sum(ls0); ls1 = wave_sum(ls1);
+    if (lane == 0) { lw[sw] = ls0; lw[4 + sw] = ls1; }
+    Q3_LDS_BARRIER();
+    Q3_STAMP(a, 2);
+    float o0[8], o1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { o0[e] = 0.0f; o1[e] = 0.0f; }
+    const uint4 vn = *(const uint4*)(vnew + 4 * dl);
+#pragma unroll
+    for (int tr = 0; tr < 4; ++tr) {  // the first four trips: value rows already in registers
+        const int t0 = 64 * tr + 4 * sw + kg;
+        if (64 * tr >= T) break;  // (uniform)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + 16 * u;
+            if (t < T) {
+                const float pa = p0[t], pb = p1[t];
+                const uint4 w = (t == pos) ? vn : vv[tr][u];
+                const float v0 = q3_u2f(w.x << 16), v1 = q3_u2f(w.x & 0xffff0000u), v2 = q3_u2f(w.y << 16), v3 = q3_u2f(w.y & 0xffff0000u);
+                const float v4 = q3_u2f(w.z << 16), v5 = q3_u2f(w.z & 0xffff0000u), v6 = q3_u2f(w.w << 16), v7 = q3_u2f(w.w & 0xffff0000u);
+                o0[0] = fmaf(pa, v0, o0[0]); o0[1] = fmaf(pa, v1, o0[1]); o0[2] = fmaf(pa, v2, o0[2]); o0[3] = fmaf(pa, v3, o0[3]);
+                o0[4] = fmaf(pa, v4, o0[4]); o0[5] = fmaf(pa, v5, o0[5]); o0[6] = fmaf(pa, v6, o0[6]); o0[7] = fmaf(pa, v7, o0[7]);
+                o1[0] = fmaf(pb, v0, o1[0]); o1[1] = fmaf(pb, v1, o1[1]); o1[2] = fmaf(pb, v2, o1[2]); o1[3] = fmaf(pb, v3, o1[3]);
+                o1[4] = fmaf(pb, v4, o1[4]); o1[5] = fmaf(pb, v5, o1[5]); o1[6] = fmaf(pb, v6, o1[6]); o1[7] = fmaf(pb, v7, o1[7]);
+            }
+        }
+    }
+    for (int t0 = 256 + 4 * sw + kg; t0 < T; t0 += 64) {  // contexts beyond 256 keys: four value rows loaded together per trip (ascending keys per lane, as above)
+        uint4 vl[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vl[u] = *(const uint4*)(vb + (size_t)min(t0 + 16 * u, T - 1) * hd + dl * 8);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + 16 * u;
+            if (t < T) {
+                const float pa = p0[t], pb = p1[t];
+                const uint4 w = (t == pos) ? vn : vl[u];
+                const float v0 = q3_u2f(w.x << 16), v1 = q3_u2f(w.x & 0xffff0000u), v2 = q3_u2f(w.y << 16), v3 = q3_u2f(w.y & 0xffff0000u);
+                const float v4 = q3_u2f(w.z << 16), v5 = q3_u2f(w.z & 0xffff0000u), v6 = q3_u2f(w.w << 16), v7 = q3_u2f(w.w & 0xffff0000u);
+                o0[0] = fmaf(pa, v0, o0[0]); o0[1] = fmaf(pa, v1, o0[1]); o0[2] = fmaf(pa, v2, o0[2]); o0[3] = fmaf(pa, v3, o0[3]);
+                o0[4] = fmaf(pa, v4, o0[4]); o0[5] = fmaf(pa, v5, o0[5]); o0[6] = fmaf(pa, v6, o0[6]); o0[7] = fmaf(pa, v7, o0[7]);
+                o1[0] = fmaf(pb, v0, o1[0]); o1[1] = fmaf(pb, v1, o1[1]); o1[2] = fmaf(pb, v2, o1[2]); o1[3] = fmaf(pb, v3, o1[3]);
+                o1[4] = fmaf(pb, v4, o1[4]); o1[5] = fmaf(pb, v5, o1[5]); o1[6] = fmaf(pb, v6, o1[6]); o1[7] = fmaf(pb, v7, o1[7]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        o0[e] = o0[e] + __shfl_xor(o0[e], 16); o0[e] = o0[e] + __shfl_xor(o0[e], 32);
+        o1[e] = o1[e] + __shfl_xor(o1[e], 16); o1[e] = o1[e] + __shfl_xor(o1[e], 32);
+    }
+    if (kg == 0) {
+        *(float4*)(ow + (0 * 4 + sw) * hd + dl * 8) = (float4){o0[0], o0[1], o0[2], o0[3]}; *(float4*)(ow + (0 * 4 + sw) * hd + dl * 8 + 4) = (float4){o0[4], o0[5], o0[6], o0[7]};
+        *(float4*)(ow + (1 * 4 + sw) * hd + dl * 8) = (float4){o1[0], o1[1], o1[2], o1[3]}; *(float4*)(ow + (1 * 4 + sw) * hd + dl * 8 + 4) = (float4){o1[4], o1[5], o1[6], o1[7]};
+    }
+    Q3_LDS_BARRIER();
+    Q3_STAMP(a, 3);
+    if (tid < 128) {  // two consecutive dims of one head per thread: one 4-byte store of the bf16 pair
+        const int h2 = tid >> 6, d0 = 2 * (tid & 63);
+        const float l = ((lw[h2 * 4] + lw[h2 * 4 + 1]) + lw[h2 * 4 + 2]) + lw[h2 * 4 + 3];
+        float ov[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int d = d0 + q;
+            const float r0 = ow[(h2 * 4 + 0) * hd + d], r1 = ow[(h2 * 4 + 1) * hd + d], r2 = ow[(h2 * 4 + 2) * hd + d], r3 = ow[(h2 * 4 + 3) * hd + d];
+            ov[q] = (((r0 + r1) + r2) + r3) / l;
+        }
+        const int hq = g * 2 + h2;
+        if (a.out_bf16) *(uint32_t*)((uint16_t*)a.out + q3_atile_off(row, hq * hd + d0, (a.Hq * hd) >> 5)) = (uint32_t)q3_bf16(ov[0]) | ((uint32_t)q3_bf16(ov[1]) << 16);
+        else *(float2*)(a.out + (size_t)row * a.ldo + (size_t)hq * hd + d0) = make_float2(ov[0], ov[1]);
+    }
+#ifdef Q3_STAMPS
+    Q3_STAMP(a, 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    Q3_STAMP(a, 5);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The same attention for short caches (n_ctx <= 64: the Predictor's <= 17 keys per frame), one row per slot. Every output follows the
 // canonical order of k_attend bit for bit. Built around the kernel's dependent chain, measured with in-kernel timestamps
 // (tools/chain_stamps.hip: the round-2 kernel spent 3.2 us before its first barrier on three dependent load round trips, 2.0 us on two
@@ -566,6 +786,16 @@ void q3_launch_attend(const Q3Attend& a, hipStream_t s) {
         if (R == 2) hipLaunchKernelGGL((k_attend_small<2>), grid, dim3(192), 0, s, a);
         else hipLaunchKernelGGL((k_attend_small<1>), grid, dim3(128), 0, s, a);
         return;
+    }
+    if (a.fused && R == 2 && a.hd == 128) {  // the Talker's decode step: one workgroup of four waves per (slot, KV head), both query heads
+        static const bool old_kernel = getenv("Q3TTS_ATT_OLD") && atoi(getenv("Q3TTS_ATT_OLD"));  // A/B runs and the test that compares the two (same bits)
+        if (!old_kernel) {
+            const size_t lds2 = ((size_t)2 * a.n_ctx + 2 * a.hd + 8 * a.hd + 16 + 128) * sizeof(float);
+            static Q3PerDevice pd2;
+            if (lds2 > 65536) pd2.ensure(lds2, [&]() { hipFuncSetAttribute((const void*)k_attend_gqa2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); });
+            hipLaunchKernelGGL(k_attend_gqa2, grid, dim3(256), lds2, s, a);
+            return;
+        }
     }
     if (a.fused) {
         if (R == 2) hipLaunchKernelGGL((k_attend<2, true>), grid, dim3(512), lds, s, a);

@@ -192,6 +192,31 @@ def test_generate_greedy_ids_bit_exact(oracle, tiny):
     assert np.array_equal(res2.codes, ref)
 
 
+@pytest.mark.parametrize("n_text", [60, 250, 600])
+def test_generate_long_contexts_through_the_decode_attention(oracle, n_text):
+    """The Talker's decode attention (k_attend_gqa2: four waves per (slot, KV head), wave sw owns key blocks sw, sw + 4, ...) across its
+    block structure: 71 prompt rows (two blocks on two waves), 261 (every wave one block, the first a second one), 611 (a third trip of
+    the value pass, blocks 8 and 9 on waves 0 and 1) — two utterances of different length side by side, greedy ids equal the oracle's."""
+    from q3tts import _abi, native
+    cfg = _abi.tiny_config(max_batch=2, n_ctx=1024, with_vocoder=0)
+    eng = native.NativeEngine(cfg)
+    om = oracle.OracleModel(cfg.model, seed=0, n_ctx=1024, n_threads=4)
+    try:
+        rng = np.random.default_rng(n_text)
+        reqs, refs = [], []
+        for nt in (n_text, n_text // 2 + 3):
+            desc, keep = oracle.make_prompt_desc(rng.integers(0, 151643, size=nt), spk_emb=_spk(cfg.model.d_embed))
+            pe = om.build_prompt(desc)
+            assert pe.shape[0] == nt + 11
+            refs.append(om.generate(pe, temperature=0.0, max_steps=9, min_frames=9)[0])
+            reqs.append(dict(embd=pe, temperature=0.0, max_steps=9, min_frames=9))
+        for o, r in zip(eng.generate_batch(reqs), refs):
+            assert o.status == 0 and r.shape == (9, 16) and np.array_equal(o.codes, r)
+    finally:
+        eng.close()
+        om.close()
+
+
 def test_generate_sampled_ids_and_eos_controls(oracle, tiny):
     cfg, eng, om = tiny
     desc, keep = oracle.make_prompt_desc(np.arange(300, 310), spk_emb=_spk(cfg.model.d_embed))
