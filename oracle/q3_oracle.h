@@ -168,6 +168,7 @@ void q3o_vocoder_destroy(q3o_vocoder* v);
 void q3o_vocoder_reset(q3o_vocoder* v);
 /* 0 (default): GEMM / conv inputs rounded to bf16 (the device's operand precision); 1: plain f32 inputs */
 void q3o_vocoder_set_arith(q3o_vocoder* v, int32_t f32_inputs);
+void q3o_vocoder_set_arith_mask(q3o_vocoder* v, uint32_t f32_groups_mask);  /* bit g: stage group g keeps f32 GEMM inputs (error budget) */
 /* tests: intermediate tensors of one whole decode (stage 1 transformer input, 2 transformer output, 3 up-sampled latent, 4 PCM before
  * the clamp) and the synthetic tensors by id, for loading the same model into the family code */
 int32_t q3o_vocoder_stage(q3o_vocoder* v, const int32_t* codes, int32_t n_frames, int32_t stage, float* out);

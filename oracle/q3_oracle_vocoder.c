@@ -37,6 +37,7 @@ enum { VW_W = 0, VW_B = 1, VW_IN_NORM = 2, VW_Q = 3, VW_K = 4, VW_V = 5, VW_O = 
        VW_PW2 = 19, VW_PW2_B = 20, VW_GAMMA = 21, VW_ALPHA = 22, VW_BETA = 23, VW_W2 = 24, VW_B2 = 25, VW_ALPHA2 = 26, VW_BETA2 = 27 };
 
 static int g_vthreads = 1;
+static unsigned g_vf32_mask = 0; static int g_vgroup = 0;  /* per-stage-group override (q3o_vocoder_set_arith_mask): bit g set = group g keeps f32 inputs */
 static int g_vf32 = 0;  /* 1: GEMM / conv inputs stay f32 (q3o_vocoder_set_arith): the f32 arithmetic of the reference's ORT CPU path, up to summation order */
 
 /* bf16-representable matrix [rows][cols], std = gain / sqrt(fan_in) */
@@ -70,7 +71,7 @@ static conv_t gen_conv(uint64_t seed, int comp, int ww, int wb, int ntap, int di
 /* out[t][n] = bias[n % bias_n] + sum_tap sum_ci rb(X[t - (ntap-1-tap)*dil][ci]) * W[tap][n][ci]; X rows < 0 are zero */
 static void conv_fwd(const conv_t* c, const float* x, int T, float* out) {
     float* xr = malloc((size_t)T * c->cin * 4);
-    for (size_t i = 0; i < (size_t)T * c->cin; ++i) xr[i] = g_vf32 ? x[i] : rb(x[i]);
+    for (size_t i = 0; i < (size_t)T * c->cin; ++i) xr[i] = (g_vf32 || ((g_vf32_mask >> g_vgroup) & 1u)) ? x[i] : rb(x[i]);
 #pragma omp parallel for schedule(static) num_threads(g_vthreads)
     for (int t = 0; t < T; ++t)
         for (int n = 0; n < c->nout; ++n) {
@@ -193,6 +194,10 @@ void q3o_vocoder_vec(const q3o_vocoder* v, int32_t comp, int32_t which, int64_t 
 /* 0 (default): GEMM / conv inputs rounded to bf16 like the device path; 1: plain f32 — used to state how far the bf16 vocoder is from
  * f32 arithmetic (the reference runs the graph in f32 on the ORT CPU provider, src/models/onnx.rs:47-62) and by the family test */
 void q3o_vocoder_set_arith(q3o_vocoder* v, int32_t f32_inputs) { (void)v; g_vf32 = f32_inputs ? 1 : 0; }
+/* Error budget of the bf16 operand rounding, stage group by stage group: bit g of `mask` set = the convolutions / GEMMs of group g take f32
+ * inputs while the others round theirs to bf16. Groups: 0 pre-conv + transformer, 1 up-sampling stages, 2 decoder input convolution,
+ * 3 + b decoder block b (transposed convolution + three residual units), 3 + n_dec_blocks output convolution. */
+void q3o_vocoder_set_arith_mask(q3o_vocoder* v, uint32_t mask) { (void)v; g_vf32_mask = mask; }
 
 /* whole-utterance decode of frames [0, T): returns malloc'd pcm of T*spf samples */
 /* stage / stage_out (tests): 1 the transformer's input [T][d], 2 its output after the final norm [T][d], 3 the up-sampled latent
@@ -212,6 +217,7 @@ static float* decode_all(q3o_vocoder* v, int T) {
             for (int i = 0; i < c->codebook_dim; ++i) e[(size_t)t * c->codebook_dim + i] += row[i];
         }
     /* V2: causal pre-conv */
+    g_vgroup = 0;
     float* x = malloc((size_t)T * d * 4);
     conv_fwd(&v->pre, e, T, x); free(e);
     STAGE(1, x, (size_t)T * d);
@@ -263,6 +269,7 @@ static float* decode_all(q3o_vocoder* v, int T) {
     STAGE(2, xn, (size_t)T * d);
     free(q); free(k); free(vv); free(att); free(y); free(g); free(u); free(x);
     /* V5a: upsample stages */
+    g_vgroup = 1;
     float* cur = xn; int Tc = T;
     for (int s = 0; s < c->n_upsample; ++s) {
         vup* p = &v->U[s]; const int r = p->r;
@@ -296,9 +303,11 @@ static float* decode_all(q3o_vocoder* v, int T) {
     /* V5b: decoder */
     int ch = c->decoder_dim;
     float* z = malloc((size_t)Tc * ch * 4);
+    g_vgroup = 2;
     conv_fwd(&v->dec_in, cur, Tc, z); free(cur);
     for (int b = 0; b < c->n_dec_blocks; ++b) {
         vblk* k2 = &v->B[b];
+        g_vgroup = 3 + b;
         snake(z, Tc, k2->cin, k2->ea, k2->ib);
         float* o = malloc((size_t)Tc * k2->r * k2->cout * 4);
         conv_fwd(&k2->ct, z, Tc, o); free(z); Tc *= k2->r; ch = k2->cout;
@@ -315,6 +324,7 @@ static float* decode_all(q3o_vocoder* v, int T) {
         free(t1); free(t2); z = o;
     }
     /* V6 */
+    g_vgroup = 3 + c->n_dec_blocks;
     snake(z, Tc, ch, v->oea, v->oib);
     float* pcm = malloc((size_t)Tc * 4);
     conv_fwd(&v->out, z, Tc, pcm); free(z);

@@ -267,8 +267,11 @@ PCM_RMS_TOL = 2e-3  # of full scale (+-1.0), small vocoder shapes; bf16 MFMA vs 
 # The full shape is deeper and wider (8 transformer layers, 4 decoder blocks from 1536 channels): each bf16-operand GEMM adds its
 # 2^-9 relative rounding, so the device (bf16 operands, MFMA accumulation) sits further from BOTH oracles — the one that rounds GEMM
 # inputs to bf16 like the device, and the plain-f32 one (the reference's ORT CPU arithmetic up to summation order). Measured on
-# MI355X, 8 frames of the synthetic model: 2.5e-3 / see the printed values; signal RMS is ~0.3, i.e. ~40 dB below the signal.
-PCM_RMS_TOL_FULL = 5e-3
+# MI355X, 8 frames of the synthetic model: 2.4-2.6e-3 / see the printed values; signal RMS is ~0.23, i.e. ~39 dB below the signal.
+# The error budget (tests/test_vocoder_family_cpu.py::test_full_shape_pcm_error_budget_of_the_bf16_operand_rounding): every stage group
+# contributes 0.4-1.2e-3 and they add in quadrature to 2.4e-3; no single stage — in particular not the HBM-bound last blocks, where wider
+# operands would be free — can be fixed to reach 2e-3, so the full-shape bound is 3.5e-3 (was 5e-3 in round 2).
+PCM_RMS_TOL_FULL = 3.5e-3
 
 
 @pytest.fixture(scope="module")

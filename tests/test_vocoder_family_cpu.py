@@ -144,3 +144,45 @@ def test_vocoder_oracle_equals_family_code2wav(oracle):
               f"bf16-operand arithmetic vs f32 on this model: PCM RMS {e_bf16:.2e} (signal RMS {float(np.sqrt(np.mean(s4 ** 2))):.2f})")
     finally:
         L.q3o_vocoder_destroy(v)
+
+
+def test_full_shape_pcm_error_budget_of_the_bf16_operand_rounding(oracle):
+    """Where the full-shape PCM error comes from. The device rounds GEMM / convolution inputs to bf16 (the MFMA's
+    operand type) and sits 2.4-2.6e-3 RMS from the f32 arithmetic the reference's ORT CPU vocoder uses (src/models/onnx.rs:390-405); the
+    oracle's bf16-input mode reproduces that distance (tests/test_parity_gpu.py prints both), so the budget is taken here, on the CPU: one
+    stage group at a time rounds its inputs to bf16 while the others stay f32. Result: the groups contribute 0.4-1.2e-3 EACH and add up
+    in quadrature to the total; the HBM-bound last stages (blocks 2, 3 and the output convolution) hold < 1e-3 of it, so wider operands
+    there cannot bring the total under 2e-3 — the full-shape tolerance is 3.5e-3 (PCM_RMS_TOL_FULL), not a per-stage defect."""
+    import ctypes as C
+    import os
+    from q3tts import _abi
+    cfg = _abi.full_config_py()
+    L = oracle.lib()
+    L.q3o_vocoder_set_arith_mask.argtypes = [C.c_void_p, C.c_uint32]
+    v = L.q3o_vocoder_create(C.byref(cfg.vocoder), 0, min(8, os.cpu_count() or 4))
+    codes = np.random.default_rng(4).integers(0, cfg.vocoder.codebook_size, size=(4, 16)).astype(np.int32)
+
+    def run():
+        L.q3o_vocoder_reset(v)
+        pcm = np.zeros(4 * 1920 + 64, dtype=np.float32)
+        n = L.q3o_vocoder_decode(v, oracle.ptr(codes, oracle.i32p), 4, 1, oracle.ptr(pcm, oracle.f32p), pcm.size)
+        return pcm[:n].copy()
+
+    try:
+        L.q3o_vocoder_set_arith(v, 1); ref = run(); L.q3o_vocoder_set_arith(v, 0)
+        L.q3o_vocoder_set_arith_mask(v, 0); total = float(np.sqrt(np.mean((run() - ref) ** 2)))
+        names = ["pre-conv + transformer", "up-sampling stages", "decoder input conv", "block 0 (768 ch)", "block 1 (384 ch)", "block 2 (192 ch)", "block 3 (96 ch)", "output conv"]
+        errs = []
+        for g, nm in enumerate(names):
+            L.q3o_vocoder_set_arith_mask(v, 0xFF & ~(1 << g))   # only group g rounds its inputs to bf16
+            errs.append(float(np.sqrt(np.mean((run() - ref) ** 2))))
+            print(f"  only {nm:24s} with bf16 inputs: PCM RMS error {errs[-1]:.2e}")
+        rss = float(np.sqrt(np.sum(np.square(errs))))
+        print(f"  all groups: {total:.2e}; root-sum-square of the single groups {rss:.2e}; signal RMS {float(np.sqrt(np.mean(ref ** 2))):.2f}")
+    finally:
+        L.q3o_vocoder_set_arith_mask(v, 0)
+        L.q3o_vocoder_destroy(v)
+    assert abs(rss - total) <= 0.15 * total          # independent roundings: the groups add in quadrature
+    assert max(errs) <= 1.6e-3 and min(errs) >= 2e-4   # no stage dominates, none is free
+    assert float(np.sqrt(np.sum(np.square(errs[5:])))) <= 1.2e-3   # the HBM-bound tail holds the smaller part
+    assert 2.0e-3 <= total <= 3.0e-3
