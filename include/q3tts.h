@@ -100,6 +100,12 @@ typedef struct q3tts_engine_config {
                                * (src/assets_manager.rs:14-26). Shapes must match `model`; the table row counts
                                * (text_vocab, codec0_rows, codecq_rows) are taken from the files. The vocoder stays
                                * synthetic: the reference ships it as ONNX only. */
+    int32_t talker_q8_0;      /* 1: the Talker's matrices and lm_head stay ggml Q8_0 blocks ON THE DEVICE (f16 scale + 32 int8 per block,
+                               * 1.06 bytes per weight instead of 2) and are multiplied in that form (W8A16: bf16 activations, every block's
+                               * MFMA product scaled by f32(d)) — the reference's default quantisation (gguf_q8_0,
+                               * src/tts/engine.rs:91-95). Q8_0 tensors of weights_path are kept as stored; other tensor types and the
+                               * synthetic weights are quantised with ggml's reference rule. 0 (default): bf16 weights. The Predictor
+                               * keeps bf16 weights either way (157 MB, Infinity-Cache resident: its launches are latency-bound). */
 } q3tts_engine_config;
 
 typedef struct q3tts_engine q3tts_engine;
@@ -338,6 +344,12 @@ int q3tts_k_bgemm(int32_t device, const uint16_t* xb, int32_t B, int32_t K, cons
 /* Which kernel serves launches of >= 256 rows: 1 = the many-row kernel (k_bgemm_big) whenever eligible, -1 = never, 0 = when it fills the
  * chip (default; the environment variable Q3TTS_BG_BIG sets the initial value once per process). The results are the same bits. */
 int q3tts_k_bgemm_policy(int32_t big);
+/* The same launch with ggml Q8_0 weights kept in block form on the device: q int8 [N][K] row-major (epilogue 2: the
+ * N/2 gate rows, then the N/2 up rows), d_f16 the blocks' f16 scales as bit patterns [N][K/32]; K % 512 == 0. Equals oracle q3o_bgemm_q8
+ * bit for bit. */
+int q3tts_k_bgemm_q8(int32_t device, const uint16_t* xb, int32_t B, int32_t K, const int8_t* q, const uint16_t* d_f16, int32_t N, const float* ssp,
+                     int32_t ntiles, int32_t d_norm, float eps, int32_t epilogue, const float* nw_next, float* y, uint16_t* yb, float* ssp_out,
+                     uint64_t* keys, int32_t iters, float* mean_kernel_ms);
 /* The same GEMM with the epilogue extras only the vocoder uses (nothing in the reference: its vocoder is an ONNX graph, src/models/onnx.rs:342-459):
  * bias[col % bias_n] added to RAW first; epilogue 0: y = RAW + bias; 1: y += col_scale[col] * (RAW + bias), optionally yb = bf16(y);
  * 4: yb = bf16(gelu_erf(RAW + bias)). seg_rows > 0: the f32 rows live in B / seg_rows segments separated by gap_rows rows the kernel

@@ -486,6 +486,10 @@ int32_t q3o_chunk_plan(int32_t n_frames, int32_t* cf, int32_t* cl, int32_t max_c
 /* q3_oracle_bf16.c: the canonical bf16-MFMA arithmetic both transformers run in */
 void q3o_permute_rows_bf16(const uint16_t* src, int32_t rows, int32_t K, uint16_t* dst);
 void q3o_bgemm_raw_p(const uint16_t* xp, int32_t rows, int32_t K, const uint16_t* wp, int32_t N, float* out, int32_t ldo, int32_t threads);
+void q3o_bgemm_q8_raw_p(const uint16_t* xp, int32_t rows, int32_t K, const uint16_t* qp, const float* dsc, int32_t N, float* out, int32_t ldo, int32_t threads);
+void q3o_quantize_q8_0(const float* x, int64_t n, int8_t* q, uint16_t* d_f16);
+void q3o_permute_rows_q8(const int8_t* src, int32_t rows, int32_t K, uint16_t* dst);
+float q3o_f16_to_f32(uint16_t h);
 
 typedef struct {
     int L, d, Hq, Hkv, hd, F;
@@ -493,6 +497,9 @@ typedef struct {
     float** attn_norm; uint16_t** wqkv; float** qn; float** kn; uint16_t** wo; float** ffn_norm;
     uint16_t** wg; uint16_t** wu; uint16_t** wd;
     float* out_norm; uint16_t* head; int head_n;
+    /* Q8_0 mode (q3o_set_talker_q8): the matrices above then hold the block quants as (exact) bf16 in operand order and these the
+     * block scales f32(f16 d) [N][K/32]; NULL = bf16 weights */
+    float** s_qkv; float** s_o; float** s_g; float** s_u; float** s_d; float* s_head;
     float *kc, *vc; int n_ctx; /* [L][Hkv][n_ctx][hd] */
     float *cs, *sn;
 } tfm;
@@ -566,13 +573,45 @@ static void tfm_free(tfm* t) {
     free(t->attn_norm); free(t->wqkv); free(t->qn); free(t->kn); free(t->wo); free(t->ffn_norm);
     free(t->wg); free(t->wu); free(t->wd); free(t->out_norm); free(t->head); free(t->kc); free(t->vc);
     free(t->cs); free(t->sn);
+    if (t->s_qkv) {
+        for (int l = 0; l < t->L; ++l) { free(t->s_qkv[l]); free(t->s_o[l]); free(t->s_g[l]); free(t->s_u[l]); free(t->s_d[l]); }
+        free(t->s_qkv); free(t->s_o); free(t->s_g); free(t->s_u); free(t->s_d); free(t->s_head);
+    }
+}
+
+/* one matrix (bf16, operand order) -> its ggml Q8_0 blocks, in place: quants as bf16 in operand order + the returned f32 scales. The
+ * quantiser sees the weights in their NATURAL order (a block = 32 consecutive input columns of one output row), as a GGUF file holds them */
+static float* matrix_to_q8(uint16_t* wp, int N, int K) {
+    float* dsc = (float*)malloc((size_t)N * (K / 32) * 4);
+#pragma omp parallel for schedule(static) num_threads(g_threads > 0 ? g_threads : 1)
+    for (int n = 0; n < N; ++n) {
+        float row[32]; int8_t q[32]; uint16_t d16;
+        for (int k0 = 0; k0 < K; k0 += 32) {
+            for (int k = 0; k < 32; ++k) row[k] = w_nat(wp, K, n, k0 + k);
+            q3o_quantize_q8_0(row, 32, q, &d16);
+            dsc[(size_t)n * (K / 32) + k0 / 32] = q3o_f16_to_f32(d16);
+            q3o_permute_rows_q8(q, 1, 32, wp + (size_t)n * K + k0);
+        }
+    }
+    return dsc;
+}
+static void tfm_to_q8(tfm* t) {
+    if (t->s_qkv) return;
+    const int L = t->L, d = t->d, nq = t->Hq * t->hd, nkv = t->Hkv * t->hd, nqkv = nq + 2 * nkv, F = t->F;
+    t->s_qkv = calloc(L, sizeof(void*)); t->s_o = calloc(L, sizeof(void*)); t->s_g = calloc(L, sizeof(void*)); t->s_u = calloc(L, sizeof(void*)); t->s_d = calloc(L, sizeof(void*));
+    for (int l = 0; l < L; ++l) {
+        t->s_qkv[l] = matrix_to_q8(t->wqkv[l], nqkv, d); t->s_o[l] = matrix_to_q8(t->wo[l], d, nq);
+        t->s_g[l] = matrix_to_q8(t->wg[l], F, d); t->s_u[l] = matrix_to_q8(t->wu[l], F, d); t->s_d[l] = matrix_to_q8(t->wd[l], d, F);
+    }
+    t->s_head = matrix_to_q8(t->head, t->head_n, d);
 }
 
 /* RAW of natural-order bf16 rows against one of the model's matrices */
-static void bgemm_rows(const uint16_t* ab, int n, int K, const uint16_t* wp, int N, float* out, int ldo) {
+static void bgemm_rows(const uint16_t* ab, int n, int K, const uint16_t* wp, const float* dsc, int N, float* out, int ldo) {
     uint16_t* ap = (uint16_t*)malloc((size_t)n * K * 2);
     q3o_permute_rows_bf16(ab, n, K, ap);
-    q3o_bgemm_raw_p(ap, n, K, wp, N, out, ldo, g_threads > 0 ? g_threads : 1);
+    if (dsc) q3o_bgemm_q8_raw_p(ap, n, K, wp, dsc, N, out, ldo, g_threads > 0 ? g_threads : 1);  /* Q8_0 weights (the Talker in Q8 mode) */
+    else q3o_bgemm_raw_p(ap, n, K, wp, N, out, ldo, g_threads > 0 ? g_threads : 1);
     free(ap);
 }
 
@@ -591,21 +630,21 @@ static void tfm_layers(tfm* t, float* x, uint16_t* xb, float* ssp, int n, int po
     float* sc = malloc((size_t)n * 4);
     for (int l = 0; l < t->L; ++l) {
         for (int r = 0; r < n; ++r) sc[r] = q3o_row_scale(ssp + (size_t)r * nt, nt, d, eps);
-        bgemm_rows(xb, n, d, t->wqkv[l], nqkv, qkv, nqkv);
+        bgemm_rows(xb, n, d, t->wqkv[l], t->s_qkv ? t->s_qkv[l] : NULL, nqkv, qkv, nqkv);
         scale_rows(qkv, n, nqkv, nqkv, sc);
         size_t co = (size_t)l * t->Hkv * t->n_ctx * t->hd;
         attn_rows(qkv, n, pos0, t->Hq, t->Hkv, t->hd, t->qn[l], t->kn[l], eps, t->cs, t->sn, t->kc + co, t->vc + co, t->n_ctx, att);
         for (size_t i = 0; i < (size_t)n * nq; ++i) ab[i] = q3o_bf16(att[i]);
-        bgemm_rows(ab, n, nq, t->wo[l], d, y, d);
+        bgemm_rows(ab, n, nq, t->wo[l], t->s_o ? t->s_o[l] : NULL, d, y, d);
         for (size_t i = 0; i < (size_t)n * d; ++i) x[i] = x[i] + y[i];
         for (int r = 0; r < n; ++r) q3o_norm_inputs(x + (size_t)r * d, d, t->ffn_norm[l], xb + (size_t)r * d, ssp + (size_t)r * nt);
         for (int r = 0; r < n; ++r) sc[r] = q3o_row_scale(ssp + (size_t)r * nt, nt, d, eps);
-        bgemm_rows(xb, n, d, t->wg[l], F, g, F);
-        bgemm_rows(xb, n, d, t->wu[l], F, u, F);
+        bgemm_rows(xb, n, d, t->wg[l], t->s_g ? t->s_g[l] : NULL, F, g, F);
+        bgemm_rows(xb, n, d, t->wu[l], t->s_u ? t->s_u[l] : NULL, F, u, F);
         scale_rows(g, n, F, F, sc);
         scale_rows(u, n, F, F, sc);
         for (size_t i = 0; i < (size_t)n * F; ++i) ab[i] = q3o_bf16(swiglu(g[i], u[i]));
-        bgemm_rows(ab, n, F, t->wd[l], d, y, d);
+        bgemm_rows(ab, n, F, t->wd[l], t->s_d ? t->s_d[l] : NULL, d, y, d);
         for (size_t i = 0; i < (size_t)n * d; ++i) x[i] = x[i] + y[i];
         const float* nxt = l + 1 < t->L ? t->attn_norm[l + 1] : t->out_norm;
         for (int r = 0; r < n; ++r) q3o_norm_inputs(x + (size_t)r * d, d, nxt, xb + (size_t)r * d, ssp + (size_t)r * nt);
@@ -716,6 +755,9 @@ void q3o_destroy(q3o_model* m) {
     tfm_free(&m->T); tfm_free(&m->P); free(m->proj_w); free(m->proj_b); free(m);
 }
 void q3o_set_arith(q3o_model* m, int32_t arith) { m->arith = arith; }
+/* The Talker's matrices (and lm_head) as ggml Q8_0 blocks, multiplied in the canonical Q8 order of q3_oracle_bf16.c — what the device
+ * computes with q3tts_engine_config.talker_q8_0 = 1. One-way (the bf16 weights are replaced). */
+void q3o_set_talker_q8(q3o_model* m) { tfm_to_q8(&m->T); }
 void q3o_set_threads(int32_t n) { g_threads = n > 0 ? n : 1; }  /* OpenMP threads of the GEMMs (bench.py: the 4-thread and all-cores legs) */
 /* natural-order f32 copies of the synthetic tensors, for loading the same model into the family code (tests) */
 const float* q3o_norm_weight(const q3o_model* m, int32_t talker, int32_t layer, int32_t which) {
@@ -849,7 +891,7 @@ static void head_row(const q3o_model* m, tfm* t, const float* xrow, const uint16
     }
     if (hidden_out) q3o_rmsnorm(xrow, t->d, t->out_norm, eps, hidden_out); /* standalone canonical RMSNorm (§4.2): the projection's input */
     const float sc = q3o_row_scale(ssp, t->d / 16, t->d, eps);
-    bgemm_rows(xb, 1, t->d, t->head + (size_t)col0 * t->d, ncols, logits, ncols);
+    bgemm_rows(xb, 1, t->d, t->head + (size_t)col0 * t->d, t->s_head ? t->s_head + (size_t)col0 * (t->d / 32) : NULL, ncols, logits, ncols);
     scale_rows(logits, 1, ncols, ncols, &sc);
 }
 

@@ -206,6 +206,84 @@ void q3o_bgemm_raw_p(const uint16_t* xp, int32_t rows, int32_t K, const uint16_t
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* Q8_0 weights on the device: the Talker's matrices stay in ggml's block_q8_0 form — 32 int8 quants and one f16 scale  */
+/* per block, w = f16(d) * q (the reference's default quantisation: src/tts/engine.rs:91-95, README.md:29-32) — and are never widened to   */
+/* bf16 in memory. Canonical order: RAW8[r][n] = ((s_0 + s_1) + ...) + s_7 over the same 8 K-slices; inside a slice the blocks b ascend:  */
+/*   P_b = the bf16 MFMA instruction on (x[r][32 b ..], q[n][32 b ..] as bf16: every int8 is exact in bf16) from a ZERO accumulator,      */
+/*   t = fmaf(f32(d[n][b]), P_b, t)  from t = +0.                                                                                         */
+/* Activations keep their bf16 form (no int8 activation blocks as in ggml's CPU vec_dot): W8A16.                                           */
+/* ------------------------------------------------------------------------------------------ */
+static uint16_t f32_to_f16_rne(float f) {
+    const uint32_t u = f2u(f), sign = (u >> 16) & 0x8000u;
+    const int32_t e = (int32_t)((u >> 23) & 0xff) - 127;
+    uint32_t m = u & 0x7fffffu;
+    if (((u >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (m ? 0x200u : 0));
+    if (e > 15) return (uint16_t)(sign | 0x7c00u);
+    if (e >= -14) {  /* normal half */
+        uint32_t h = ((uint32_t)(e + 15) << 10) | (m >> 13);
+        const uint32_t rem = m & 0x1fffu;
+        if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;  /* carries into the exponent correctly */
+        return (uint16_t)(sign | h);
+    }
+    if (e < -25) return (uint16_t)sign;  /* below half of the smallest subnormal */
+    m |= 0x800000u;
+    const int sh = -14 - e + 13;  /* 14 .. 24 */
+    uint32_t h = m >> sh;
+    const uint32_t rem = m & ((1u << sh) - 1u), halfway = 1u << (sh - 1);
+    if (rem > halfway || (rem == halfway && (h & 1u))) ++h;
+    return (uint16_t)(sign | h);
+}
+float q3o_f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1f, m = h & 0x3ffu;
+    if (e == 0x1f) return u2f(sign | 0x7f800000u | (m << 13));
+    if (e) return u2f(sign | ((e + 112u) << 23) | (m << 13));
+    if (!m) return u2f(sign);
+    return (sign ? -1.0f : 1.0f) * ldexpf((float)m, -24);
+}
+/* ggml's reference quantiser (quantize_row_q8_0_ref): per block of 32, d = amax / 127, id = d ? 1 / d : 0, q = roundf(x * id), d stored as f16 */
+void q3o_quantize_q8_0(const float* x, int64_t n, int8_t* q, uint16_t* d_f16) {
+    for (int64_t b = 0; b < n / 32; ++b) {
+        float amax = 0.0f;
+        for (int i = 0; i < 32; ++i) { const float a = fabsf(x[b * 32 + i]); if (a > amax) amax = a; }
+        const float d = amax / 127.0f, id = d != 0.0f ? 1.0f / d : 0.0f;
+        d_f16[b] = f32_to_f16_rne(d);
+        for (int i = 0; i < 32; ++i) q[b * 32 + i] = (int8_t)roundf(x[b * 32 + i] * id);
+    }
+}
+static inline uint16_t int8_bf16(int8_t v) { return (uint16_t)(f2u((float)v) >> 16); }  /* exact: |v| <= 128 */
+/* natural-order int8 rows [rows][K] -> bf16 rows in the MFMA operand order (the same permutation as q3o_permute_rows_bf16) */
+void q3o_permute_rows_q8(const int8_t* src, int32_t rows, int32_t K, uint16_t* dst) {
+    for (int r = 0; r < rows; ++r)
+        for (int k0 = 0; k0 < K; k0 += 32)
+            for (int p = 0; p < 32; ++p) dst[(size_t)r * K + k0 + p] = int8_bf16(src[(size_t)r * K + k0 + kperm(p)]);
+}
+/* RAW8 for permuted bf16 activation rows against Q8_0 weights: qp = the quants as permuted bf16 rows [N][K], dsc = f32(d) [N][K/32] */
+void q3o_bgemm_q8_raw_p(const uint16_t* xp, int32_t rows, int32_t K, const uint16_t* qp, const float* dsc, int32_t N, float* out, int32_t ldo,
+                        int32_t threads) {
+    const int per = K / 256, kb = K / 32;
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+    for (int n = 0; n < N; ++n) {
+        const uint16_t* w = qp + (size_t)n * K;
+        const float* dn = dsc + (size_t)n * kb;
+        for (int r = 0; r < rows; ++r) {
+            const uint16_t* x = xp + (size_t)r * K;
+            float tot = 0.0f;
+            for (int sl = 0; sl < 8; ++sl) {
+                float acc = 0.0f;
+                for (int st = 0; st < per; ++st) {
+                    const int b = sl * per + st, k0 = b * 32;
+                    float P = 0.0f;
+                    for (int g = 0; g < 4; ++g) P = step8(x + k0 + 8 * g, w + k0 + 8 * g, P);
+                    acc = fmaf(dn[b], P, acc);
+                }
+                tot = sl == 0 ? acc : tot + acc;
+            }
+            out[(size_t)r * ldo + n] = tot;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* RMSNorm split between producer and consumer                                */
 /* ------------------------------------------------------------------------------------------ */
 /* sum of squares of 16 consecutive columns: squares, then the 16-lane butterfly v += v[lane ^ m], m = 1, 2, 4, 8 */
@@ -256,6 +334,8 @@ static inline uint64_t argmax_key(float v, uint32_t n) {
 }
 static inline float swiglu(float g, float u) { return (g / (1.0f + q3o_expf(-g))) * u; }
 
+static void bgemm_epilogues(float* raw, int32_t B, int32_t N, const float* ssp, int32_t ntiles, int32_t d_norm, float eps, int32_t epi,
+                            const float* nw_next, float* y, uint16_t* yb, float* ssp_out, uint64_t* keys);
 void q3o_bgemm(const uint16_t* xb, int32_t B, int32_t K, const uint16_t* w, int32_t N, const float* ssp, int32_t ntiles, int32_t d_norm,
                float eps, int32_t epi, const float* nw_next, float* y, uint16_t* yb, float* ssp_out, uint64_t* keys) {
     uint16_t* xp = (uint16_t*)malloc((size_t)B * K * 2);
@@ -264,6 +344,25 @@ void q3o_bgemm(const uint16_t* xb, int32_t B, int32_t K, const uint16_t* w, int3
     q3o_permute_rows_bf16(xb, B, K, xp);
     q3o_permute_rows_bf16(w, N, K, wp);
     q3o_bgemm_raw_p(xp, B, K, wp, N, raw, N, 8);
+    bgemm_epilogues(raw, B, N, ssp, ntiles, d_norm, eps, epi, nw_next, y, yb, ssp_out, keys);
+    free(raw); free(wp); free(xp);
+}
+/* the same launch with Q8_0 weights: q int8 [N][K] (epi 2: the F gate rows, then the F up rows), d f16 bits [N][K/32] */
+void q3o_bgemm_q8(const uint16_t* xb, int32_t B, int32_t K, const int8_t* q, const uint16_t* d_f16, int32_t N, const float* ssp, int32_t ntiles,
+                  int32_t d_norm, float eps, int32_t epi, const float* nw_next, float* y, uint16_t* yb, float* ssp_out, uint64_t* keys) {
+    uint16_t* xp = (uint16_t*)malloc((size_t)B * K * 2);
+    uint16_t* qp = (uint16_t*)malloc((size_t)N * K * 2);
+    float* dsc = (float*)malloc((size_t)N * (K / 32) * 4);
+    float* raw = (float*)malloc((size_t)B * N * 4);
+    q3o_permute_rows_bf16(xb, B, K, xp);
+    q3o_permute_rows_q8(q, N, K, qp);
+    for (size_t i = 0; i < (size_t)N * (K / 32); ++i) dsc[i] = q3o_f16_to_f32(d_f16[i]);
+    q3o_bgemm_q8_raw_p(xp, B, K, qp, dsc, N, raw, N, 8);
+    bgemm_epilogues(raw, B, N, ssp, ntiles, d_norm, eps, epi, nw_next, y, yb, ssp_out, keys);
+    free(raw); free(dsc); free(qp); free(xp);
+}
+static void bgemm_epilogues(float* raw, int32_t B, int32_t N, const float* ssp, int32_t ntiles, int32_t d_norm, float eps, int32_t epi,
+                            const float* nw_next, float* y, uint16_t* yb, float* ssp_out, uint64_t* keys) {
     for (int b = 0; b < B; ++b) {
         const float s = ssp ? q3o_row_scale(ssp + (size_t)b * ntiles, ntiles, d_norm, eps) : 1.0f;
         float* r = raw + (size_t)b * N;
@@ -282,5 +381,4 @@ void q3o_bgemm(const uint16_t* xb, int32_t B, int32_t K, const uint16_t* w, int3
             keys[b] = best;
         }
     }
-    free(raw); free(wp); free(xp);
 }

@@ -33,7 +33,20 @@ __device__ __forceinline__ float bg_gelu_erf(float x) { return 0.5f * x * (1.0f 
 
 __device__ __forceinline__ u32x4 bg_ldw(const u32x4* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
 
-template <int RT, int NT, int D, bool NTW>
+// 8 int8 quants (lo = elements 0..3, hi = 4..7 of the lane's fragment) as a bf16 MFMA operand: f32(int8) has an exact bf16 in its upper half
+__device__ __forceinline__ bf16x8 bg_q8_frag(uint32_t lo, uint32_t hi) {
+    union { u32x4 u; bf16x8 v; } r;
+#define Q8F(w_, b_) __float_as_uint((float)(int)(signed char)((w_) >> (8 * (b_))))
+    r.u.x = (Q8F(lo, 0) >> 16) | (Q8F(lo, 1) & 0xffff0000u); r.u.y = (Q8F(lo, 2) >> 16) | (Q8F(lo, 3) & 0xffff0000u);
+    r.u.z = (Q8F(hi, 0) >> 16) | (Q8F(hi, 1) & 0xffff0000u); r.u.w = (Q8F(hi, 2) >> 16) | (Q8F(hi, 3) & 0xffff0000u);
+#undef Q8F
+    return r.v;
+}
+__device__ __forceinline__ float bg_f16(uint32_t bits) { return (float)__builtin_bit_cast(_Float16, (unsigned short)bits); }
+
+// Q8: the weights are ggml Q8_0 blocks in the tiled Q8 layout (q3_kernels.h): 1.06 bytes per weight instead of 2 through
+// the same ring; every 32-wide K step is one block: P = MFMA from a zero accumulator, acc = fmaf(f32(d), P, acc).
+template <int RT, int NT, int D, bool NTW, bool Q8>
 __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
     extern __shared__ float part[];  // [8 waves][RT*NT*4 regs][64 lanes]
     __shared__ float srow[64];
@@ -75,18 +88,42 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
             sp1[i] = lane + 64 < g.ntiles ? sp[lane + 64] : 0.0f;
         }
     }
-    u32x4 aq[D][RT], bq[D][NT];
+    constexpr int DQ = (D + 1) & ~1, DP = DQ / 2;  // Q8: an even number of steps in flight = DP block pairs (one 16-byte weight load covers two steps)
+    u32x4 aq[Q8 ? DQ : D][RT], bq[Q8 ? DP : D][NT];
+    uint32_t sc8[Q8 ? DP : 1][NT];                 // Q8: the two f16 block scales of a pair
+    const u32x4* wq[NT]; const uint32_t* sq[NT];
+    const int npair = per >> 1;
+    if constexpr (Q8) {
 #pragma unroll
-    for (int s = 0; s < D; ++s) {
-        const size_t so = (size_t)min(s, per - 1) * 64;
+        for (int j = 0; j < NT; ++j) {
+            wq[j] = (const u32x4*)g.w + ((size_t)(nb0 + j) * (kblocks >> 1) + (kb0 >> 1)) * 64 + lane;
+            sq[j] = (const uint32_t*)(g.wscale + (size_t)((nb0 + j) * 16 + r) * kblocks + kb0);
+        }
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bq[s][j] = bg_ldw(wp[j] + so, NTW);
-    }
+        for (int p = 0; p < DP; ++p) {
+            const int pc = min(p, npair - 1);
 #pragma unroll
-    for (int s = 0; s < D; ++s) {
-        const size_t so = (size_t)min(s, per - 1) * 64;
+            for (int j = 0; j < NT; ++j) { bq[p][j] = bg_ldw(wq[j] + (size_t)pc * 64, NTW); sc8[p][j] = sq[j][pc]; }
+        }
 #pragma unroll
-        for (int i = 0; i < RT; ++i) aq[s][i] = ap[i][so];
+        for (int s = 0; s < DQ; ++s) {
+            const size_t so = (size_t)min(s, per - 1) * 64;
+#pragma unroll
+            for (int i = 0; i < RT; ++i) aq[s][i] = ap[i][so];
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            const size_t so = (size_t)min(s, per - 1) * 64;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bq[s][j] = bg_ldw(wp[j] + so, NTW);
+        }
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            const size_t so = (size_t)min(s, per - 1) * 64;
+#pragma unroll
+            for (int i = 0; i < RT; ++i) aq[s][i] = ap[i][so];
+        }
     }
     // epilogue operands, fetched up front instead of at the very end (each was a dependent round trip behind the slice reduction)
     constexpr int NOUT = (TR * 64 + 511) / 512;
@@ -143,6 +180,46 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
     for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (Q8) {
+        const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int p0 = 0; p0 < npair; p0 += DP) {
+#pragma unroll
+            for (int dp = 0; dp < DP; ++dp) {
+                const int p = p0 + dp;
+                if (p < npair) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        float dsc[NT]; bf16x8 bf[NT];
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            dsc[j] = bg_f16(h ? sc8[dp][j] >> 16 : sc8[dp][j] & 0xffffu);
+                            bf[j] = h ? bg_q8_frag(bq[dp][j].z, bq[dp][j].w) : bg_q8_frag(bq[dp][j].x, bq[dp][j].y);
+                        }
+#pragma unroll
+                        for (int i = 0; i < RT; ++i) {
+                            union { u32x4 u; bf16x8 v; } a; a.u = aq[2 * dp + h][i];
+#pragma unroll
+                            for (int j = 0; j < NT; ++j) {
+                                const f32x4 P = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, bf[j], zero4, 0, 0, 0);
+                                acc[i][j][0] = fmaf(dsc[j], P[0], acc[i][j][0]); acc[i][j][1] = fmaf(dsc[j], P[1], acc[i][j][1]);
+                                acc[i][j][2] = fmaf(dsc[j], P[2], acc[i][j][2]); acc[i][j][3] = fmaf(dsc[j], P[3], acc[i][j][3]);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (p + DP < npair) {
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) { bq[dp][j] = bg_ldw(wq[j] + (size_t)(p + DP) * 64, NTW); sc8[dp][j] = sq[j][p + DP]; }
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int i = 0; i < RT; ++i) aq[2 * dp + h][i] = ap[i][(size_t)(2 * (p + DP) + h) * 64];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    } else
     for (int s0 = 0; s0 < per; s0 += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -405,7 +482,7 @@ __global__ __launch_bounds__(256) void k_bgemm_big(Q3BGemm g) {
         }
 }
 static bool bg_big_ok(const Q3BGemm& g) {
-    return g.B >= 256 && (g.epi == Q3_EPI_STORE || g.epi == Q3_EPI_RESID || g.epi == Q3_EPI_SWIGLU) && g.N % 128 == 0 && g.a_row0 % 16 == 0 &&
+    return g.B >= 256 && !g.wscale && (g.epi == Q3_EPI_STORE || g.epi == Q3_EPI_RESID || g.epi == Q3_EPI_SWIGLU) && g.N % 128 == 0 && g.a_row0 % 16 == 0 &&
            !g.bias && !g.col_scale && !g.seg_rows && !(g.epi == Q3_EPI_RESID && g.yb && !g.nw_next);
 }
 static void bg_launch_big(const Q3BGemm& g, hipStream_t s) {
@@ -426,14 +503,20 @@ struct BgInst {
     static constexpr size_t lds = (size_t)8 * RT * NT * 4 * 64 * 4;
     static void prepare() {  // dynamic LDS above 64 KiB has to be allowed per kernel
         if (lds > 65536) {
-            hipFuncSetAttribute((const void*)k_bgemm<RT, NT, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipFuncSetAttribute((const void*)k_bgemm<RT, NT, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute((const void*)k_bgemm<RT, NT, D, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute((const void*)k_bgemm<RT, NT, D, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute((const void*)k_bgemm<RT, NT, D, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute((const void*)k_bgemm<RT, NT, D, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         }
     }
     static void launch(const Q3BGemm& g, dim3 grid, hipStream_t s) {
         // once-read weight streams (the Talker at decode: every tile goes to exactly one workgroup) take non-temporal loads
-        if (g.w_once && grid.y == 1) hipLaunchKernelGGL((k_bgemm<RT, NT, D, true>), grid, dim3(512), lds, s, g);
-        else hipLaunchKernelGGL((k_bgemm<RT, NT, D, false>), grid, dim3(512), lds, s, g);
+        const bool nt = g.w_once && grid.y == 1;
+        if (g.wscale) {  // Q8_0 weights
+            if (nt) hipLaunchKernelGGL((k_bgemm<RT, NT, D, true, true>), grid, dim3(512), lds, s, g);
+            else hipLaunchKernelGGL((k_bgemm<RT, NT, D, false, true>), grid, dim3(512), lds, s, g);
+        } else if (nt) hipLaunchKernelGGL((k_bgemm<RT, NT, D, true, false>), grid, dim3(512), lds, s, g);
+        else hipLaunchKernelGGL((k_bgemm<RT, NT, D, false, false>), grid, dim3(512), lds, s, g);
     }
 };
 // once per process, outside any stream capture (the engine calls it before it records its graphs)
@@ -461,6 +544,7 @@ void q3_bgemm_big_policy(int policy) { q3_bgemm_prepare(); g_big_policy = policy
 
 int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s) {
     if (g.B < 1 || g.N % 16 || g.K % 256 || g.K < 256 || !g.a || !g.w || g.a_row0 < 0) return -1;
+    if (g.wscale && g.K % 512) return -1;  // Q8_0: two blocks per 16-byte weight load, an even number of blocks per K slice
     if (g.yb && (((g.epi == Q3_EPI_RESID || g.epi == Q3_EPI_GELU) && g.N % 32) || (g.epi == Q3_EPI_SWIGLU && g.N % 64))) return -1;  // the A-tiled output has N (N/2) columns in 32-blocks
     if ((g.epi == Q3_EPI_SWIGLU || g.epi == Q3_EPI_GELU) && (!g.yb)) return -1;
     if (g.bias && g.bias_n < 1) return -1;
@@ -482,7 +566,7 @@ int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s) {
             const long chunks = (g.B + 16 * RT - 1) / (16 * RT);
             if (g.B <= 64 && RT > 1 && 16 * (RT - 1) * chunks >= g.B) continue;  // a smaller RT covers the rows with the same chunk count
             const long wgs = (long)(tiles / NT) * chunks, rounds = (wgs + 255) / 256;
-            const long cost = rounds * (32L * (RT + NT) * g.K + 24000L);  // + a fixed cost per round (ramp, reduction)
+            const long cost = rounds * ((g.wscale ? 32L * RT + 17L * NT : 32L * (RT + NT)) * g.K + 24000L);  // + a fixed cost per round (ramp, reduction); Q8_0 weights: 17 bytes per k per column tile
             if (bestCost < 0 || cost < bestCost || (cost == bestCost && (wgs > bestWgs || (wgs == bestWgs && NT > bestNT)))) { bestCost = cost; bestRT = RT; bestNT = NT; bestWgs = wgs; }
         }
     if (g_force_rt > 0 && g_force_nt > 0 && tiles % g_force_nt == 0) { bestRT = g_force_rt; bestNT = g_force_nt; }

@@ -17,6 +17,9 @@ struct Q3Tfm {
     std::vector<uint4*> wqkv, wo, wgu, wd;
     float* out_norm = nullptr;
     uint4* head = nullptr;
+    // Q8_0 mode (cfg.talker_q8_0, the Talker only): the matrices above hold ggml block quants in the tiled Q8 layout (q3_kernels.h) and
+    // these the f16 block scales [N][K/32]; empty / null = bf16 weights
+    std::vector<uint16_t*> sqkv, so, sgu, sd; uint16_t* shead = nullptr; bool q8 = false;
     uint16_t *kc = nullptr, *vc = nullptr;  // [L][slots][Hkv][n_ctx*hd]
     size_t layer_stride = 0;
     int n_ctx = 0, n_slots = 0;

@@ -44,7 +44,7 @@ extern "C" void q3tts_default_config(q3tts_engine_config* c) {
     v.dec_rates[0] = 8; v.dec_rates[1] = 5; v.dec_rates[2] = 4; v.dec_rates[3] = 3;
     v.lookahead_frames = 0; v.sample_rate = 24000;
     c->device = 0; c->max_batch = 1; c->n_ctx = 4096; c->max_steps_cap = 512; c->with_vocoder = 1;
-    c->synth_seed = 0; c->weights_path = nullptr;
+    c->synth_seed = 0; c->weights_path = nullptr; c->talker_q8_0 = 0;
 }
 
 static int validate(const q3tts_engine_config& c, std::string& why) {
@@ -68,6 +68,7 @@ static int validate(const q3tts_engine_config& c, std::string& why) {
     REQ(c.n_ctx >= 64 && c.n_ctx % 64 == 0 && c.n_ctx <= 8192);
     REQ(c.max_steps_cap >= 1 && c.max_steps_cap < c.n_ctx);
     REQ(m.n_codebooks + 1 <= 64);
+    if (c.talker_q8_0) REQ(m.t_d_model % 512 == 0 && m.t_d_ffn % 512 == 0 && (m.t_n_head * m.t_head_dim) % 512 == 0);  // Q8_0: an even number of 32-blocks per K slice
 #undef REQ
     return Q3TTS_OK;
 }
@@ -114,7 +115,7 @@ static void rope_tables(int n_pos, int hd, float theta, const int* sections, std
 struct GgSrc {
     q3tts_engine* e; const Q3Gguf* g; const char* file;
     std::vector<uint16_t> host; uint16_t* dev[2] = {nullptr, nullptr}; size_t dev_cap[2] = {0, 0};
-    ~GgSrc() { for (auto p : dev) if (p) hipFree(p); }
+    ~GgSrc() { for (auto p : dev) if (p) hipFree(p); for (auto p : dev8) if (p) hipFree(p); }
     int fail(const std::string& msg) { return q3_set_err(e, Q3TTS_ERR_INVALID, std::string(file) + ": " + msg); }
     const Q3GgufTensor* need(const std::string& name, uint64_t ne0, uint64_t ne1, int* rc) {
         const Q3GgufTensor* t = g->find(name);
@@ -137,6 +138,27 @@ struct GgSrc {
         Q3_HIP(e, hipMemcpy(dst, h.data(), n * 4, hipMemcpyHostToDevice));  // (h is a local: synchronous copy)
         return Q3TTS_OK;
     }
+    // Q8_0 mode: a tensor stored as Q8_0 goes to the device as it is ([N][K/32] blocks of 34 bytes) into staging buffer `which`
+    // (raw[which] = true); any other type is widened to bf16 as below and quantised on the device
+    uint8_t* dev8[2] = {nullptr, nullptr}; size_t dev8_cap[2] = {0, 0}; bool raw[2] = {false, false};
+    int mat_q8(const std::string& name, size_t N, size_t K, int which) {
+        int rc; const Q3GgufTensor* t = need(name, K, N, &rc);
+        if (!t) return rc;
+        raw[which] = false;
+        if (t->type != Q3_GGML_Q8_0) return mat(name, N, K, which);
+        const size_t bytes = N * (K / 32) * 34;
+        if (t->nbytes < bytes) return fail("tensor '" + name + "' is shorter than its Q8_0 shape");
+        if (dev8_cap[which] < bytes) {
+            if (dev8[which]) hipFree(dev8[which]);
+            dev8[which] = nullptr; dev8_cap[which] = 0;
+            void* p = nullptr;
+            if (hipMalloc(&p, bytes) != hipSuccess) return q3_set_err(e, Q3TTS_ERR_OOM, "hipMalloc (Q8_0 staging)");
+            dev8[which] = (uint8_t*)p; dev8_cap[which] = bytes;
+        }
+        Q3_HIP(e, hipMemcpy(dev8[which], t->data, bytes, hipMemcpyHostToDevice));
+        raw[which] = true;
+        return Q3TTS_OK;
+    }
     // [N][K] matrix -> bf16 row-major staging buffer `which` on the device
     int mat(const std::string& name, size_t N, size_t K, int which) {
         int rc; const Q3GgufTensor* t = need(name, K, N, &rc);
@@ -156,75 +178,90 @@ struct GgSrc {
 };
 
 static int init_tfm(q3tts_engine* e, Q3Tfm& t, int grp, int L, int d, int Hq, int Hkv, int hd, int F, int head_n, float theta,
-                    const int* sections, int n_ctx, int n_slots, GgSrc* gg = nullptr) {
+                    const int* sections, int n_ctx, int n_slots, GgSrc* gg = nullptr, bool q8 = false) {
     t.L = L; t.d = d; t.Hq = Hq; t.Hkv = Hkv; t.hd = hd; t.F = F; t.nq = Hq * hd; t.nkv = Hkv * hd; t.nqkv = t.nq + 2 * t.nkv;
-    t.head_n = head_n; t.n_ctx = n_ctx; t.n_slots = n_slots;
+    t.head_n = head_n; t.n_ctx = n_ctx; t.n_slots = n_slots; t.q8 = q8;
     const uint64_t seed = e->cfg.synth_seed;
     const float ms = 0.02f / Q3_IH4_STD, ns = 0.05f / Q3_IH4_STD;
     hipStream_t s = e->stream;
     t.attn_norm.resize(L); t.ffn_norm.resize(L); t.qn.resize(L); t.kn.resize(L);
     t.wqkv.resize(L); t.wo.resize(L); t.wgu.resize(L); t.wd.resize(L);
+    if (q8) { t.sqkv.assign(L, nullptr); t.so.assign(L, nullptr); t.sgu.assign(L, nullptr); t.sd.assign(L, nullptr); }
+    // a matrix [N][K]: bf16 tiles (2 bytes per weight), or in Q8_0 mode block quants (1 byte) + f16 block scales [N][K/32]
+    const size_t wdiv = q8 ? 16 : 8;  // weights per uint4
+    auto alloc_mat = [&](uint4** w, uint16_t** sc, size_t N, size_t K) -> int {
+        TRY(dalloc(e, w, N * K / wdiv));
+        if (q8) TRY(dalloc(e, sc, N * K / 32));
+        return Q3TTS_OK;
+    };
+    auto fill = [&](Q3Fill& f, uint16_t* sc) { if (q8) { f.dst_scale = sc; q3_launch_fill_tiled_q8(f, s); } else q3_launch_fill_tiled(f, s); };
+    const double bpw = q8 ? 1.0625 : 2.0;  // bytes per weight streamed by a GEMM
     for (int l = 0; l < L; ++l) {
         TRY(dalloc(e, &t.attn_norm[l], (size_t)d)); TRY(dalloc(e, &t.ffn_norm[l], (size_t)d));
         TRY(dalloc(e, &t.qn[l], (size_t)hd)); TRY(dalloc(e, &t.kn[l], (size_t)hd));
+        uint16_t *sc_qkv = nullptr, *sc_o = nullptr, *sc_gu = nullptr, *sc_d = nullptr;
+        TRY(alloc_mat(&t.wqkv[l], &sc_qkv, t.nqkv, d)); TRY(alloc_mat(&t.wo[l], &sc_o, d, t.nq));
+        TRY(alloc_mat(&t.wgu[l], &sc_gu, (size_t)2 * F, d)); TRY(alloc_mat(&t.wd[l], &sc_d, d, F));
+        if (q8) { t.sqkv[l] = sc_qkv; t.so[l] = sc_o; t.sgu[l] = sc_gu; t.sd[l] = sc_d; }
+        t.weight_bytes += (size_t)(bpw * (double)((size_t)t.nqkv * d + (size_t)d * t.nq + 3ull * F * d));
         if (gg) {  // blk.N.* of a llama.cpp qwen3 GGUF (weights [out][in], NeoX RoPE: no q/k permutation)
             const std::string b = "blk." + std::to_string(l) + ".";
             Q3_HIP(e, hipStreamSynchronize(s));
             TRY(gg->vec(b + "attn_norm.weight", d, t.attn_norm[l])); TRY(gg->vec(b + "ffn_norm.weight", d, t.ffn_norm[l]));
             TRY(gg->vec(b + "attn_q_norm.weight", hd, t.qn[l])); TRY(gg->vec(b + "attn_k_norm.weight", hd, t.kn[l]));
-            TRY(dalloc(e, &t.wqkv[l], (size_t)t.nqkv * d / 8)); TRY(dalloc(e, &t.wo[l], (size_t)d * t.nq / 8));
-            TRY(dalloc(e, &t.wgu[l], (size_t)2 * F * d / 8)); TRY(dalloc(e, &t.wd[l], (size_t)d * F / 8));
             Q3Fill f{}; f.mode = 0;
-            auto put = [&](const std::string& name, uint4* dst, int Ntot, int K, int row0, int rows) -> int {
-                TRY(gg->mat(name, rows, K, 0));
-                f.dst = dst; f.N = Ntot; f.K = K; f.mode = 0; f.row0 = row0; f.rows = rows; f.src_a = gg->dev[0]; f.src_b = nullptr;
-                q3_launch_fill_tiled(f, s);
+            auto stage = [&](const std::string& name, size_t N, size_t K, int which) -> int { return q8 ? gg->mat_q8(name, N, K, which) : gg->mat(name, N, K, which); };
+            auto put = [&](const std::string& name, uint4* dst, uint16_t* sc, int Ntot, int K, int row0, int rows) -> int {
+                TRY(stage(name, rows, K, 0));
+                f.dst = dst; f.N = Ntot; f.K = K; f.mode = 0; f.row0 = row0; f.rows = rows; f.src_b = nullptr; f.src8_b = nullptr;
+                f.src_a = (q8 && gg->raw[0]) ? nullptr : gg->dev[0]; f.src8_a = (q8 && gg->raw[0]) ? gg->dev8[0] : nullptr;
+                fill(f, sc);
                 Q3_HIP(e, hipStreamSynchronize(s));  // the staging buffer is reused by the next tensor
                 return Q3TTS_OK;
             };
-            TRY(put(b + "attn_q.weight", t.wqkv[l], t.nqkv, d, 0, t.nq));
-            TRY(put(b + "attn_k.weight", t.wqkv[l], t.nqkv, d, t.nq, t.nkv));
-            TRY(put(b + "attn_v.weight", t.wqkv[l], t.nqkv, d, t.nq + t.nkv, t.nkv));
-            TRY(put(b + "attn_output.weight", t.wo[l], d, t.nq, 0, d));
-            TRY(gg->mat(b + "ffn_gate.weight", F, d, 0)); TRY(gg->mat(b + "ffn_up.weight", F, d, 1));
-            f.dst = t.wgu[l]; f.N = 2 * F; f.K = d; f.mode = 1; f.src_a = gg->dev[0]; f.src_b = gg->dev[1];
-            q3_launch_fill_tiled(f, s);
+            TRY(put(b + "attn_q.weight", t.wqkv[l], sc_qkv, t.nqkv, d, 0, t.nq));
+            TRY(put(b + "attn_k.weight", t.wqkv[l], sc_qkv, t.nqkv, d, t.nq, t.nkv));
+            TRY(put(b + "attn_v.weight", t.wqkv[l], sc_qkv, t.nqkv, d, t.nq + t.nkv, t.nkv));
+            TRY(put(b + "attn_output.weight", t.wo[l], sc_o, d, t.nq, 0, d));
+            TRY(stage(b + "ffn_gate.weight", F, d, 0)); TRY(stage(b + "ffn_up.weight", F, d, 1));
+            f.dst = t.wgu[l]; f.N = 2 * F; f.K = d; f.mode = 1;
+            f.src_a = (q8 && gg->raw[0]) ? nullptr : gg->dev[0]; f.src8_a = (q8 && gg->raw[0]) ? gg->dev8[0] : nullptr;
+            f.src_b = (q8 && gg->raw[1]) ? nullptr : gg->dev[1]; f.src8_b = (q8 && gg->raw[1]) ? gg->dev8[1] : nullptr;
+            if (q8 && gg->raw[0] != gg->raw[1]) return gg->fail("ffn_gate / ffn_up of block " + std::to_string(l) + " differ in type (one Q8_0, one not)");
+            fill(f, sc_gu);
             Q3_HIP(e, hipStreamSynchronize(s));
-            TRY(put(b + "ffn_down.weight", t.wd[l], d, F, 0, d));
-            t.weight_bytes += 2ull * ((size_t)t.nqkv * d + (size_t)d * t.nq + 3ull * F * d);
+            TRY(put(b + "ffn_down.weight", t.wd[l], sc_d, d, F, 0, d));
             continue;
         }
         q3_launch_fill_f32(t.attn_norm[l], d, seed, Q3_TID(grp, l, Q3W_ATTN_NORM), 1.0f, ns, 0, s);
         q3_launch_fill_f32(t.ffn_norm[l], d, seed, Q3_TID(grp, l, Q3W_FFN_NORM), 1.0f, ns, 0, s);
         q3_launch_fill_f32(t.qn[l], hd, seed, Q3_TID(grp, l, Q3W_QNORM), 1.0f, ns, 0, s);
         q3_launch_fill_f32(t.kn[l], hd, seed, Q3_TID(grp, l, Q3W_KNORM), 1.0f, ns, 0, s);
-        TRY(dalloc(e, &t.wqkv[l], (size_t)t.nqkv * d / 8)); TRY(dalloc(e, &t.wo[l], (size_t)d * t.nq / 8));
-        TRY(dalloc(e, &t.wgu[l], (size_t)2 * F * d / 8)); TRY(dalloc(e, &t.wd[l], (size_t)d * F / 8));
         Q3Fill f{}; f.seed = seed; f.scale = ms;
         f.dst = t.wqkv[l]; f.N = t.nqkv; f.K = d; f.mode = 0;
-        f.row0 = 0; f.rows = t.nq; f.tid_a = Q3_TID(grp, l, Q3W_Q); q3_launch_fill_tiled(f, s);
-        f.row0 = t.nq; f.rows = t.nkv; f.tid_a = Q3_TID(grp, l, Q3W_K); q3_launch_fill_tiled(f, s);
-        f.row0 = t.nq + t.nkv; f.rows = t.nkv; f.tid_a = Q3_TID(grp, l, Q3W_V); q3_launch_fill_tiled(f, s);
-        f.dst = t.wo[l]; f.N = d; f.K = t.nq; f.row0 = 0; f.rows = d; f.tid_a = Q3_TID(grp, l, Q3W_O); q3_launch_fill_tiled(f, s);
+        f.row0 = 0; f.rows = t.nq; f.tid_a = Q3_TID(grp, l, Q3W_Q); fill(f, sc_qkv);
+        f.row0 = t.nq; f.rows = t.nkv; f.tid_a = Q3_TID(grp, l, Q3W_K); fill(f, sc_qkv);
+        f.row0 = t.nq + t.nkv; f.rows = t.nkv; f.tid_a = Q3_TID(grp, l, Q3W_V); fill(f, sc_qkv);
+        f.dst = t.wo[l]; f.N = d; f.K = t.nq; f.row0 = 0; f.rows = d; f.tid_a = Q3_TID(grp, l, Q3W_O); fill(f, sc_o);
         f.dst = t.wgu[l]; f.N = 2 * F; f.K = d; f.mode = 1; f.tid_a = Q3_TID(grp, l, Q3W_GATE); f.tid_b = Q3_TID(grp, l, Q3W_UP);
-        q3_launch_fill_tiled(f, s);
-        f.dst = t.wd[l]; f.N = d; f.K = F; f.mode = 0; f.row0 = 0; f.rows = d; f.tid_a = Q3_TID(grp, l, Q3W_DOWN); q3_launch_fill_tiled(f, s);
-        t.weight_bytes += 2ull * ((size_t)t.nqkv * d + (size_t)d * t.nq + 3ull * F * d);
+        fill(f, sc_gu);
+        f.dst = t.wd[l]; f.N = d; f.K = F; f.mode = 0; f.row0 = 0; f.rows = d; f.tid_a = Q3_TID(grp, l, Q3W_DOWN); fill(f, sc_d);
     }
     TRY(dalloc(e, &t.out_norm, (size_t)d));
-    TRY(dalloc(e, &t.head, (size_t)head_n * d / 8));
-    t.weight_bytes += 2ull * (size_t)head_n * d;
+    TRY(alloc_mat(&t.head, &t.shead, (size_t)head_n, d));
+    t.weight_bytes += (size_t)(bpw * (double)((size_t)head_n * d));
     if (gg) {
         Q3_HIP(e, hipStreamSynchronize(s));
         TRY(gg->vec("output_norm.weight", d, t.out_norm));
-        TRY(gg->mat("output.weight", head_n, d, 0));
-        Q3Fill f{}; f.dst = t.head; f.N = head_n; f.K = d; f.mode = 0; f.row0 = 0; f.rows = head_n; f.src_a = gg->dev[0];
-        q3_launch_fill_tiled(f, s);
+        TRY(q8 ? gg->mat_q8("output.weight", head_n, d, 0) : gg->mat("output.weight", head_n, d, 0));
+        Q3Fill f{}; f.dst = t.head; f.N = head_n; f.K = d; f.mode = 0; f.row0 = 0; f.rows = head_n;
+        f.src_a = (q8 && gg->raw[0]) ? nullptr : gg->dev[0]; f.src8_a = (q8 && gg->raw[0]) ? gg->dev8[0] : nullptr;
+        fill(f, t.shead);
         Q3_HIP(e, hipStreamSynchronize(s));
     } else {
         q3_launch_fill_f32(t.out_norm, d, seed, Q3_TID(grp, Q3_L_MODEL, Q3WM_OUT_NORM), 1.0f, ns, 0, s);
         Q3Fill f{}; f.seed = seed; f.scale = ms; f.dst = t.head; f.N = head_n; f.K = d; f.mode = 0; f.row0 = 0; f.rows = head_n;
-        f.tid_a = Q3_TID(grp, Q3_L_MODEL, Q3WM_HEAD); q3_launch_fill_tiled(f, s);
+        f.tid_a = Q3_TID(grp, Q3_L_MODEL, Q3WM_HEAD); fill(f, t.shead);
     }
     t.layer_stride = (size_t)n_slots * Hkv * n_ctx * hd;
     TRY(dalloc(e, &t.kc, t.layer_stride * L)); TRY(dalloc(e, &t.vc, t.layer_stride * L));
@@ -241,6 +278,8 @@ static void free_tfm(Q3Tfm& t) {
     for (auto p : t.kn) hipFree(p); for (auto p : t.wqkv) hipFree(p); for (auto p : t.wo) hipFree(p);
     for (auto p : t.wgu) hipFree(p); for (auto p : t.wd) hipFree(p);
     hipFree(t.out_norm); hipFree(t.head); hipFree(t.kc); hipFree(t.vc); hipFree(t.cs); hipFree(t.sn);
+    for (auto p : t.sqkv) hipFree(p); for (auto p : t.so) hipFree(p); for (auto p : t.sgu) hipFree(p); for (auto p : t.sd) hipFree(p);
+    hipFree(t.shead);
 }
 
 static int alloc_scratch(q3tts_engine* e, Q3Scratch& sc, int rows, int nqkv, int nq, int F, int dmax) {
@@ -264,7 +303,7 @@ static int run_layers(q3tts_engine* e, Q3Tfm& t, float* x, uint16_t* xb, float* 
     for (int l = 0; l < t.L; ++l) {
         Q3BGemm g{};
         g.w_once = once;
-        g.a = xb; g.B = rows; g.w = t.wqkv[l]; g.K = t.d; g.N = t.nqkv; g.ssp = ssp; g.ld_ssp = nt; g.ntiles = nt; g.d_norm = t.d; g.eps = eps;
+        g.a = xb; g.B = rows; g.w = t.wqkv[l]; g.wscale = t.q8 ? t.sqkv[l] : nullptr; g.K = t.d; g.N = t.nqkv; g.ssp = ssp; g.ld_ssp = nt; g.ntiles = nt; g.d_norm = t.d; g.eps = eps;
         g.epi = Q3_EPI_STORE; g.y = sc.qkv; g.ldy = t.nqkv;
         const int pk = (probe && l == 0) ? e->probe_kind : -1;  // which launch of block 0 the probe events bracket (q3tts_k_probe)
         if (pk == 1) hipEventRecord(probe[0], s);
@@ -284,17 +323,17 @@ static int run_layers(q3tts_engine* e, Q3Tfm& t, float* x, uint16_t* xb, float* 
         if (pk == 2) hipEventRecord(probe[0], s);
         q3_launch_attend(at, s);
         if (pk == 2) hipEventRecord(probe[1], s);
-        g = Q3BGemm{}; g.w_once = once; g.a = sc.att; g.B = rows; g.w = t.wo[l]; g.K = t.nq; g.N = t.d; g.epi = Q3_EPI_RESID; g.y = x; g.ldy = t.d;
+        g = Q3BGemm{}; g.w_once = once; g.a = sc.att; g.B = rows; g.w = t.wo[l]; g.wscale = t.q8 ? t.so[l] : nullptr; g.K = t.nq; g.N = t.d; g.epi = Q3_EPI_RESID; g.y = x; g.ldy = t.d;
         g.yb = xb; g.nw_next = t.ffn_norm[l]; g.ssp_out = ssp; g.ld_ssp_out = nt;
         if (pk == 3) hipEventRecord(probe[0], s);
         bad += q3_launch_bgemm(g, s) != 0;
         if (pk == 3) hipEventRecord(probe[1], s);
-        g = Q3BGemm{}; g.w_once = once; g.a = xb; g.B = rows; g.w = t.wgu[l]; g.K = t.d; g.N = 2 * t.F; g.ssp = ssp; g.ld_ssp = nt; g.ntiles = nt; g.d_norm = t.d;
+        g = Q3BGemm{}; g.w_once = once; g.a = xb; g.B = rows; g.w = t.wgu[l]; g.wscale = t.q8 ? t.sgu[l] : nullptr; g.K = t.d; g.N = 2 * t.F; g.ssp = ssp; g.ld_ssp = nt; g.ntiles = nt; g.d_norm = t.d;
         g.eps = eps; g.epi = Q3_EPI_SWIGLU; g.yb = sc.h;
         if (pk == 0) hipEventRecord(probe[0], s);
         bad += q3_launch_bgemm(g, s) != 0;
         if (pk == 0) hipEventRecord(probe[1], s);
-        g = Q3BGemm{}; g.w_once = once; g.a = sc.h; g.B = rows; g.w = t.wd[l]; g.K = t.F; g.N = t.d; g.epi = Q3_EPI_RESID; g.y = x; g.ldy = t.d;
+        g = Q3BGemm{}; g.w_once = once; g.a = sc.h; g.B = rows; g.w = t.wd[l]; g.wscale = t.q8 ? t.sd[l] : nullptr; g.K = t.F; g.N = t.d; g.epi = Q3_EPI_RESID; g.y = x; g.ldy = t.d;
         g.yb = xb; g.nw_next = l + 1 < t.L ? t.attn_norm[l + 1] : t.out_norm; g.ssp_out = ssp; g.ld_ssp_out = nt;
         if (pk == 4) hipEventRecord(probe[0], s);
         bad += q3_launch_bgemm(g, s) != 0;
@@ -350,7 +389,7 @@ static int record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
     hipEvent_t* pt = nullptr;  // probe mode 2: the Talker's layer-0 gate/up GEMM (the largest GEMM of the frame step)
     if (e->probe == 2 && B == L.nb && e->probe_i + 2 <= 8) { pt = &e->probe_ev[e->probe_i]; e->probe_i += 2; }
     bad += run_layers(e, e->T, L.xT, L.xbT, L.sspT, B, L.row_pos_t, L.slot_id, L.sc, s, true, pt);
-    Q3BGemm g{}; g.w_once = 1; g.a = L.xbT; g.B = B; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab;
+    Q3BGemm g{}; g.w_once = 1; g.a = L.xbT; g.B = B; g.w = e->T.head; g.wscale = e->T.q8 ? e->T.shead : nullptr; g.K = m.t_d_model; g.N = m.t_vocab;
     g.ssp = L.sspT; g.ld_ssp = m.t_d_model / 16; g.ntiles = m.t_d_model / 16; g.d_norm = m.t_d_model; g.eps = eps;
     g.epi = Q3_EPI_STORE; g.y = L.logits; g.ldy = m.t_vocab;
     bad += q3_launch_bgemm(g, s) != 0;
@@ -470,7 +509,7 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
         if (gt.open(wdir + "/qwen3_tts_talker.gguf", er) || gp.open(wdir + "/qwen3_tts_predictor.gguf", er)) { q3_set_err(e, Q3TTS_ERR_INVALID, er); return fail(Q3TTS_ERR_INVALID); }
     }
     TRYC(init_tfm(e, e->T, Q3G_TALKER, m.t_n_layer, m.t_d_model, m.t_n_head, m.t_n_kv_head, m.t_head_dim, m.t_d_ffn, m.t_vocab,
-                  m.t_rope_theta, m.t_mrope_sections, cfg->n_ctx, B, wdir.empty() ? nullptr : &st));
+                  m.t_rope_theta, m.t_mrope_sections, cfg->n_ctx, B, wdir.empty() ? nullptr : &st, cfg->talker_q8_0 != 0));
     TRYC(init_tfm(e, e->P, Q3G_PRED, m.p_n_layer, m.p_d_model, m.p_n_head, m.p_n_kv_head, m.p_head_dim, m.p_d_ffn,
                   (m.n_codebooks - 1) * m.codebook_size, m.p_rope_theta, nullptr, 64, B, wdir.empty() ? nullptr : &sp));
     // assets (F32 tables like qwen3_assets.gguf: src/assets_manager.rs:212-241; values bf16-representable)
@@ -830,7 +869,7 @@ static int admit_group(q3tts_engine* e, std::vector<Adm>& grp, int total) {
         const int row = e->row_of_slot[b];
         q3_launch_copy_rows(L.xT + (size_t)row * m.t_d_model, m.t_d_model, e->xp + (size_t)(a.row0 + a.n - 1) * m.t_d_model, m.t_d_model, 1, m.t_d_model, s);
         const size_t lastr = (size_t)(a.row0 + a.n - 1);  // the last prompt row's norm inputs for out_norm came out of the last block
-        Q3BGemm g{}; g.a = e->xbp; g.a_row0 = (int)lastr; g.B = 1; g.w = e->T.head; g.K = m.t_d_model; g.N = m.t_vocab;
+        Q3BGemm g{}; g.a = e->xbp; g.a_row0 = (int)lastr; g.B = 1; g.w = e->T.head; g.wscale = e->T.q8 ? e->T.shead : nullptr; g.K = m.t_d_model; g.N = m.t_vocab;
         g.ssp = e->sspp + lastr * (m.t_d_model / 16); g.ld_ssp = m.t_d_model / 16; g.ntiles = m.t_d_model / 16; g.d_norm = m.t_d_model; g.eps = m.rms_eps;
         g.epi = Q3_EPI_STORE; g.y = L.logits + (size_t)row * m.t_vocab; g.ldy = m.t_vocab;
         if (q3_launch_bgemm(g, s)) return q3_set_err(e, Q3TTS_ERR_INVALID, "prefill head: launch refused for this model shape");
@@ -1376,6 +1415,70 @@ extern "C" int q3tts_k_bgemm(int32_t device, const uint16_t* xb, int32_t B, int3
         HK(hipMemcpy(ssp_out, dso.p, (size_t)B * (N / 16) * 4, hipMemcpyDeviceToHost));
     }
     if (epi == Q3_EPI_ARGMAX) {  // the kernel leaves one maximum per (row, 16-column tile); the consumer (here: the hook) takes the row maximum
+        std::vector<uint64_t> parts((size_t)B * (N / 16));
+        HK(hipMemcpy(parts.data(), dk.p, parts.size() * 8, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b) { uint64_t m = 0; for (int t = 0; t < N / 16; ++t) m = std::max(m, parts[(size_t)b * (N / 16) + t]); keys[b] = m; }
+    }
+    if (iters > 0 && mean_ms) {
+        if (epi == Q3_EPI_RESID) { g.epi = Q3_EPI_STORE; g.nw_next = nullptr; }
+        hipEvent_t a, b; HK(hipEventCreate(&a)); HK(hipEventCreate(&b));
+        q3_launch_bgemm(g, nullptr);
+        HK(hipEventRecord(a, nullptr));
+        for (int i = 0; i < iters; ++i) q3_launch_bgemm(g, nullptr);
+        HK(hipEventRecord(b, nullptr)); HK(hipEventSynchronize(b));
+        float ms = 0; hipEventElapsedTime(&ms, a, b); *mean_ms = ms / iters;
+        hipEventDestroy(a); hipEventDestroy(b);
+    }
+    return Q3TTS_OK;
+}
+
+// the same launch with ggml Q8_0 weights kept in block form: q int8 [N][K], d_f16 [N][K/32]. Mirrors oracle q3o_bgemm_q8.
+extern "C" int q3tts_k_bgemm_q8(int32_t device, const uint16_t* xb, int32_t B, int32_t K, const int8_t* q, const uint16_t* d_f16, int32_t N, const float* ssp,
+                                int32_t ntiles, int32_t d_norm, float eps, int32_t epi, const float* nw_next, float* y, uint16_t* yb, float* ssp_out,
+                                uint64_t* keys, int32_t iters, float* mean_ms) {
+    if (!xb || !q || !d_f16 || B <= 0 || K % 512 || K < 512 || N % 16 || epi < 0 || epi > 3) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm_q8 hook: K % 512 == 0, N % 16 == 0");
+    if (epi == Q3_EPI_SWIGLU && (N % 64 || !yb)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm_q8 hook: swiglu needs N % 64 == 0 and yb");
+    if (epi == Q3_EPI_RESID && nw_next && (N % 32 || !yb || !ssp_out)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm_q8 hook: norm outputs");
+    if ((epi == Q3_EPI_STORE || epi == Q3_EPI_RESID) && !y) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm_q8 hook: y missing");
+    if (epi == Q3_EPI_ARGMAX && !keys) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm_q8 hook: keys missing");
+    HK(hipSetDevice(device));
+    const int F = N / 2, kb = K / 32;
+    const size_t B16 = ((size_t)B + 15) & ~(size_t)15;
+    std::vector<uint8_t> blocks((size_t)N * kb * 34);  // the rows as a GGUF file holds them: block_q8_0 = f16 d, 32 x int8
+    for (size_t n = 0; n < (size_t)N; ++n)
+        for (int b = 0; b < kb; ++b) {
+            uint8_t* blk = &blocks[(n * kb + b) * 34];
+            const uint16_t dd = d_f16[n * kb + b];
+            blk[0] = (uint8_t)(dd & 0xff); blk[1] = (uint8_t)(dd >> 8);
+            memcpy(blk + 2, q + n * K + (size_t)b * 32, 32);
+        }
+    DevBuf dx, dw, dwt, dsc, ds, dn, dy, dyb, dso, dk;
+    if (dx.alloc(B16 * K * 2) || dw.alloc(blocks.size()) || dwt.alloc((size_t)N * K) || dsc.alloc((size_t)N * kb * 2) || ds.alloc((size_t)B * (ntiles > 0 ? ntiles : 1) * 4) ||
+        dn.alloc((size_t)N * 4) || dy.alloc((size_t)B * N * 4) || dyb.alloc(B16 * N * 2) || dso.alloc((size_t)B * (N / 16) * 4) || dk.alloc((size_t)B * (N / 16) * 8))
+        return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
+    { const std::vector<uint16_t> xt = atile_host(xb, B, K); HK(hipMemcpy(dx.p, xt.data(), xt.size() * 2, hipMemcpyHostToDevice)); }
+    HK(hipMemcpy(dw.p, blocks.data(), blocks.size(), hipMemcpyHostToDevice));
+    if (ssp) HK(hipMemcpy(ds.p, ssp, (size_t)B * ntiles * 4, hipMemcpyHostToDevice));
+    if (nw_next) HK(hipMemcpy(dn.p, nw_next, (size_t)N * 4, hipMemcpyHostToDevice));
+    if (epi == Q3_EPI_RESID) HK(hipMemcpy(dy.p, y, (size_t)B * N * 4, hipMemcpyHostToDevice));
+    Q3Fill f{}; f.dst = (uint4*)dwt.p; f.dst_scale = (uint16_t*)dsc.p; f.N = N; f.K = K;
+    if (epi == Q3_EPI_SWIGLU) { f.mode = 1; f.src8_a = (const uint8_t*)dw.p; f.src8_b = (const uint8_t*)dw.p + (size_t)F * kb * 34; }
+    else { f.mode = 0; f.row0 = 0; f.rows = N; f.src8_a = (const uint8_t*)dw.p; }
+    q3_launch_fill_tiled_q8(f, nullptr);
+    Q3BGemm g{}; g.a = (const uint16_t*)dx.p; g.a_row0 = 0; g.B = B; g.w = (const uint4*)dwt.p; g.wscale = (const uint16_t*)dsc.p; g.K = K; g.N = N;
+    g.ssp = ssp ? (const float*)ds.p : nullptr; g.ld_ssp = ntiles; g.ntiles = ntiles; g.d_norm = d_norm; g.eps = eps; g.epi = epi;
+    g.y = (float*)dy.p; g.ldy = N; g.yb = (uint16_t*)dyb.p;
+    g.nw_next = nw_next ? (const float*)dn.p : nullptr; g.ssp_out = (float*)dso.p; g.ld_ssp_out = N / 16;
+    g.keys = (unsigned long long*)dk.p; g.key_stride = N / 16;
+    if (q3_launch_bgemm(g, nullptr)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm_q8: shape");
+    HK(hipDeviceSynchronize());
+    if (epi == Q3_EPI_STORE || epi == Q3_EPI_RESID) HK(hipMemcpy(y, dy.p, (size_t)B * N * 4, hipMemcpyDeviceToHost));
+    if (epi == Q3_EPI_SWIGLU) { std::vector<uint16_t> t(B16 * F); HK(hipMemcpy(t.data(), dyb.p, t.size() * 2, hipMemcpyDeviceToHost)); untile_host(t, B, F, yb); }
+    if (epi == Q3_EPI_RESID && nw_next) {
+        { std::vector<uint16_t> t(B16 * N); HK(hipMemcpy(t.data(), dyb.p, t.size() * 2, hipMemcpyDeviceToHost)); untile_host(t, B, N, yb); }
+        HK(hipMemcpy(ssp_out, dso.p, (size_t)B * (N / 16) * 4, hipMemcpyDeviceToHost));
+    }
+    if (epi == Q3_EPI_ARGMAX) {
         std::vector<uint64_t> parts((size_t)B * (N / 16));
         HK(hipMemcpy(parts.data(), dk.p, parts.size() * 8, hipMemcpyDeviceToHost));
         for (int b = 0; b < B; ++b) { uint64_t m = 0; for (int t = 0; t < N / 16; ++t) m = std::max(m, parts[(size_t)b * (N / 16) + t]); keys[b] = m; }

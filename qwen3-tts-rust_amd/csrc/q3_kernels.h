@@ -73,6 +73,11 @@ struct Q3BGemm {
     const float* bias; int bias_n;
     int seg_rows; size_t seg_stride;
     unsigned long long* keys; int key_stride;   // ARGMAX: per-tile maxima, [B][key_stride]
+    // Q8_0 weights (the Talker with q3tts_engine_config.talker_q8_0): w then holds ggml block_q8_0 quants in the tiled
+    // Q8 layout — tile PAIR (nb = n/16, kp = k/64) is 1 KiB, lane l = (kq, n) owns 16 bytes: the 8 int8 of k-block 2 kp that its bf16
+    // fragment would hold (k = 4kq..4kq+3, 16+4kq..16+4kq+3), then the 8 of k-block 2 kp + 1 — and wscale the f16 block scales
+    // [N][K/32] (physical column order). RAW = the canonical Q8 order: per block P = MFMA from zero, t = fmaf(f32(d), P, t). K % 512 == 0.
+    const uint16_t* wscale;
     Q3_STAMP_FIELD
 };
 int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s);
@@ -112,8 +117,13 @@ struct Q3Fill {
     uint32_t tid_a, tid_b;           // synthetic tensor ids (mode 1: a = gate, b = up)
     const uint16_t* src_a; const uint16_t* src_b;  // row-major [rows][K] bf16 or nullptr -> synthetic
     uint64_t seed; float scale;
+    // Q8_0 destination (q3_launch_fill_tiled_q8): dst = the tiled Q8 layout above, dst_scale = f16 [N][K/32]. Sources: raw ggml block_q8_0
+    // rows (src8_a / src8_b: [rows][K/32] blocks of 34 bytes, kept as stored), else the bf16 / synthetic sources above, quantised with
+    // ggml's reference rule (d = amax / 127, q = roundf(x / d))
+    uint16_t* dst_scale; const uint8_t* src8_a; const uint8_t* src8_b;
 };
 void q3_launch_fill_tiled(const Q3Fill& f, hipStream_t s);
+void q3_launch_fill_tiled_q8(const Q3Fill& f, hipStream_t s);
 void q3_launch_fill_f32(float* dst, size_t n, uint64_t seed, uint32_t tid, float base, float scale, int round_bf16, hipStream_t s);
 
 // q/k RMSNorm + RoPE (q in place) + bf16 K/V append. One wave per (row, head).

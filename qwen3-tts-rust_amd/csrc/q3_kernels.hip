@@ -65,6 +65,61 @@ void q3_launch_fill_tiled(const Q3Fill& f, hipStream_t s) {
     const size_t total = (size_t)nbc * (f.K >> 5) * 64;
     hipLaunchKernelGGL(k_fill_tiled, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, f, nb0, nbc);
 }
+// The same matrices as ggml Q8_0 blocks in the tiled Q8 layout (q3_kernels.h): one thread per (column tile, k-block pair, lane) = 16 output
+// bytes. A thread needs the scale of both of its blocks, i.e. the largest magnitude of all 32 weights of each: it re-reads them (8 x
+// redundant: load-time only). Quantiser = ggml's quantize_row_q8_0_ref: d = amax / 127, id = d ? 1 / d : 0, q = roundf(x * id), d kept as f16.
+__global__ void k_fill_tiled_q8(Q3Fill f, int nb0, int nb_count) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int kpairs = f.K >> 6, kblocks = f.K >> 5;
+    const size_t total = (size_t)nb_count * kpairs * 64;
+    if (gid >= total) return;
+    const int lane = (int)(gid & 63);
+    const size_t t = gid >> 6;
+    const int kp = (int)(t % kpairs), nb = nb0 + (int)(t / kpairs);
+    const int n = nb * 16 + (lane & 15), kq = lane >> 4;
+    uint32_t tid; int lr; const uint16_t* src; const uint8_t* src8;
+    if (f.mode == 0) { tid = f.tid_a; lr = n - f.row0; src = f.src_a; src8 = f.src8_a; }
+    else {
+        const int tile = n >> 4, c = n & 15;
+        if (c < 8) { tid = f.tid_a; lr = tile * 8 + c; src = f.src_a; src8 = f.src8_a; }
+        else { tid = f.tid_b; lr = tile * 8 + c - 8; src = f.src_b; src8 = f.src8_b; }
+    }
+    uint32_t out[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int kb = 2 * kp + h;
+        int8_t q[8]; uint16_t d16;
+        if (src8) {  // a block_q8_0 as stored: f16 d, 32 x int8
+            const uint8_t* blk = src8 + ((size_t)lr * kblocks + kb) * 34;
+            d16 = (uint16_t)blk[0] | ((uint16_t)blk[1] << 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q[e] = (int8_t)blk[2 + (e >> 2) * 16 + kq * 4 + (e & 3)];
+        } else {
+            float amax = 0.0f, mine[8];
+            for (int k = 0; k < 32; ++k) {
+                const size_t idx = (size_t)lr * f.K + (size_t)kb * 32 + k;
+                const float v = src ? q3_bf16f(src[idx]) : q3_round_bf16(q3_synth(f.seed, tid, idx, f.scale));
+                amax = fmaxf(amax, fabsf(v));
+                const int kk = k & 15;
+                if ((kk >> 2) == kq) mine[((k >> 4) << 2) + (kk & 3)] = v;
+            }
+            const float d = amax / 127.0f, id = d != 0.0f ? 1.0f / d : 0.0f;
+            d16 = __builtin_bit_cast(unsigned short, (_Float16)d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q[e] = (int8_t)(int)roundf(mine[e] * id);
+        }
+        out[2 * h] = (uint32_t)(uint8_t)q[0] | ((uint32_t)(uint8_t)q[1] << 8) | ((uint32_t)(uint8_t)q[2] << 16) | ((uint32_t)(uint8_t)q[3] << 24);
+        out[2 * h + 1] = (uint32_t)(uint8_t)q[4] | ((uint32_t)(uint8_t)q[5] << 8) | ((uint32_t)(uint8_t)q[6] << 16) | ((uint32_t)(uint8_t)q[7] << 24);
+        if (kq == 0) f.dst_scale[(size_t)n * kblocks + kb] = d16;
+    }
+    f.dst[((size_t)nb * kpairs + kp) * 64 + lane] = make_uint4(out[0], out[1], out[2], out[3]);
+}
+void q3_launch_fill_tiled_q8(const Q3Fill& f, hipStream_t s) {
+    int nb0, nbc;
+    if (f.mode == 0) { nb0 = f.row0 / 16; nbc = f.rows / 16; } else { nb0 = 0; nbc = f.N / 16; }
+    const size_t total = (size_t)nbc * (f.K >> 6) * 64;
+    hipLaunchKernelGGL(k_fill_tiled_q8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, f, nb0, nbc);
+}
 __global__ void k_fill_f32(float* dst, size_t n, uint64_t seed, uint32_t tid, float base, float scale, int rb) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;

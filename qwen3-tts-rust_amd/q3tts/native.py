@@ -362,6 +362,27 @@ def k_bgemm(xb, wb, ssp, d_norm, eps, epi, nw_next=None, y0=None, device=0, iter
     return dict(y=y, yb=yb, ssp_out=sso, keys=keys, ms=ms.value)
 
 
+def k_bgemm_q8(xb, q, d16, ssp, d_norm, eps, epi, nw_next=None, y0=None, device=0, iters=0):
+    """The same launch with ggml Q8_0 weights kept in block form on the device (q3tts_k_bgemm_q8): q int8 [N][K], d16 f16 bits [N][K/32]."""
+    lib = _abi.load_library()
+    xb = np.ascontiguousarray(xb, dtype=np.uint16); q = np.ascontiguousarray(q, dtype=np.int8); d16 = np.ascontiguousarray(d16, dtype=np.uint16)
+    B, K = xb.shape
+    N = q.shape[0]
+    y = np.zeros((B, N), dtype=np.float32) if y0 is None else np.ascontiguousarray(y0, dtype=np.float32).copy()
+    yb = np.zeros((B, N // 2 if epi == 2 else N), dtype=np.uint16)
+    sso = np.zeros((B, N // 16), dtype=np.float32)
+    keys = np.zeros(B, dtype=np.uint64)
+    sp = None if ssp is None else np.ascontiguousarray(ssp, dtype=np.float32)
+    nw = None if nw_next is None else np.ascontiguousarray(nw_next, dtype=np.float32)
+    ms = C.c_float(0)
+    rc = lib.q3tts_k_bgemm_q8(device, xb.ctypes.data, B, K, q.ctypes.data, d16.ctypes.data, N, None if sp is None else sp.ctypes.data,
+                              0 if sp is None else sp.shape[1], d_norm, eps, epi, None if nw is None else nw.ctypes.data, y.ctypes.data, yb.ctypes.data,
+                              sso.ctypes.data, keys.ctypes.data, iters, C.byref(ms))
+    if rc != 0:
+        raise _abi.Q3Error(f"q3tts_k_bgemm_q8 failed ({rc}): {lib.q3tts_last_error(None).decode()}")
+    return dict(y=y, yb=yb, ssp_out=sso, keys=keys, ms=ms.value)
+
+
 def k_bgemm_voc(xb, wb, epi, bias=None, col_scale=None, seg_rows=0, gap_rows=0, y0=None, want_yb=False, device=0):
     """The decoder's GEMM with the vocoder's epilogue extras (q3tts_k_bgemm_voc): returns dict(y=[B][N] f32 or None, yb=[B][N] bf16 bits or None)."""
     lib = _abi.load_library()

@@ -26,7 +26,8 @@ def quantize_q8_0(x):
     amax = np.abs(x).max(axis=1)
     d = (amax / 127.0).astype(np.float32)
     inv = np.where(d > 0, 1.0 / np.where(d > 0, d, 1.0), 0.0).astype(np.float32)
-    q = np.rint(x * inv[:, None]).astype(np.int8)
+    v = x * inv[:, None]
+    q = (np.sign(v) * np.floor(np.abs(v) + np.float32(0.5))).astype(np.int8)   # C roundf (half away from zero), as ggml's quantize_row_q8_0_ref
     out = np.zeros((x.shape[0], 34), dtype=np.uint8)
     out[:, :2] = d.astype(np.float16).view(np.uint8).reshape(-1, 2)
     out[:, 2:] = q.view(np.uint8)

@@ -93,6 +93,13 @@ def lib():
     L.q3o_bgemm.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32,
                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.q3o_bgemm.restype = None
+    L.q3o_bgemm_q8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.q3o_bgemm_q8.restype = None
+    L.q3o_quantize_q8_0.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    L.q3o_quantize_q8_0.restype = None
+    L.q3o_set_talker_q8.argtypes = [vp]
+    L.q3o_set_talker_q8.restype = None
     L.q3o_project_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     L.q3o_project_rows.restype = None
     L.q3o_norm_inputs.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -144,6 +151,10 @@ class OracleModel:
 
     def __del__(self):
         self.close()
+
+    def set_talker_q8(self):
+        """The Talker's matrices + lm_head as ggml Q8_0 blocks in the canonical Q8 order (device: q3tts_engine_config.talker_q8_0 = 1). One-way."""
+        self.L.q3o_set_talker_q8(self.h)
 
     def set_arith(self, mode):
         """0: the canonical bf16-MFMA order (default); 1: plain f32 of the same structure (family pinning)."""
@@ -198,6 +209,30 @@ def bgemm(xb, wb, ssp, d_norm, eps, epi, nw_next=None, y0=None):
     nw = None if nw_next is None else np.ascontiguousarray(nw_next, dtype=np.float32)
     lib().q3o_bgemm(xb.ctypes.data, B, K, wb.ctypes.data, N, None if sp is None else sp.ctypes.data, 0 if sp is None else sp.shape[1], d_norm, eps, epi,
                     None if nw is None else nw.ctypes.data, y.ctypes.data, yb.ctypes.data, sso.ctypes.data, keys.ctypes.data)
+    return dict(y=y, yb=yb, ssp_out=sso, keys=keys)
+
+
+def quantize_q8_0(x):
+    """ggml's reference Q8_0 quantiser through the oracle's C restatement: x [..., K] f32 -> (q int8 same shape, d f16 bits [..., K/32])."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    q = np.zeros(x.shape, dtype=np.int8); d = np.zeros(x.shape[:-1] + (x.shape[-1] // 32,), dtype=np.uint16)
+    lib().q3o_quantize_q8_0(x.ctypes.data, x.size, q.ctypes.data, d.ctypes.data)
+    return q, d
+
+
+def bgemm_q8(xb, q, d16, ssp, d_norm, eps, epi, nw_next=None, y0=None):
+    """oracle/q3_oracle_bf16.c q3o_bgemm_q8: the canonical Q8_0 order (per block P = MFMA from zero, t = fmaf(f32(d), P, t))."""
+    xb = np.ascontiguousarray(xb, dtype=np.uint16); q = np.ascontiguousarray(q, dtype=np.int8); d16 = np.ascontiguousarray(d16, dtype=np.uint16)
+    B, K = xb.shape
+    N = q.shape[0]
+    y = np.zeros((B, N), dtype=np.float32) if y0 is None else np.ascontiguousarray(y0, dtype=np.float32).copy()
+    yb = np.zeros((B, N // 2 if epi == 2 else N), dtype=np.uint16)
+    sso = np.zeros((B, N // 16), dtype=np.float32)
+    keys = np.zeros(B, dtype=np.uint64)
+    sp = None if ssp is None else np.ascontiguousarray(ssp, dtype=np.float32)
+    nw = None if nw_next is None else np.ascontiguousarray(nw_next, dtype=np.float32)
+    lib().q3o_bgemm_q8(xb.ctypes.data, B, K, q.ctypes.data, d16.ctypes.data, N, None if sp is None else sp.ctypes.data, 0 if sp is None else sp.shape[1],
+                       d_norm, eps, epi, None if nw is None else nw.ctypes.data, y.ctypes.data, yb.ctypes.data, sso.ctypes.data, keys.ctypes.data)
     return dict(y=y, yb=yb, ssp_out=sso, keys=keys)
 
 
@@ -278,13 +313,15 @@ def synth_asset_tensors(m, seed, with_text=True):
     return t
 
 
-def write_model_dir(path, m, seed, matrix_type=30, assets="gguf", with_text=True):
-    """The synthetic model as the reference's quant directory: two llama.cpp-style GGUFs + qwen3_assets.gguf (or NPY)."""
+def write_model_dir(path, m, seed, matrix_type=30, assets="gguf", with_text=True, predictor_type=None):
+    """The synthetic model as the reference's quant directory: two llama.cpp-style GGUFs + qwen3_assets.gguf (or NPY).
+    predictor_type: tensor type of the Predictor's matrices when it differs from the Talker's (matrix_type)."""
     import _gguf as G
     os.makedirs(path, exist_ok=True)
     for talker, fname in ((True, "qwen3_tts_talker.gguf"), (False, "qwen3_tts_predictor.gguf")):
         tens = synth_transformer_tensors(m, seed, talker)
-        G.write(os.path.join(path, fname), [(k, v, matrix_type if v.ndim == 2 else G.F32) for k, v in tens.items()],
+        mt = matrix_type if (talker or predictor_type is None) else predictor_type
+        G.write(os.path.join(path, fname), [(k, v, mt if v.ndim == 2 else G.F32) for k, v in tens.items()],
                 meta={"general.architecture": "qwen3", "general.alignment": 32, "qwen3.block_count": m.t_n_layer if talker else m.p_n_layer,
                       "tokenizer.ggml.tokens": ["<a>", "<b>"], "tokenizer.ggml.token_type": [1, 1]})
     at = synth_asset_tensors(m, seed, with_text)

@@ -406,3 +406,39 @@ def test_sampler_expf_vs_libm_boundary_flips(oracle):
             total += 1
     print(f"sampler exp: q3_expf vs libm over {total} draws: {flips} different ids")
     assert total == 100000 and flips <= 20   # expected ~ 2 * 40 * 2.2e-7 * 1e5 < 2
+
+
+def test_q8_0_quantiser_and_canonical_gemm(oracle):
+    """Q8_0 row of the oracle: its C quantiser is ggml's reference rule (d = amax / 127 as f16, q = roundf(x / d), ties away
+    from zero) and agrees with the numpy writer of tests/_gguf.py block for block; the canonical Q8 GEMM (per block: bf16 MFMA from zero,
+    then fmaf with f32(d)) is the product with the de-quantised weights to f32 rounding; the Talker switched to Q8 still generates."""
+    import _gguf as G
+    rng = np.random.default_rng(0)
+    w = (rng.standard_normal((48, 1024)) * 0.02).astype(np.float32)
+    w[3, :32] = 0.0
+    w[5, 32:64] = np.float32(0.5) * np.arange(32, dtype=np.float32)   # x / d lands on .5 ties
+    q, d = oracle.quantize_q8_0(w)
+    raw = G.quantize_q8_0(w).reshape(-1, 34)
+    assert np.array_equal(d, raw[:, :2].copy().view(np.uint16).reshape(d.shape)) and np.array_equal(q, raw[:, 2:].copy().view(np.int8).reshape(q.shape))
+    assert np.abs(q).max() == 127 and not q[3, :32].any() and d[3, 0] == 0
+    deq = (q.astype(np.float64).reshape(48, 32, 32) * d.view(np.float16).astype(np.float64)[:, :, None]).reshape(48, 1024)
+    assert np.abs(deq - w).max() <= np.abs(w).max() / 127.0 * 0.51 + 1e-4
+    x = rng.standard_normal((7, 1024)).astype(np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    xb = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    xf = (xb.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    y = oracle.bgemm_q8(xb, q, d, None, 1024, 1e-6, 0)["y"]
+    want = xf @ deq.T
+    assert np.abs(y - want).max() <= 3e-5 * np.abs(want).max()
+    from q3tts import _abi
+    cfg = _abi.tiny_config(max_batch=1, n_ctx=64, with_vocoder=0)
+    om = oracle.OracleModel(cfg.model, seed=0, n_ctx=64, n_threads=4)
+    try:
+        desc, keep = oracle.make_prompt_desc(np.arange(100, 108), spk_emb=((np.arange(cfg.model.d_embed) % 13 - 6) * 0.03125).astype(np.float32))
+        pe = om.build_prompt(desc)
+        bf, _ = om.generate(pe, temperature=0.0, max_steps=4, min_frames=4)
+        om.set_talker_q8()
+        q8, _ = om.generate(pe, temperature=0.0, max_steps=4, min_frames=4)
+        assert q8.shape == bf.shape == (4, 16) and not np.array_equal(q8, bf)
+    finally:
+        om.close()

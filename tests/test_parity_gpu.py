@@ -741,6 +741,138 @@ def test_bgemm_argmax_ties_resolve_to_the_first_index(oracle, native):
     assert np.array_equal(native.k_bgemm(xb, wb, None, 512, 1e-6, 3)["keys"], oracle.bgemm(xb, wb, None, 512, 1e-6, 3)["keys"])
 
 
+# ---- Q8_0 weights kept in block form on the device (q3tts_engine_config.talker_q8_0) -----------------------------------
+@pytest.mark.parametrize("B,K,N,epi", [(64, 2048, 12288, 2), (64, 2048, 4096, 0), (64, 6144, 2048, 1), (64, 2048, 2048, 1), (1, 2048, 3072, 0), (1, 6144, 2048, 1),
+                                       (37, 512, 1024, 2), (48, 2048, 4096, 0), (9, 1024, 96, 3), (130, 512, 512, 1), (300, 2048, 4096, 0), (5, 1536, 32, 0)])
+def test_bgemm_q8_matches_oracle(oracle, native, B, K, N, epi):
+    """The decoder's GEMM on ggml Q8_0 blocks as stored (f16 d, 32 x int8): per block P = the bf16 MFMA of (x, q) from a zero accumulator,
+    t = fmaf(f32(d), P, t) over the blocks of a K slice, the 8 slices added in order — bit for bit the oracle's q3o_bgemm_q8, every epilogue,
+    the Talker's shapes at 64 rows, ragged row tiles, many rows (k_bgemm_big does not take Q8: 64-row chunks), blocks of zeros, q = -128."""
+    rng = np.random.default_rng(B + K + N + epi)
+    x = _rand(rng, (B, K), 1.5); x[:, :7] *= 300.0; x[:, 100:140] *= 1e-3
+    w = _rand(rng, (N, K), 0.02); w[3, 64:96] = 0.0; w[5 % N, :32] *= 40.0
+    q, d16 = oracle.quantize_q8_0(w)
+    q[1, 0] = -128   # valid in a file, never produced by the quantiser
+    xb = _bf16_bits(x)
+    scaled = epi in (0, 2, 3)
+    ssp = (np.abs(_rand(rng, (B, K // 16), 4.0)) + 0.5).astype(np.float32) if scaled else None
+    nw_next = (1.0 + _rand(rng, (N,), 0.05)).astype(np.float32) if epi == 1 and N % 32 == 0 else None
+    y0 = _rand(rng, (B, N), 2.0) if epi == 1 else None
+    ref = oracle.bgemm_q8(xb, q, d16, ssp, K, 1e-6, epi, nw_next, y0)
+    got = native.k_bgemm_q8(xb, q, d16, ssp, K, 1e-6, epi, nw_next, y0)
+    if epi in (0, 1):
+        assert np.array_equal(_bits(got["y"]), _bits(ref["y"]))
+    if epi == 1 and nw_next is not None:
+        assert np.array_equal(got["yb"], ref["yb"]) and np.array_equal(_bits(got["ssp_out"]), _bits(ref["ssp_out"]))
+    if epi == 2:
+        assert np.array_equal(got["yb"], ref["yb"]) and np.count_nonzero(got["yb"] & 0x7fff) > got["yb"].size // 2
+    if epi == 3:
+        assert np.array_equal(got["keys"], ref["keys"])
+    if epi == 0 and B == 64:   # and it IS the product with the de-quantised weights, to f32 rounding
+        xf = (xb.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+        wd = (q.astype(np.float64).reshape(N, K // 32, 32) * d16.view(np.float16).astype(np.float64)[:, :, None]).reshape(N, K)
+        s = np.array([oracle.row_scale(ssp[r], K, 1e-6) for r in range(B)], dtype=np.float64)
+        want = (xf @ wd.T) * s[:, None]
+        assert np.abs(got["y"] - want).max() <= 3e-5 * np.abs(want).max()
+
+
+def _q8_engine_and_oracle(oracle, cfg, n_ctx):
+    from q3tts import native
+    cfg.talker_q8_0 = 1
+    eng = native.NativeEngine(cfg)
+    om = oracle.OracleModel(cfg.model, seed=0, n_ctx=n_ctx, n_threads=min(16, os.cpu_count() or 4))
+    om.set_talker_q8()
+    return eng, om
+
+
+def test_talker_q8_0_on_the_device_ids_match_the_oracle(oracle):
+    """q3tts_engine_config.talker_q8_0 = 1 with the synthetic model: device and oracle quantise the same bf16 weights with ggml's reference
+    rule and multiply the blocks in the canonical Q8 order — prompt rows, prefill logits / hidden, greedy and sampled ids are equal, on one
+    slot and on several of different length; and the ids DIFFER from the bf16 engine's (the quantisation is really in the path)."""
+    from q3tts import _abi, native
+    cfg = _abi.tiny_config(max_batch=4, n_ctx=256, with_vocoder=0)
+    eng, om = _q8_engine_and_oracle(oracle, cfg, 256)
+    try:
+        desc, keep = oracle.make_prompt_desc(np.arange(100, 120), spk_emb=_spk(cfg.model.d_embed))
+        pe = om.build_prompt(desc)
+        h_ref, l_ref = om.talker_prefill(pe)
+        h, l = eng.talker_prefill(pe)
+        assert np.array_equal(_bits(l), _bits(l_ref)) and np.array_equal(_bits(h), _bits(h_ref))
+        ref, _ = om.generate(pe, temperature=0.0, max_steps=12, min_frames=12)
+        res = eng.generate(embd=pe, temperature=0.0, max_steps=12, min_frames=12)
+        assert np.array_equal(res.codes, ref)
+        rng = np.random.default_rng(8)
+        reqs, refs = [], []
+        for i in range(6):
+            d2, k2 = oracle.make_prompt_desc(rng.integers(0, 151643, size=int(rng.integers(3, 40))), spk_emb=_spk(cfg.model.d_embed))
+            p2 = om.build_prompt(d2)
+            t = int(rng.integers(3, 15))
+            kw = dict(temperature=0.7, top_k=40, top_p=0.9, seed=70 + i, max_steps=20, min_frames=t, force_eos_at=t)
+            refs.append(om.generate(p2, **kw)[0]); reqs.append(dict(embd=p2, **kw))
+        for o, r in zip(eng.generate_batch(reqs), refs):
+            assert o.status == 0 and np.array_equal(o.codes, r)
+        cfg16 = _abi.tiny_config(max_batch=4, n_ctx=256, with_vocoder=0)
+        e16 = native.NativeEngine(cfg16)
+        try:
+            assert not np.array_equal(e16.generate(embd=pe, temperature=0.0, max_steps=12, min_frames=12).codes, ref)
+        finally:
+            e16.close()
+    finally:
+        eng.close()
+        om.close()
+
+
+@pytest.mark.parametrize("talker_type", [8, 30])
+def test_talker_q8_0_from_model_files(oracle, tmp_path, talker_type):
+    """weights_path + talker_q8_0 = 1. A Q8_0 Talker container (type 8: the reference's gguf_q8_0 directory, src/tts/engine.rs:91-95) goes
+    to the device AS STORED — the file's own f16 scales and int8 quants, never widened to bf16 — and a BF16 container (type 30) is quantised
+    on the device with ggml's rule; either way the ids equal the oracle's Q8 mode (tests/_gguf.py's writer and the oracle's quantiser are
+    the same rule: checked in the CPU suite). The Predictor file is BF16 in both cases (it keeps bf16 weights)."""
+    import _gguf as G
+    from q3tts import _abi, native
+    cfg = _abi.tiny_config(max_batch=2, n_ctx=128, with_vocoder=0)
+    oracle.write_model_dir(str(tmp_path), cfg.model, 0, matrix_type=talker_type, predictor_type=G.BF16)
+    cfg.weights_path = str(tmp_path).encode()
+    cfg.talker_q8_0 = 1
+    eng = native.NativeEngine(cfg)
+    om = oracle.OracleModel(_abi.tiny_config(max_batch=2, n_ctx=128, with_vocoder=0).model, seed=0, n_ctx=128, n_threads=4)
+    om.set_talker_q8()
+    try:
+        desc, keep = oracle.make_prompt_desc(np.arange(900, 912), spk_emb=_spk(cfg.model.d_embed))
+        pe = om.build_prompt(desc)
+        assert np.array_equal(_bits(eng.build_prompt(desc)), _bits(pe))
+        for kw in (dict(temperature=0.0, max_steps=6, min_frames=6), dict(temperature=0.7, top_k=40, top_p=0.9, seed=11, max_steps=6, min_frames=6)):
+            ref, _ = om.generate(pe, **kw)
+            assert ref.shape[0] == 6 and np.array_equal(eng.generate(desc=desc, **kw).codes, ref)
+    finally:
+        eng.close()
+        om.close()
+
+
+def test_talker_q8_0_full_shape_prefill_and_frames(oracle):
+    """The same at the benchmarked shape (28 x 2048 Talker in Q8_0 blocks, 1.5 GB instead of 2.8 GB of weights): prefill logits / hidden
+    and 4 greedy frames equal the oracle's."""
+    import time
+    from q3tts import _abi
+    cfg = _abi.full_config_py()
+    cfg.max_batch, cfg.n_ctx, cfg.max_steps_cap, cfg.with_vocoder = 2, 128, 16, 0
+    eng, om = _q8_engine_and_oracle(oracle, cfg, 128)
+    try:
+        t0 = time.time()
+        desc, keep = oracle.make_prompt_desc(np.random.default_rng(1234).integers(0, 151643, size=12), spk_emb=_spk(cfg.model.d_embed))
+        pe = om.build_prompt(desc)
+        h_ref, l_ref = om.talker_prefill(pe)
+        h, l = eng.talker_prefill(pe)
+        assert np.array_equal(_bits(l), _bits(l_ref)) and np.array_equal(_bits(h), _bits(h_ref))
+        ref, _ = om.generate(pe, temperature=0.0, max_steps=4, min_frames=4)
+        res = eng.generate(desc=desc, temperature=0.0, max_steps=4, min_frames=4)
+        assert ref.shape == (4, 16) and np.array_equal(res.codes, ref)
+        print(f"full shape, Talker in Q8_0 blocks: prefill + 4 frames equal; oracle {time.time() - t0:.0f} s")
+    finally:
+        eng.close()
+        om.close()
+
+
 @pytest.mark.parametrize("rows,n_in,n_out", [(1, 2048, 1024), (64, 2048, 1024), (37, 512, 512), (130, 256, 96)])
 def test_projection_follows_the_reference_sequence(oracle, native, rows, n_in, n_out):
     """H6 (src/assets_manager.rs:383-399): `sum = bias; sum += h * w` in ascending input order, f32 weights. The device kernel
