@@ -273,6 +273,7 @@ def main():
     ap.add_argument("--no-vocoder", action="store_true", help="codes only (diagnostic; the JSON line is then marked invalid)")
     ap.add_argument("--no-single", action="store_true", help="skip the batch=1 RTF / first-chunk leg")
     ap.add_argument("--n-ctx", type=int, default=4096)
+    ap.add_argument("--no-q8", action="store_true", help="skip the Talker-in-Q8_0 leg (a second engine after the probe legs)")
     ap.add_argument("--no-probe", action="store_true", help="skip the in-situ dominant-kernel measurement (roofline.achieved falls back to the whole frame step)")
     ap.add_argument("--probe-only", nargs="?", const="talker", default=None, choices=["talker", "predictor", "vocoder"],
                     help=f"run only one probe leg (the commands profiled for profiles/{ROUND}/*): the Talker's gate/up (default), the Predictor's, or the vocoder alone")
@@ -352,18 +353,20 @@ def main():
 
     KINDS = {0: "gate/up GEMM", 1: "QKV GEMM", 2: "attention", 3: "O projection", 4: "down projection"}
 
-    def probe_leg(mode=2, kind=0):
+    def probe_leg(mode=2, kind=0, engine=None, q8=False):
         """One launch, in situ: the same batch of 64 utterances for 24 forced frames (codes only, so nothing else shares the GPU), frame
         steps launched eagerly with HIP events on the decode stream around ONE launch per frame — block 0 of the Talker step (mode 2)
         or of the Predictor's pass 1 (mode 1); kind 0 gate/up GEMM, 1 QKV GEMM, 2 attention, 3 O projection, 4 down projection.
         Algorithmic bytes per launch follow SURVEY.md §8(d)'s accounting (weights streamed once per launch + the operand / result rows
         + for attention the K / V bytes of the live context), stated per kind below."""
-        eng.probe(mode + 16 * kind)
+        pe = engine or eng
+        pe.probe(mode + 16 * kind)
         preqs = [dict(r, min_frames=24, force_eos_at=24, max_steps=32, want_pcm=0) for r in reqs]
         for _ in range(2):
-            pouts = eng.generate_batch(preqs)
-        ptm = eng.timings()
-        eng.probe(0)
+            pouts = pe.generate_batch(preqs)
+        ptm = pe.timings()
+        pe.probe(0)
+        wb = 1.0625 if q8 else 2.0   # bytes per weight: ggml Q8_0 = 34 bytes per 32 weights
         assert all(o.status == 0 and o.n_frames == 24 for o in pouts)
         m = cfg.model
         M = len(preqs)
@@ -374,13 +377,13 @@ def main():
             T_ctx = 3.0 * M  # pass 1: 3 keys per utterance in the per-frame cache
         nqkv = nq + 2 * nkv
         if kind == 0:
-            K, N = d, 2 * F; nbytes = 2.0 * N * K + 2.0 * M * K + 4.0 * M * (K // 16) + 2.0 * M * (N // 2)   # weights + bf16 rows + tile partials + bf16 SwiGLU rows
+            K, N = d, 2 * F; nbytes = wb * N * K + 2.0 * M * K + 4.0 * M * (K // 16) + 2.0 * M * (N // 2)   # weights + bf16 rows + tile partials + bf16 SwiGLU rows
         elif kind == 1:
-            K, N = d, nqkv; nbytes = 2.0 * N * K + 2.0 * M * K + 4.0 * M * (K // 16) + 4.0 * M * N            # ... + f32 q/k/v rows
+            K, N = d, nqkv; nbytes = wb * N * K + 2.0 * M * K + 4.0 * M * (K // 16) + 4.0 * M * N            # ... + f32 q/k/v rows
         elif kind == 3:
-            K, N = nq, d; nbytes = 2.0 * N * K + 2.0 * M * K + 8.0 * M * N + 2.0 * M * N + 4.0 * M * (N // 16)  # weights + bf16 rows + residual read/write + next norm inputs
+            K, N = nq, d; nbytes = wb * N * K + 2.0 * M * K + 8.0 * M * N + 2.0 * M * N + 4.0 * M * (N // 16)  # weights + bf16 rows + residual read/write + next norm inputs
         elif kind == 4:
-            K, N = F, d; nbytes = 2.0 * N * K + 2.0 * M * K + 8.0 * M * N + 2.0 * M * N + 4.0 * M * (N // 16)
+            K, N = F, d; nbytes = wb * N * K + 2.0 * M * K + 8.0 * M * N + 2.0 * M * N + 4.0 * M * (N // 16)
         else:
             K, N = hd, nq; nbytes = 2.0 * 2.0 * nkv * T_ctx + 4.0 * M * nqkv + 2.0 * 2.0 * M * nkv + 2.0 * M * nq   # K + V of the context, f32 q/k/v rows, bf16 K/V append, bf16 out rows
         flops = 2.0 * M * K * N if kind != 2 else 2.0 * 2.0 * nq * T_ctx
@@ -545,6 +548,29 @@ def main():
             line["frame_step_64_rows_codes_only_ms"] = round(step_us * 1e-3, 4)
             if cfg.with_vocoder:
                 line["roofline_vocoder"] = vocoder_leg()
+            if not args.no_q8:
+                # The Talker on ggml Q8_0 blocks kept in block form on the device (q3tts_engine_config.talker_q8_0 = 1; the reference's default
+                # quantisation, src/tts/engine.rs:91-95): NOT the headline configuration (BASELINE configs name bf16) — a second engine, same
+                # probe legs, so the halved weight stream is measured next to the bf16 one. ids bit-exact vs the oracle: tests/test_parity_gpu.py.
+                eng.close()
+                cfg8 = _abi.full_config_py()
+                cfg8.device, cfg8.max_batch, cfg8.n_ctx, cfg8.max_steps_cap, cfg8.with_vocoder, cfg8.talker_q8_0 = local_rank, cfg.max_batch, args.n_ctx, 512, 0, 1
+                e8 = native.NativeEngine(cfg8)
+                l8 = [probe_leg(2, kind, engine=e8, q8=True) for kind in (0, 1, 3, 4)]
+                preqs = [dict(r, min_frames=24, force_eos_at=24, max_steps=32, want_pcm=0) for r in reqs]
+                for _ in range(2):
+                    e8.generate_batch(preqs)
+                g8 = e8.timings().frame_step_ms
+                e8.close()
+                ent = []
+                for p in l8:
+                    us = max(p["kernel_ms"] - p["empty_ms"], 1e-6) * 1e3
+                    bf = [k for k in by_kernel if k["kernel"] == "%s %s" % (p["model"], p["kind"])][0]
+                    ent.append({"kernel": "Talker %s" % p["kind"], "us_per_launch": round(us, 2), "bf16_us_per_launch": bf["us_per_launch"], "algorithmic_bytes_per_launch": int(p["bytes"]),
+                                "bytes_per_us": round(p["bytes"] / us, 0), "achieved_GBs": round(p["bytes"] / (us * 1e-6) / 1e9, 1), "frac": round(p["bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)})
+                line["talker_q8_0"] = {"what": "the same 64-row frame step with the Talker's matrices as ggml Q8_0 blocks on the device (1.0625 bytes per weight; W8A16: bf16 activations, "
+                                               "per-block f16 scales applied to each block's MFMA product); second engine, codes only; not the headline configuration",
+                                       "frame_step_64_rows_codes_only_ms": round(g8, 4), "bf16_frame_step_64_rows_codes_only_ms": round(step_us * 1e-3, 4), "by_kernel": ent}
         else:
             line["roofline"] = {"bound": "hbm", "achieved": round(hbm_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_gbs / HBM_PEAK_GBS, 4), "traffic": None,
                                 "kernel": "whole frame step (no per-kernel probe in this run)"}
