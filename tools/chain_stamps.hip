@@ -42,8 +42,10 @@ int main(int argc, char** argv) {
     std::vector<Launch> L;
     size_t woff = 0;
     auto wnext = [&](size_t bytes, bool cold) { if (woff + bytes > WBYTES) woff = 0; char* p = w + woff; woff += bytes; return (const uint4*)p; };
+    uint16_t* wsc; CK(hipMalloc(&wsc, (size_t)16384 * 256 * 2)); CK(hipMemset(wsc, 0x2c, (size_t)16384 * 256 * 2));  // f16 block scales (any finite value)
+    bool q8 = false;
     auto gemm = [&](const char* name, const uint16_t* a, int K, int N, int epi, bool scaled, bool cold, const uint4* wt) -> int {
-        Q3BGemm q{}; q.a = a; q.B = rows; q.w = wt; q.K = K; q.N = N; q.w_once = cold ? 1 : 0;
+        Q3BGemm q{}; q.a = a; q.B = rows; q.w = wt; q.K = K; q.N = N; q.w_once = cold ? 1 : 0; q.wscale = q8 ? wsc : nullptr;
         if (scaled) { q.ssp = ssp; q.ld_ssp = K / 16; q.ntiles = K / 16; q.d_norm = K; q.eps = 1e-6f; }
         q.epi = epi; q.y = epi == Q3_EPI_STORE ? qkv : x; q.ldy = N; q.yb = epi == Q3_EPI_SWIGLU ? h : xb; q.keys = keys; q.key_stride = N / 16;
         if (epi == Q3_EPI_RESID) { q.nw_next = nw; q.ssp_out = ssp; q.ld_ssp_out = N / 16; }
@@ -84,6 +86,15 @@ int main(int argc, char** argv) {
         if (gemm("T gate/up", xb, 2048, 12288, Q3_EPI_SWIGLU, true, true, wnext((size_t)12288 * 2048 * 2, true))) return 1;
         if (gemm("T down", h, 6144, 2048, Q3_EPI_RESID, false, true, wnext((size_t)2048 * 6144 * 2, true))) return 1;
     }
+    q8 = true;  // the Talker block on ggml Q8_0 blocks (1.0625 bytes per weight; the weight buffers are read as int8 tiles)
+    for (int l = 0; l < 4; ++l) {
+        if (gemm("T8 qkv", xb, 2048, 4096, Q3_EPI_STORE, true, true, wnext((size_t)4096 * 2048, true))) return 1;
+        attend("T8 attend", 4096, n_ctx_t, 150, false);
+        if (gemm("T8 o", att, 2048, 2048, Q3_EPI_RESID, false, true, wnext((size_t)2048 * 2048, true))) return 1;
+        if (gemm("T8 gate/up", xb, 2048, 12288, Q3_EPI_SWIGLU, true, true, wnext((size_t)12288 * 2048, true))) return 1;
+        if (gemm("T8 down", h, 6144, 2048, Q3_EPI_RESID, false, true, wnext((size_t)2048 * 6144, true))) return 1;
+    }
+    q8 = false;
     CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(ge, s));
     CK(hipStreamSynchronize(s));
