@@ -1,9 +1,10 @@
-# Collects the round's profile summaries on the GPU box into gpurun_out/prof_final/ (copy what is to be judged into profiles/rNN/).
-#   bash tools/collect_profiles.sh
+# Collects the round's profile summaries on the GPU box into gpurun_out/prof_r03/ (copy what is to be judged into profiles/r03/).
+#   bash tools/collect_profiles.sh [1|2]     part 1: rocprofv3 kernel stats + PMC passes; part 2: timelines, in-kernel timestamps, the bench line
 # Every rocprofv3 call runs the program itself after "--"; counters (--pmc) in their own passes; graph replay is traceable with
 # DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (profiles/README.md).
 set -o pipefail
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_final; mkdir -p $OUT
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_r03; mkdir -p $OUT
+PART=${1:-1}
 cd /tmp && export TMPDIR=/tmp && export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 stats() {  # name, env assignment or "-", bench args...
   name=$1; shift; envv=$1; shift
@@ -13,14 +14,24 @@ stats() {  # name, env assignment or "-", bench args...
   f=$(find /tmp/prof_$name -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" $OUT/${name}_kernel_stats.csv && echo "$name: $(wc -l < $OUT/${name}_kernel_stats.csv) kernels"
 }
-stats probe - --probe-only && \
-stats vocoder_only - --probe-only vocoder && \
-stats bench_b64_graph - --steps 1 --warmup 0 --no-single --no-cpu-baseline --no-probe && \
-stats bench_b64_eager Q3TTS_NO_GRAPH=1 --steps 1 --warmup 0 --no-single --no-cpu-baseline --no-probe
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 $R/bench.py --probe-only > $OUT/pmc_$c.log 2>&1
-  cp "$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)" $OUT/pmc_$c.csv
-done
-python3 $R/tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv $OUT/pmc_traffic.json > $OUT/pmc_traffic.log 2>&1
-cd $R && python bench.py > $OUT/bench_b64_n1.json 2> $OUT/bench_b64_n1.err; tail -c 600 $OUT/bench_b64_n1.json
+if [ "$PART" = "1" ]; then
+  stats probe - --probe-only && \
+  stats vocoder_only - --probe-only vocoder && \
+  stats bench_b64_graph - --steps 1 --warmup 0 --no-single --no-cpu-baseline --no-probe && \
+  stats bench_b64_eager Q3TTS_NO_GRAPH=1 --steps 1 --warmup 0 --no-single --no-cpu-baseline --no-probe
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc_$c
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 $R/bench.py --probe-only > $OUT/pmc_$c.log 2>&1
+    cp "$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)" $OUT/pmc_$c.csv
+    echo "pmc $c done"
+  done
+  python3 $R/tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv $OUT/pmc_traffic.json > $OUT/pmc_traffic.log 2>&1
+  rm -f $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv   # (tens of MB each; the summary is what is kept)
+  tail -c 400 $OUT/pmc_traffic.log
+else
+  bash $R/tools/frame_trace.sh > $OUT/frame_step_timeline.txt 2>&1; tail -3 $OUT/frame_step_timeline.txt
+  bash $R/tools/voc_trace.sh > $OUT/vocoder_call_timeline.txt 2>&1; tail -2 $OUT/vocoder_call_timeline.txt
+  bash $R/tools/prefill_trace.sh > $OUT/prefill_timeline.txt 2>&1; head -3 $OUT/prefill_timeline.txt
+  timeout -k 10 120 $R/tools/chain_stamps 64 > $OUT/chain_stamps.txt 2>&1; tail -3 $OUT/chain_stamps.txt
+  cd $R && python bench.py > $OUT/bench_b64_n1.json 2> $OUT/bench_b64_n1.err; tail -c 600 $OUT/bench_b64_n1.json
+fi
