@@ -14,7 +14,16 @@ stats() {  # name, env assignment or "-", bench args...
   f=$(find /tmp/prof_$name -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" $OUT/${name}_kernel_stats.csv && echo "$name: $(wc -l < $OUT/${name}_kernel_stats.csv) kernels"
 }
-if [ "$PART" = "1" ]; then
+if [ "$PART" = "pmc" ]; then
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc_$c
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 $R/bench.py --probe-only > $OUT/pmc_$c.log 2>&1
+    cp "$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)" $OUT/pmc_$c.csv
+  done
+  python3 $R/tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv $OUT/pmc_traffic.json > $OUT/pmc_traffic.log 2>&1
+  rm -f $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv
+  tail -c 300 $OUT/pmc_traffic.log
+elif [ "$PART" = "1" ]; then
   stats probe - --probe-only && \
   stats vocoder_only - --probe-only vocoder && \
   stats bench_b64_graph - --steps 1 --warmup 0 --no-single --no-cpu-baseline --no-probe && \
