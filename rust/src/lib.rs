@@ -48,6 +48,9 @@ pub struct q3tts_result {
 }
 pub enum q3tts_engine {}
 pub enum q3tts_stream {}
+pub enum q3tts_node {}
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct q3tts_node_timings { pub generate_ms: c_float, pub gather_ms: c_float, pub total_ms: c_float, pub gathered_bytes: i64, pub n_devices: i32 }
 
 #[link(name = "q3tts")]
 extern "C" {
@@ -64,6 +67,14 @@ extern "C" {
     pub fn q3tts_stream_begin(e: *mut q3tts_engine, req: *const q3tts_request, out: *mut *mut q3tts_stream) -> c_int;
     pub fn q3tts_stream_poll(s: *mut q3tts_stream, chunk: *mut *const c_float, n_samples: *mut i32, is_final: *mut i32) -> c_int;
     pub fn q3tts_stream_end(s: *mut q3tts_stream, out_codes_optional: *mut q3tts_result) -> c_int;
+    pub fn q3tts_free(p: *mut std::ffi::c_void);
+    // one node, several GPUs (no counterpart in the reference: n_seq_max = 1, src/models/llama/mod.rs:413): one engine + host thread per device
+    // inside the library, request i on device i % n_devices, optional RCCL gather of the i16 PCM to the first device
+    pub fn q3tts_node_create(cfg: *const q3tts_engine_config, devices: *const i32, n_devices: i32, out: *mut *mut q3tts_node) -> c_int;
+    pub fn q3tts_node_destroy(n: *mut q3tts_node);
+    pub fn q3tts_node_generate_batch(n: *mut q3tts_node, reqs: *const q3tts_request, n_reqs: i32, outs: *mut q3tts_result, pcm_i16: *mut *mut i16) -> c_int;
+    pub fn q3tts_node_get_timings(n: *const q3tts_node, out: *mut q3tts_node_timings) -> c_int;
+    pub fn q3tts_node_last_error(n: *const q3tts_node) -> *const c_char;
     // voice-clone encoders (replace AudioEncoder / SpeakerEncoder, src/models/onnx.rs:82-160)
     pub fn q3tts_clone_default_config(cfg: *mut q3tts_clone_config);
     pub fn q3tts_clone_init(e: *mut q3tts_engine, cfg: *const q3tts_clone_config) -> c_int;
