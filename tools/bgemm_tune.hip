@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void k_touch(const uint4* w, size_t n16, unsig
     if (acc == 0x9e3779b9u) sink[0] = acc;
 }
 
-struct Shape { const char* name; int M, K, N, epi, scaled, cold; };
+struct Shape { const char* name; int M, K, N, epi, scaled, cold, q8 = 0; };  // q8: ggml Q8_0 blocks kept in block form (1.0625 bytes per weight)
 
 int main(int argc, char** argv) {
     hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -34,7 +34,10 @@ int main(int argc, char** argv) {
         {"P qkv", 48, 1024, 4096, Q3_EPI_STORE, 1, 0}, {"P o", 48, 2048, 1024, Q3_EPI_RESID, 0, 0}, {"P gate/up", 48, 1024, 6144, Q3_EPI_SWIGLU, 1, 0},
         {"P down", 48, 3072, 1024, Q3_EPI_RESID, 0, 0},
         {"P qkv", 128, 1024, 4096, Q3_EPI_STORE, 1, 0}, {"P gate/up", 128, 1024, 6144, Q3_EPI_SWIGLU, 1, 0}, {"P down", 128, 3072, 1024, Q3_EPI_RESID, 0, 0},
+        {"T8 qkv", 64, 2048, 4096, Q3_EPI_STORE, 1, 1, 1}, {"T8 o", 64, 2048, 2048, Q3_EPI_RESID, 0, 1, 1}, {"T8 gate/up", 64, 2048, 12288, Q3_EPI_SWIGLU, 1, 1, 1},
+        {"T8 down", 64, 6144, 2048, Q3_EPI_RESID, 0, 1, 1}, {"T8 head", 64, 2048, 3072, Q3_EPI_STORE, 1, 1, 1}, {"T8 gate/up", 1, 2048, 12288, Q3_EPI_SWIGLU, 1, 1, 1}, {"T8 down", 1, 6144, 2048, Q3_EPI_RESID, 0, 1, 1},
     };
+    uint16_t* wsc; CK(hipMalloc(&wsc, (size_t)16384 * 256 * 2)); CK(hipMemset(wsc, 0x2c, (size_t)16384 * 256 * 2));
     const size_t WBYTES = (size_t)2 << 30;
     uint4* w; CK(hipMalloc(&w, WBYTES)); CK(hipMemset(w, 0x3c, WBYTES));
     uint16_t *a, *yb; float *y, *ssp, *sso, *nw; unsigned long long* keys;
@@ -45,7 +48,7 @@ int main(int argc, char** argv) {
     q3_bgemm_prepare();
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (const Shape& sh : shapes) {
-        const size_t wb = (size_t)sh.N * sh.K * 2;
+        const size_t wb = (size_t)sh.N * sh.K * (sh.q8 ? 1 : 2);
         const int copies = sh.cold ? (int)(WBYTES / wb) : 1;
         printf("%-10s M=%3d K=%4d N=%5d %s:", sh.name, sh.M, sh.K, sh.N, sh.cold ? "cold" : "hot ");
         float best = 1e9f; int brt = 0, bnt = 0; float chosen = 0;
@@ -60,6 +63,7 @@ int main(int argc, char** argv) {
                     const int iters = 50;
                     for (int i = 0; i < iters; ++i) {
                         Q3BGemm q{}; q.a = a; q.B = sh.M; q.w = (const uint4*)((const char*)w + (size_t)(i % copies) * wb); q.K = sh.K; q.N = sh.N; q.w_once = sh.cold;
+                        if (sh.q8) q.wscale = wsc;
                         if (sh.scaled) { q.ssp = ssp; q.ld_ssp = sh.K / 16; q.ntiles = sh.K / 16; q.d_norm = sh.K; q.eps = 1e-6f; }
                         q.epi = sh.epi; q.y = y; q.ldy = sh.N; q.yb = yb; q.keys = keys; q.key_stride = sh.N / 16;
                         if (sh.epi == Q3_EPI_RESID) { q.nw_next = nw; q.ssp_out = sso; q.ld_ssp_out = sh.N / 16; }
