@@ -527,29 +527,58 @@ def main():
                                   "frac_lower_bound": round(p["bytes"] / max(p["kernel_ms"] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
                                   "share_of_step": round(p["per_step"] * us / step_us, 4), "M": p["rows"], "K": p["K"], "N": p["N"]})
             by_kernel.sort(key=lambda k: -k["share_of_step"])
-            top = by_kernel[0]
-            tl = [p for p in legs if "%s %s" % (p["model"], p["kind"]) == top["kernel"]][0]
-            traffic = traffic_src = step_traffic = None
+            # The headline is quoted per kernel SYMBOL, the unit rocprofv3's kernel stats (profiles/r03/*_kernel_stats.csv) are in: kinds that run the
+            # same k_bgemm instance at 64 rows (the launcher's cost model, q3_bgemm.hip) are one symbol. Launch-weighted means over its kinds.
+            symbols = [("k_bgemm<1, 1, 8, false, false>", ("Predictor O projection", "Predictor down projection")),
+                       ("k_bgemm<2, 2, 5, false, false>", ("Talker QKV GEMM", "Predictor QKV GEMM")),
+                       ("k_bgemm<1, 2, 8, false, false>", ("Talker O projection", "Talker down projection")),
+                       ("k_bgemm<2, 3, 4, false, false>", ("Predictor gate/up GEMM",)),
+                       ("k_bgemm<4, 3, 2, true, false>", ("Talker gate/up GEMM",)),
+                       ("k_attend_small<2>", ("Predictor attention",)),
+                       ("k_attend_gqa2", ("Talker attention",))]
+            traffic_src = step_traffic = None
+            tj = {}
             tpath = os.path.join(REPO, "profiles", ROUND, "pmc_traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
                     tj = json.load(f)
-                ent = tj.get("by_kernel", {}).get(top["kernel"])
-                traffic = ent.get("hbm_bytes_per_launch") if ent else None
                 step_traffic = tj.get("frame_step")
                 traffic_src = f"profiled offline (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --probe-only`, profiles/{ROUND}/pmc_traffic.json), not measured in this run"
+            by_symbol = []
+            for sym, kinds in symbols:
+                ks = [k for k in by_kernel if k["kernel"] in kinds]
+                if not ks:
+                    continue
+                n = float(sum(k["launches_per_frame_step"] for k in ks))
+                wmean = lambda f: sum(k["launches_per_frame_step"] * f(k) for k in ks) / n
+                ls = [[p for p in legs if "%s %s" % (p["model"], p["kind"]) == k["kernel"]][0] for k in ks]
+                ents = [tj.get("by_kernel", {}).get(k["kernel"]) for k in ks]
+                by_symbol.append({
+                    "symbol": sym, "kinds": [k["kernel"] for k in ks], "launches_per_frame_step": int(n), "us": wmean(lambda k: k["us_per_launch"]),
+                    "us_bracket": wmean(lambda k: k["us_per_launch_whole_bracket"]), "bytes": wmean(lambda k: k["algorithmic_bytes_per_launch"]),
+                    "share": sum(k["share_of_step"] for k in ks), "launches_timed": sum(k["launches_timed"] for k in ks),
+                    "empty_us": sum(k["launches_per_frame_step"] * l["empty_ms"] * 1e3 for k, l in zip(ks, ls)) / n,
+                    "intensity": sum(l["flops"] for l in ls) / sum(l["bytes"] for l in ls),
+                    "traffic": int(sum(k["launches_per_frame_step"] * e["hbm_bytes_per_launch"] for k, e in zip(ks, ents)) / n) if all(ents) else None,
+                    "shapes": ["M=%d K=%d N=%d" % (k["M"], k["K"], k["N"]) for k in ks]})
+            by_symbol.sort(key=lambda k: -k["share"])
+            top = by_symbol[0]
+            gbs, gbs_lb = top["bytes"] / (top["us"] * 1e-6) / 1e9, top["bytes"] / (top["us_bracket"] * 1e-6) / 1e9
             line["roofline"] = {
-                "bound": "hbm", "achieved": top["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac"],
-                "achieved_lower_bound": round(top["frac_lower_bound"] * HBM_PEAK_GBS, 1), "frac_lower_bound": top["frac_lower_bound"],
-                "traffic": traffic, "traffic_source": traffic_src, "share_of_step": top["share_of_step"],
-                "kernel": "%s (k_bgemm / attention kernel of csrc/), M=%d K=%d N=%d, %d launches per frame step: the kernel kind with the largest share of the frame step's time "
-                          "(launches x period); bf16 ridge 2500 TF / 8 TB/s = 312 flop/B > %.0f flop/B => HBM-bound by SURVEY.md §8(d)'s streaming accounting "
-                          "(the Predictor's 157 MB of weights are re-read 15 x per frame and stay Infinity-Cache resident, so its launches are latency-, not bandwidth-limited)" %
-                          (top["kernel"], top["M"], top["K"], top["N"], top["launches_per_frame_step"], tl["flops"] / tl["bytes"]),
-                "launch_us": top["us_per_launch_whole_bracket"], "empty_bracket_us": round(tl["empty_ms"] * 1e3, 2), "launch_us_minus_empty_bracket": top["us_per_launch"],
-                "launches_timed": top["launches_timed"], "algorithmic_bytes_per_launch": top["algorithmic_bytes_per_launch"],
+                "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "achieved_lower_bound": round(gbs_lb, 1), "frac_lower_bound": round(gbs_lb / HBM_PEAK_GBS, 4),
+                "traffic": top["traffic"], "traffic_source": traffic_src, "share_of_step": round(top["share"], 4),
+                "kernel": "%s = %s (%s), %d launches per frame step: the kernel SYMBOL with the largest share of the frame step's time (launches x period, summed over the "
+                          "kinds that run this instance; launch-weighted means); bf16 ridge 2500 TF / 8 TB/s = 312 flop/B > %.0f flop/B => HBM-bound by SURVEY.md §8(d)'s streaming "
+                          "accounting (the Predictor's 157 MB of weights are re-read 15 x per frame and stay Infinity-Cache resident, so its launches are latency-, not bandwidth-limited)" %
+                          (top["symbol"], " + ".join(top["kinds"]), "; ".join(top["shapes"]), top["launches_per_frame_step"], top["intensity"]),
+                "launch_us": round(top["us_bracket"], 2), "empty_bracket_us": round(top["empty_us"], 2), "launch_us_minus_empty_bracket": round(top["us"], 2),
+                "launches_timed": top["launches_timed"], "algorithmic_bytes_per_launch": int(top["bytes"]),
                 "how": "achieved = algorithmic bytes / (launch_us - empty_bracket_us); HIP events on the decode stream around this launch in block 0 of every frame step, eager frame steps, "
                        f"64 live utterances, codes only (q3tts_k_probe); rocprofv3 of the same leg: profiles/{ROUND}/probe_kernel_stats.csv"}
+            line["roofline_by_symbol"] = [{"symbol": g["symbol"], "kinds": g["kinds"], "launches_per_frame_step": g["launches_per_frame_step"], "us_per_launch": round(g["us"], 2),
+                                           "algorithmic_bytes_per_launch": int(g["bytes"]), "frac": round(g["bytes"] / (g["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                           "share_of_step": round(g["share"], 4), "traffic": g["traffic"]} for g in by_symbol]
             line["roofline_by_kernel"] = by_kernel
             line["roofline_by_kernel_what"] = ("every kernel kind of a decoder block, sorted by share of the frame step (launches_per_frame_step x us_per_launch / the probe legs' frame step of "
                                                "%.0f us); us_per_launch = event bracket - empty bracket (the lower end of a launch's period: the in-kernel timestamps of "

@@ -591,54 +591,3 @@ __global__ __launch_bounds__(256) void k_norm_inputs(const float* x, int ldx, in
 void q3_launch_norm_inputs(const float* x, int ldx, int rows, int d, const float* nw, uint16_t* xb, int xb_row0, float* ssp, int ld_ssp, hipStream_t s) {
     hipLaunchKernelGGL(k_norm_inputs, dim3(rows), dim3(256), 0, s, x, ldx, d, nw, xb, xb_row0, ssp, ld_ssp);
 }
-
-// ---------------------------------------------------------------------------------------------------------------------
-// H6 — Assets::project (/root/reference/src/assets_manager.rs:383-399) in the reference's OWN arithmetic: f32 weights, the
-// accumulator starts from the bias and takes `sum += h * w` (one f32 multiply, one f32 add: the build has -ffp-contract=off)
-// over the inputs in ascending order. One thread per output element (a 2048-long dependent chain: latency-bound by design);
-// 16 consecutive lanes = 16 consecutive outputs of one row, so the same kernel can emit the Predictor's norm inputs.
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_project(Q3Project p) {
-    // tile = 16 rows x 16 outputs, one thread per output element; the operands of 64 inputs at a time are staged through LDS by
-    // coalesced loads (a thread reading its own weight row straight from memory touches 16 cache lines per wave-load). The
-    // row stride of 68 floats keeps the 16 weight rows of a 128-bit LDS read on distinct banks.
-    constexpr int KC = 64, LD = KC + 4;
-    __shared__ __attribute__((aligned(16))) float ws[2][16 * LD];
-    __shared__ __attribute__((aligned(16))) float xs[2][16 * LD];
-    const int tid = threadIdx.x, oc = tid & 15, rr = tid >> 4;
-    const int o = blockIdx.x * 16 + oc, row = blockIdx.y * 16 + rr;
-    // staging role: thread t loads 4 consecutive inputs (t & 15) of weight row / activation row (t >> 4)
-    const float* wsrc = p.w + (size_t)(blockIdx.x * 16 + rr) * p.n_in + 4 * oc;
-    const float* xsrc = p.x + (size_t)min(blockIdx.y * 16 + rr, p.rows - 1) * p.ldx + 4 * oc;
-    float sum = p.bias[o];
-    const int nch = p.n_in / KC;
-    float4 wv = *(const float4*)wsrc, xv = *(const float4*)xsrc;
-    for (int c = 0; c < nch; ++c) {
-        float* wl = ws[c & 1]; float* xl = xs[c & 1];
-        *(float4*)(wl + rr * LD + 4 * oc) = wv; *(float4*)(xl + rr * LD + 4 * oc) = xv;
-        if (c + 1 < nch) { wv = *(const float4*)(wsrc + (c + 1) * KC); xv = *(const float4*)(xsrc + (c + 1) * KC); }
-        __syncthreads();  // (two buffers: the stores of chunk c + 2 come after the barrier of chunk c + 1, which every reader of chunk c has passed)
-        const float* wr = wl + oc * LD; const float* xr = xl + rr * LD;
-#pragma unroll
-        for (int k = 0; k < KC; k += 4) {
-            const float4 a = *(const float4*)(xr + k), w4 = *(const float4*)(wr + k);
-            sum += a.x * w4.x; sum += a.y * w4.y; sum += a.z * w4.z; sum += a.w * w4.w;
-        }
-    }
-    const bool live = row < p.rows;
-    if (live) p.y[(size_t)row * p.ldy + o] = sum;
-    if (p.nw) {
-        uint16_t hb = q3_bf16(sum * p.nw[o]);
-        float sq = sum * sum;
-        sq = sq + __shfl_xor(sq, 1); sq = sq + __shfl_xor(sq, 2); sq = sq + __shfl_xor(sq, 4); sq = sq + __shfl_xor(sq, 8);
-        if (live) {
-            p.xb[q3_atile_off(row, o, p.n_out >> 5)] = hb;
-            if (oc == 0) p.ssp[(size_t)row * p.ld_ssp + (o >> 4)] = sq;
-        }
-    }
-}
-int q3_launch_project(const Q3Project& p, hipStream_t s) {
-    if (p.rows < 1 || p.n_out % 16 || p.n_in % 64 || p.ldx % 4) return -1;
-    hipLaunchKernelGGL(k_project, dim3(p.n_out / 16, (p.rows + 15) / 16), dim3(256), 0, s, p);
-    return 0;
-}

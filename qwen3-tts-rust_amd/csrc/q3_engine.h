@@ -37,7 +37,7 @@ struct Q3Scratch {
 struct Q3Lane {
     int nb = 0;                       // row capacity = max_batch
     hipStream_t stream = nullptr;
-    float *xT = nullptr, *logits = nullptr, *logits_tmp = nullptr, *X = nullptr, *fb = nullptr, *px = nullptr;
+    float *xT = nullptr, *logits = nullptr, *logits_tmp = nullptr, *fb = nullptr, *px = nullptr;
     // norm inputs of the residual rows: bf16(x * nw) and the per-tile sums of squares, Talker [nb] / Predictor [2 nb]
     uint16_t *xbT = nullptr, *xbP = nullptr;
     float *sspT = nullptr, *sspP = nullptr;

@@ -354,13 +354,14 @@ static int record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
     Q3Sample sa{}; sa.logits = L.logits; sa.ld = m.t_vocab; sa.limit = m.sample_limit; sa.eos = m.eos_code; sa.slots = slots; sa.B = B; sa.row_slot = L.slot_id;
     sa.rng = e->rng; sa.codes = codes; sa.max_steps_cap = cap; sa.ncb = ncb;
     Q3PredInput pi{}; pi.xT = L.xT; pi.out_norm = e->T.out_norm; pi.eps = eps; pi.d = de; pi.codec0 = e->codec[0]; pi.codec0_rows = m.codec0_rows;
-    pi.slots = slots; pi.row_slot = L.slot_id; pi.X = L.X; pi.fb = L.fb; pi.B = B; pi.pproj0 = e->pproj[0]; pi.proj_b = e->proj_b; pi.dp = dp; pi.px = L.px;
+    pi.slots = slots; pi.row_slot = L.slot_id; pi.X = nullptr; pi.fb = L.fb; pi.B = B; pi.pproj0 = e->pproj[0]; pi.proj_b = e->proj_b; pi.dp = dp; pi.px = L.px;
     pi.nw = e->P.attn_norm[0]; pi.xb = L.xbP; pi.ssp = L.sspP;
-    q3_launch_sample_input(sa, pi, s);
-    {   // H6 (src/assets_manager.rs:383-399) for the hidden rows only: every code embedding arrives pre-projected
-        Q3Project pj{}; pj.x = L.X; pj.ldx = de; pj.rows = B; pj.w = e->proj_w; pj.bias = e->proj_b; pj.n_in = de; pj.n_out = dp; pj.y = L.px; pj.ldy = dp;
+    {   // H6 (src/assets_manager.rs:383-399) for the hidden rows only (every code embedding arrives pre-projected), in the same launch
+        // as the sampler: the tiles normalise the Talker's raw output rows themselves
+        Q3Project pj{}; pj.x = L.xT; pj.ldx = de; pj.rows = B; pj.w = e->proj_w; pj.bias = e->proj_b; pj.n_in = de; pj.n_out = dp; pj.y = L.px; pj.ldy = dp;
         pj.nw = e->P.attn_norm[0]; pj.xb = L.xbP; pj.ssp = L.sspP; pj.ld_ssp = dp / 16;  // rows [0, B) of pass A
-        bad += q3_launch_project(pj, s) != 0;
+        pj.norm_w = e->T.out_norm; pj.eps = eps;
+        bad += q3_launch_sample_input(sa, pi, pj, s) != 0;
     }
     const size_t head_tile_stride = (size_t)(cbs / 16) * (dp / 32) * 64;  // uint4 per predictor head
     auto pred_next = [&](int q) {
@@ -562,7 +563,7 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
         HIPC(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         HIPC(hipEventCreate(&L.ev_begin)); HIPC(hipEventCreate(&L.ev_end));
         TRYC(dalloc(e, &L.xT, (size_t)nb * m.t_d_model)); TRYC(dalloc(e, &L.logits, (size_t)nb * m.t_vocab)); TRYC(dalloc(e, &L.logits_tmp, (size_t)nb * std::max(m.t_vocab, m.t_d_model)));
-        TRYC(dalloc(e, &L.X, (size_t)2 * nb * m.d_embed)); TRYC(dalloc(e, &L.fb, (size_t)nb * m.d_embed));
+        TRYC(dalloc(e, &L.fb, (size_t)nb * m.d_embed));
         TRYC(dalloc(e, &L.px, (size_t)2 * nb * m.p_d_model)); TRYC(dalloc(e, &L.keys, (size_t)nb * (m.codebook_size / 16)));
         const size_t nb16 = ((size_t)nb + 15) & ~(size_t)15, nb2_16 = ((size_t)2 * nb + 15) & ~(size_t)15;  // A-tiled buffers hold whole 16-row tiles
         TRYC(dalloc(e, &L.xbT, nb16 * m.t_d_model)); TRYC(dalloc(e, &L.sspT, (size_t)nb * (m.t_d_model / 16)));
@@ -647,7 +648,7 @@ extern "C" void q3tts_engine_destroy(q3tts_engine* e) {
         for (auto ge : L.execs) if (ge) hipGraphExecDestroy(ge);
         for (auto gr : L.graphs) if (gr) hipGraphDestroy(gr);
         hipFree(L.logits_tmp); hipFree(L.perm);
-        hipFree(L.xT); hipFree(L.logits); hipFree(L.X); hipFree(L.fb); hipFree(L.px); hipFree(L.keys);
+        hipFree(L.xT); hipFree(L.logits); hipFree(L.fb); hipFree(L.px); hipFree(L.keys);
         hipFree(L.xbT); hipFree(L.sspT); hipFree(L.xbP); hipFree(L.sspP);
         hipFree(L.row_pos_t); hipFree(L.slot_id); hipFree(L.posA); hipFree(L.slotA); hipFree(L.pos_q);
         hipFree(L.sc.qkv); hipFree(L.sc.att); hipFree(L.sc.h);
@@ -1627,8 +1628,8 @@ extern "C" int q3tts_k_talker_prefill(q3tts_engine* e, const float* embd, int32_
     const q3tts_model_config& m = e->cfg.model;
     hipStream_t s = e->stream;
     if (hidden_out) {
-        q3_launch_rmsnorm_rows(e->lanes[0].xT, m.t_d_model, e->T.out_norm, m.rms_eps, m.t_d_model, 1, e->lanes[0].X, m.t_d_model, s);
-        Q3_HIP(e, hipMemcpyAsync(hidden_out, e->lanes[0].X, (size_t)m.t_d_model * 4, hipMemcpyDeviceToHost, s));
+        q3_launch_rmsnorm_rows(e->lanes[0].xT, m.t_d_model, e->T.out_norm, m.rms_eps, m.t_d_model, 1, e->lanes[0].logits_tmp, m.t_d_model, s);
+        Q3_HIP(e, hipMemcpyAsync(hidden_out, e->lanes[0].logits_tmp, (size_t)m.t_d_model * 4, hipMemcpyDeviceToHost, s));
     }
     if (logits_out) Q3_HIP(e, hipMemcpyAsync(logits_out, e->lanes[0].logits, (size_t)m.t_vocab * 4, hipMemcpyDeviceToHost, s));
     Q3Slot* stage = e->slots_host + e->B; memset(stage, 0, sizeof(Q3Slot));

@@ -93,6 +93,7 @@ struct Q3Project {
     const float* w; const float* bias; int n_in, n_out;   // w f32 row-major [n_out][n_in]
     float* y; int ldy;
     const float* nw; uint16_t* xb; float* ssp; int ld_ssp;   // xb A-tiled (n_out columns), rows as y
+    const float* norm_w; float eps;   // != nullptr: x holds raw rows, the kernel projects rmsnorm(x) * norm_w (normalised while staging)
 };
 int q3_launch_project(const Q3Project& p, hipStream_t s);
 #ifdef __HIPCC__
@@ -168,7 +169,7 @@ void q3_launch_sample_rows(const float* logits, int n, int ld, int limit, float 
                            const float* r, int* out, hipStream_t s);
 
 // predictor input of pass A (rows [0, B): the projected hidden rows, rows [B, 2B): the code rows):
-// X[b] = rmsnorm(xT[b]) (projected by k_project into px[b]); px[B + b] = proj(codec0[code0]) taken
+// X[b] = rmsnorm(xT[b]) (X == nullptr: left to the projection tile, Q3Project.norm_w); px[B + b] = proj(codec0[code0]) taken
 // from the pre-projected table (row-independent exact GEMM: the table row IS what projecting on the fly gives);
 // fb[b] = 0 + codec0[code0]
 struct Q3PredInput {
@@ -179,7 +180,8 @@ struct Q3PredInput {
     const float* nw; uint16_t* xb; float* ssp;         // norm inputs of px row B + b (the code row; A-tiled xb, ssp ld dp/16)
 };
 void q3_launch_pred_input(const Q3PredInput& a, hipStream_t s);
-void q3_launch_sample_input(const Q3Sample& a, const Q3PredInput& p, hipStream_t s);  // both in one launch (the frame's first kernel)
+// the frame's first kernel: sampler + code rows (B workgroups) and the H6 tiles of the hidden rows (pj, with norm_w) side by side in one launch
+int q3_launch_sample_input(const Q3Sample& a, const Q3PredInput& p, const Q3Project& pj, hipStream_t s);
 
 // after pass q-1: code_q from the argmax key, record it, fb += codec_q[code_q]; q<ncb-1: px[b] = projected emb;
 // last: fb += tts_pad -> xT[b], row_pos_t[b] = cur_pos++, n_frames++

@@ -1042,7 +1042,8 @@ __device__ void pred_input_row(const Q3PredInput& a, int b, int code0) {
     __shared__ float rinv_s;
     const int tid = threadIdx.x, d = a.d;
     const float* x = a.xT + (size_t)b * d;
-    if (tid < 64) {
+    const bool wantX = a.X != nullptr;  // (uniform) the frame step normalises inside the projection tile instead
+    if (wantX && tid < 64) {
         float acc = 0.0f;
         for (int c = tid; c < (d >> 2); c += 64) {
             const float4 v = ((const float4*)x)[c];
@@ -1052,7 +1053,7 @@ __device__ void pred_input_row(const Q3PredInput& a, int b, int code0) {
         if (tid == 0) rinv_s = 1.0f / sqrtf(acc / (float)d + a.eps);
     }
     __syncthreads();
-    const float rinv = rinv_s;
+    const float rinv = wantX ? rinv_s : 0.0f;
     const bool ok = code0 >= 0 && code0 < a.codec0_rows;  // OOB rows embed as zeros: src/assets_manager.rs:419-437
     const float* e = a.codec0 + (size_t)(ok ? code0 : 0) * d;
     const float* pr = ok ? a.pproj0 + (size_t)code0 * a.dp : a.proj_b;  // proj(0) = bias
@@ -1064,12 +1065,12 @@ __device__ void pred_input_row(const Q3PredInput& a, int b, int code0) {
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
             const int i = min(i0 + tid + u * 256, d - 1);
-            xv[u] = x[i]; nv[u] = a.out_norm[i]; ev[u] = ok ? e[i] : 0.0f;
+            xv[u] = wantX ? x[i] : 0.0f; nv[u] = wantX ? a.out_norm[i] : 0.0f; ev[u] = ok ? e[i] : 0.0f;
         }
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
             const int i = i0 + tid + u * 256;
-            if (i < d) { a.X[(size_t)b * d + i] = (xv[u] * rinv) * nv[u]; a.fb[(size_t)b * d + i] = 0.0f + ev[u]; }
+            if (i < d) { if (wantX) a.X[(size_t)b * d + i] = (xv[u] * rinv) * nv[u]; a.fb[(size_t)b * d + i] = 0.0f + ev[u]; }
         }
     }
     const int r1 = a.B + b;  // pass A rows: [0, B) the projected hidden rows, [B, 2B) the code rows
@@ -1093,15 +1094,112 @@ __global__ __launch_bounds__(256) void k_pred_input(Q3PredInput a) {
     pred_input_row(a, blockIdx.x, sl->code0);
 }
 void q3_launch_pred_input(const Q3PredInput& a, hipStream_t s) { hipLaunchKernelGGL(k_pred_input, dim3(a.B), dim3(256), 0, s, a); }
-// the frame's first launch: H4/H5 (sample, EOS, bookkeeping) and, for rows that go on, the Predictor's pass-A inputs
-__global__ __launch_bounds__(256) void k_sample_input(Q3Sample a, Q3PredInput p) {
-    __shared__ unsigned long long keys[SAMP_MAX];
+
+// ---------------------------------------------------------------------------------------------------------------------
+// H6 — Assets::project (/root/reference/src/assets_manager.rs:383-399) in the reference's OWN arithmetic: f32 weights, the
+// accumulator starts from the bias and takes `sum += h * w` (one f32 multiply, one f32 add: the build has -ffp-contract=off)
+// over the inputs in ascending order. One thread per output element (a 2048-long dependent chain: latency-bound by design);
+// 16 consecutive lanes = 16 consecutive outputs of one row, so the same kernel can emit the Predictor's norm inputs.
+// tile = 16 rows x 16 outputs; the operands of 64 inputs at a time are staged through LDS by coalesced loads (a thread reading
+// its own weight row straight from memory touches 16 cache lines per wave-load). The row stride of 68 floats keeps the 16 weight
+// rows of a 128-bit LDS read on distinct banks.
+// p.norm_w != nullptr: x holds RAW rows and the tile applies the RMSNorm itself while staging, x' = (x * rinv) * norm_w with rinv from
+// the canonical 64-lane chain (the same operations pred_input_row used to store as X), so that the projection
+// does not wait for another kernel's normalised copy.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int PJ_KC = 64, PJ_LD = PJ_KC + 4, PJ_LDS_FLOATS = 4 * 16 * PJ_LD;
+__device__ void project_tile(const Q3Project& p, int bx, int by, float* lds) {
+    constexpr int KC = PJ_KC, LD = PJ_LD;
+    float* ws = lds; float* xs = lds + 2 * 16 * LD;  // [2][16 * LD] each
+    __shared__ float rinv16[16];
+    const int tid = threadIdx.x, oc = tid & 15, rr = tid >> 4;
+    const int o = bx * 16 + oc, row = by * 16 + rr;
+    // staging role: thread t loads 4 consecutive inputs (t & 15) of weight row / activation row (t >> 4)
+    const float* wsrc = p.w + (size_t)(bx * 16 + rr) * p.n_in + 4 * oc;
+    const float* xsrc = p.x + (size_t)min(by * 16 + rr, p.rows - 1) * p.ldx + 4 * oc;
+    const float* nsrc = p.norm_w ? p.norm_w + 4 * oc : nullptr;
+    float sum = p.bias[o];
+    const int nch = p.n_in / KC;
+    float4 wv = *(const float4*)wsrc, xv = *(const float4*)xsrc, nv = nsrc ? *(const float4*)nsrc : float4{1.0f, 1.0f, 1.0f, 1.0f};
+    float rinv = 1.0f;
+    if (nsrc) {  // (uniform) wave w owns rows 4w .. 4w + 3 of the tile: four chains side by side, lane c takes the float4 chunks c, c + 64, ...
+        const int wave = tid >> 6, lane = tid & 63;
+        const float4* xr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xr[u] = (const float4*)(p.x + (size_t)min(by * 16 + wave * 4 + u, p.rows - 1) * p.ldx);
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int c = lane; c < (p.n_in >> 2); c += 64) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = xr[u][c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc[u] = fmaf(v[u].x, v[u].x, acc[u]); acc[u] = fmaf(v[u].y, v[u].y, acc[u]); acc[u] = fmaf(v[u].z, v[u].z, acc[u]); acc[u] = fmaf(v[u].w, v[u].w, acc[u]); }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const float t = wave_sum(acc[u]); if (lane == 0) rinv16[wave * 4 + u] = 1.0f / sqrtf(t / (float)p.n_in + p.eps); }
+        __syncthreads();
+        rinv = rinv16[rr];
+    }
+    for (int c = 0; c < nch; ++c) {
+        float* wl = ws + (c & 1) * 16 * LD; float* xl = xs + (c & 1) * 16 * LD;
+        if (nsrc) { xv.x = (xv.x * rinv) * nv.x; xv.y = (xv.y * rinv) * nv.y; xv.z = (xv.z * rinv) * nv.z; xv.w = (xv.w * rinv) * nv.w; }
+        *(float4*)(wl + rr * LD + 4 * oc) = wv; *(float4*)(xl + rr * LD + 4 * oc) = xv;
+        if (c + 1 < nch) {
+            wv = *(const float4*)(wsrc + (c + 1) * KC); xv = *(const float4*)(xsrc + (c + 1) * KC);
+            if (nsrc) nv = *(const float4*)(nsrc + (c + 1) * KC);
+        }
+        __syncthreads();  // (two buffers: the stores of chunk c + 2 come after the barrier of chunk c + 1, which every reader of chunk c has passed)
+        const float* wr = wl + oc * LD; const float* xr = xl + rr * LD;
+#pragma unroll
+        for (int k = 0; k < KC; k += 4) {
+            const float4 a = *(const float4*)(xr + k), w4 = *(const float4*)(wr + k);
+            sum += a.x * w4.x; sum += a.y * w4.y; sum += a.z * w4.z; sum += a.w * w4.w;
+        }
+    }
+    const bool live = row < p.rows;
+    if (live) p.y[(size_t)row * p.ldy + o] = sum;
+    if (p.nw) {
+        uint16_t hb = q3_bf16(sum * p.nw[o]);
+        float sq = sum * sum;
+        sq = sq + __shfl_xor(sq, 1); sq = sq + __shfl_xor(sq, 2); sq = sq + __shfl_xor(sq, 4); sq = sq + __shfl_xor(sq, 8);
+        if (live) {
+            p.xb[q3_atile_off(row, o, p.n_out >> 5)] = hb;
+            if (oc == 0) p.ssp[(size_t)row * p.ld_ssp + (o >> 4)] = sq;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_project(Q3Project p) {
+    __shared__ __attribute__((aligned(16))) float lds[PJ_LDS_FLOATS];
+    project_tile(p, blockIdx.x, blockIdx.y, lds);
+}
+static bool project_ok(const Q3Project& p) { return p.rows >= 1 && p.n_out % 16 == 0 && p.n_in % 64 == 0 && p.ldx % 4 == 0; }
+int q3_launch_project(const Q3Project& p, hipStream_t s) {
+    if (!project_ok(p)) return -1;
+    hipLaunchKernelGGL(k_project, dim3(p.n_out / 16, (p.rows + 15) / 16), dim3(256), 0, s, p);
+    return 0;
+}
+
+// the frame's first launch, two kinds of workgroup side by side (they touch disjoint data, so neither waits for the other):
+//  [0, B)   H4/H5 (sample, EOS, bookkeeping) and, for rows that go on, the code row of the Predictor's pass A and the feedback start
+//  [B, ...) H6 for the hidden rows, normalised in the tile (project_tile with norm_w)
+static_assert(PJ_LDS_FLOATS * sizeof(float) <= SAMP_MAX * sizeof(unsigned long long), "the projection tile stages through the sampler's key array");
+__global__ __launch_bounds__(256) void k_sample_input(Q3Sample a, Q3PredInput p, Q3Project pj) {
+    __shared__ __attribute__((aligned(16))) unsigned long long keys[SAMP_MAX];
     __shared__ float probs[SAMP_MAX];
+    if ((int)blockIdx.x >= a.B) {  // (uniform over the workgroup)
+        const int t = blockIdx.x - a.B, nx = pj.n_out >> 4;
+        project_tile(pj, t % nx, t / nx, (float*)keys);
+        return;
+    }
     const int code0 = sample_frame(a, blockIdx.x, keys, probs);  // (uniform over the workgroup)
     if (code0 < 0) return;
     pred_input_row(p, blockIdx.x, code0);
 }
-void q3_launch_sample_input(const Q3Sample& a, const Q3PredInput& p, hipStream_t s) { hipLaunchKernelGGL(k_sample_input, dim3(a.B), dim3(256), 0, s, a, p); }
+int q3_launch_sample_input(const Q3Sample& a, const Q3PredInput& p, const Q3Project& pj, hipStream_t s) {
+    if (!project_ok(pj) || !pj.norm_w) return -1;
+    hipLaunchKernelGGL(k_sample_input, dim3(a.B + (pj.n_out / 16) * ((pj.rows + 15) / 16)), dim3(256), 0, s, a, p, pj);
+    return 0;
+}
 
 __global__ __launch_bounds__(256) void k_pred_next(Q3PredNext a) {
     const int b = blockIdx.x, tid = threadIdx.x, d = a.d;

@@ -20,14 +20,14 @@ KINDS = [  # name, kernel substring, FETCH_SIZE KiB range as reported (half of t
     ("Talker QKV GEMM", "k_bgemm<2, 2, 5, false,", 6000, 1e12),
     ("Predictor QKV GEMM", "k_bgemm<2, 2, 5, false,", 0, 6000),
     ("Talker down projection", "k_bgemm<1, 2, 8, false,", 8000, 1e12),
-    ("Talker O projection", "k_bgemm<1, 2, 8, false,", 0, 8000),
+    ("Talker O projection", "k_bgemm<1, 2, 8, false,", 3500, 8000),   # (below 3500: the Predictor's 15 head GEMMs, same instance)
     ("Predictor gate/up GEMM", "k_bgemm<2, 3, 4, false,", 0, 1e12),
-    ("Predictor down projection", "k_bgemm<1, 1, 8, false,", 2600, 1e12),
-    ("Predictor O projection", "k_bgemm<1, 1, 8, false,", 0, 2600),
+    ("Predictor down projection", "k_bgemm<1, 1, 8, false,", 3200, 1e12),   # algorithmic 7.3 MB = 3 580 KiB as reported; O: 5.1 MB = 2 500
+    ("Predictor O projection", "k_bgemm<1, 1, 8, false,", 0, 3200),
     ("Talker attention", "k_attend_gqa2", 0, 1e12),
     ("Predictor attention", "k_attend_small<2>", 0, 1e12),
 ]
-DECODE = ("k_sample_input", "k_project", "k_bgemm<", "k_attend_small", "k_attend_pair", "k_attend_gqa2", "k_pred_next")
+DECODE = ("k_sample_input", "k_bgemm<", "k_attend_small", "k_attend_pair", "k_attend_gqa2", "k_pred_next")
 
 
 def rows(path, counter):
