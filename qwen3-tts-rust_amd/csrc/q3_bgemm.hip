@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void k_bgemm_big(Q3BGemm g) {
     for (int step = 0; step < nsteps; ++step) {
         if (step + BB_NS - 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((BB_NS - 2) * 4) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        Q3_LDS_BARRIER();  // (not __syncthreads(): that would wait for every stage in flight, q3_kernels.h)
         if (step + BB_NS - 1 < nsteps) issue(step + BB_NS - 1);
         const char* st = bb_ring + (size_t)(step % BB_NS) * 16384;
         bf16x8 a_[4], b_[4];

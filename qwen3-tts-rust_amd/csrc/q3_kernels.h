@@ -96,6 +96,12 @@ struct Q3Project {
     const float* norm_w; float eps;   // != nullptr: x holds raw rows, the kernel projects rmsnorm(x) * norm_w (normalised while staging)
 };
 int q3_launch_project(const Q3Project& p, hipStream_t s);
+// Workgroup barrier that orders LDS traffic only. __syncthreads() also fences global memory, and on gfx9-family parts loads and stores
+// share one counter: with global loads (or LDS-DMA) in flight it becomes s_waitcnt vmcnt(0) — the barrier waits for the wave's slowest
+// outstanding load and a software pipeline of loads collapses to a depth of one (k_attend_gqa2: first barrier 4.9 us after the start;
+// the vocoder's LDS-DMA ring: every K step waited for the stage issued one step earlier). Use it only where nothing read after the barrier
+// was written to GLOBAL memory by another wave of the workgroup; data brought by LDS-DMA needs its own s_waitcnt vmcnt(N) before it.
+#define Q3_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 #ifdef __HIPCC__
 __device__ __forceinline__ void q3_row_map(int row, const int* row_pos, const int* row_slot, int slot_mod, int pos_const, int* pos, int* slot) {
     if (slot_mod > 0) { *slot = row % slot_mod; *pos = pos_const + row / slot_mod; }

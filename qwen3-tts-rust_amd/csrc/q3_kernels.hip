@@ -368,11 +368,7 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
 //    heads; wave 2: k; wave 3: v), so the preparation runs under the memory latency instead of in front of it
 //  * the newest key / value reach their lane through LDS in the cache's packed form: one code path for cached and newest keys
 // ---------------------------------------------------------------------------------------------------------------------
-// Workgroup barrier that orders LDS traffic only. __syncthreads() also fences global memory, and on gfx9-family parts loads and stores
-// share one counter: with the key / value prefetch in flight it became s_waitcnt vmcnt(0) — every barrier of this kernel waited for the
-// slowest HBM load of the wave (in-kernel timestamps: first barrier passed 4.9 us after the start). Nothing read after these barriers was
-// written to GLOBAL memory by another wave of the workgroup (the K / V append is only read by later launches).
-#define Q3_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+// (Q3_LDS_BARRIER: q3_kernels.h)
 __global__ __launch_bounds__(256, 2) void k_attend_gqa2(Q3Attend a) {  // (<= 256 registers: two workgroups per CU; unconstrained the compiler took 405)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int g = blockIdx.x, row = blockIdx.y;

@@ -86,7 +86,14 @@ struct VGemm {
     float* y2; size_t y2_stride; int y2_off;      // optional second output: SnakeBeta(v) with the NEXT layer's parameters,
     const float *ea, *ib; int snake_n;            //   written straight into that layer's conv-input work buffer
     int y2_bf16;                                  //   ... which holds bf16 when it only ever feeds GEMMs
+    int chunked;                                  // K-step order of the wide 7-tap convolutions (vconv_chunked): channel chunks of 32, taps inside
 };
+// K step -> (tap, first channel). Default: taps ascending, 32-wide channel steps inside a tap. chunked: 32-channel chunks ascending, inside a
+// chunk the taps ascending — the order of k_vconv_tap, which keeps a chunk of the input rows in LDS for all taps.
+__device__ __forceinline__ void vstep(const VGemm& g, int step, int kpt, int& tap, int& k0) {
+    if (g.chunked) { const int ch = step / g.c.ntap; tap = step - ch * g.c.ntap; k0 = ch << 5; }
+    else { tap = step / kpt; k0 = (step - tap * kpt) << 5; }
+}
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(256) void k_vgemm_small(VGemm g) {
 #define VS_ISSUE(slot_, step_)                                                                        \
     do {                                                                                              \
         const int st__ = min((step_), steps - 1);                                                     \
-        const int tap__ = st__ / kpt, k0__ = (st__ - tap__ * kpt) << 5;                               \
+        int tap__, k0__; vstep(g, st__, kpt, tap__, k0__);                                            \
         const long sh__ = (long)(g.c.ntap - 1 - tap__) * g.c.dil * cin - k0__;                          \
         if (ABF) ra[slot_][0] = *(const float4*)(xrow16 - sh__);                                      \
         else { ra[slot_][0] = *(const float4*)(xrow - sh__); ra[slot_][ABF ? 0 : 1] = *(const float4*)(xrow - sh__ + 4); } \
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(256) void k_vgemm_lds(VGemm g) {
     { int n = n0 + ldr; if (n >= nout) n = nout - 1; wrow = g.c.w + (size_t)n * cin + half * 16; }
     auto gload = [&](VStage<ABF>& r, int step_) {  // steps past the end re-read the last tile; their A part is zeroed
         const int step = min(step_, steps - 1);
-        const int tap = step / kpt, k0 = (step - tap * kpt) << 5;
+        int tap, k0; vstep(g, step, kpt, tap, k0);
         const long sh = (long)(g.c.ntap - 1 - tap) * g.c.dil * cin - k0;
         if constexpr (ABF) { const uint4* p = (const uint4*)(xrow16 - sh); r.ab0 = p[0]; r.ab1 = p[1]; }
         else { const float* p = xrow - sh; r.a0 = ((const float4*)p)[0]; r.a1 = ((const float4*)p)[1]; r.a2 = ((const float4*)p)[2]; r.a3 = ((const float4*)p)[3]; }
@@ -284,11 +291,11 @@ __global__ __launch_bounds__(256) void k_vgemm_lds(VGemm g) {
         sstore(R0, 1);       // tile step+1 -> LDS[1] (last read before the previous barrier)
         gload(R0, step + 3);
         VT_COMPUTE(0);
-        __syncthreads();
+        Q3_LDS_BARRIER();
         sstore(R1, 0);       // tile step+2 -> LDS[0]
         gload(R1, step + 4);
         VT_COMPUTE(1);
-        __syncthreads();
+        Q3_LDS_BARRIER();
     }
     const bool rmw = g.epi == 1 || g.epi == 2;
 #pragma unroll
@@ -318,6 +325,75 @@ __global__ __launch_bounds__(256) void k_vgemm_lds(VGemm g) {
     }
 }
 
+// Second half of the LDS-staged epilogues (k_vgemm_ring, k_vconv_tap): the f32 tile Ot[ROWS][BN + 4] goes out 4 consecutive columns of a row
+// per item. A thread keeps ONE column group for all its rows (threads past the last whole row of a pass idle: 16 of 256 at BN = 96), so the
+// per-column operands — bias, layer scale, the consumer's SnakeBeta parameters — are loaded once per thread, and a row's place in the output
+// (slot, row of the slot: an integer division) is worked out once per row into rinfo[] = slot << 20 | row, -1 for a dead row, by the caller.
+// Loaded / divided per item (4 + 4 + 4 scalar loads behind an integer modulo each, re-issued for every item because the stores in between may
+// alias them) this loop was 75 % of a workgroup's life in the memory-bound layers: in-kernel stamps of the 96-column transposed convolution,
+// 6.7 of 26 us up to the tile in LDS, 20 us here. LITE: epilogues 0 / 2 only (no GELU / layer-scale code in the instruction stream).
+// Per element the arithmetic is vepi's.
+template <int BN, int ROWS, int NTHR, bool LITE>
+__device__ __forceinline__ void vepi_tile(const VGemm& g, const float* Ot, const int* rinfo, int n0) {
+    constexpr int LDO = BN + 4, C4 = BN / 4, RPP = NTHR / C4, PER = (ROWS + RPP - 1) / RPP, PB = 8;
+    const int tid = threadIdx.x, cg = tid % C4, r0 = tid / C4, nout = g.c.nout, n = n0 + cg * 4;
+    const bool act = r0 < RPP && n < nout;  // (nout is a multiple of 4: checked by the launcher)
+    const int epi = g.epi;
+    const bool rmw = epi == 2 || (!LITE && epi == 1), has_b = g.c.b != nullptr, has_y2 = g.y2 != nullptr;
+    float b4[4], sc4[4], ea4[4], ib4[4];
+    {   // column n + q of a period-P operand: (n mod P) + q when P is a multiple of 4 (n is); no division at all when P covers every column
+        const int nc = min(n, nout - 4);
+        auto base = [&](int P) { return P >= nout ? nc : nc % P; };
+        auto at = [&](const float* p, int P, int b0, int q) { return (P & 3) == 0 ? p[b0 + q] : p[(nc + q) % P]; };
+        const int bb = has_b ? base(g.c.bias_n) : 0, bs = (!LITE && epi == 1) ? base(g.scale_n) : 0, bk = has_y2 ? base(g.snake_n) : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            b4[q] = has_b ? at(g.c.b, g.c.bias_n, bb, q) : 0.0f;
+            sc4[q] = (!LITE && epi == 1) ? at(g.scale, g.scale_n, bs, q) : 1.0f;
+            ea4[q] = has_y2 ? at(g.ea, g.snake_n, bk, q) : 0.0f;
+            ib4[q] = has_y2 ? at(g.ib, g.snake_n, bk, q) : 0.0f;
+        }
+    }
+    const float* ybase = g.y + g.y_off + n;
+    for (int u0 = 0; u0 < PER; u0 += PB) {
+        float4 yo[PB]; int info[PB];
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int row = r0 + (u0 + u) * RPP;
+            info[u] = (act && u0 + u < PER && row < ROWS) ? rinfo[row] : -1;
+            if (rmw && info[u] >= 0) yo[u] = *(const float4*)(ybase + (size_t)(info[u] >> 20) * g.y_stride + (size_t)(info[u] & 0xFFFFF) * nout);
+        }
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            if (info[u] < 0) continue;
+            const int row = r0 + (u0 + u) * RPP, sl = info[u] >> 20, t = info[u] & 0xFFFFF;
+            const float4 a4 = *(const float4*)&Ot[(size_t)row * LDO + cg * 4];
+            float v[4] = {a4.x, a4.y, a4.z, a4.w};
+            const float yv[4] = {rmw ? yo[u].x : 0.f, rmw ? yo[u].y : 0.f, rmw ? yo[u].z : 0.f, rmw ? yo[u].w : 0.f};
+            float sv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (has_b) v[q] += b4[q];
+                if (!LITE && epi == 1) v[q] = yv[q] + sc4[q] * v[q];
+                else if (epi == 2) v[q] = yv[q] + v[q];
+                else if (!LITE && epi == 3) v[q] = gelu_erf(v[q]);
+                if (has_y2) {
+                    const float sn = __sinf(v[q] * ea4[q]);
+                    sv[q] = v[q] + ib4[q] * (sn * sn);
+                }
+            }
+            if (g.store) *(float4*)(g.y + g.y_off + n + (size_t)sl * g.y_stride + (size_t)t * nout) = make_float4(v[0], v[1], v[2], v[3]);
+            if (has_y2) {
+                const size_t o2 = (size_t)sl * g.y2_stride + g.y2_off + (size_t)t * nout + n;
+                if (g.y2_bf16) {
+                    __bf16 hh[4] = {(__bf16)sv[0], (__bf16)sv[1], (__bf16)sv[2], (__bf16)sv[3]};
+                    *(uint2*)((__bf16*)g.y2 + o2) = *(const uint2*)hh;
+                } else *(float4*)(g.y2 + o2) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+            }
+        }
+    }
+}
+
 // The same GEMM for bf16 A operands with the operand tiles brought in by LDS-DMA (global_load_lds_dwordx4) into a ring of VR_NS stages:
 // k_vgemm_lds keeps two K steps of lookahead in registers, which left it bound by the global-load latency (~0.7 us per 32-wide K step with
 // one workgroup on a CU, 8 % MFMA issue rate on the decoder's input convolution); here three stages (48 KiB per workgroup, two workgroups
@@ -330,8 +406,18 @@ __global__ __launch_bounds__(256) void k_vgemm_lds(VGemm g) {
 // lane l FETCHES the chunk that belongs there: row l >> 2 of its 16-row group, chunk (l & 3) ^ VR_SW(row).
 // Accumulation order per output element is unchanged (32-wide K steps ascending over taps, then channels).
 #define VR_NS 4
+#ifdef Q3_VOC_STAMPS  // experiment builds (tools/r3_voc_stamps.sh): s_memrealtime (100 MHz) stamps of three workgroups of the NJ = 3 instance
+__device__ unsigned long long g_ring_stamps[4][8];
+#define VG_STAMP(i_) do { if (NJ == 3 && vg_wg >= 0 && threadIdx.x == 0) g_ring_stamps[vg_wg][i_] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define VG_STAMP(i_) do { } while (0)
+#endif
 template <int NJ>
 __global__ __launch_bounds__(256) void k_vgemm_ring(VGemm g) {
+#ifdef Q3_VOC_STAMPS
+    const int vg_wg = blockIdx.x == 1 && blockIdx.y == 100 ? 0 : (blockIdx.x == 0 && blockIdx.y == 700 ? 1 : (blockIdx.x == 2 && blockIdx.y == 1200 ? 2 : -1));
+#endif
+    VG_STAMP(0);
     constexpr int BN = NJ * 32, LA = 2, LB = (BN / 16 + 3) / 4, L = LA + LB;
     constexpr int STAGE = (128 + BN) * 64;  // bytes
     extern __shared__ __attribute__((aligned(16))) char ring[];  // [VR_NS][A 128 x 64 B | B BN x 64 B]
@@ -370,7 +456,7 @@ __global__ __launch_bounds__(256) void k_vgemm_ring(VGemm g) {
         brow[i] = g.c.w + (size_t)n * cin + ((lane & 3) ^ VR_SW(row)) * 8;
     }
     auto issue = [&](int step) {
-        const int tap = step / kpt, k0 = (step - tap * kpt) << 5;
+        int tap, k0; vstep(g, step, kpt, tap, k0);
         const long sh = (long)(g.c.ntap - 1 - tap) * g.c.dil * cin - k0;
         char* st = ring + (size_t)(step % VR_NS) * STAGE;
 #pragma unroll
@@ -397,11 +483,13 @@ __global__ __launch_bounds__(256) void k_vgemm_ring(VGemm g) {
 #pragma unroll
     for (int p = 0; p < VR_NS - 1; ++p)
         if (p < steps) issue(p);
+    VG_STAMP(1);
     for (int step = 0; step < steps; ++step) {
         // this wave's loads of stage `step` have landed when at most the later stages' loads are outstanding
         if (step + VR_NS - 2 < steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((VR_NS - 2) * L) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // every wave's part of the stage is in LDS, and every wave is done reading stage step - 1
+        Q3_LDS_BARRIER();  // every wave's part of the stage is in LDS, and every wave is done reading stage step - 1
+        if (step == 0) VG_STAMP(2);
         if (step + VR_NS - 1 < steps) issue(step + VR_NS - 1);  // into the buffer stage step - 1 used
         const char* st = ring + (size_t)(step % VR_NS) * STAGE;
         bf16x8 a_[4], b_[NJ];
@@ -418,9 +506,9 @@ __global__ __launch_bounds__(256) void k_vgemm_ring(VGemm g) {
     // of the two), then every thread finishes 4 consecutive columns of a row per trip with 16-byte loads / stores of y (and 8-byte stores
     // of the bf16 snake output). The D layout itself gives 64-byte runs of 4-byte stores: on the memory-bound layers (1x1 convolutions,
     // the transposed convolutions) issuing those was a large part of the kernel. Per element the arithmetic is vepi's.
-    constexpr int LDO = BN + 4, C4 = BN / 4, PER = 128 * C4 / 256;
+    constexpr int LDO = BN + 4;
     float* Ot = (float*)ring;
-    const bool rmw = g.epi == 1 || g.epi == 2;
+    VG_STAMP(3);
     __syncthreads();  // every wave is done with the last stage
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -428,59 +516,164 @@ __global__ __launch_bounds__(256) void k_vgemm_ring(VGemm g) {
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) Ot[(size_t)(wm * 64 + i * 16 + 4 * kq + e) * LDO + wn * NJ * 16 + j * 16 + lr] = acc[i][j][e];
+    int* rinfo = (int*)(Ot + 128 * LDO);
+    if (tid < 128) { const int m = m0 + tid, sl = m / g.T; rinfo[tid] = m < g.M ? (sl << 20) | (m - sl * g.T) : -1; }
     __syncthreads();
-    constexpr int PB = 8;  // items in flight per batch
-    for (int u0 = 0; u0 < PER; u0 += PB) {
-        float4 yo[PB];
-        if (rmw) {
-#pragma unroll
-            for (int u = 0; u < PB; ++u) {
-                const int idx = tid + (u0 + u) * 256, row = min(idx / C4, 127), cc = (idx - (idx / C4) * C4) * 4;
-                const int m = min(m0 + row, g.M - 1), n = min(n0 + cc, nout - 4);
-                const int sl = m / g.T, t = m - sl * g.T;
-                yo[u] = *(const float4*)(g.y + (size_t)sl * g.y_stride + g.y_off + (size_t)t * nout + n);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < PB; ++u) {
-            const int idx = tid + (u0 + u) * 256, row = idx / C4, cc = (idx - row * C4) * 4;
-            const int m = m0 + row, n = n0 + cc;
-            if (u0 + u >= PER || m >= g.M || n >= nout) continue;  // (nout is a multiple of 4: checked by the launcher)
-            const int sl = m / g.T, t = m - sl * g.T;
-            const float4 a4 = *(const float4*)&Ot[(size_t)row * LDO + cc];
-            float v[4] = {a4.x, a4.y, a4.z, a4.w};
-            const float yv[4] = {rmw ? yo[u].x : 0.f, rmw ? yo[u].y : 0.f, rmw ? yo[u].z : 0.f, rmw ? yo[u].w : 0.f};
-            float sv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int nn = n + q;
-                if (g.c.b) v[q] += g.c.b[nn % g.c.bias_n];
-                if (g.epi == 1) v[q] = yv[q] + g.scale[nn % g.scale_n] * v[q];
-                else if (g.epi == 2) v[q] = yv[q] + v[q];
-                else if (g.epi == 3) v[q] = gelu_erf(v[q]);
-                if (g.y2) {
-                    const int c = nn % g.snake_n;
-                    const float sn = __sinf(v[q] * g.ea[c]);
-                    sv[q] = v[q] + g.ib[c] * (sn * sn);
-                }
-            }
-            if (g.store) *(float4*)(g.y + (size_t)sl * g.y_stride + g.y_off + (size_t)t * nout + n) = make_float4(v[0], v[1], v[2], v[3]);
-            if (g.y2) {
-                const size_t o2 = (size_t)sl * g.y2_stride + g.y2_off + (size_t)t * nout + n;
-                if (g.y2_bf16) {
-                    __bf16 hh[4] = {(__bf16)sv[0], (__bf16)sv[1], (__bf16)sv[2], (__bf16)sv[3]};
-                    *(uint2*)((__bf16*)g.y2 + o2) = *(const uint2*)hh;
-                } else *(float4*)(g.y2 + o2) = make_float4(sv[0], sv[1], sv[2], sv[3]);
-            }
-        }
-    }
+    VG_STAMP(4);
+    if (g.epi == 0 || g.epi == 2) vepi_tile<BN, 128, 256, true>(g, Ot, rinfo, n0);
+    else vepi_tile<BN, 128, 256, false>(g, Ot, rinfo, n0);
+    VG_STAMP(5);
+#ifdef Q3_VOC_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VG_STAMP(6);
+#endif
 }
 template <int NJ>
 static void launch_vgemm_ring(hipStream_t s, const VGemm& g, dim3 grid) {
-    constexpr size_t lds_ring = (size_t)VR_NS * (128 + NJ * 32) * 64, lds_out = (size_t)128 * (NJ * 32 + 4) * 4, lds = lds_ring > lds_out ? lds_ring : lds_out;
+    constexpr size_t lds_ring = (size_t)VR_NS * (128 + NJ * 32) * 64, lds_out = (size_t)128 * (NJ * 32 + 4) * 4 + 128 * 4, lds = lds_ring > lds_out ? lds_ring : lds_out;
     static Q3PerDevice pd;
     pd.ensure(lds, [&]() { hipFuncSetAttribute((const void*)k_vgemm_ring<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
     hipLaunchKernelGGL((k_vgemm_ring<NJ>), grid, dim3(256), lds, s, g);
+}
+
+// The wide 7-tap convolutions of the decoder blocks (768 / 384 channels: 40 % of a batched call) on a tile that keeps its INPUT ROWS in LDS
+// across the taps. k_vgemm_ring treats a tap as 32-wide K steps with a shifted row pointer, so every step brings 128 input rows AND 128
+// weight rows through the L2 -> LDS path: 64 flop per byte, and that path (66-73 GB/s per CU measured, MI355X_MICROARCH.md "gather into
+// LDS") together with its ~2 us latency under load — not the MFMA (22 % busy), not the LDS — set its time. Here a workgroup of 8 waves owns
+// TWO 128-row sub-tiles x 128 columns:
+//  * a 32-channel chunk of each sub-tile's rows plus its 6 * dil halo rows lands in LDS once (two image buffers, LDS-DMA) and serves all
+//    seven taps — a tap is a row offset into the same image;
+//  * the weights of one (chunk, tap) — 128 columns x 32 channels — are an 8 KiB stage of a twelve-stage LDS-DMA ring shared by both
+//    sub-tiles: ten stages (80 KiB) in flight, because a stage takes ~2 us to arrive and an MFMA-bound step lasts 0.2 us.
+// Per 2 x 128 x 128 x 32 x 7 MACs that is 7 x 8 KiB of weights + 2 x (128 + halo) x 64 B of rows: ~190 flop per byte at dil = 9.
+// One barrier per PAIR of steps (32 MFMAs per wave between barriers). Rows are 64 bytes unpadded; the 16-byte chunk c of row r sits at
+// chunk position c ^ ((r >> 1) & 3): conflict-free for ds_read_b128's 16-lane groups at ANY row offset (the taps shift the rows by
+// tap * dil; searched exhaustively over the offsets).
+// K order: vstep(chunked) — the register-staged kernels follow the same order for these shapes, so the choice of kernel never changes a bit.
+// A sub-tile never straddles two slots (its halo is the slot's own history): sub-tile q = (slot q / tps, rows (q % tps) * 128 ...).
+// Schedule: 14 steps = 2 chunks = 7 pairs per trip of the main loop. Chunk c (even) reads image buffer 0, chunk c + 1 buffer 1. After the
+// barrier of pair j a wave issues, in this order: [3 row pieces of image c + 1 at j = 0 (buffer 1 was last read in the previous trip's pair 6);
+// 3 row pieces of image c + 2 at j = 4 (buffer 0 was last read in pair 3)], then its 2 weight pieces of pair p + 5. LDS-DMA completes in
+// issue order (vmcnt), so before pair j's barrier a wave waits until at most N(j) of its operations are outstanding:
+//   the stages of pair p were issued five pairs ago, younger are the issues of the last four pairs: 4 x 2 + 3 per image in them;
+//   pair 3 reads image c + 1 (issued at pair 0) and pair 0 image c + 2 (issued at pair 4 of the trip before): younger are 3 x 2.
+#define VC_NS 12      // weight stages of 8 KiB
+#define VC_LA 5       // pairs of stages in flight
+template <int NTAP>
+__global__ __launch_bounds__(512) void k_vconv_tap(VGemm g) {
+    static_assert(NTAP == 7, "the pair schedule below is written for seven taps");
+    constexpr int BN = 128;
+    extern __shared__ __attribute__((aligned(16))) char tlds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+    const int sub = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    int bx = blockIdx.x, by = blockIdx.y;
+    {   // XCD-aware tile order (see k_vgemm_ring)
+        const int total = gridDim.x * gridDim.y;
+        if ((total & 7) == 0) {
+            const int id = blockIdx.x + gridDim.x * blockIdx.y, t = (id & 7) * (total >> 3) + (id >> 3);
+            bx = t % gridDim.x; by = t / gridDim.x;
+        }
+    }
+    const int cin = g.c.cin, nout = g.c.nout, dil = g.c.dil, halo = (NTAP - 1) * dil, n0 = bx * BN;
+    const int RA = (128 + halo + 15) & ~15, pps = RA >> 4;           // rows / 16-row pieces of one sub-tile's image
+    const int abytes = 2 * RA * 64;                                  // one image buffer (both sub-tiles)
+    char* const Bring = tlds + 2 * abytes;                           // [VC_NS][128 columns][64 B]
+    const int tps = (g.T + 127) >> 7, nsub = (g.M / g.T) * tps, nchunk = cin >> 5, steps = nchunk * NTAP;
+    // loader roles: a piece is 16 rows x 64 B (one wave-instruction); lane l fetches row l >> 2 of the piece, the 16-byte chunk that belongs
+    // at position l & 3 of that row: (l & 3) ^ ((row >> 1) & 3) = (l & 3) ^ ((l >> 3) & 3) (pieces start at multiples of 16 rows).
+    // Rows: piece pi = wave + 8 k (k < 3) of the 2 * pps <= 24 pieces.
+    const int lrow = lane >> 2, lchunk = ((lane & 3) ^ ((lane >> 3) & 3)) * 8;
+    const uint16_t* ap[3]; int adst[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int pi = min(wave + 8 * k, 2 * pps - 1);               // (a clamped duplicate re-writes the same bytes)
+        const int sb = pi / pps, r16 = pi - sb * pps;
+        const int q = min(by * 2 + sb, nsub - 1), sl = q / tps, t0 = (q - sl * tps) << 7;
+        const int t = min(t0 - halo + r16 * 16 + lrow, g.T - 1);     // rows past the call's last row are never part of a stored result
+        ap[k] = (const uint16_t*)g.x + (size_t)sl * g.x_stride + g.x_off + (long)t * cin + lchunk;
+        adst[k] = (sb * RA + r16 * 16) * 64;
+    }
+    // weights: wave w brings columns 16 w .. 16 w + 15 of a stage (one piece)
+    const uint16_t* bp = g.c.w + (size_t)min(n0 + wave * 16 + lrow, nout - 1) * cin + lchunk;
+    auto issue_a = [&](int chunk) {
+        const int c = min(chunk, nchunk - 1);                        // past the end: the last chunk again, into the idle buffer
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ap[k] + c * 32),
+                                             (__attribute__((address_space(3))) void*)(tlds + (chunk & 1) * abytes + adst[k]), 16, 0, 0);
+    };
+    auto issue_b = [&](int step) {
+        const int st = min(step, steps - 1), ch = st / NTAP, tap = st - ch * NTAP;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bp + (size_t)tap * nout * cin + ch * 32),
+                                         (__attribute__((address_space(3))) void*)(Bring + (step % VC_NS) * (BN * 64) + wave * 16 * 64), 16, 0, 0);
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int arow0 = sub * RA + wm * 64 + lr;                       // image row of this lane's fragment row at tap 0, i = 0
+    int boff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int R = wn * 64 + j * 16 + lr; boff[j] = R * 64 + ((kq ^ ((R >> 1) & 3)) << 4); }
+    issue_a(0);
+#pragma unroll
+    for (int p = 0; p < VC_LA; ++p) { issue_b(2 * p); issue_b(2 * p + 1); }
+    for (int c0 = 0; c0 < nchunk; c0 += 2) {                         // (cin % 64 == 0: an even number of chunks)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {                                // pair j of the trip: steps 14 * (c0 / 2) + 2 j, + 1
+            if (j == 0 || j == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (j == 1) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+            Q3_LDS_BARRIER();  // this pair's stages (and the image it starts) are in LDS for every wave; everyone is done with the previous pair
+            const int s0 = c0 * NTAP + 2 * j;
+            if (j == 0) issue_a(c0 + 1);
+            if (j == 4) issue_a(c0 + 2);
+            issue_b(s0 + 2 * VC_LA); issue_b(s0 + 2 * VC_LA + 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int sl = 2 * j + h, cc = sl >= NTAP ? 1 : 0, tap = sl - cc * NTAP;   // step within the trip -> (chunk parity, tap)
+                const char* img = tlds + cc * abytes;
+                const char* st = Bring + ((s0 + h) % VC_NS) * (BN * 64);
+                bf16x8 a_[4], b_[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const int R = arow0 + i * 16 + tap * dil; a_[i] = *(const bf16x8*)(img + R * 64 + ((kq ^ ((R >> 1) & 3)) << 4)); }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) b_[jj] = *(const bf16x8*)(st + boff[jj]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_[i], b_[jj], acc[i][jj], 0, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped loads past the end still write LDS
+    // Epilogue through LDS, as in k_vgemm_ring: f32 tile [256][BN + 4], then 4 consecutive columns of a row per item.
+    constexpr int LDO = BN + 4;
+    float* Ot = (float*)tlds;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Ot[(size_t)(sub * 128 + wm * 64 + i * 16 + 4 * kq + e) * LDO + wn * 64 + j * 16 + lr] = acc[i][j][e];
+    int* rinfo = (int*)(Ot + 256 * LDO);
+    if (tid < 256) {
+        const int q = by * 2 + (tid >> 7), sl = q / tps, t = ((q - sl * tps) << 7) + (tid & 127);
+        rinfo[tid] = (q < nsub && t < g.T) ? (sl << 20) | t : -1;
+    }
+    __syncthreads();
+    if (g.epi == 0 || g.epi == 2) vepi_tile<BN, 256, 512, true>(g, Ot, rinfo, n0);
+    else vepi_tile<BN, 256, 512, false>(g, Ot, rinfo, n0);
+}
+static void launch_vconv_tap(hipStream_t s, const VGemm& g) {
+    const int halo = (g.c.ntap - 1) * g.c.dil, RA = (128 + halo + 15) & ~15;
+    const size_t lds_main = (size_t)2 * 2 * RA * 64 + (size_t)VC_NS * 128 * 64, lds_out = (size_t)256 * (128 + 4) * 4 + 256 * 4, lds = std::max(lds_main, lds_out);
+    static Q3PerDevice pd;
+    pd.ensure(1, []() { hipFuncSetAttribute((const void*)k_vconv_tap<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); });
+    const int tps = (g.T + 127) / 128, nsub = (g.M / g.T) * tps;
+    hipLaunchKernelGGL((k_vconv_tap<7>), dim3(g.c.nout / 128, (nsub + 1) / 2), dim3(512), lds, s, g);
 }
 
 // Fused residual unit of the narrow decoder blocks (C <= 192 channels, where everything is HBM-bound):
@@ -498,15 +691,18 @@ struct VResUnit {
     float* o; size_t o_stride; int store_o;
     float* y2; size_t y2_stride; int y2_off; const float *ea3, *ib3;  // snake of the consumer, written (bf16) into its work buffer
 };
-#ifdef Q3_STAMPS
-__device__ unsigned long long g_voc_stamps[4][16];  // experiment builds: s_memtime stamps of four workgroups' wave 0
-#define VR_STAMP(i_) do { if (stamp_wg >= 0 && threadIdx.x == 0) g_voc_stamps[stamp_wg][i_] = __builtin_amdgcn_s_memtime(); } while (0)
+#if defined(Q3_STAMPS) || defined(Q3_VOC_STAMPS)
+__device__ unsigned long long g_voc_stamps[2][4][16];  // experiment builds: s_memrealtime (100 MHz) stamps of three workgroups' wave 0, [192-channel unit, others]
+#define VR_STAMP(i_) do { if (stamp_wg >= 0 && threadIdx.x == 0) g_voc_stamps[NT == 12 ? 0 : 1][stamp_wg][i_] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define VR_STAMP(i_) do { } while (0)
 #endif
+// (the step barrier stays __syncthreads(): with the LDS-only barrier the 96-channel unit measured 183 us instead of 137, the 192-channel one
+//  unchanged — the weight loads it lets run ahead share the CU's in-order return path with the other workgroups' HBM phases)
+#define VR_BARRIER() __syncthreads()
 template <int NT, int MT>
 __global__ __launch_bounds__(256) void k_voc_resunit(VResUnit g) {
-#ifdef Q3_STAMPS
+#if defined(Q3_STAMPS) || defined(Q3_VOC_STAMPS)
     const int stamp_wg = (blockIdx.y == 5 && (blockIdx.x == 3 || blockIdx.x == 20)) ? (blockIdx.x == 3 ? 0 : 1) : ((blockIdx.y == 40 && blockIdx.x == 11) ? 2 : -1);
 #endif
     VR_STAMP(0);
@@ -598,7 +794,7 @@ __global__ __launch_bounds__(256) void k_voc_resunit(VResUnit g) {
                     acc[i][j][e] = 0.0f;                                                                                \
                 }                                                                                                       \
             }                                                                                                           \
-        __syncthreads();                                                                                                \
+        VR_BARRIER();                                                                                                \
     } while (0)
 #define VR_STEP(step_, X_)  /* X_ = the set holding chunk step_ + 1 */                                                  \
     do {                                                                                                                \
@@ -614,7 +810,7 @@ __global__ __launch_bounds__(256) void k_voc_resunit(VResUnit g) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a__[i], b__[j], acc[i][j], 0, 0, 0);                \
         VR_SSTOREB(X_, buf__ ^ 1);                                                                                      \
         VR_GLOADB(X_, sp__ + 1 + LK);                                                                                        \
-        __syncthreads();                                                                                                \
+        VR_BARRIER();                                                                                                \
     } while (0)
     static_assert(S % LK == 0, "the step loop is unrolled by the number of register sets");
     for (int step0 = 0; step0 < S; step0 += LK) {  // S = 8 KS; S1 = 7 KS falls on sub-step S1 % LK of its trip
@@ -649,26 +845,27 @@ __global__ __launch_bounds__(256) void k_voc_resunit(VResUnit g) {
             for (int e = 0; e < 4; ++e) Ot[(size_t)(wrow0 + i * 16 + 4 * kq + e) * LDO + n] = acc[i][j][e] + bb;
         }
     __syncthreads();
-    {
-        constexpr int c4n = C / 4, total = R * c4n, PER = (total + 255) / 256;
+    {   // a thread keeps one group of 4 channels for all its rows (16 of 256 threads idle at 96 / 192 channels): the consumer's SnakeBeta
+        // parameters are loaded once, not per item
+        constexpr int c4n = C / 4, RPP = 256 / c4n, PER = (R + RPP - 1) / RPP;
         float* ob = g.o + (size_t)sidx * g.o_stride;
         __bf16* yb = (__bf16*)g.y2 + (size_t)sidx * g.y2_stride + g.y2_off;
-        constexpr int PB = PER < 12 ? PER : 12;  // residual loads in flight per thread: all of them for every instantiated shape
+        const int cg = tid % c4n, r0 = tid / c4n, c = cg * 4;
+        const bool act = r0 < RPP;
+        const float4 ea = *(const float4*)(g.ea3 + c), ib = *(const float4*)(g.ib3 + c);
+        constexpr int PB = PER < 13 ? PER : 13;  // residual loads in flight per thread: all of them for every instantiated shape
         for (int p0 = 0; p0 < PER; p0 += PB) {
             float4 ov[PB];
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
-                const int idx = min(tid + (p0 + u) * 256, total - 1), row = idx / c4n, c = (idx - row * c4n) * 4;
+                const int row = min(r0 + (p0 + u) * RPP, R - 1);
                 ov[u] = *(const float4*)(ob + (size_t)min(t0 + row, T - 1) * C + c);
             }
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
-                const int idx = tid + (p0 + u) * 256;
-                if (p0 + u >= PER || idx >= total) continue;
-                const int row = idx / c4n, c = (idx - row * c4n) * 4, t = t0 + row;
-                if (t >= T) continue;
+                const int row = r0 + (p0 + u) * RPP, t = t0 + row;
+                if (!act || p0 + u >= PER || row >= R || t >= T) continue;
                 const float4 a = *(const float4*)&Ot[(size_t)row * LDO + c];
-                const float4 ea = *(const float4*)(g.ea3 + c), ib = *(const float4*)(g.ib3 + c);
                 float4 v; v.x = ov[u].x + a.x; v.y = ov[u].y + a.y; v.z = ov[u].z + a.z; v.w = ov[u].w + a.w;
                 if (g.store_o) *(float4*)(ob + (size_t)t * C + c) = v;
                 float sn; __bf16 h[4];
@@ -910,6 +1107,65 @@ __global__ __launch_bounds__(256) void k_voc_out(VCall cl, const float* x, size_
     }
 }
 
+// V6 for channel counts that are multiples of 8 (every shipped shape): the window is staged as the bf16 it is stored as, with 16-byte
+// loads in one round trip, and every thread owns 8 channels x 8 consecutive samples: 14 window rows (one ds_read_b128 each) and its 56
+// weights in registers feed 448 FMAs — 0.03 LDS reads per MAC. k_voc_out reads both operands of every MAC from LDS and stages the window
+// two bytes at a time in four round trips: 114 us for 94 MB of input (0.8 TB/s) at the full shape.
+// Order per sample: a slice's chain runs over the taps, inside a tap over its 8 channels (fmaf); the C / 8 slices are then added in
+// ascending order, then the bias. (Its own fixed order — independent of the tile position, so chunked == one-shot holds bit for bit.)
+__global__ __launch_bounds__(256) void k_voc_out8(VCall cl, const uint16_t* x, size_t x_stride, int H, int T, int C, const float* w, const float* b,
+                                                  float* pcm, size_t pcm_stride, int spf, int G) {
+    extern __shared__ __attribute__((aligned(16))) char sm8[];  // window [G * 8 + 6][C bf16 + 16 B] | partial sums [C / 8][G * 8]
+    const int NS = C >> 3, R = G * 8, nrow = R + 6, ld = C * 2 + 16;
+    float* part = (float*)(sm8 + (size_t)nrow * ld);
+    const int s = blockIdx.y, slot = cl.slot[s], t0 = blockIdx.x * R, tid = threadIdx.x;
+    const uint16_t* xp = x + (size_t)s * x_stride + (size_t)(H + t0 - 6) * C;  // window row 0 = t0 - 6
+    const int lim = min(nrow, T - t0 + 6), total = nrow * NS;
+    for (int base = tid; base < total; base += 8 * 256) {
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = min(base + u * 256, total - 1), r = i / NS, c = i - r * NS; v[u] = *(const uint4*)(xp + (size_t)min(r, lim - 1) * C + c * 8); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = base + u * 256; if (i < total) { const int r = i / NS, c = i - r * NS; *(uint4*)(sm8 + (size_t)r * ld + c * 16) = v[u]; } }
+    }
+    const int g = tid / NS, k = tid - g * NS;
+    float wr[7][8];
+    if (g < G) {
+#pragma unroll
+        for (int tap = 0; tap < 7; ++tap) {
+            const float4 w0 = *(const float4*)(w + tap * C + k * 8), w1 = *(const float4*)(w + tap * C + k * 8 + 4);
+            wr[tap][0] = w0.x; wr[tap][1] = w0.y; wr[tap][2] = w0.z; wr[tap][3] = w0.w; wr[tap][4] = w1.x; wr[tap][5] = w1.y; wr[tap][6] = w1.z; wr[tap][7] = w1.w;
+        }
+    }
+    __syncthreads();
+    if (g < G) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 14; ++j) {
+            const uint4 q = *(const uint4*)(sm8 + (size_t)(g * 8 + j) * ld + k * 16);
+            const float xv[8] = {q3_u2f(q.x << 16), q3_u2f(q.x & 0xFFFF0000u), q3_u2f(q.y << 16), q3_u2f(q.y & 0xFFFF0000u),
+                                 q3_u2f(q.z << 16), q3_u2f(q.z & 0xFFFF0000u), q3_u2f(q.w << 16), q3_u2f(q.w & 0xFFFF0000u)};
+#pragma unroll
+            for (int tap = 0; tap < 7; ++tap) {
+                const int o = j - tap;  // sample g * 8 + o reads window row o + tap
+                if (o >= 0 && o < 8) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[o] = fmaf(xv[c], wr[tap][c], acc[o]);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 8; ++o) part[k * R + g * 8 + o] = acc[o];
+    }
+    __syncthreads();
+    if (tid < R && t0 + tid < T) {
+        float r = 0.0f;
+        for (int kk = 0; kk < NS; ++kk) r += part[kk * R + tid];
+        r += b[0];
+        pcm[(size_t)slot * pcm_stride + (size_t)cl.pos[s] * spf + t0 + tid] = fminf(1.0f, fmaxf(-1.0f, r));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------------------------------
@@ -1147,6 +1403,13 @@ struct VSnake { float* y2 = nullptr; size_t stride = 0; int off = 0; const float
 static VSnake snake_into(const VBuf& dst, const float* ea, const float* ib, int C) {
     VSnake k; k.y2 = dst.p; k.stride = dst.stride(); k.off = dst.H * dst.C; k.ea = ea; k.ib = ib; k.n = C; k.bf16 = dst.bf16; return k;
 }
+// the wide 7-tap convolutions run their K steps chunk by chunk (vstep), whichever kernel serves them
+static bool vconv_chunked(const VConv& c) { return c.ntap == 7 && c.cin % 64 == 0 && c.cin >= 256; }
+// Q3TTS_VOC_NOTAP=1: those convolutions on the ring / register-staged GEMMs instead of k_vconv_tap (same bits; A/B runs and tests)
+static bool voc_tap() { const char* ev = getenv("Q3TTS_VOC_NOTAP"); return !(ev && atoi(ev)); }
+// fewer workgroups than this (a draining batch, a single stream) leave most CUs idle under 256-row tiles: the finer 128 x 128 tiles serve them.
+// Q3TTS_VOC_TAP_MIN overrides it (tests force k_vconv_tap onto one-slot calls with 1)
+static long voc_tap_min() { const char* ev = getenv("Q3TTS_VOC_TAP_MIN"); return ev ? atol(ev) : 128; }
 // Q3TTS_VOC_NORING=1: the register-staged kernel for bf16 A as well (A/B runs and the tests that compare the two)
 static bool voc_ring() { const char* ev = getenv("Q3TTS_VOC_NORING"); return !(ev && atoi(ev)); }
 // (its epilogue moves 4 columns at a time: nout and every row start are multiples of 4 elements for all convolutions of the vocoder)
@@ -1157,8 +1420,13 @@ static void vgemm(hipStream_t s, const VConv& c, const float* x, size_t x_stride
     g.scale = scale; g.scale_n = scale_n; g.epi = epi; g.store = store; g.a_bf16 = a_bf16; g.y_bf16 = y_bf16;
     g.y2 = nullptr; g.y2_stride = 0; g.y2_off = 0; g.ea = g.ib = nullptr; g.snake_n = 1; g.y2_bf16 = 0;
     if (sk) { g.y2 = sk->y2; g.y2_stride = sk->stride; g.y2_off = sk->off; g.ea = sk->ea; g.ib = sk->ib; g.snake_n = sk->n; g.y2_bf16 = sk->bf16; }
+    g.chunked = vconv_chunked(c) ? 1 : 0;
     // every kernel accumulates the same 32-wide K steps in the same order: the choice never changes a result
-    if (g.M <= 512 || epi == 4) {
+    if (g.chunked && a_bf16 && voc_tap() && voc_ring_ok(g) && c.nout % 128 == 0 && 6 * c.dil <= 64 && epi != 4 &&
+        ((T + 127) / 128) * 128 * 3 <= T * 4 &&  /* at most a quarter of the 128-row sub-tiles' rows beyond T */
+        (long)(c.nout / 128) * ((ns * ((T + 127) / 128) + 1) / 2) >= voc_tap_min()) {
+        launch_vconv_tap(s, g);
+    } else if (g.M <= 512 || epi == 4) {
         // the kernel is bound by what one CU's load path delivers: a narrow N runs 64 x 16 tiles to put a workgroup on
         // every CU instead of on half of them
         const long wg32 = (long)((c.nout + 31) / 32) * ((g.M + 63) / 64);
@@ -1356,8 +1624,13 @@ static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
         }
     }
     // V6
-    hipLaunchKernelGGL(k_voc_out, dim3((T + 63) / 64, ns), dim3(256), (size_t)(70 * (ch + 1) + 7 * ch) * 4, s, cl, v->out_in.p, v->out_in.stride(), v->out_in.H, T, ch, v->out_w, v->out_b,
-                       v->pcm, v->pcm_stride, v->spf);
+    if (ch % 8 == 0 && ch / 8 <= 32 && !getenv("Q3TTS_VOC_OUT_OLD")) {
+        const int NS = ch / 8, G = std::min(16, 256 / NS), R = G * 8;
+        hipLaunchKernelGGL(k_voc_out8, dim3((T + R - 1) / R, ns), dim3(256), (size_t)(R + 6) * (ch * 2 + 16) + (size_t)NS * R * 4, s, cl, (const uint16_t*)v->out_in.p,
+                           v->out_in.stride(), v->out_in.H, T, ch, v->out_w, v->out_b, v->pcm, v->pcm_stride, v->spf, G);
+    } else
+        hipLaunchKernelGGL(k_voc_out, dim3((T + 63) / 64, ns), dim3(256), (size_t)(70 * (ch + 1) + 7 * ch) * 4, s, cl, v->out_in.p, v->out_in.stride(), v->out_in.H, T, ch, v->out_w, v->out_b,
+                           v->pcm, v->pcm_stride, v->spf);
     hist_all(s, cl, v, nf, 1);
     Q3_HIP(e, hipGetLastError());
     return Q3TTS_OK;
@@ -1425,13 +1698,14 @@ extern "C" int q3tts_k_vocoder(q3tts_engine* e, const int32_t* codes, int32_t n_
 // Measurement hook (bench.py's roofline_vocoder): the batched vocoder alone — n_slots slots x 4-frame chunks, `chunks` calls on the
 // engine's stream with nothing else on the GPU, HIP events around them. Codes are seeded pseudo-random. *ms_per_chunk = the mean
 // duration of one batched 4-frame call (n_slots x 4 frames of PCM).
-#ifdef Q3_STAMPS
+#if defined(Q3_STAMPS) || defined(Q3_VOC_STAMPS)
 static void voc_print_stamps() {
-    unsigned long long st[4][16];
+    unsigned long long st[2][4][16];
     if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_voc_stamps), sizeof(st)) != hipSuccess) return;
-    for (int w = 0; w < 3; ++w)
-        fprintf(stderr, "resunit stamps wg %d (100 MHz ticks from entry): first weights requested %llu | input staged + barrier %llu | conv1 done %llu | snake tile done %llu | conv2 done %llu | stores issued %llu\n",
-                w, st[w][1] - st[w][0], st[w][2] - st[w][0], st[w][3] - st[w][0], st[w][4] - st[w][0], st[w][5] - st[w][0], st[w][6] - st[w][0]);
+    for (int k = 0; k < 2; ++k)
+        for (int w = 0; w < 3; ++w)
+            fprintf(stderr, "resunit stamps (%s) wg %d (100 MHz ticks from entry): first weights requested %llu | input staged + barrier %llu | conv1 done %llu | snake tile done %llu | conv2 done %llu | stores issued %llu\n",
+                    k == 0 ? "192 channels" : "96 channels", w, st[k][w][1] - st[k][w][0], st[k][w][2] - st[k][w][0], st[k][w][3] - st[k][w][0], st[k][w][4] - st[k][w][0], st[k][w][5] - st[k][w][0], st[k][w][6] - st[k][w][0]);
 }
 #endif
 extern "C" int q3tts_k_vocoder_bench(q3tts_engine* e, int32_t n_slots, int32_t chunks, float* ms_per_chunk) {
@@ -1456,8 +1730,17 @@ extern "C" int q3tts_k_vocoder_bench(q3tts_engine* e, int32_t n_slots, int32_t c
     float ms = 0.0f;
     Q3_HIP(e, hipEventElapsedTime(&ms, e->ev0, e->ev2));
     *ms_per_chunk = ms / (float)chunks;
-#ifdef Q3_STAMPS
+#if defined(Q3_STAMPS) || defined(Q3_VOC_STAMPS)
     voc_print_stamps();
+#endif
+#ifdef Q3_VOC_STAMPS
+    {
+        unsigned long long st[4][8];
+        if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_ring_stamps), sizeof(st)) == hipSuccess)
+            for (int w = 0; w < 3; ++w)
+                fprintf(stderr, "ring<3> stamps wg %d (10 ns ticks from entry): prologue issued %llu | first stage in LDS %llu | main loop done %llu | tile in LDS %llu | stores issued %llu | stores done %llu\n",
+                        w, st[w][1] - st[w][0], st[w][2] - st[w][0], st[w][3] - st[w][0], st[w][4] - st[w][0], st[w][5] - st[w][0], st[w][6] - st[w][0]);
+    }
 #endif
     for (int i = 0; i < n_slots; ++i) VTRY(q3_voc_reset(e, i));
     return Q3TTS_OK;

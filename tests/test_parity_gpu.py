@@ -357,6 +357,12 @@ def test_vocoder_narrow_block_kernels(oracle):
             assert np.array_equal(eng.vocoder(codes), one)
         finally:
             del os.environ["Q3TTS_VOC_NORING"]
+        os.environ["Q3TTS_VOC_TAP_MIN"] = "1"   # the 384-channel 7-tap convolutions on k_vconv_tap (a batch of 64 takes it by itself): same bits
+        try:
+            for ch in (0, 3):
+                assert np.array_equal(eng.vocoder(codes, chunk_frames=ch), one), ch
+        finally:
+            del os.environ["Q3TTS_VOC_TAP_MIN"]
     finally:
         eng.close()
         L.q3o_vocoder_destroy(v)
@@ -1095,6 +1101,12 @@ def test_full_shape_vocoder_pcm_vs_oracle(oracle, n_frames):
             assert np.array_equal(eng.vocoder(codes), one)
         finally:
             del os.environ["Q3TTS_VOC_NORING"]
+        os.environ["Q3TTS_VOC_TAP_MIN"] = "1"   # the 768- and 384-channel 7-tap convolutions on k_vconv_tap (what a batch of 64 runs): same bits
+        try:
+            assert np.array_equal(eng.vocoder(codes), one)
+            assert np.array_equal(eng.vocoder(codes, chunk_frames=3), one)   # partial tiles: 96 / 480 rows per call
+        finally:
+            del os.environ["Q3TTS_VOC_TAP_MIN"]
     finally:
         eng.close()
         L.q3o_vocoder_destroy(v)
