@@ -491,8 +491,14 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
     HIPC(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     // Q3TTS_VOC_SERIAL=1: the vocoder shares the decoder stream (no overlap): isolates its kernels in a profile
     // (highest / lowest stream priority for the decoder / vocoder streams was measured in both rounds: no change, left out)
+    // Q3TTS_VOC_CUMASK=<hex word>: experiment — the vocoder stream only runs on the CUs whose bit is set in the word (repeated over the
+    // 256 CUs), so that decoder workgroups always find CUs without long-lived vocoder workgroups (profiles/README.md, r03)
     if (getenv("Q3TTS_VOC_SERIAL") && atoi(getenv("Q3TTS_VOC_SERIAL"))) e->vstream = e->stream;
-    else HIPC(hipStreamCreateWithFlags(&e->vstream, hipStreamNonBlocking));
+    else if (getenv("Q3TTS_VOC_CUMASK")) {
+        uint32_t w = (uint32_t)strtoul(getenv("Q3TTS_VOC_CUMASK"), nullptr, 16), mask[8];
+        for (auto& x : mask) x = w;
+        HIPC(hipExtStreamCreateWithCUMask(&e->vstream, 8, mask));
+    } else HIPC(hipStreamCreateWithFlags(&e->vstream, hipStreamNonBlocking));
     HIPC(hipEventCreate(&e->ev0)); HIPC(hipEventCreate(&e->ev1)); HIPC(hipEventCreate(&e->ev2)); HIPC(hipEventCreate(&e->ev3));
     e->fin_ev.resize(cfg->max_batch, nullptr);
     for (auto& ev : e->fin_ev) HIPC(hipEventCreateWithFlags(&ev, hipEventDisableTiming));

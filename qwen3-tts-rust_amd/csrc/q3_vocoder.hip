@@ -700,14 +700,16 @@ __device__ unsigned long long g_voc_stamps[2][4][16];  // experiment builds: s_m
 // (the step barrier stays __syncthreads(): with the LDS-only barrier the 96-channel unit measured 183 us instead of 137, the 192-channel one
 //  unchanged — the weight loads it lets run ahead share the CU's in-order return path with the other workgroups' HBM phases)
 #define VR_BARRIER() __syncthreads()
-template <int NT, int MT>
-__global__ __launch_bounds__(256) void k_voc_resunit(VResUnit g) {
+// NWV waves: 4, or 8 for the 192-channel unit — two 64-row halves behind ONE weight stream: with two 4-wave workgroups of 64 rows on a CU the
+// weight chunks (12 KiB per step each) ran at 49 GB/s per CU through the L2 path that tops out at 66-73 (stamps: 0.49 us per step, 40 % MFMA)
+template <int NT, int MT, int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_voc_resunit(VResUnit g) {
 #if defined(Q3_STAMPS) || defined(Q3_VOC_STAMPS)
     const int stamp_wg = (blockIdx.y == 5 && (blockIdx.x == 3 || blockIdx.x == 20)) ? (blockIdx.x == 3 ? 0 : 1) : ((blockIdx.y == 40 && blockIdx.x == 11) ? 2 : -1);
 #endif
     VR_STAMP(0);
     constexpr int C = NT * 16, KS = C / 32, R = 64 * MT, LDA = C + 16, S1 = 7 * KS, S = 8 * KS;  // row stride 2 C + 32 bytes = 32 mod 64: conflict-free fragment reads
-    constexpr int BPASS = (C + 63) / 64;  // weight-chunk loader passes: 64 rows x 64 B per pass
+    constexpr int NTHR = 64 * NWV, BROWS = NTHR / 4, BPASS = (C + BROWS - 1) / BROWS;  // weight-chunk loader passes: BROWS rows x 64 B per pass
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
     const int halo = 6 * g.dil;
     __bf16* At = lds;                                  // [R + halo][LDA]
@@ -727,15 +729,15 @@ __global__ __launch_bounds__(256) void k_voc_resunit(VResUnit g) {
         const int st__ = min((step_), S - 1);                                                                           \
         const uint16_t* base__ = (st__ < S1 ? g.w1 + (size_t)(st__ / KS) * C * C + (st__ % KS) * 32 : g.w2 + (st__ - S1) * 32) + bpart * 8; \
         X_##0 = *(const uint4*)(base__ + (size_t)min(bn, C - 1) * C);                                                    \
-        if (BPASS > 1) X_##1 = *(const uint4*)(base__ + (size_t)min(bn + 64, C - 1) * C);                                \
-        if (BPASS > 2) X_##2 = *(const uint4*)(base__ + (size_t)min(bn + 128, C - 1) * C);                               \
+        if (BPASS > 1) X_##1 = *(const uint4*)(base__ + (size_t)min(bn + BROWS, C - 1) * C);                                \
+        if (BPASS > 2) X_##2 = *(const uint4*)(base__ + (size_t)min(bn + 2 * BROWS, C - 1) * C);                               \
     } while (0)
 #define VR_SSTOREB(X_, buf_)                                                                                            \
     do {                                                                                                                \
         __bf16* d__ = &Bs[((size_t)(buf_) * C + bn) * 32 + ((bpart ^ VR_SW(bn)) << 3)];  /* VR_SW(bn + 64 k) = VR_SW(bn) */     \
         if (bn < C) *(uint4*)d__ = X_##0;                                                                               \
-        if (BPASS > 1 && bn + 64 < C) *(uint4*)(d__ + 64 * 32) = X_##1;                                                 \
-        if (BPASS > 2 && bn + 128 < C) *(uint4*)(d__ + 128 * 32) = X_##2;                                               \
+        if (BPASS > 1 && bn + BROWS < C) *(uint4*)(d__ + BROWS * 32) = X_##1;                                                 \
+        if (BPASS > 2 && bn + 2 * BROWS < C) *(uint4*)(d__ + 2 * BROWS * 32) = X_##2;                                               \
     } while (0)
     VR_GLOADB(ra, 0);
     VR_STAMP(1);
@@ -744,16 +746,16 @@ __global__ __launch_bounds__(256) void k_voc_resunit(VResUnit g) {
     {
         const uint16_t* xp = (const uint16_t*)g.xin + (size_t)sidx * g.xin_stride + (size_t)t0 * C;  // buffer row t0 = output row t0 - halo
         const int nrow = R + halo, c8 = C / 8, total = nrow * c8;
-        for (int base = tid; base < total; base += 12 * 256) {
+        for (int base = tid; base < total; base += 12 * NTHR) {
             uint4 v[12];
 #pragma unroll
             for (int u = 0; u < 12; ++u) {
-                const int i = min(base + u * 256, total - 1), r = i / c8, c = (i - r * c8) * 8;
+                const int i = min(base + u * NTHR, total - 1), r = i / c8, c = (i - r * c8) * 8;
                 v[u] = *(const uint4*)(xp + (size_t)min(r, T + halo - 1 - t0) * C + c);
             }
 #pragma unroll
             for (int u = 0; u < 12; ++u) {
-                const int i = base + u * 256;
+                const int i = base + u * NTHR;
                 if (i < total) {
                     const int r = i / c8, c = (i - r * c8) * 8;
                     const bool live = t0 + r < T + halo;
@@ -773,7 +775,7 @@ __global__ __launch_bounds__(256) void k_voc_resunit(VResUnit g) {
     // wave tiling: a wave owns MTW row tiles x NTW column tiles. The wide blocks (one row tile per wave, >= 8 column tiles) split the
     // columns over wave pairs instead — 2 row tiles x NT/2 column tiles per wave: 2 + NT/2 fragment reads per K step instead of 1 + NT
     // for the same MFMAs (at 192 channels the LDS reads, 13 KiB per wave-step for 12 MFMAs, were what bounded the loop)
-    constexpr int WN = (MT == 1 && NT >= 8) ? 2 : 1, MTW = MT * WN, NTW = NT / WN;
+    constexpr int WN = ((MT == 1 || NWV == 8) && NT >= 8) ? 2 : 1, MTW = (R / 16) / (NWV / WN), NTW = NT / WN;
     f32x4 acc[MTW][NTW];
 #pragma unroll
     for (int i = 0; i < MTW; ++i)
@@ -847,7 +849,7 @@ __global__ __launch_bounds__(256) void k_voc_resunit(VResUnit g) {
     __syncthreads();
     {   // a thread keeps one group of 4 channels for all its rows (16 of 256 threads idle at 96 / 192 channels): the consumer's SnakeBeta
         // parameters are loaded once, not per item
-        constexpr int c4n = C / 4, RPP = 256 / c4n, PER = (R + RPP - 1) / RPP;
+        constexpr int c4n = C / 4, RPP = NTHR / c4n, PER = (R + RPP - 1) / RPP;
         float* ob = g.o + (size_t)sidx * g.o_stride;
         __bf16* yb = (__bf16*)g.y2 + (size_t)sidx * g.y2_stride + g.y2_off;
         const int cg = tid % c4n, r0 = tid / c4n, c = cg * 4;
@@ -1462,13 +1464,13 @@ static bool resunit_ok(int C) {
     const int off = ev ? atoi(ev) : 0;
     return !off && (C == 32 || C == 64 || C == 96 || C == 128 || C == 192);
 }
-template <int NT, int MT>
+template <int NT, int MT, int NWV = 4>
 static void launch_resunit_t(hipStream_t s, const VResUnit& g, int ns) {
     constexpr int C = NT * 16, R = 64 * MT, LDA = C + 16;
     const size_t lds = std::max(((size_t)(R + 6 * g.dil) * LDA + (size_t)2 * C * 32) * 2, (size_t)R * (C + 4) * 4);  // input tile + weight ring, later the f32 output tile
     static Q3PerDevice pd;
-    pd.ensure(1, []() { hipFuncSetAttribute((const void*)k_voc_resunit<NT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); });
-    hipLaunchKernelGGL((k_voc_resunit<NT, MT>), dim3((g.T + R - 1) / R, ns), dim3(256), lds, s, g);
+    pd.ensure(1, []() { hipFuncSetAttribute((const void*)k_voc_resunit<NT, MT, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); });
+    hipLaunchKernelGGL((k_voc_resunit<NT, MT, NWV>), dim3((g.T + R - 1) / R, ns), dim3(64 * NWV), lds, s, g);
 }
 static void launch_resunit(hipStream_t s, const VRes& r, int ns, int T, int C, float* o, int store_o, const VSnake& sk) {
     VResUnit g;
@@ -1481,7 +1483,7 @@ static void launch_resunit(hipStream_t s, const VRes& r, int ns, int T, int C, f
         case 64: launch_resunit_t<4, 3>(s, g, ns); break;
         case 96: launch_resunit_t<6, 2>(s, g, ns); break;
         case 128: launch_resunit_t<8, 1>(s, g, ns); break;
-        default: launch_resunit_t<12, 1>(s, g, ns); break;  // (128-row tiles, one workgroup per CU: 215 us against 182)
+        default: launch_resunit_t<12, 2, 8>(s, g, ns); break;  // (64-row tiles, 4 waves, two workgroups per CU: 182 us; 128 rows with 4 waves: 215; 128 rows with 8 waves: 168)
     }
 }
 static void hist(hipStream_t s, const VCall& cl, VBuf& b, int T, int save) {

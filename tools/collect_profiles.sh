@@ -42,5 +42,9 @@ else
   bash $R/tools/voc_trace.sh > $OUT/vocoder_call_timeline.txt 2>&1; tail -2 $OUT/vocoder_call_timeline.txt
   bash $R/tools/prefill_trace.sh > $OUT/prefill_timeline.txt 2>&1; head -3 $OUT/prefill_timeline.txt
   timeout -k 10 120 $R/tools/chain_stamps 64 > $OUT/chain_stamps.txt 2>&1; tail -3 $OUT/chain_stamps.txt
+  if [ -f $R/tools/exp/libq3tts_vstamps.so ]; then  # tools/r3_voc_stamps.sh: in-kernel stamps of the vocoder's ring GEMM and residual units
+    (cd $R && Q3TTS_LIB=$R/tools/exp/libq3tts_vstamps.so python bench.py --probe-only vocoder 2>&1 >/dev/null | grep stamps > $OUT/vocoder_stamps.txt); tail -2 $OUT/vocoder_stamps.txt
+  fi
+  bash $R/tools/overlap_trace.sh > $OUT/decoder_vocoder_overlap.txt 2>&1; tail -4 $OUT/decoder_vocoder_overlap.txt
   cd $R && python bench.py > $OUT/bench_b64_n1.json 2> $OUT/bench_b64_n1.err; tail -c 600 $OUT/bench_b64_n1.json
 fi

@@ -8,7 +8,7 @@ python3 - "$f" <<'PY'
 import csv, sys, collections
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('k_sample') and int(r['Grid_Size_X']) == 64 * 256]
+idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('k_sample') and int(r['Grid_Size_X']) == (64 + 64 * 4) * 256]
 fr = rows[idx[12]:idx[13]]
 dur = lambda r: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
 agg = collections.defaultdict(lambda: [0, 0.0])

@@ -22,8 +22,10 @@ KINDS = [  # name, kernel substring, FETCH_SIZE KiB range as reported (half of t
     ("Talker down projection", "k_bgemm<1, 2, 8, false,", 8000, 1e12),
     ("Talker O projection", "k_bgemm<1, 2, 8, false,", 3500, 8000),   # (below 3500: the Predictor's 15 head GEMMs, same instance)
     ("Predictor gate/up GEMM", "k_bgemm<2, 3, 4, false,", 0, 1e12),
-    ("Predictor down projection", "k_bgemm<1, 1, 8, false,", 3200, 1e12),   # algorithmic 7.3 MB = 3 580 KiB as reported; O: 5.1 MB = 2 500
-    ("Predictor O projection", "k_bgemm<1, 1, 8, false,", 0, 3200),
+    # memory-side bytes = the weights once + the row operands once PER XCD (eight L2s): O 4.19 + 8 x 0.26 + 0.26 MB = 3 190 KiB as reported,
+    # down 6.29 + 8 x 0.39 + 0.26 MB = 4 730 KiB
+    ("Predictor down projection", "k_bgemm<1, 1, 8, false,", 3900, 1e12),
+    ("Predictor O projection", "k_bgemm<1, 1, 8, false,", 0, 3900),
     ("Talker attention", "k_attend_gqa2", 0, 1e12),
     ("Predictor attention", "k_attend_small<2>", 0, 1e12),
 ]
