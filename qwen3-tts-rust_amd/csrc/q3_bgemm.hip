@@ -46,6 +46,7 @@ __device__ __forceinline__ float bg_f16(uint32_t bits) { return (float)__builtin
 
 // Q8: the weights are ggml Q8_0 blocks in the tiled Q8 layout (q3_kernels.h): 1.06 bytes per weight instead of 2 through
 // the same ring; every 32-wide K step is one block: P = MFMA from a zero accumulator, acc = fmaf(f32(d), P, acc).
+#define BG_PH(RT_, NT_) ((8 * (RT_) * (NT_) > 64 && ((RT_) * (NT_)) % 2 == 0) ? 2 : 1)  // slice-reduction phases (k_bgemm, BgInst::lds)
 template <int RT, int NT, int D, bool NTW, bool Q8>
 __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
     extern __shared__ float part[];  // [8 waves][RT*NT*4 regs][64 lanes]
@@ -251,74 +252,80 @@ __global__ __launch_bounds__(512) void k_bgemm(Q3BGemm g) {
 #ifdef Q3_STAMPS
     asm volatile("" :: "v"(acc[0][0][0])); Q3_STAMP(g, 3);
 #endif
-#pragma unroll
-    for (int i = 0; i < RT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) part[((size_t)wave * TR + (i * NT + j) * 4 + e) * 64 + lane] = acc[i][j][e];
-    __syncthreads();
-    Q3_STAMP(g, 4);
-    // slice partials combined in slice order; element (tile t, reg e, lane l) -> row 16 i + 4 (l >> 4) + e, col 16 j + (l & 15)
+    // The slice buffer holds TRP = TR / PH registers per wave: instances whose 8 x TR x 256 bytes exceed 64 KiB ((4,3): 96) reduce in PH = 2
+    // phases of half their tiles, so that no decode workgroup needs more than 64 KiB of LDS — what is left beside one resident vocoder
+    // workgroup. Same sums in the same slice order per element; a thread's elements keep their places (o = tid + 512 it).
+    constexpr int PH = BG_PH(RT, NT), TP = RT * NT / PH, TRP = TR / PH, NOUTP = NOUT / PH;
+    static_assert(PH == 1 || ((RT * NT) % 2 == 0 && (TRP * 64) % 512 == 0), "two phases need an even tile count and whole items per phase");
     const int epi = g.epi;
-    if (epi == Q3_EPI_SWIGLU) {
-        // one thread per (gate, up) pair: pair p of the 32 in a (tile, register) block of 64 lanes sits in lanes l = 16 (p / 8) + p % 8 (gate,
-        // column c = p % 8 < 8 of the tile) and l + 8 (up, the same row 8 columns further); every thread has work (a loop over all
-        // TR * 64 elements left the up lanes idle: half of the epilogue's issue slots)
-        constexpr int NP = (TR * 32 + 511) / 512;
 #pragma unroll
-        for (int it = 0; it < NP; ++it) {
-            const int p = threadIdx.x + it * 512;
-            if (p >= TR * 32) break;  // (TR * 32 is a multiple of 128: whole waves leave together)
-            const int q = p & 31, l = ((q >> 3) << 4) + (q & 7), o = ((p >> 5) << 6) + l;
-            const int e = (o >> 6) & 3, t = o >> 8, i = t / NT, j = t - i * NT;
-            const int rl = 16 * i + 4 * (l >> 4) + e, row = row0 + rl, c = l & 15;
-            const float sc = g.ssp ? srow[rl] : 1.0f;
-            float gt = part[o], up = part[o + 8];
+    for (int ph = 0; ph < PH; ++ph) {
+        if (ph) __syncthreads();  // every wave is done reading the previous phase's partials
 #pragma unroll
-            for (int wv = 1; wv < 8; ++wv) { gt = gt + part[(size_t)wv * (TR * 64) + o]; up = up + part[(size_t)wv * (TR * 64) + o + 8]; }
-            if (row < B) g.yb[q3_atile_off(row, (nb0 + j) * 8 + c, g.N >> 6)] = q3_bf16(q3_swiglu(sc * gt, sc * up));
-        }
-#ifdef Q3_STAMPS
-        Q3_STAMP(g, 5);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        Q3_STAMP(g, 6);
-#endif
-        return;
-    }
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
-    for (int it = 0; it < NOUT; ++it) {
-        const int o = threadIdx.x + it * 512;
-        if (o >= TR * 64) break;  // whole waves leave together (TR * 64 is a multiple of 256)
-        const int l = o & 63, e = (o >> 6) & 3, t = o >> 8, i = t / NT, j = t - i * NT;
-        const int rl = 16 * i + 4 * (l >> 4) + e, row = row0 + rl, c = l & 15;
-        const int col = (nb0 + j) * 16 + c;
-        const bool live = row < B;
-        const float sc = g.ssp ? srow[rl] : 1.0f;
-        float v = part[o];
+            for (int j = 0; j < NT; ++j) {
+                if ((i * NT + j) / TP != ph) continue;
 #pragma unroll
-        for (int wv = 1; wv < 8; ++wv) v = v + part[(size_t)wv * (TR * 64) + o];
-        if (g.bias) v = v + bsv[it];
-        if (epi == Q3_EPI_STORE) {
-            if (live) g.y[bg_yoff(g, row) + col] = g.ssp ? sc * v : v;
-        } else if (epi == Q3_EPI_GELU) {
-            if (live) g.yb[q3_atile_off(row, col, g.N >> 5)] = q3_bf16(bg_gelu_erf(v));
-        } else if (epi == Q3_EPI_RESID) {
-            const float xv = g.col_scale ? yres[it] + csv[it] * v : yres[it] + v;
-            if (live) g.y[bg_yoff(g, row) + col] = xv;
-            if (g.yb && !g.nw_next && live) g.yb[q3_atile_off(row, col, g.N >> 5)] = q3_bf16(xv);
-            if (g.nw_next) {  // the consumer's norm inputs: bf16(x * nw) and the tile's sum of squares (16-lane butterfly)
-                if (live) g.yb[q3_atile_off(row, col, g.N >> 5)] = q3_bf16(xv * nwv[it]);
-                float sq = xv * xv;
-                sq = sq + __shfl_xor(sq, 1); sq = sq + __shfl_xor(sq, 2); sq = sq + __shfl_xor(sq, 4); sq = sq + __shfl_xor(sq, 8);
-                if (live && c == 0) g.ssp_out[(size_t)row * g.ld_ssp_out + (nb0 + j)] = sq;
+                for (int e = 0; e < 4; ++e) part[((size_t)wave * TRP + ((i * NT + j) - ph * TP) * 4 + e) * 64 + lane] = acc[i][j][e];
             }
-        } else {  // Q3_EPI_ARGMAX: the largest key of the tile's 16 columns goes to keys[row][column tile]; the consumer takes the maximum
-                  // over the row's N/16 entries (an atomicMax per (row, tile) on one word per row cost ~8 us of the launch)
-            unsigned long long key = q3_argmax_key(g.ssp ? sc * v : v, (uint32_t)col);
+        __syncthreads();
+        if (ph == 0) Q3_STAMP(g, 4);
+        // slice partials combined in slice order; element (tile t, reg e, lane l) -> row 16 i + 4 (l >> 4) + e, col 16 j + (l & 15)
+        if (epi == Q3_EPI_SWIGLU) {
+            // one thread per (gate, up) pair: pair p of the 32 in a (tile, register) block of 64 lanes sits in lanes l = 16 (p / 8) + p % 8 (gate,
+            // column c = p % 8 < 8 of the tile) and l + 8 (up, the same row 8 columns further); every thread has work (a loop over all
+            // TR * 64 elements left the up lanes idle: half of the epilogue's issue slots)
+            constexpr int NP = (TRP * 32 + 511) / 512;
 #pragma unroll
-            for (int m = 1; m <= 8; m <<= 1) { const unsigned long long ok = __shfl_xor(key, m); key = ok > key ? ok : key; }
-            if (live && c == 0) g.keys[(size_t)row * g.key_stride + (nb0 + j)] = key;
+            for (int it = 0; it < NP; ++it) {
+                const int p = threadIdx.x + it * 512;
+                if (p >= TRP * 32) break;  // (TRP * 32 is a multiple of 128: whole waves leave together)
+                const int q = p & 31, l = ((q >> 3) << 4) + (q & 7), o = ((p >> 5) << 6) + l;
+                const int e = (o >> 6) & 3, t = ph * TP + (o >> 8), i = t / NT, j = t - i * NT;
+                const int rl = 16 * i + 4 * (l >> 4) + e, row = row0 + rl, c = l & 15;
+                const float sc = g.ssp ? srow[rl] : 1.0f;
+                float gt = part[o], up = part[o + 8];
+#pragma unroll
+                for (int wv = 1; wv < 8; ++wv) { gt = gt + part[(size_t)wv * (TRP * 64) + o]; up = up + part[(size_t)wv * (TRP * 64) + o + 8]; }
+                if (row < B) g.yb[q3_atile_off(row, (nb0 + j) * 8 + c, g.N >> 6)] = q3_bf16(q3_swiglu(sc * gt, sc * up));
+            }
+            continue;
+        }
+#pragma unroll
+        for (int itp = 0; itp < NOUTP; ++itp) {
+            const int it = ph * NOUTP + itp, o = threadIdx.x + itp * 512;  // o: place in this phase's buffer; tid + 512 it in the whole tile set
+            if (o >= TRP * 64) break;  // whole waves leave together (TRP * 64 is a multiple of 256)
+            const int l = o & 63, e = (o >> 6) & 3, t = ph * TP + (o >> 8), i = t / NT, j = t - i * NT;
+            const int rl = 16 * i + 4 * (l >> 4) + e, row = row0 + rl, c = l & 15;
+            const int col = (nb0 + j) * 16 + c;
+            const bool live = row < B;
+            const float sc = g.ssp ? srow[rl] : 1.0f;
+            float v = part[o];
+#pragma unroll
+            for (int wv = 1; wv < 8; ++wv) v = v + part[(size_t)wv * (TRP * 64) + o];
+            if (g.bias) v = v + bsv[it];
+            if (epi == Q3_EPI_STORE) {
+                if (live) g.y[bg_yoff(g, row) + col] = g.ssp ? sc * v : v;
+            } else if (epi == Q3_EPI_GELU) {
+                if (live) g.yb[q3_atile_off(row, col, g.N >> 5)] = q3_bf16(bg_gelu_erf(v));
+            } else if (epi == Q3_EPI_RESID) {
+                const float xv = g.col_scale ? yres[it] + csv[it] * v : yres[it] + v;
+                if (live) g.y[bg_yoff(g, row) + col] = xv;
+                if (g.yb && !g.nw_next && live) g.yb[q3_atile_off(row, col, g.N >> 5)] = q3_bf16(xv);
+                if (g.nw_next) {  // the consumer's norm inputs: bf16(x * nw) and the tile's sum of squares (16-lane butterfly)
+                    if (live) g.yb[q3_atile_off(row, col, g.N >> 5)] = q3_bf16(xv * nwv[it]);
+                    float sq = xv * xv;
+                    sq = sq + __shfl_xor(sq, 1); sq = sq + __shfl_xor(sq, 2); sq = sq + __shfl_xor(sq, 4); sq = sq + __shfl_xor(sq, 8);
+                    if (live && c == 0) g.ssp_out[(size_t)row * g.ld_ssp_out + (nb0 + j)] = sq;
+                }
+            } else {  // Q3_EPI_ARGMAX: the largest key of the tile's 16 columns goes to keys[row][column tile]; the consumer takes the maximum
+                      // over the row's N/16 entries (an atomicMax per (row, tile) on one word per row cost ~8 us of the launch)
+                unsigned long long key = q3_argmax_key(g.ssp ? sc * v : v, (uint32_t)col);
+#pragma unroll
+                for (int m = 1; m <= 8; m <<= 1) { const unsigned long long ok = __shfl_xor(key, m); key = ok > key ? ok : key; }
+                if (live && c == 0) g.keys[(size_t)row * g.key_stride + (nb0 + j)] = key;
+            }
         }
     }
 #ifdef Q3_STAMPS
@@ -500,7 +507,7 @@ template <int RT, int NT>
 struct BgInst {
     static constexpr int S = RT + NT;
     static constexpr int D = S <= 3 ? 8 : (S == 4 ? 5 : (S == 5 ? 4 : (S == 6 ? 3 : 2)));
-    static constexpr size_t lds = (size_t)8 * RT * NT * 4 * 64 * 4;
+    static constexpr size_t lds = (size_t)8 * RT * NT * 4 * 64 * 4 / BG_PH(RT, NT);
     static void prepare() {  // dynamic LDS above 64 KiB has to be allowed per kernel
         if (lds > 65536) {
             hipFuncSetAttribute((const void*)k_bgemm<RT, NT, D, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -520,11 +527,15 @@ struct BgInst {
     }
 };
 // once per process, outside any stream capture (the engine calls it before it records its graphs)
+static int g_lds_cap_kb = 0;  // Q3TTS_BG_LDS_CAP (KiB), read once: tile instances whose slice buffer is larger are not chosen (experiment: DESIGN.md §16)
 static int g_big_policy = 0;  // Q3TTS_BG_BIG, read once: 1 = the many-row kernel whenever it is eligible, -1 = never, 0 = when it fills the chip
 void q3_bgemm_prepare() {  // once per DEVICE (function attributes are per device: q3tts_node_* drives several from one process)
     static Q3PerDevice pd;
     static std::once_flag env_once;
-    std::call_once(env_once, []() { const char* ev = getenv("Q3TTS_BG_BIG"); g_big_policy = ev ? atoi(ev) : 0; });
+    std::call_once(env_once, []() {
+        const char* ev = getenv("Q3TTS_BG_BIG"); g_big_policy = ev ? atoi(ev) : 0;
+        ev = getenv("Q3TTS_BG_LDS_CAP"); g_lds_cap_kb = ev ? atoi(ev) : 0;
+    });
     pd.ensure(1, []() {
         hipFuncSetAttribute((const void*)k_bgemm_big, hipFuncAttributeMaxDynamicSharedMemorySize, BB_NS * 16384);
 #define P(RT_, NT_) BgInst<RT_, NT_>::prepare();
@@ -562,6 +573,7 @@ int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s) {
     for (int RT = 1; RT <= 4; ++RT)
         for (int NT = 1; NT <= 3; ++NT) {
             if (tiles % NT) continue;
+            if (g_lds_cap_kb > 0 && 8 * RT * NT / BG_PH(RT, NT) > g_lds_cap_kb && !(RT == 1 && NT == 1)) continue;
             if (g.B > 64 && RT != 4 && !(RT == 2 && g.B <= 128)) continue;  // many rows (prefill): 64-row chunks
             const long chunks = (g.B + 16 * RT - 1) / (16 * RT);
             if (g.B <= 64 && RT > 1 && 16 * (RT - 1) * chunks >= g.B) continue;  // a smaller RT covers the rows with the same chunk count

@@ -69,6 +69,11 @@ struct Q3Voc {
     std::vector<void*> allocs;
 };
 
+// Q3TTS_VOC_POLITE=1 (experiment): every long-lived vocoder workgroup is ONE per CU (>= 81 KiB of LDS declared) with 4 waves of
+// <= 208 VGPRs, so that 79 KiB of LDS and >= 304 VGPRs per SIMD stay free for the decoder's 8-wave workgroups, which otherwise wait for a
+// vocoder workgroup to retire on every CU (tools/coresidency_bench.hip: 3.7 us per launch alone, 30.7 beside 30-us workgroups that leave no room)
+static bool voc_polite() { static int v = -1; if (v < 0) { const char* ev = getenv("Q3TTS_VOC_POLITE"); v = ev && atoi(ev) ? 1 : 0; } return v == 1; }
+static size_t voc_lds_floor(size_t lds) { return voc_polite() ? std::max(lds, (size_t)81 * 1024) : lds; }
 // ------------------------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------------------------
@@ -532,8 +537,9 @@ template <int NJ>
 static void launch_vgemm_ring(hipStream_t s, const VGemm& g, dim3 grid) {
     constexpr size_t lds_ring = (size_t)VR_NS * (128 + NJ * 32) * 64, lds_out = (size_t)128 * (NJ * 32 + 4) * 4 + 128 * 4, lds = lds_ring > lds_out ? lds_ring : lds_out;
     static Q3PerDevice pd;
-    pd.ensure(lds, [&]() { hipFuncSetAttribute((const void*)k_vgemm_ring<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-    hipLaunchKernelGGL((k_vgemm_ring<NJ>), grid, dim3(256), lds, s, g);
+    const size_t ldsp = voc_lds_floor(lds);
+    pd.ensure(ldsp, [&]() { hipFuncSetAttribute((const void*)k_vgemm_ring<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp); });
+    hipLaunchKernelGGL((k_vgemm_ring<NJ>), grid, dim3(256), ldsp, s, g);
 }
 
 // The wide 7-tap convolutions of the decoder blocks (768 / 384 channels: 40 % of a batched call) on a tile that keeps its INPUT ROWS in LDS
@@ -1408,7 +1414,7 @@ static VSnake snake_into(const VBuf& dst, const float* ea, const float* ib, int 
 // the wide 7-tap convolutions run their K steps chunk by chunk (vstep), whichever kernel serves them
 static bool vconv_chunked(const VConv& c) { return c.ntap == 7 && c.cin % 64 == 0 && c.cin >= 256; }
 // Q3TTS_VOC_NOTAP=1: those convolutions on the ring / register-staged GEMMs instead of k_vconv_tap (same bits; A/B runs and tests)
-static bool voc_tap() { const char* ev = getenv("Q3TTS_VOC_NOTAP"); return !(ev && atoi(ev)); }
+static bool voc_tap() { const char* ev = getenv("Q3TTS_VOC_NOTAP"); return !(ev && atoi(ev)) && !voc_polite(); }
 // fewer workgroups than this (a draining batch, a single stream) leave most CUs idle under 256-row tiles: the finer 128 x 128 tiles serve them.
 // Q3TTS_VOC_TAP_MIN overrides it (tests force k_vconv_tap onto one-slot calls with 1)
 static long voc_tap_min() { const char* ev = getenv("Q3TTS_VOC_TAP_MIN"); return ev ? atol(ev) : 128; }
@@ -1467,7 +1473,7 @@ static bool resunit_ok(int C) {
 template <int NT, int MT, int NWV = 4>
 static void launch_resunit_t(hipStream_t s, const VResUnit& g, int ns) {
     constexpr int C = NT * 16, R = 64 * MT, LDA = C + 16;
-    const size_t lds = std::max(((size_t)(R + 6 * g.dil) * LDA + (size_t)2 * C * 32) * 2, (size_t)R * (C + 4) * 4);  // input tile + weight ring, later the f32 output tile
+    const size_t lds = voc_lds_floor(std::max(((size_t)(R + 6 * g.dil) * LDA + (size_t)2 * C * 32) * 2, (size_t)R * (C + 4) * 4));  // input tile + weight ring, later the f32 output tile
     static Q3PerDevice pd;
     pd.ensure(1, []() { hipFuncSetAttribute((const void*)k_voc_resunit<NT, MT, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); });
     hipLaunchKernelGGL((k_voc_resunit<NT, MT, NWV>), dim3((g.T + R - 1) / R, ns), dim3(64 * NWV), lds, s, g);
@@ -1483,7 +1489,7 @@ static void launch_resunit(hipStream_t s, const VRes& r, int ns, int T, int C, f
         case 64: launch_resunit_t<4, 3>(s, g, ns); break;
         case 96: launch_resunit_t<6, 2>(s, g, ns); break;
         case 128: launch_resunit_t<8, 1>(s, g, ns); break;
-        default: launch_resunit_t<12, 2, 8>(s, g, ns); break;  // (64-row tiles, 4 waves, two workgroups per CU: 182 us; 128 rows with 4 waves: 215; 128 rows with 8 waves: 168)
+        default: if (voc_polite()) launch_resunit_t<12, 1>(s, g, ns); else launch_resunit_t<12, 2, 8>(s, g, ns); break;  // (64-row tiles, 4 waves, two workgroups per CU: 182 us; 128 rows with 4 waves: 215; 128 rows with 8 waves: 168)
     }
 }
 static void hist(hipStream_t s, const VCall& cl, VBuf& b, int T, int save) {
@@ -1628,7 +1634,9 @@ static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
     // V6
     if (ch % 8 == 0 && ch / 8 <= 32 && !getenv("Q3TTS_VOC_OUT_OLD")) {
         const int NS = ch / 8, G = std::min(16, 256 / NS), R = G * 8;
-        hipLaunchKernelGGL(k_voc_out8, dim3((T + R - 1) / R, ns), dim3(256), (size_t)(R + 6) * (ch * 2 + 16) + (size_t)NS * R * 4, s, cl, (const uint16_t*)v->out_in.p,
+        static Q3PerDevice pd8;
+        pd8.ensure(1, []() { hipFuncSetAttribute((const void*)k_voc_out8, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); });
+        hipLaunchKernelGGL(k_voc_out8, dim3((T + R - 1) / R, ns), dim3(256), voc_lds_floor((size_t)(R + 6) * (ch * 2 + 16) + (size_t)NS * R * 4), s, cl, (const uint16_t*)v->out_in.p,
                            v->out_in.stride(), v->out_in.H, T, ch, v->out_w, v->out_b, v->pcm, v->pcm_stride, v->spf, G);
     } else
         hipLaunchKernelGGL(k_voc_out, dim3((T + 63) / 64, ns), dim3(256), (size_t)(70 * (ch + 1) + 7 * ch) * 4, s, cl, v->out_in.p, v->out_in.stride(), v->out_in.H, T, ch, v->out_w, v->out_b,

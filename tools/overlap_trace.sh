@@ -41,4 +41,22 @@ for lo, hi in ((50, 1000), (1000, 2000), (2000, 3000), (3000, 4000), (4000, 1e9)
     s = [o for o in full if lo <= o[2] < hi]
     if s: print(f"  vocoder {lo}-{hi} us inside: {len(s)} steps, span {m([o[1] for o in s]):.0f} us, kernel time {m([o[3] for o in s]):.0f}")
 allspan = m([o[1] for o in full]); print(f"all: {allspan:.0f} us")
+# who is on the GPU while the decoder waits? every gap > 5 us between two consecutive decode kernels, attributed to the vocoder-queue kernels
+# that overlap it (by overlapped time)
+import collections
+vk = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0][:44] + ' wg' + r['Workgroup_Size_X']) for r in rows if r.get('Queue_Id', '?') == vq]
+vstart = [v[0] for v in vk]
+blame = collections.defaultdict(float); tot_gap = 0.0; unexplained = 0.0
+for a, b in zip(dec[:-1], dec[1:]):
+    g0, g1 = int(a['End_Timestamp']), int(b['Start_Timestamp'])
+    if g1 - g0 < 5000 or g1 - g0 > 5e6: continue
+    tot_gap += (g1 - g0) / 1e3
+    cov = 0
+    for s_, e_, n_ in vk[max(0, bisect.bisect_left(vstart, g0) - 50):]:
+        if s_ >= g1: break
+        ov = max(0, min(e_, g1) - max(s_, g0))
+        if ov > 0: blame[n_] += ov / 1e3; cov = max(cov, ov)
+    if cov == 0: unexplained += (g1 - g0) / 1e3
+print(f"decode gaps > 5 us: {tot_gap / 1e3:.1f} ms in total, {unexplained / 1e3:.1f} ms with no vocoder-queue kernel running; vocoder-queue kernels running during the gaps (ms of overlap):")
+for n_, v_ in sorted(blame.items(), key=lambda kv: -kv[1])[:14]: print(f"  {v_ / 1e3:8.2f}  {n_}")
 PY
