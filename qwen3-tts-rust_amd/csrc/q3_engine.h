@@ -129,7 +129,8 @@ int q3_voc_reset(q3tts_engine* e, int slot);
 int q3_voc_decode(q3tts_engine* e, int slot, int f0, int nf, int is_last, hipStream_t s);
 // batched: nf (<= 4) frames for every listed slot in one set of launches; real[i] <= nf of them are real for slot i (the
 // rest are throw-away padding behind a finished utterance's last frame)
-int q3_voc_decode_batch(q3tts_engine* e, const int* slots, const int* real, int ns, int nf, hipStream_t s);
+// beside_decoder: frame steps will run while this call executes (its long-lived workgroups are then launched one per CU: q3_vocoder.hip, "polite")
+int q3_voc_decode_batch(q3tts_engine* e, const int* slots, const int* real, int ns, int nf, hipStream_t s, int beside_decoder);
 void q3_voc_mark_last(q3tts_engine* e, int slot);
 // PCM buffer of a slot (device) and samples produced so far
 float* q3_voc_pcm(q3tts_engine* e, int slot);

@@ -1113,7 +1113,9 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
                 }
                 if (!ns) break;
                 TRY(ensure_wait());
-                TRY(q3_voc_decode_batch(e, list, real, ns, 4, vs));
+                int still = 0;  // slots that go on decoding while this call runs
+                for (int b = 0; b < B; ++b) if (run[b].req >= 0 && e->slots_host[b].active) ++still;
+                TRY(q3_voc_decode_batch(e, list, real, ns, 4, vs, (still > 0 || next < n) ? 1 : 0));
                 for (int i = 0; i < ns; ++i) { if (run[list[i]].voc_frames == 0) first = true; run[list[i]].voc_frames += real[i]; }
             }
             if (first) {  // first-chunk latency: the first chunk's PCM resident on the host

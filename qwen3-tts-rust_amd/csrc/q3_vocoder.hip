@@ -69,10 +69,16 @@ struct Q3Voc {
     std::vector<void*> allocs;
 };
 
-// Q3TTS_VOC_POLITE=1 (experiment): every long-lived vocoder workgroup is ONE per CU (>= 81 KiB of LDS declared) with 4 waves of
-// <= 208 VGPRs, so that 79 KiB of LDS and >= 304 VGPRs per SIMD stay free for the decoder's 8-wave workgroups, which otherwise wait for a
-// vocoder workgroup to retire on every CU (tools/coresidency_bench.hip: 3.7 us per launch alone, 30.7 beside 30-us workgroups that leave no room)
-static bool voc_polite() { static int v = -1; if (v < 0) { const char* ev = getenv("Q3TTS_VOC_POLITE"); v = ev && atoi(ev) ? 1 : 0; } return v == 1; }
+// "Polite" launches: while the decoder is running beside it, every long-lived vocoder workgroup is ONE per CU (>= 81 KiB of LDS
+// declared: a second cannot join it) with 4 waves of <= 208 VGPRs, so that 79 KiB of LDS and >= 304 VGPRs per SIMD stay free for the decoder's
+// 8-wave workgroups — which otherwise wait, launch after launch, for a vocoder workgroup to retire on every CU (tools/coresidency_bench.hip:
+// 3.7 us per launch alone, 24-81 us beside workgroups of 30-80 us that leave no room, 3.6-4.0 beside one that does). The vocoder itself is
+// slower that way, which costs nothing while it hides behind the decoder; a call that has the GPU to itself (a draining batch's tail, the
+// stand-alone hooks) and small calls (short-lived workgroups anyway) are launched greedily. The engine sets the mode per call
+// (q3_voc_decode_batch); Q3TTS_VOC_POLITE=0 / 1 forces never / always. Same bits either way (a launch parameter and a tile choice).
+static thread_local bool g_voc_polite_now = false;   // (one host thread drives an engine: q3tts_node_* runs one per device)
+static int voc_polite_env() { const char* ev = getenv("Q3TTS_VOC_POLITE"); return ev ? (atoi(ev) ? 1 : 0) : -1; }  // (read per launch: the tests compare both modes in one process)
+static bool voc_polite() { const int ev = voc_polite_env(); return ev >= 0 ? ev == 1 : g_voc_polite_now; }
 static size_t voc_lds_floor(size_t lds) { return voc_polite() ? std::max(lds, (size_t)81 * 1024) : lds; }
 // ------------------------------------------------------------------------------------------------------------------
 // kernels
@@ -1662,14 +1668,17 @@ int q3_voc_decode(q3tts_engine* e, int slot, int f0, int nf, int is_last, hipStr
     return Q3TTS_OK;
 }
 // batched variant: the same nf (<= VOC_FCAP) new frames for every listed slot
-int q3_voc_decode_batch(q3tts_engine* e, const int* slots, const int* real, int ns, int nf, hipStream_t s) {
+int q3_voc_decode_batch(q3tts_engine* e, const int* slots, const int* real, int ns, int nf, hipStream_t s, int beside_decoder) {
     Q3Voc* v = e->voc;
     if (!v) return q3_set_err(e, Q3TTS_ERR_STATE, "engine has no vocoder");
     if (ns <= 0 || ns > VOC_MAX_NS || nf <= 0 || nf > VOC_FCAP) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder batch shape");
     VCall cl; memset(&cl, 0, sizeof(cl));
     cl.ns = ns; cl.nf = nf;
     for (int i = 0; i < ns; ++i) { cl.slot[i] = slots[i]; cl.pos[i] = v->frames_done[slots[i]]; }
-    VTRY(voc_call(e, cl, s));
+    g_voc_polite_now = beside_decoder && ns >= 16;  // (fewer slots: few and short-lived workgroups — greedy launches, the least latency)
+    const int rc = voc_call(e, cl, s);
+    g_voc_polite_now = false;
+    VTRY(rc);
     for (int i = 0; i < ns; ++i) v->frames_done[slots[i]] += real ? real[i] : nf;
     return Q3TTS_OK;
 }
@@ -1732,9 +1741,9 @@ extern "C" int q3tts_k_vocoder_bench(q3tts_engine* e, int32_t n_slots, int32_t c
     Q3_HIP(e, hipStreamSynchronize(s));
     std::vector<int> slots(n_slots);
     for (int i = 0; i < n_slots; ++i) { slots[i] = i; VTRY(q3_voc_reset(e, i)); }
-    for (int w = 0; w < 2; ++w) VTRY(q3_voc_decode_batch(e, slots.data(), nullptr, n_slots, 4, s));  // warm-up (and fills the sliding window)
+    for (int w = 0; w < 2; ++w) VTRY(q3_voc_decode_batch(e, slots.data(), nullptr, n_slots, 4, s, 0));  // warm-up (and fills the sliding window)
     Q3_HIP(e, hipEventRecord(e->ev0, s));
-    for (int c = 0; c < chunks; ++c) VTRY(q3_voc_decode_batch(e, slots.data(), nullptr, n_slots, 4, s));
+    for (int c = 0; c < chunks; ++c) VTRY(q3_voc_decode_batch(e, slots.data(), nullptr, n_slots, 4, s, 0));
     Q3_HIP(e, hipEventRecord(e->ev2, s));
     Q3_HIP(e, hipStreamSynchronize(s));
     float ms = 0.0f;

@@ -363,6 +363,11 @@ def test_vocoder_narrow_block_kernels(oracle):
                 assert np.array_equal(eng.vocoder(codes, chunk_frames=ch), one), ch
         finally:
             del os.environ["Q3TTS_VOC_TAP_MIN"]
+        os.environ["Q3TTS_VOC_POLITE"] = "1"   # one workgroup per CU (81 KiB of LDS declared), 4-wave units: what runs beside the decoder; same bits
+        try:
+            assert np.array_equal(eng.vocoder(codes), one)
+        finally:
+            del os.environ["Q3TTS_VOC_POLITE"]
     finally:
         eng.close()
         L.q3o_vocoder_destroy(v)
@@ -1107,6 +1112,11 @@ def test_full_shape_vocoder_pcm_vs_oracle(oracle, n_frames):
             assert np.array_equal(eng.vocoder(codes, chunk_frames=3), one)   # partial tiles: 96 / 480 rows per call
         finally:
             del os.environ["Q3TTS_VOC_TAP_MIN"]
+        os.environ["Q3TTS_VOC_POLITE"] = "1"   # the launches a wide call gets beside the decoder (one workgroup per CU, 4-wave units): same bits
+        try:
+            assert np.array_equal(eng.vocoder(codes), one)
+        finally:
+            del os.environ["Q3TTS_VOC_POLITE"]
     finally:
         eng.close()
         L.q3o_vocoder_destroy(v)
