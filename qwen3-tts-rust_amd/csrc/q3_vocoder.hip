@@ -12,6 +12,8 @@
 // chunked streaming equals one-shot decoding; each conv input keeps its last (k-1)*d rows per slot.
 #include <algorithm>
 #include <cmath>
+#include <map>
+#include <set>
 #include <vector>
 
 #include "q3_engine.h"
@@ -66,6 +68,10 @@ struct Q3Voc {
     float *t1 = nullptr, *t2 = nullptr;  // generic scratch (largest stage)
     float* pcm = nullptr; size_t pcm_stride = 0;         // [B][max_steps_cap * spf]
     std::vector<int> frames_done, last_flag;
+    VCall* call_dev = nullptr;                   // the running call's slot / position table (kernels read it; voc_call uploads it in stream order)
+    VCall* call_host = nullptr; hipEvent_t call_ev[16] = {}; unsigned call_i = 0;  // pinned staging ring of the uploads + "copy done" events
+    std::map<unsigned long long, hipGraphExec_t> call_graphs;  // one captured call per (slots, frames, launch mode, switches): voc_call
+    std::set<unsigned long long> call_seen;
     std::vector<void*> allocs;
 };
 
@@ -894,8 +900,9 @@ __global__ __launch_bounds__(64 * NWV) void k_voc_resunit(VResUnit g) {
     VR_STAMP(6);
 }
 
-__global__ void k_voc_embed(VCall cl, const int* codes, int max_steps_cap, int ncb_model, const float* const* cb, int ncb, int cbs, int cd,
+__global__ void k_voc_embed(const VCall* __restrict__ clp, const int* codes, int max_steps_cap, int ncb_model, const float* const* cb, int ncb, int cbs, int cd,
                             float* out, size_t out_stride, int out_off) {
+    const VCall& cl = *clp;
     const int s = blockIdx.y, t = blockIdx.x;
     const int slot = cl.slot[s], frame = min(cl.pos[s] + t, max_steps_cap - 1);  // (padding frames may point past the last row)
     const int* cp = codes + ((size_t)slot * max_steps_cap + frame) * ncb_model;
@@ -935,7 +942,8 @@ __global__ void k_voc_rows_bf16(const float* src, size_t src_stride, uint16_t* d
 
 // history rows: work[s][0:H] <- hist[slot]  (load)   /   hist[slot] <- work[s][T : T+H]  (save)
 template <class E>
-__global__ void k_voc_hist(VCall cl, E* work, size_t stride, E* hist, int H, int C, int T, int save) {
+__global__ void k_voc_hist(const VCall* __restrict__ clp, E* work, size_t stride, E* hist, int H, int C, int T, int save) {
+    const VCall& cl = *clp;
     const int s = blockIdx.y, slot = cl.slot[s];
     const size_t n = (size_t)H * C;
     E* w = work + (size_t)s * stride + (save ? (size_t)T * C : 0);
@@ -951,7 +959,8 @@ struct VHistTab {
     int n;
     struct Ent { char* work; char* hist; unsigned long long stride_b, block_b, tail_b; } e[24];  // bytes: per-slot stride, H*C block, offset T*C
 };
-__global__ void k_voc_hist_all(VCall cl, VHistTab tab, int save) {
+__global__ void k_voc_hist_all(const VCall* __restrict__ clp, VHistTab tab, int save) {
+    const VCall& cl = *clp;
     const VHistTab::Ent z = tab.e[blockIdx.z];
     const int s = blockIdx.y, slot = cl.slot[s];
     uint32_t* w = (uint32_t*)(z.work + (size_t)s * z.stride_b + (save ? z.tail_b : 0));
@@ -995,10 +1004,11 @@ __global__ __launch_bounds__(64) void k_voc_rmsnorm(const float* x, const float*
 // RoPE + ring append + sliding-window attention; one workgroup per (slot, head), one wave per new token. All tokens append their
 // K / V rows first; the ring holds W + VOC_FCAP rows, so no token of the call overwrites a row another token of the call still reads.
 // Per token the arithmetic is what the one-wave kernel of round 1 did (same chains, same order); cos / sin come from the host table.
-__global__ __launch_bounds__(64 * VOC_FCAP) void k_voc_attn(VCall cl, const float* qkv, float* kring, float* vring, const float* rope,
+__global__ __launch_bounds__(64 * VOC_FCAP) void k_voc_attn(const VCall* __restrict__ clp, const float* qkv, float* kring, float* vring, const float* rope,
                                                             int H, int hd, int RW, int W, float* att, int tiled) {
     __shared__ float sc_s[VOC_FCAP][512];
     __shared__ float qs_s[VOC_FCAP][128];
+    const VCall& cl = *clp;
     const int s = blockIdx.y, h = blockIdx.x, t = threadIdx.x >> 6, lane = threadIdx.x & 63, HH = H * hd, half = hd >> 1;
     const int slot = cl.slot[s], T = cl.nf;  // blockDim.x = 64 * T
     float* kr = kring + (size_t)slot * RW * HH + h * hd;
@@ -1097,9 +1107,10 @@ __global__ __launch_bounds__(64) void k_voc_dw_ln(const float* x, size_t x_strid
 // V6: Conv k7 C -> 1 over the snaked input (with history) + clamp -> PCM of the slot. A block produces 64 samples:
 // the 70-row input window is staged in LDS with coalesced loads (rows padded to C+1 floats: the per-thread row
 // stride then walks all banks), weights in LDS too; same summation order as before (per tap, channels ascending).
-__global__ __launch_bounds__(256) void k_voc_out(VCall cl, const float* x, size_t x_stride, int H, int T, int C, const float* w, const float* b,
+__global__ __launch_bounds__(256) void k_voc_out(const VCall* __restrict__ clp, const float* x, size_t x_stride, int H, int T, int C, const float* w, const float* b,
                                                  float* pcm, size_t pcm_stride, int spf) {
     extern __shared__ float sm[];  // win[70][C+1] | wl[7*C]
+    const VCall& cl = *clp;
     const int s = blockIdx.y, slot = cl.slot[s], t0 = blockIdx.x * 64, tid = threadIdx.x, CP = C + 1;
     float* win = sm; float* wl = sm + 70 * CP;
     const uint16_t* xp = (const uint16_t*)x + (size_t)s * x_stride + (size_t)(H + t0 - 6) * C;  // window row 0 = t0 - 6 (bf16 buffer)
@@ -1141,11 +1152,12 @@ __global__ __launch_bounds__(256) void k_voc_out(VCall cl, const float* x, size_
 // two bytes at a time in four round trips: 114 us for 94 MB of input (0.8 TB/s) at the full shape.
 // Order per sample: a slice's chain runs over the taps, inside a tap over its 8 channels (fmaf); the C / 8 slices are then added in
 // ascending order, then the bias. (Its own fixed order — independent of the tile position, so chunked == one-shot holds bit for bit.)
-__global__ __launch_bounds__(256) void k_voc_out8(VCall cl, const uint16_t* x, size_t x_stride, int H, int T, int C, const float* w, const float* b,
+__global__ __launch_bounds__(256) void k_voc_out8(const VCall* __restrict__ clp, const uint16_t* x, size_t x_stride, int H, int T, int C, const float* w, const float* b,
                                                   float* pcm, size_t pcm_stride, int spf, int G) {
     extern __shared__ __attribute__((aligned(16))) char sm8[];  // window [G * 8 + 6][C bf16 + 16 B] | partial sums [C / 8][G * 8]
     const int NS = C >> 3, R = G * 8, nrow = R + 6, ld = C * 2 + 16;
     float* part = (float*)(sm8 + (size_t)nrow * ld);
+    const VCall& cl = *clp;
     const int s = blockIdx.y, slot = cl.slot[s], t0 = blockIdx.x * R, tid = threadIdx.x;
     const uint16_t* xp = x + (size_t)s * x_stride + (size_t)(H + t0 - 6) * C;  // window row 0 = t0 - 6
     const int lim = min(nrow, T - t0 + 6), total = nrow * NS;
@@ -1388,6 +1400,8 @@ int q3_voc_create(q3tts_engine* e) {
     v->pcm_stride = (size_t)(e->cfg.max_steps_cap + VOC_FCAP) * v->spf;  // + padding frames behind a finished utterance
     VTRY(valloc(e, v, &v->pcm, (size_t)v->B * v->pcm_stride));
     v->frames_done.assign(v->B, 0); v->last_flag.assign(v->B, 0);
+    VTRY(valloc(e, v, &v->call_dev, 1));
+    Q3_HIP(e, hipHostMalloc((void**)&v->call_host, 16 * sizeof(VCall)));
     Q3_HIP(e, hipStreamSynchronize(e->stream));
     return Q3TTS_OK;
 }
@@ -1395,6 +1409,9 @@ int q3_voc_create(q3tts_engine* e) {
 void q3_voc_destroy(q3tts_engine* e) {
     Q3Voc* v = e->voc;
     if (!v) return;
+    for (auto& kv : v->call_graphs) hipGraphExecDestroy(kv.second);
+    for (auto& ev : v->call_ev) if (ev) hipEventDestroy(ev);
+    if (v->call_host) hipHostFree(v->call_host);
     for (void* p : v->allocs) hipFree(p);
     delete v;
     e->voc = nullptr;
@@ -1512,16 +1529,16 @@ static void launch_resunit(hipStream_t s, const VRes& r, int ns, int T, int C, f
         default: if (voc_polite()) launch_resunit_t<12, 1>(s, g, ns); else launch_resunit_t<12, 2, 8>(s, g, ns); break;  // (64-row tiles, 4 waves, two workgroups per CU: 182 us; 128 rows with 4 waves: 215; 128 rows with 8 waves: 168)
     }
 }
-static void hist(hipStream_t s, const VCall& cl, VBuf& b, int T, int save) {
+static void hist(hipStream_t s, const VCall& cl, const VCall* cld, VBuf& b, int T, int save) {
     if (b.H == 0) return;
     const size_t n = (size_t)b.H * b.C;
     const dim3 grid((unsigned)std::min<size_t>((n + 255) / 256, 64), cl.ns);
-    if (b.bf16) hipLaunchKernelGGL((k_voc_hist<uint16_t>), grid, dim3(256), 0, s, cl, (uint16_t*)b.p, b.stride(), (uint16_t*)b.hist, b.H, b.C, T, save);
-    else hipLaunchKernelGGL((k_voc_hist<float>), grid, dim3(256), 0, s, cl, b.p, b.stride(), b.hist, b.H, b.C, T, save);
+    if (b.bf16) hipLaunchKernelGGL((k_voc_hist<uint16_t>), grid, dim3(256), 0, s, cld, (uint16_t*)b.p, b.stride(), (uint16_t*)b.hist, b.H, b.C, T, save);
+    else hipLaunchKernelGGL((k_voc_hist<float>), grid, dim3(256), 0, s, cld, b.p, b.stride(), b.hist, b.H, b.C, T, save);
 }
 // every history-bearing buffer with the rows it receives in a call of nf frames, in pipeline order; the ConvNeXt buffers (dw_in) are
 // loaded with the others but saved by their own launch (their rows are modified in place right after the depthwise convolution)
-static void hist_all(hipStream_t s, const VCall& cl, Q3Voc* v, int nf, int save) {
+static void hist_all(hipStream_t s, const VCall& cl, const VCall* cld, Q3Voc* v, int nf, int save) {
     VHistTab tab; tab.n = 0;
     auto add = [&](const VBuf& b, int T, bool with_save) {
         if (b.H == 0 || (save && !with_save) || tab.n >= 24) return;
@@ -1534,16 +1551,17 @@ static void hist_all(hipStream_t s, const VCall& cl, Q3Voc* v, int nf, int save)
     add(v->dec_in_in, T, true);
     for (auto& k : v->Bk) { add(k.ct_in, T, true); T *= k.r; for (auto& r : k.res) add(r.c1_in, T, true); }
     add(v->out_in, T, true);
-    if (tab.n) hipLaunchKernelGGL(k_voc_hist_all, dim3(16, cl.ns, tab.n), dim3(256), 0, s, cl, tab, save);
+    if (tab.n) hipLaunchKernelGGL(k_voc_hist_all, dim3(16, cl.ns, tab.n), dim3(256), 0, s, cld, tab, save);
 }
 // one batched streaming call: ns slots x nf new frames each (uniform nf <= VOC_FCAP)
-static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
+static int voc_call_body(q3tts_engine* e, const VCall& cl, hipStream_t s) {
     Q3Voc* v = e->voc;
+    const VCall* cld = v->call_dev;
     const q3tts_vocoder_config& c = v->c;
     const int ns = cl.ns, nf = cl.nf, d = c.latent_dim, HH = c.n_head * c.head_dim, M = ns * nf;
-    hist_all(s, cl, v, nf, 0);
+    hist_all(s, cl, cld, v, nf, 0);
     // V1 + V2
-    hipLaunchKernelGGL(k_voc_embed, dim3(nf, ns), dim3(128), 0, s, cl, e->codes, e->cfg.max_steps_cap, e->cfg.model.n_codebooks, v->cb_dev,
+    hipLaunchKernelGGL(k_voc_embed, dim3(nf, ns), dim3(128), 0, s, cld, e->codes, e->cfg.max_steps_cap, e->cfg.model.n_codebooks, v->cb_dev,
                        c.n_codebooks, c.codebook_size, c.codebook_dim, v->pre_in.p, v->pre_in.stride(), v->pre_in.H * v->pre_in.C);
     vgemm(s, v->pre, v->pre_in.p, v->pre_in.stride(), v->pre_in.H * v->pre_in.C, ns, nf, v->x, (size_t)nf * d, 0);
     // V3 transformer (rows m = s*nf + t)
@@ -1556,7 +1574,7 @@ static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
             hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, L.in_norm, c.rms_eps, d, v->xnb, 2);
             g.a = (const uint16_t*)v->xnb; g.w = L.qkv_t; g.K = d; g.N = 3 * HH; g.epi = Q3_EPI_STORE; g.y = v->qkv; g.ldy = 3 * HH;
             if (q3_launch_bgemm(g, s)) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder: qkv GEMM shape");
-            hipLaunchKernelGGL(k_voc_attn, dim3(c.n_head, ns), dim3(64 * nf), 0, s, cl, v->qkv, kr, vr, v->rope, c.n_head, c.head_dim, v->RW, c.sliding_window, v->att, 1);
+            hipLaunchKernelGGL(k_voc_attn, dim3(c.n_head, ns), dim3(64 * nf), 0, s, cld, v->qkv, kr, vr, v->rope, c.n_head, c.head_dim, v->RW, c.sliding_window, v->att, 1);
             g.a = (const uint16_t*)v->att; g.w = L.o_t; g.K = HH; g.N = d; g.epi = Q3_EPI_RESID; g.y = v->x; g.ldy = d; g.col_scale = L.ls_attn;
             if (q3_launch_bgemm(g, s)) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder: o GEMM shape");
             hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, L.post_norm, c.rms_eps, d, v->xnb, 2);
@@ -1568,7 +1586,7 @@ static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
         }
         hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, L.in_norm, c.rms_eps, d, v->xnb, 1);
         vgemm(s, L.qkv, v->xnb, 0, 0, 1, M, v->qkv, 0, 0, 0, nullptr, 1, nullptr, 1, 1);
-        hipLaunchKernelGGL(k_voc_attn, dim3(c.n_head, ns), dim3(64 * nf), 0, s, cl, v->qkv, kr, vr, v->rope, c.n_head, c.head_dim, v->RW, c.sliding_window, v->att, 0);
+        hipLaunchKernelGGL(k_voc_attn, dim3(c.n_head, ns), dim3(64 * nf), 0, s, cld, v->qkv, kr, vr, v->rope, c.n_head, c.head_dim, v->RW, c.sliding_window, v->att, 0);
         vgemm(s, L.o, v->att, 0, 0, 1, M, v->x, 0, 0, 1, L.ls_attn, d, nullptr, 1, 1);
         hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, L.post_norm, c.rms_eps, d, v->xnb, 1);
         vgemm(s, L.gu, v->xnb, 0, 0, 1, M, v->g, 0, 0, 4, nullptr, 1, nullptr, 1, 1, 1);  // gate | up in one launch, SwiGLU in the epilogue
@@ -1588,7 +1606,7 @@ static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
             if (q3_launch_bgemm(g, s)) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder: upsample ConvTranspose GEMM shape");
             T *= p.r;
             hipLaunchKernelGGL(k_voc_dw_ln, dim3(T, ns), dim3(64), (size_t)d * 4, s, p.dw_in.p, p.dw_in.stride(), p.dw_in.H, T, d, p.dw_w, p.dw_b, p.ln_w, p.ln_b, v->t1, 1);
-            hist(s, cl, p.dw_in, T, 1);  // history = the raw ConvTranspose output, saved before the in-place residual below
+            hist(s, cl, cld, p.dw_in, T, 1);  // history = the raw ConvTranspose output, saved before the in-place residual below
             Q3BGemm h{}; h.a = (const uint16_t*)v->t1; h.B = ns * T; h.w = p.pw1_t; h.K = d; h.N = 4 * d; h.epi = Q3_EPI_GELU;
             h.bias = p.pw1.b; h.bias_n = p.pw1.bias_n; h.yb = (uint16_t*)v->t2;
             if (q3_launch_bgemm(h, s)) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder: pointwise-1 GEMM shape");
@@ -1605,7 +1623,7 @@ static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
             vgemm(s, p.ct, cur, cur_stride, cur_off, ns, T, p.dw_in.p, p.dw_in.stride(), p.dw_in.H * d);  // [T][r*d] == [T*r][d]
             T *= p.r;
             hipLaunchKernelGGL(k_voc_dw_ln, dim3(T, ns), dim3(64), (size_t)d * 4, s, p.dw_in.p, p.dw_in.stride(), p.dw_in.H, T, d, p.dw_w, p.dw_b, p.ln_w, p.ln_b, v->t1, 0);
-            hist(s, cl, p.dw_in, T, 1);  // history = the raw ConvTranspose output, saved before the in-place residual below
+            hist(s, cl, cld, p.dw_in, T, 1);  // history = the raw ConvTranspose output, saved before the in-place residual below
             vgemm(s, p.pw1, v->t1, (size_t)T * d, 0, ns, T, v->t2, (size_t)T * 4 * d, 0, 3);
             vgemm(s, p.pw2, v->t2, (size_t)T * 4 * d, 0, ns, T, p.dw_in.p, p.dw_in.stride(), p.dw_in.H * d, 1, p.gamma, d);  // residual in place
             cur = p.dw_in.p; cur_stride = p.dw_in.stride(); cur_off = p.dw_in.H * d;
@@ -1656,13 +1674,58 @@ static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
         const int NS = ch / 8, G = std::min(16, 256 / NS), R = G * 8;
         static Q3PerDevice pd8;
         pd8.ensure(1, []() { hipFuncSetAttribute((const void*)k_voc_out8, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); });
-        hipLaunchKernelGGL(k_voc_out8, dim3((T + R - 1) / R, ns), dim3(256), voc_lds_floor((size_t)(R + 6) * (ch * 2 + 16) + (size_t)NS * R * 4), s, cl, (const uint16_t*)v->out_in.p,
+        hipLaunchKernelGGL(k_voc_out8, dim3((T + R - 1) / R, ns), dim3(256), voc_lds_floor((size_t)(R + 6) * (ch * 2 + 16) + (size_t)NS * R * 4), s, cld, (const uint16_t*)v->out_in.p,
                            v->out_in.stride(), v->out_in.H, T, ch, v->out_w, v->out_b, v->pcm, v->pcm_stride, v->spf, G);
     } else
-        hipLaunchKernelGGL(k_voc_out, dim3((T + 63) / 64, ns), dim3(256), (size_t)(70 * (ch + 1) + 7 * ch) * 4, s, cl, v->out_in.p, v->out_in.stride(), v->out_in.H, T, ch, v->out_w, v->out_b,
+        hipLaunchKernelGGL(k_voc_out, dim3((T + 63) / 64, ns), dim3(256), (size_t)(70 * (ch + 1) + 7 * ch) * 4, s, cld, v->out_in.p, v->out_in.stride(), v->out_in.H, T, ch, v->out_w, v->out_b,
                            v->pcm, v->pcm_stride, v->spf);
-    hist_all(s, cl, v, nf, 1);
+    hist_all(s, cl, cld, v, nf, 1);
     Q3_HIP(e, hipGetLastError());
+    return Q3TTS_OK;
+}
+
+// One vocoder call = ~100 launches whose shapes depend only on (slots, frames) and the launch mode: the slot / position table goes to the
+// device in stream order and the launches are replayed as ONE hipGraph per (slots, frames, mode, switches) — issuing them one by one took the
+// host 0.5 ms per 4-frame chunk, time in which the engine's loop launches no frame step. The first call of a shape runs eagerly (it also sets
+// the kernels' attributes), the second is captured. Q3TTS_VOC_NO_GRAPH=1: always eager.
+static unsigned long long voc_call_key(const VCall& cl) {
+    unsigned long long k = (unsigned long long)cl.ns | ((unsigned long long)cl.nf << 8) | ((unsigned long long)(voc_polite() ? 1 : 0) << 12);
+    unsigned long long h = 1469598103934665603ull;  // the launch-time switches (tests flip them inside one process)
+    for (const char* name : {"Q3TTS_VOC_NORING", "Q3TTS_VOC_NOFUSE", "Q3TTS_VOC_NOTAP", "Q3TTS_VOC_TAP_MIN", "Q3TTS_VOC_OUT_OLD"}) {
+        const char* ev = getenv(name);
+        for (const char* c = ev ? ev : "-"; *c; ++c) h = (h ^ (unsigned char)*c) * 1099511628211ull;
+        h = (h ^ 0xFFu) * 1099511628211ull;
+    }
+    return k | (h << 16);
+}
+static int voc_call(q3tts_engine* e, const VCall& cl, hipStream_t s) {
+    Q3Voc* v = e->voc;
+    {   // upload through a pinned ring: entry i is reused only after its copy has been seen done
+        const unsigned i = v->call_i++ & 15;
+        if (v->call_ev[i]) Q3_HIP(e, hipEventSynchronize(v->call_ev[i]));
+        else Q3_HIP(e, hipEventCreateWithFlags(&v->call_ev[i], hipEventDisableTiming));
+        v->call_host[i] = cl;
+        Q3_HIP(e, hipMemcpyAsync(v->call_dev, &v->call_host[i], sizeof(VCall), hipMemcpyHostToDevice, s));
+        Q3_HIP(e, hipEventRecord(v->call_ev[i], s));
+    }
+    static const bool no_graph = [] { const char* ev = getenv("Q3TTS_VOC_NO_GRAPH"); return ev && atoi(ev); }();
+    if (no_graph) return voc_call_body(e, cl, s);
+    const unsigned long long key = voc_call_key(cl);
+    auto it = v->call_graphs.find(key);
+    if (it == v->call_graphs.end()) {
+        if (!v->call_seen.count(key)) { v->call_seen.insert(key); return voc_call_body(e, cl, s); }
+        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+        Q3_HIP(e, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        const int rc = voc_call_body(e, cl, s);
+        const hipError_t er = hipStreamEndCapture(s, &graph);
+        if (rc != Q3TTS_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+        if (er != hipSuccess || !graph) return q3_set_err(e, Q3TTS_ERR_DEVICE, std::string("vocoder call capture: ") + hipGetErrorString(er));
+        const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (ei != hipSuccess) return q3_set_err(e, Q3TTS_ERR_DEVICE, std::string("vocoder call graph: ") + hipGetErrorString(ei));
+        it = v->call_graphs.emplace(key, exec).first;
+    }
+    Q3_HIP(e, hipGraphLaunch(it->second, s));
     return Q3TTS_OK;
 }
 
