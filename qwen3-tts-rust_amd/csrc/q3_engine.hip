@@ -814,9 +814,12 @@ static int plan_rows(q3tts_engine* e, const std::vector<int>& live_in) {
 }
 
 // CH frame steps over the current row bucket; afterwards the slot mirror is on the host. Returns the device time (ms).
+static double now_ms();
+static double g_hp_launch = 0, g_hp_sync = 0;  // Q3TTS_HOST_PROF: host wall of run_chunk's launch part / of its wait
 static int run_chunk(q3tts_engine* e, int CH, float* dev_ms) {
     hipStream_t s = e->stream;
     Q3Lane& L = e->lanes[0];
+    const double hp0 = now_ms();
     Q3_HIP(e, hipEventRecord(e->ev1, s));  // admissions (prefill, state uploads) precede the frames
     Q3_HIP(e, hipStreamWaitEvent(L.stream, e->ev1, 0));
     Q3_HIP(e, hipEventRecord(L.ev_begin, L.stream));
@@ -834,7 +837,9 @@ static int run_chunk(q3tts_engine* e, int CH, float* dev_ms) {
     Q3_HIP(e, hipStreamWaitEvent(s, L.ev_end, 0));
     Q3_HIP(e, hipEventRecord(e->ev3, s));  // the vocoder stream waits on this
     Q3_HIP(e, hipMemcpyAsync(e->slots_host, e->slots, sizeof(Q3Slot) * e->B, hipMemcpyDeviceToHost, s));
+    const double hp1 = now_ms();
     Q3_HIP(e, hipStreamSynchronize(s));
+    g_hp_launch += hp1 - hp0; g_hp_sync += now_ms() - hp1;
     if (dev_ms) { *dev_ms = 0.0f; hipEventElapsedTime(dev_ms, L.ev_begin, L.ev_end); }
     for (int i = 0; i + 1 < e->probe_i; i += 2) {
         float ms = 0.0f;
@@ -1059,6 +1064,9 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
     };
     int next = 0, done = 0;
     double dec_ms = 0, pre_ms = 0, voc_ms = 0;
+    static const bool host_prof = [] { const char* ev = getenv("Q3TTS_HOST_PROF"); return ev && atoi(ev); }();  // host wall time per phase of this loop, to stderr
+    double hp_admit = 0, hp_chunk = 0, hp_voc = 0, hp_fin = 0, hp_tail = 0, hp_t = now_ms();
+    auto hp_lap = [&](double& acc) { if (host_prof) { const double t = now_ms(); acc += t - hp_t; hp_t = t; } };
     long long steps = 0, ctx_tokens = 0, live_slot_steps = 0;
     e->probe_ms = 0; e->probe_cnt = 0; e->row_steps = 0; e->probe_empty_ms = 0; e->probe_empty_cnt = 0;
     hipStream_t s = e->stream;
@@ -1085,11 +1093,13 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
             }
         }
         if (admitted) { Q3_HIP(e, hipEventRecord(e->ev2, s)); }
+        hp_lap(hp_admit);
         bool any = false;
         for (int b = 0; b < B; ++b) if (run[b].req >= 0) any = true;
         if (!any) break;
         float ms = 0;
         TRY(run_chunk(e, CH, &ms));
+        hp_lap(hp_chunk);
         dec_ms += ms; steps += CH;
         if (admitted) { hipEventElapsedTime(&ms, e->ev0, e->ev2); pre_ms += ms; }
         for (int b = 0; b < B; ++b) if (run[b].req >= 0) { ctx_tokens += (long long)e->slots_host[b].cur_pos * CH; live_slot_steps += CH; }
@@ -1130,6 +1140,7 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
             }
             voc_ms += now_ms() - tv0;
         }
+        hp_lap(hp_voc);
         // results whose PCM copy has landed are completed now, so total_ms is an utterance's own latency (to one chunk's granularity)
         for (int j = 0; j < B; ++j)
             if (pending[j] >= 0 && hipEventQuery(e->fin_ev[j]) == hipSuccess) TRY(drain(j));
@@ -1143,8 +1154,15 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
             pending[b] = run[b].req;
             run[b].req = -1; ++done;
         }
+        hp_lap(hp_fin);
     }
     for (int b = 0; b < B; ++b) TRY(drain(b));
+    hp_lap(hp_tail);
+    if (host_prof) {
+        fprintf(stderr, "q3tts_generate_batch host wall (ms): admit + plan %.1f | chunks (launch + wait) %.1f = launch %.1f + wait %.1f, device events %.1f over %lld steps | vocoder issue %.1f | finalize %.1f | tail (last results) %.1f | total %.1f\n",
+                hp_admit, hp_chunk, g_hp_launch, g_hp_sync, dec_ms, steps, hp_voc, hp_fin, hp_tail, now_ms() - t0);
+        g_hp_launch = g_hp_sync = 0;
+    }
     e->tm.prefill_ms = (float)pre_ms; e->tm.decode_ms = (float)dec_ms; e->tm.vocoder_ms = (float)voc_ms;
     e->tm.total_ms = (float)(now_ms() - t0); e->tm.frame_steps = steps; e->tm.frame_step_ms = steps ? (float)(dec_ms / steps) : 0.0f;
     // bytes = 2*W_T + 15*2*W_P(layers) + 15*2*h + 16*2*pj + KV bytes of the live context + gathers
