@@ -575,12 +575,23 @@ static void launch_vgemm_ring(hipStream_t s, const VGemm& g, dim3 grid) {
 // issue order (vmcnt), so before pair j's barrier a wave waits until at most N(j) of its operations are outstanding:
 //   the stages of pair p were issued five pairs ago, younger are the issues of the last four pairs: 4 x 2 + 3 per image in them;
 //   pair 3 reads image c + 1 (issued at pair 0) and pair 0 image c + 2 (issued at pair 4 of the trip before): younger are 3 x 2.
-#define VC_NS 12      // weight stages of 8 KiB
-#define VC_LA 5       // pairs of stages in flight
-template <int NTAP>
-__global__ __launch_bounds__(512) void k_vconv_tap(VGemm g) {
+// Two forms: NSUB = 2 (8 waves, 12 stages, 5 pairs in flight: the call has the GPU to itself) and NSUB = 1 (4 waves on ONE 128-row sub-tile,
+// 8 stages, 3 pairs in flight, 82-90 KiB of LDS: the "polite" form beside the decoder — one workgroup per CU by its LDS, 72 KiB and 336 VGPRs
+// per SIMD left for the decoder's workgroups). Per pair a wave issues [3 row pieces at pairs 0 and 4] then 2 BP weight pieces (BP = 8 / waves).
+template <int N> __device__ __forceinline__ void vc_waitcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// operations a wave may leave outstanding before pair j's barrier: the issues of the last LA - 1 pairs (this pair's stages went out LA pairs ago,
+// last in their group); pairs 3 and 0 also start an image issued three pairs earlier, FIRST in its group: everything after those pieces
+constexpr int vc_cnt(int q, int BP) { return 2 * BP + ((((q % 7) + 7) % 7 == 0 || ((q % 7) + 7) % 7 == 4) ? 3 : 0); }
+constexpr int vc_wait(int j, int LA, int BP) {
+    int n = 0;
+    for (int q = j - LA + 1; q <= j - 1; ++q) n += vc_cnt(q, BP);
+    const int special = 6 * BP;  // the stages of the image's own group and of the two groups after it
+    return ((j == 0 || j == 3) && special < n) ? special : n;
+}
+template <int NTAP, int NSUB>
+__global__ __launch_bounds__(256 * NSUB) void k_vconv_tap(VGemm g) {
     static_assert(NTAP == 7, "the pair schedule below is written for seven taps");
-    constexpr int BN = 128;
+    constexpr int BN = 128, NW = 4 * NSUB, BP = 8 / NW, NS = NSUB == 2 ? 12 : 8, LA = NS / 2 - 1;
     extern __shared__ __attribute__((aligned(16))) char tlds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
     const int sub = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
@@ -594,25 +605,27 @@ __global__ __launch_bounds__(512) void k_vconv_tap(VGemm g) {
     }
     const int cin = g.c.cin, nout = g.c.nout, dil = g.c.dil, halo = (NTAP - 1) * dil, n0 = bx * BN;
     const int RA = (128 + halo + 15) & ~15, pps = RA >> 4;           // rows / 16-row pieces of one sub-tile's image
-    const int abytes = 2 * RA * 64;                                  // one image buffer (both sub-tiles)
-    char* const Bring = tlds + 2 * abytes;                           // [VC_NS][128 columns][64 B]
+    const int abytes = NSUB * RA * 64;                               // one image buffer (all sub-tiles)
+    char* const Bring = tlds + 2 * abytes;                           // [NS][128 columns][64 B]
     const int tps = (g.T + 127) >> 7, nsub = (g.M / g.T) * tps, nchunk = cin >> 5, steps = nchunk * NTAP;
     // loader roles: a piece is 16 rows x 64 B (one wave-instruction); lane l fetches row l >> 2 of the piece, the 16-byte chunk that belongs
     // at position l & 3 of that row: (l & 3) ^ ((row >> 1) & 3) = (l & 3) ^ ((l >> 3) & 3) (pieces start at multiples of 16 rows).
-    // Rows: piece pi = wave + 8 k (k < 3) of the 2 * pps <= 24 pieces.
+    // Rows: piece pi = wave + NW k (k < 3) of the NSUB * pps <= 3 NW pieces.
     const int lrow = lane >> 2, lchunk = ((lane & 3) ^ ((lane >> 3) & 3)) * 8;
     const uint16_t* ap[3]; int adst[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const int pi = min(wave + 8 * k, 2 * pps - 1);               // (a clamped duplicate re-writes the same bytes)
+        const int pi = min(wave + NW * k, NSUB * pps - 1);           // (a clamped duplicate re-writes the same bytes)
         const int sb = pi / pps, r16 = pi - sb * pps;
-        const int q = min(by * 2 + sb, nsub - 1), sl = q / tps, t0 = (q - sl * tps) << 7;
+        const int q = min(by * NSUB + sb, nsub - 1), sl = q / tps, t0 = (q - sl * tps) << 7;
         const int t = min(t0 - halo + r16 * 16 + lrow, g.T - 1);     // rows past the call's last row are never part of a stored result
         ap[k] = (const uint16_t*)g.x + (size_t)sl * g.x_stride + g.x_off + (long)t * cin + lchunk;
         adst[k] = (sb * RA + r16 * 16) * 64;
     }
-    // weights: wave w brings columns 16 w .. 16 w + 15 of a stage (one piece)
-    const uint16_t* bp = g.c.w + (size_t)min(n0 + wave * 16 + lrow, nout - 1) * cin + lchunk;
+    // weights: wave w brings columns 16 BP w .. 16 BP (w + 1) - 1 of a stage (BP pieces)
+    const uint16_t* bp[BP];
+#pragma unroll
+    for (int h = 0; h < BP; ++h) bp[h] = g.c.w + (size_t)min(n0 + (wave * BP + h) * 16 + lrow, nout - 1) * cin + lchunk;
     auto issue_a = [&](int chunk) {
         const int c = min(chunk, nchunk - 1);                        // past the end: the last chunk again, into the idle buffer
 #pragma unroll
@@ -622,8 +635,10 @@ __global__ __launch_bounds__(512) void k_vconv_tap(VGemm g) {
     };
     auto issue_b = [&](int step) {
         const int st = min(step, steps - 1), ch = st / NTAP, tap = st - ch * NTAP;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bp + (size_t)tap * nout * cin + ch * 32),
-                                         (__attribute__((address_space(3))) void*)(Bring + (step % VC_NS) * (BN * 64) + wave * 16 * 64), 16, 0, 0);
+#pragma unroll
+        for (int h = 0; h < BP; ++h)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bp[h] + (size_t)tap * nout * cin + ch * 32),
+                                             (__attribute__((address_space(3))) void*)(Bring + (step % NS) * (BN * 64) + (wave * BP + h) * 16 * 64), 16, 0, 0);
     };
     f32x4 acc[4][4];
 #pragma unroll
@@ -636,23 +651,27 @@ __global__ __launch_bounds__(512) void k_vconv_tap(VGemm g) {
     for (int j = 0; j < 4; ++j) { const int R = wn * 64 + j * 16 + lr; boff[j] = R * 64 + ((kq ^ ((R >> 1) & 3)) << 4); }
     issue_a(0);
 #pragma unroll
-    for (int p = 0; p < VC_LA; ++p) { issue_b(2 * p); issue_b(2 * p + 1); }
+    for (int p = 0; p < LA; ++p) { issue_b(2 * p); issue_b(2 * p + 1); }
     for (int c0 = 0; c0 < nchunk; c0 += 2) {                         // (cin % 64 == 0: an even number of chunks)
 #pragma unroll
         for (int j = 0; j < 7; ++j) {                                // pair j of the trip: steps 14 * (c0 / 2) + 2 j, + 1
-            if (j == 0 || j == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (j == 1) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+            if (j == 0) vc_waitcnt<vc_wait(0, LA, BP)>();
+            else if (j == 1) vc_waitcnt<vc_wait(1, LA, BP)>();
+            else if (j == 2) vc_waitcnt<vc_wait(2, LA, BP)>();
+            else if (j == 3) vc_waitcnt<vc_wait(3, LA, BP)>();
+            else if (j == 4) vc_waitcnt<vc_wait(4, LA, BP)>();
+            else if (j == 5) vc_waitcnt<vc_wait(5, LA, BP)>();
+            else vc_waitcnt<vc_wait(6, LA, BP)>();
             Q3_LDS_BARRIER();  // this pair's stages (and the image it starts) are in LDS for every wave; everyone is done with the previous pair
             const int s0 = c0 * NTAP + 2 * j;
             if (j == 0) issue_a(c0 + 1);
             if (j == 4) issue_a(c0 + 2);
-            issue_b(s0 + 2 * VC_LA); issue_b(s0 + 2 * VC_LA + 1);
+            issue_b(s0 + 2 * LA); issue_b(s0 + 2 * LA + 1);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int sl = 2 * j + h, cc = sl >= NTAP ? 1 : 0, tap = sl - cc * NTAP;   // step within the trip -> (chunk parity, tap)
                 const char* img = tlds + cc * abytes;
-                const char* st = Bring + ((s0 + h) % VC_NS) * (BN * 64);
+                const char* st = Bring + ((s0 + h) % NS) * (BN * 64);
                 bf16x8 a_[4], b_[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { const int R = arow0 + i * 16 + tap * dil; a_[i] = *(const bf16x8*)(img + R * 64 + ((kq ^ ((R >> 1) & 3)) << 4)); }
@@ -666,8 +685,8 @@ __global__ __launch_bounds__(512) void k_vconv_tap(VGemm g) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped loads past the end still write LDS
-    // Epilogue through LDS, as in k_vgemm_ring: f32 tile [256][BN + 4], then 4 consecutive columns of a row per item.
-    constexpr int LDO = BN + 4;
+    // Epilogue through LDS, as in k_vgemm_ring: f32 tile [128 NSUB][BN + 4], then 4 consecutive columns of a row per item.
+    constexpr int LDO = BN + 4, ROWS = 128 * NSUB;
     float* Ot = (float*)tlds;
     __syncthreads();
 #pragma unroll
@@ -676,22 +695,25 @@ __global__ __launch_bounds__(512) void k_vconv_tap(VGemm g) {
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) Ot[(size_t)(sub * 128 + wm * 64 + i * 16 + 4 * kq + e) * LDO + wn * 64 + j * 16 + lr] = acc[i][j][e];
-    int* rinfo = (int*)(Ot + 256 * LDO);
-    if (tid < 256) {
-        const int q = by * 2 + (tid >> 7), sl = q / tps, t = ((q - sl * tps) << 7) + (tid & 127);
+    int* rinfo = (int*)(Ot + ROWS * LDO);
+    if (tid < ROWS) {
+        const int q = by * NSUB + (tid >> 7), sl = q / tps, t = ((q - sl * tps) << 7) + (tid & 127);
         rinfo[tid] = (q < nsub && t < g.T) ? (sl << 20) | t : -1;
     }
     __syncthreads();
-    if (g.epi == 0 || g.epi == 2) vepi_tile<BN, 256, 512, true>(g, Ot, rinfo, n0);
-    else vepi_tile<BN, 256, 512, false>(g, Ot, rinfo, n0);
+    if (g.epi == 0 || g.epi == 2) vepi_tile<BN, ROWS, 64 * NW, true>(g, Ot, rinfo, n0);
+    else vepi_tile<BN, ROWS, 64 * NW, false>(g, Ot, rinfo, n0);
 }
+template <int NSUB>
 static void launch_vconv_tap(hipStream_t s, const VGemm& g) {
+    constexpr int NS = NSUB == 2 ? 12 : 8;
     const int halo = (g.c.ntap - 1) * g.c.dil, RA = (128 + halo + 15) & ~15;
-    const size_t lds_main = (size_t)2 * 2 * RA * 64 + (size_t)VC_NS * 128 * 64, lds_out = (size_t)256 * (128 + 4) * 4 + 256 * 4, lds = std::max(lds_main, lds_out);
+    const size_t lds_main = (size_t)2 * NSUB * RA * 64 + (size_t)NS * 128 * 64, lds_out = (size_t)128 * NSUB * (128 + 4) * 4 + 128 * NSUB * 4;
+    const size_t lds = voc_lds_floor(std::max(lds_main, lds_out));
     static Q3PerDevice pd;
-    pd.ensure(1, []() { hipFuncSetAttribute((const void*)k_vconv_tap<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); });
+    pd.ensure(1, []() { hipFuncSetAttribute((const void*)k_vconv_tap<7, NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); });
     const int tps = (g.T + 127) / 128, nsub = (g.M / g.T) * tps;
-    hipLaunchKernelGGL((k_vconv_tap<7>), dim3(g.c.nout / 128, (nsub + 1) / 2), dim3(512), lds, s, g);
+    hipLaunchKernelGGL((k_vconv_tap<7, NSUB>), dim3(g.c.nout / 128, (nsub + NSUB - 1) / NSUB), dim3(256 * NSUB), lds, s, g);
 }
 
 // Fused residual unit of the narrow decoder blocks (C <= 192 channels, where everything is HBM-bound):
@@ -1451,7 +1473,7 @@ static VSnake snake_into(const VBuf& dst, const float* ea, const float* ib, int 
 // the wide 7-tap convolutions run their K steps chunk by chunk (vstep), whichever kernel serves them
 static bool vconv_chunked(const VConv& c) { return c.ntap == 7 && c.cin % 64 == 0 && c.cin >= 256; }
 // Q3TTS_VOC_NOTAP=1: those convolutions on the ring / register-staged GEMMs instead of k_vconv_tap (same bits; A/B runs and tests)
-static bool voc_tap() { const char* ev = getenv("Q3TTS_VOC_NOTAP"); return !(ev && atoi(ev)) && !voc_polite(); }
+static bool voc_tap() { const char* ev = getenv("Q3TTS_VOC_NOTAP"); return !(ev && atoi(ev)); }
 // fewer workgroups than this (a draining batch, a single stream) leave most CUs idle under 256-row tiles: the finer 128 x 128 tiles serve them.
 // Q3TTS_VOC_TAP_MIN overrides it (tests force k_vconv_tap onto one-slot calls with 1)
 static long voc_tap_min() { const char* ev = getenv("Q3TTS_VOC_TAP_MIN"); return ev ? atol(ev) : 128; }
@@ -1467,10 +1489,11 @@ static void vgemm(hipStream_t s, const VConv& c, const float* x, size_t x_stride
     if (sk) { g.y2 = sk->y2; g.y2_stride = sk->stride; g.y2_off = sk->off; g.ea = sk->ea; g.ib = sk->ib; g.snake_n = sk->n; g.y2_bf16 = sk->bf16; }
     g.chunked = vconv_chunked(c) ? 1 : 0;
     // every kernel accumulates the same 32-wide K steps in the same order: the choice never changes a result
+    const long tap_wgs = (long)(c.nout / 128) * ((ns * ((T + 127) / 128) + 1) / 2);  // (counted in 256-row workgroups for both forms)
     if (g.chunked && a_bf16 && voc_tap() && voc_ring_ok(g) && c.nout % 128 == 0 && 6 * c.dil <= 64 && epi != 4 &&
         ((T + 127) / 128) * 128 * 3 <= T * 4 &&  /* at most a quarter of the 128-row sub-tiles' rows beyond T */
-        (long)(c.nout / 128) * ((ns * ((T + 127) / 128) + 1) / 2) >= voc_tap_min()) {
-        launch_vconv_tap(s, g);
+        tap_wgs >= voc_tap_min()) {
+        if (voc_polite()) launch_vconv_tap<1>(s, g); else launch_vconv_tap<2>(s, g);
     } else if (g.M <= 512 || epi == 4) {
         // the kernel is bound by what one CU's load path delivers: a narrow N runs 64 x 16 tiles to put a workgroup on
         // every CU instead of on half of them

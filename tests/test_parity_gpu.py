@@ -366,8 +366,12 @@ def test_vocoder_narrow_block_kernels(oracle):
         os.environ["Q3TTS_VOC_POLITE"] = "1"   # one workgroup per CU (81 KiB of LDS declared), 4-wave units: what runs beside the decoder; same bits
         try:
             assert np.array_equal(eng.vocoder(codes), one)
+            os.environ["Q3TTS_VOC_TAP_MIN"] = "1"   # ... with the 4-wave form of k_vconv_tap
+            assert np.array_equal(eng.vocoder(codes), one)
+            assert np.array_equal(eng.vocoder(codes, chunk_frames=3), one)
         finally:
             del os.environ["Q3TTS_VOC_POLITE"]
+            os.environ.pop("Q3TTS_VOC_TAP_MIN", None)
     finally:
         eng.close()
         L.q3o_vocoder_destroy(v)
@@ -1115,8 +1119,12 @@ def test_full_shape_vocoder_pcm_vs_oracle(oracle, n_frames):
         os.environ["Q3TTS_VOC_POLITE"] = "1"   # the launches a wide call gets beside the decoder (one workgroup per CU, 4-wave units): same bits
         try:
             assert np.array_equal(eng.vocoder(codes), one)
+            os.environ["Q3TTS_VOC_TAP_MIN"] = "1"   # ... with the 4-wave form of k_vconv_tap (768 and 384 channels)
+            assert np.array_equal(eng.vocoder(codes), one)
+            assert np.array_equal(eng.vocoder(codes, chunk_frames=3), one)
         finally:
             del os.environ["Q3TTS_VOC_POLITE"]
+            os.environ.pop("Q3TTS_VOC_TAP_MIN", None)
     finally:
         eng.close()
         L.q3o_vocoder_destroy(v)
