@@ -422,14 +422,14 @@ __device__ __forceinline__ void vepi_tile(const VGemm& g, const float* Ot, const
 // ((r >> 2) & 3 alone leaves every group 2-way conflicted). A DMA load writes lane l's 16 bytes at (wave-uniform base) + 16 l, so
 // lane l FETCHES the chunk that belongs there: row l >> 2 of its 16-row group, chunk (l & 3) ^ VR_SW(row).
 // Accumulation order per output element is unchanged (32-wide K steps ascending over taps, then channels).
-#define VR_NS 4
+// VR_NS stages (4: three in flight)
 #ifdef Q3_VOC_STAMPS  // experiment builds (tools/r3_voc_stamps.sh): s_memrealtime (100 MHz) stamps of three workgroups of the NJ = 3 instance
 __device__ unsigned long long g_ring_stamps[4][8];
 #define VG_STAMP(i_) do { if (NJ == 3 && vg_wg >= 0 && threadIdx.x == 0) g_ring_stamps[vg_wg][i_] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define VG_STAMP(i_) do { } while (0)
 #endif
-template <int NJ>
+template <int NJ, int VR_NS>
 __global__ __launch_bounds__(256) void k_vgemm_ring(VGemm g) {
 #ifdef Q3_VOC_STAMPS
     const int vg_wg = blockIdx.x == 1 && blockIdx.y == 100 ? 0 : (blockIdx.x == 0 && blockIdx.y == 700 ? 1 : (blockIdx.x == 2 && blockIdx.y == 1200 ? 2 : -1));
@@ -545,13 +545,17 @@ __global__ __launch_bounds__(256) void k_vgemm_ring(VGemm g) {
     VG_STAMP(6);
 #endif
 }
-template <int NJ>
-static void launch_vgemm_ring(hipStream_t s, const VGemm& g, dim3 grid) {
-    constexpr size_t lds_ring = (size_t)VR_NS * (128 + NJ * 32) * 64, lds_out = (size_t)128 * (NJ * 32 + 4) * 4 + 128 * 4, lds = lds_ring > lds_out ? lds_ring : lds_out;
+template <int NJ, int NS>
+static void launch_vgemm_ring_t(hipStream_t s, const VGemm& g, dim3 grid) {
+    constexpr size_t lds_ring = (size_t)NS * (128 + NJ * 32) * 64, lds_out = (size_t)128 * (NJ * 32 + 4) * 4 + 128 * 4, lds = lds_ring > lds_out ? lds_ring : lds_out;
     static Q3PerDevice pd;
     const size_t ldsp = voc_lds_floor(lds);
-    pd.ensure(ldsp, [&]() { hipFuncSetAttribute((const void*)k_vgemm_ring<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp); });
-    hipLaunchKernelGGL((k_vgemm_ring<NJ>), grid, dim3(256), ldsp, s, g);
+    pd.ensure(ldsp, [&]() { hipFuncSetAttribute((const void*)k_vgemm_ring<NJ, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp); });
+    hipLaunchKernelGGL((k_vgemm_ring<NJ, NS>), grid, dim3(256), ldsp, s, g);
+}
+template <int NJ>
+static void launch_vgemm_ring(hipStream_t s, const VGemm& g, dim3 grid) {
+    launch_vgemm_ring_t<NJ, 4>(s, g, grid);  // (six stages for the one-workgroup-per-CU launches beside the decoder: 107 against 104 us — depth is not their limit)
 }
 
 // The wide 7-tap convolutions of the decoder blocks (768 / 384 channels: 40 % of a batched call) on a tile that keeps its INPUT ROWS in LDS
@@ -1547,7 +1551,7 @@ static void launch_resunit(hipStream_t s, const VRes& r, int ns, int T, int C, f
     switch (C) {
         case 32: launch_resunit_t<2, 4>(s, g, ns); break;
         case 64: launch_resunit_t<4, 3>(s, g, ns); break;
-        case 96: launch_resunit_t<6, 2>(s, g, ns); break;
+        case 96: launch_resunit_t<6, 2>(s, g, ns); break;  // (beside the decoder, one workgroup per CU: 192-row tiles 233 us against 200, 232 VGPRs)
         case 128: launch_resunit_t<8, 1>(s, g, ns); break;
         default: if (voc_polite()) launch_resunit_t<12, 1>(s, g, ns); else launch_resunit_t<12, 2, 8>(s, g, ns); break;  // (64-row tiles, 4 waves, two workgroups per CU: 182 us; 128 rows with 4 waves: 215; 128 rows with 8 waves: 168)
     }
@@ -1697,7 +1701,7 @@ static int voc_call_body(q3tts_engine* e, const VCall& cl, hipStream_t s) {
         const int NS = ch / 8, G = std::min(16, 256 / NS), R = G * 8;
         static Q3PerDevice pd8;
         pd8.ensure(1, []() { hipFuncSetAttribute((const void*)k_voc_out8, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); });
-        hipLaunchKernelGGL(k_voc_out8, dim3((T + R - 1) / R, ns), dim3(256), voc_lds_floor((size_t)(R + 6) * (ch * 2 + 16) + (size_t)NS * R * 4), s, cld, (const uint16_t*)v->out_in.p,
+        hipLaunchKernelGGL(k_voc_out8, dim3((T + R - 1) / R, ns), dim3(256), (size_t)(R + 6) * (ch * 2 + 16) + (size_t)NS * R * 4, s,  /* (workgroups of a few us: no need to make room) */ cld, (const uint16_t*)v->out_in.p,
                            v->out_in.stride(), v->out_in.H, T, ch, v->out_w, v->out_b, v->pcm, v->pcm_stride, v->spf, G);
     } else
         hipLaunchKernelGGL(k_voc_out, dim3((T + 63) / 64, ns), dim3(256), (size_t)(70 * (ch + 1) + 7 * ch) * 4, s, cld, v->out_in.p, v->out_in.stride(), v->out_in.H, T, ch, v->out_w, v->out_b,
