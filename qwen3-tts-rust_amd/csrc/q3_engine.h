@@ -80,6 +80,7 @@ struct q3tts_engine {
     float* xp = nullptr;                  // [n_ctx][d]
     uint16_t* xbp = nullptr; float* sspp = nullptr;  // norm inputs of the prefill rows
     int *pf_pos = nullptr, *pf_slot = nullptr;
+    int* pf_seg = nullptr; int pf_nseg = 0, pf_seg_max = 0;  // the prefill launch's rows as per-slot runs {first row, n, slot} (device, 3 ints each): admit_group -> run_layers
     Q3PromptRow* prow_dev = nullptr; int prow_cap = 0;
     float* spk_dev = nullptr; int* refcodes_dev = nullptr;
     // sampler defaults (SamplerConfig::default: src/tts/engine.rs:25-34)

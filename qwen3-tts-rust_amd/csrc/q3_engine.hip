@@ -320,6 +320,7 @@ static int run_layers(q3tts_engine* e, Q3Tfm& t, float* x, uint16_t* xb, float* 
         Q3Attend at{}; at.qkv = sc.qkv; at.ld = t.nqkv; at.rows = rows; at.out = (float*)sc.att; at.ldo = t.nq; at.Hq = t.Hq; at.Hkv = t.Hkv; at.hd = t.hd;
         at.kc = qp.kc; at.vc = qp.vc; at.n_ctx = t.n_ctx; at.row_pos = row_pos; at.row_slot = row_slot;
         at.fused = pair ? 2 : (fused ? 1 : 0); at.prep = qp; at.out_bf16 = 1; at.slot_mod = slot_mod; at.pos_const = pos_const;
+        if (!fused && !pair && e->pf_nseg > 0 && &t == &e->T) { at.seg = e->pf_seg; at.n_seg = e->pf_nseg; at.seg_max_n = e->pf_seg_max; }  // prefill of whole prompts (admit_group)
         if (pk == 2) hipEventRecord(probe[0], s);
         q3_launch_attend(at, s);
         if (pk == 2) hipEventRecord(probe[1], s);
@@ -598,7 +599,7 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
     TRYC(alloc_scratch(e, e->sc_pre, cfg->n_ctx, e->T.nqkv, e->T.nq, e->T.F, m.t_d_model));
     TRYC(dalloc(e, &e->xp, (size_t)cfg->n_ctx * m.t_d_model));
     TRYC(dalloc(e, &e->xbp, (((size_t)cfg->n_ctx + 15) & ~(size_t)15) * m.t_d_model)); TRYC(dalloc(e, &e->sspp, (size_t)cfg->n_ctx * (m.t_d_model / 16)));
-    TRYC(dalloc(e, &e->pf_pos, (size_t)cfg->n_ctx)); TRYC(dalloc(e, &e->pf_slot, (size_t)cfg->n_ctx));
+    TRYC(dalloc(e, &e->pf_pos, (size_t)cfg->n_ctx)); TRYC(dalloc(e, &e->pf_slot, (size_t)cfg->n_ctx)); TRYC(dalloc(e, &e->pf_seg, (size_t)3 * cfg->max_batch));
     { std::vector<int> pp(cfg->n_ctx); for (int i = 0; i < cfg->n_ctx; ++i) pp[i] = i;
       HIPC(hipMemcpyAsync(e->pf_pos, pp.data(), pp.size() * 4, hipMemcpyHostToDevice, s)); HIPC(hipStreamSynchronize(s)); }
     e->prow_cap = cfg->n_ctx;
@@ -667,7 +668,7 @@ extern "C" void q3tts_engine_destroy(q3tts_engine* e) {
     hipFree(e->slots); if (e->slots_host) hipHostFree(e->slots_host);
     hipFree(e->codes); hipFree(e->rng);
     hipFree(e->sc_pre.qkv); hipFree(e->sc_pre.att); hipFree(e->sc_pre.h);
-    hipFree(e->xp); hipFree(e->xbp); hipFree(e->sspp); hipFree(e->pf_pos); hipFree(e->pf_slot); hipFree(e->prow_dev); hipFree(e->spk_dev); hipFree(e->refcodes_dev);
+    hipFree(e->xp); hipFree(e->xbp); hipFree(e->sspp); hipFree(e->pf_pos); hipFree(e->pf_slot); hipFree(e->pf_seg); hipFree(e->prow_dev); hipFree(e->spk_dev); hipFree(e->refcodes_dev);
     for (auto ev : e->fin_ev) if (ev) hipEventDestroy(ev);
     for (auto ev : e->probe_ev) if (ev) hipEventDestroy(ev);
     if (e->ev0) hipEventDestroy(e->ev0); if (e->ev1) hipEventDestroy(e->ev1); if (e->ev2) hipEventDestroy(e->ev2); if (e->ev3) hipEventDestroy(e->ev3);
@@ -869,10 +870,15 @@ static int admit_group(q3tts_engine* e, std::vector<Adm>& grp, int total) {
     for (const Adm& a : grp) for (int i = 0; i < a.n; ++i) { pos[a.row0 + i] = i; slot[a.row0 + i] = a.b; }
     Q3_HIP(e, hipMemcpyAsync(e->pf_pos, pos.data(), (size_t)total * 4, hipMemcpyHostToDevice, s));
     Q3_HIP(e, hipMemcpyAsync(e->pf_slot, slot.data(), (size_t)total * 4, hipMemcpyHostToDevice, s));
+    std::vector<int> seg; int seg_max = 0;  // the same rows as runs: every request's rows are consecutive, positions 0 .. n - 1
+    for (const Adm& a : grp) { seg.push_back(a.row0); seg.push_back(a.n); seg.push_back(a.b); seg_max = std::max(seg_max, a.n); }
+    Q3_HIP(e, hipMemcpyAsync(e->pf_seg, seg.data(), seg.size() * 4, hipMemcpyHostToDevice, s));
+    e->pf_nseg = (int)grp.size(); e->pf_seg_max = seg_max;
     Q3_HIP(e, hipStreamSynchronize(s));  // pos/slot are locals
     q3_launch_norm_inputs(e->xp, m.t_d_model, total, m.t_d_model, e->T.attn_norm[0], e->xbp, 0, e->sspp, m.t_d_model / 16, s);
-    if (run_layers(e, e->T, e->xp, e->xbp, e->sspp, total, e->pf_pos, e->pf_slot, e->sc_pre, s))
-        return q3_set_err(e, Q3TTS_ERR_INVALID, "prefill: a kernel launch was refused for this model shape");
+    const int rl = run_layers(e, e->T, e->xp, e->xbp, e->sspp, total, e->pf_pos, e->pf_slot, e->sc_pre, s);
+    e->pf_nseg = 0;
+    if (rl) return q3_set_err(e, Q3TTS_ERR_INVALID, "prefill: a kernel launch was refused for this model shape");
     Q3_HIP(e, hipGetLastError());
     for (const Adm& a : grp) {
         const q3tts_request* r = a.r;

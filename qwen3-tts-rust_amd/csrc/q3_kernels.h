@@ -157,6 +157,9 @@ struct Q3Attend {
     int fused;        // 1: every slot has exactly one row in this launch -> q/k prep + KV append done in-kernel (R >= 2)
                       // 2: rows b (position 0) and slot_mod + b (position 1) of every slot, nothing cached yet (R == 2, hd == 128): k_attend_pair
     Q3QkPrep prep;    // used when fused
+    // prefill (fused == 0): the launch's rows as per-slot runs of consecutive positions 0 .. n - 1 — seg[i] = {first row, n, slot}, device memory.
+    // With it (and hd = 128, two query heads per KV head, every n <= 128) one workgroup serves a whole run from LDS: k_attend_prefill
+    const int* seg; int n_seg; int seg_max_n;
     Q3_STAMP_FIELD
 };
 void q3_launch_attend(const Q3Attend& a, hipStream_t s);

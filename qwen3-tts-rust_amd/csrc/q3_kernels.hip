@@ -816,6 +816,115 @@ __global__ __launch_bounds__(256) void k_attend_pair(Q3Attend a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Prefill attention of a whole prompt run: one workgroup per (KV head, slot) keeps the run's keys (in the cache's packed block form) and
+// values in LDS and its 8 waves each take (row, query head) tasks — k_attend<2, false> starts one 8-wave workgroup per (row, KV head) that
+// fetches the same keys again (23 500 workgroups for 64 prompts: 220 us per layer). hd = 128, two query heads per KV head, runs of
+// n <= 128 rows at positions 0 .. n - 1 (what admit_group builds). The canonical order is k_attend's, element for element:
+//   score t: the d-ascending fmaf chain of lane t % 64 over block t / 64, times the scale; maximum over all t;
+//   weights: q3_expf(score - max); their sum: per key-block class sw = block % 4 the lanes' sums in block order, the 64-lane butterfly,
+//            then ((l0 + l1) + l2) + l3;
+//   value pass: 16 partials per (row, head, 8 dims) — class u = t % 16 lives in lane group kg = u % 4 of class sw = u / 4, keys ascending —
+//            combined (kg0 + kg1) + (kg2 + kg3) by the two shuffles, then ((r0 + r1) + r2) + r3 over sw; output = sum / l.
+// A wave runs the four sw classes one after the other where k_attend runs them on four waves: the same sums in the same order.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_attend_prefill(Q3Attend a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int g = blockIdx.x, sg = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int row0 = a.seg[3 * sg], n = a.seg[3 * sg + 1], slot = a.seg[3 * sg + 2];
+    constexpr int hd = 128;
+    const int nblk = (n + 63) >> 6;
+    uint4* kl = (uint4*)smem;                                  // [nblk][16 chunks][64 lanes]: a key block as the cache stores it
+    uint4* vl = kl + (size_t)nblk * 1024;                       // [n][16]: value rows
+    float* scr = (float*)(vl + (size_t)n * 16) + wave * 256;    // per wave: weights p[128] | query q[128]
+    float* p = scr; float* q = scr + 128;
+    const size_t hb = ((size_t)slot * a.Hkv + g) * a.n_ctx;
+    {
+        const uint4* kb = (const uint4*)(a.kc + hb * hd);
+        const uint4* vb = (const uint4*)(a.vc + hb * hd);
+        for (int i = tid; i < nblk * 1024; i += 512) kl[i] = kb[i];
+        for (int i = tid; i < n * 16; i += 512) vl[i] = vb[i];
+    }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)hd);
+    const int kg = lane >> 4, dl = lane & 15;
+    for (int task = wave; task < 2 * n; task += 8) {
+        const int r = task >> 1, hh = task & 1, row = row0 + r, T = r + 1;
+        {
+            const float2 qv = *(const float2*)(a.qkv + (size_t)row * a.ld + (size_t)(g * 2 + hh) * hd + 2 * lane);
+            *(float2*)(q + 2 * lane) = qv;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: its LDS operations complete in order; the compiler must not reorder around this)
+        float mloc = -INFINITY;
+        for (int blk = 0; blk * 64 < T; ++blk) {
+            const int t = blk * 64 + lane;
+            const uint4* kp = kl + (size_t)blk * 1024 + lane;
+            float s = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const uint4 kv = kp[c * 64];
+                const float4 qa = *(const float4*)(q + c * 8), qb = *(const float4*)(q + c * 8 + 4);
+                s = fmaf(qa.x, q3_u2f(kv.x << 16), s); s = fmaf(qa.y, q3_u2f(kv.x & 0xffff0000u), s);
+                s = fmaf(qa.z, q3_u2f(kv.y << 16), s); s = fmaf(qa.w, q3_u2f(kv.y & 0xffff0000u), s);
+                s = fmaf(qb.x, q3_u2f(kv.z << 16), s); s = fmaf(qb.y, q3_u2f(kv.z & 0xffff0000u), s);
+                s = fmaf(qb.z, q3_u2f(kv.w << 16), s); s = fmaf(qb.w, q3_u2f(kv.w & 0xffff0000u), s);
+            }
+            s = s * scale;
+            if (t < T) { p[t] = s; mloc = fmaxf(mloc, s); }
+        }
+        const float m = wave_max(mloc);
+        float lw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int sw = 0; sw < 4; ++sw) {
+            float lsum = 0.0f;
+            for (int blk = sw; blk * 64 < T; blk += 4) {
+                const int t = blk * 64 + lane;
+                if (t < T) { const float e = q3_expf(p[t] - m); p[t] = e; lsum += e; }
+            }
+            lw[sw] = wave_sum(lsum);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float rsw[4][8];
+#pragma unroll
+        for (int sw = 0; sw < 4; ++sw) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = 0.0f;
+            for (int t0 = 4 * sw + kg; t0 < T; t0 += 64) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + 16 * u;
+                    if (t < T) {
+                        const uint4 vv = vl[(size_t)t * 16 + dl];
+                        const float pt = p[t];
+                        o[0] = fmaf(pt, q3_u2f(vv.x << 16), o[0]); o[1] = fmaf(pt, q3_u2f(vv.x & 0xffff0000u), o[1]);
+                        o[2] = fmaf(pt, q3_u2f(vv.y << 16), o[2]); o[3] = fmaf(pt, q3_u2f(vv.y & 0xffff0000u), o[3]);
+                        o[4] = fmaf(pt, q3_u2f(vv.z << 16), o[4]); o[5] = fmaf(pt, q3_u2f(vv.z & 0xffff0000u), o[5]);
+                        o[6] = fmaf(pt, q3_u2f(vv.w << 16), o[6]); o[7] = fmaf(pt, q3_u2f(vv.w & 0xffff0000u), o[7]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[e] = o[e] + __shfl_xor(o[e], 16);
+                o[e] = o[e] + __shfl_xor(o[e], 32);
+                rsw[sw][e] = o[e];
+            }
+        }
+        const float l = ((lw[0] + lw[1]) + lw[2]) + lw[3];
+        if (kg == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float ov = ((rsw[0][e] + rsw[1][e]) + rsw[2][e]) + rsw[3][e];
+                const int d = dl * 8 + e, col = (g * 2 + hh) * hd + d;
+                if (a.out_bf16) ((uint16_t*)a.out)[q3_atile_off(row, col, (a.Hq * hd) >> 5)] = q3_bf16(ov / l);
+                else a.out[(size_t)row * a.ldo + col] = ov / l;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next task overwrites p / q
+    }
+}
+
 void q3_launch_attend(const Q3Attend& a, hipStream_t s) {
     const int R = a.Hq / a.Hkv;
     const size_t lds = ((size_t)R * a.n_ctx + R * a.hd + R * 4 * a.hd + R * 8 + 2 * a.hd) * sizeof(float);
@@ -852,6 +961,17 @@ void q3_launch_attend(const Q3Attend& a, hipStream_t s) {
         if (R == 2) hipLaunchKernelGGL((k_attend<2, true>), grid, dim3(512), lds, s, a);
         else hipLaunchKernelGGL((k_attend<4, true>), grid, dim3(1024), lds, s, a);
         return;
+    }
+    if (R == 2 && a.hd == 128 && a.seg && a.n_seg > 0 && a.seg_max_n <= 128) {  // whole prompt runs (admit_group): keys and values once per run
+        static const bool off = getenv("Q3TTS_ATT_PREFILL_OLD") && atoi(getenv("Q3TTS_ATT_PREFILL_OLD"));  // A/B runs, the test that compares the two
+        if (!off) {
+            const int nblk = (a.seg_max_n + 63) / 64;
+            const size_t lds3 = (size_t)nblk * 16384 + (size_t)a.seg_max_n * 256 + 8 * 256 * sizeof(float);
+            static Q3PerDevice pd3;
+            if (lds3 > 65536) pd3.ensure(lds3, [&]() { hipFuncSetAttribute((const void*)k_attend_prefill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); });
+            hipLaunchKernelGGL(k_attend_prefill, dim3(a.Hkv, a.n_seg), dim3(512), lds3, s, a);
+            return;
+        }
     }
     if (R == 1) hipLaunchKernelGGL((k_attend<1, false>), grid, dim3(256), lds, s, a);
     else if (R == 2) hipLaunchKernelGGL((k_attend<2, false>), grid, dim3(512), lds, s, a);
