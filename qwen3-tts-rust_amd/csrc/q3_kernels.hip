@@ -962,7 +962,9 @@ void q3_launch_attend(const Q3Attend& a, hipStream_t s) {
         else hipLaunchKernelGGL((k_attend<4, true>), grid, dim3(1024), lds, s, a);
         return;
     }
-    if (R == 2 && a.hd == 128 && a.seg && a.n_seg > 0 && a.seg_max_n <= 128) {  // whole prompt runs (admit_group): keys and values once per run
+    // whole prompt runs (admit_group): keys and values once per run — when there are enough runs to occupy the chip (one workgroup per run and
+    // KV head walks its rows 8 at a time: a single prompt of 31 rows took 45 us per layer on 8 workgroups against 9 us on k_attend's 248)
+    if (R == 2 && a.hd == 128 && a.seg && a.n_seg * a.Hkv >= 128 && a.seg_max_n <= 128) {
         static const bool off = getenv("Q3TTS_ATT_PREFILL_OLD") && atoi(getenv("Q3TTS_ATT_PREFILL_OLD"));  // A/B runs, the test that compares the two
         if (!off) {
             const int nblk = (a.seg_max_n + 63) / 64;
