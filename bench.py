@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 FRAME_SEC = 0.08  # 1 frame = 16 codes = 1920 samples @ 24 kHz (reference: src/tts/engine.rs:509-512,653)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
-ROUND = "r03"
+ROUND = "r04"
 
 
 def vivian():
@@ -35,16 +35,20 @@ def vivian():
         return np.asarray(json.load(f)["spk_emb"], dtype=np.float32)
 
 
-def make_workload(n_per_gpu, rank, world, spk, keepalive, want_pcm):
-    """the GLOBAL list of n_per_gpu*world utterances is a function of the global index
-    only (n_text ~ U{8..64}, n_frames ~ U{25..250} with EOS forced at the target, sampler seed 1000 + index);
-    rank r owns {i : i mod world == r}, so per-utterance results do not depend on the number of GPUs."""
+def make_workload(n_per_gpu, rank, world, spk, keepalive, want_pcm, n_classes=64):
+    """the GLOBAL list of n_per_gpu*world utterances is a function of the global index only; rank r
+    owns {i : i mod world == r}, so per-utterance results do not depend on the number of GPUs. An utterance's prompt
+    (n_text ~ U{8..64}) and forced length (n_frames ~ U{25..250}, EOS forced at the target) are drawn from its length CLASS
+    c(i) = (i + i // 64) mod 64 (q3tts.dist.workload_class; 64 = the benchmark's utterances per GPU, a constant so that an utterance does
+    not depend on the number of ranks or on --batch), its sampler seed is 1000 + i: with 64 utterances per GPU every rank's indices hit
+    every class exactly once, so every rank — and N = 1, whose classes are its indices: the round-3 workload unchanged — runs the same
+    64 lengths with different sampler streams (weak scaling measures the hardware, not the draw)."""
     from q3tts import dist as qd
     from q3tts.native import make_prompt_desc
     reqs, frames = [], []
     meta = []  # (global index, prompt ids, target frames, sampler seed): what the oracle needs to replay an utterance
     for gi in qd.shard_indices(n_per_gpu * world, rank, world):
-        r = np.random.default_rng(977 * gi + 1)
+        r = np.random.default_rng(977 * qd.workload_class(gi, n_classes) + 1)
         n_text = int(r.integers(8, 65))
         ids = r.integers(0, 151643, size=n_text)
         target = int(r.integers(25, 251))
@@ -468,8 +472,15 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed, total_frames, elapsed_nog = float(tmax[0].item()), float(t[1].item()), float(tmax[2].item())
+        # per-rank view of the weak-scaling workload: every rank runs the same 64 lengths (make_workload), so these rows must agree
+        mine = torch.tensor([float(sum(frames)), float(steps_dev) / max(1, args.steps), float(max(frames)), dec_ms / max(1, steps_dev)], dtype=torch.float64, device=tdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "frames": int(x[0].item()), "frame_steps": int(round(x[1].item())), "longest_utterance_frames": int(x[2].item()),
+                     "frame_step_ms": round(float(x[3].item()), 4)} for r, x in enumerate(allr)]
     else:
         total_frames, elapsed_nog = float(step_frames), elapsed
+        per_rank = None
 
     line = None
     if rank == 0:
@@ -503,6 +514,7 @@ def main():
                 "tflops": round(mfma_tf, 2), "hbm_GBs": round(hbm_gbs, 1), "frac_of_8TBs": round(hbm_gbs / HBM_PEAK_GBS, 4)},
         }
         if use_dist:
+            line["per_rank"] = per_rank
             line["value_without_gather"] = round(audio_sec / elapsed_nog, 2)
             line["gather_ms_per_step"] = round(t_gather / args.steps * 1e3, 3)
         if cont:
@@ -530,21 +542,31 @@ def main():
             by_kernel.sort(key=lambda k: -k["share_of_step"])
             # The headline is quoted per kernel SYMBOL, the unit rocprofv3's kernel stats (profiles/r03/*_kernel_stats.csv) are in: kinds that run the
             # same k_bgemm instance at 64 rows (the launcher's cost model, q3_bgemm.hip) are one symbol. Launch-weighted means over its kinds.
-            symbols = [("k_bgemm<1, 1, 8, false, false>", ("Predictor O projection", "Predictor down projection")),
-                       ("k_bgemm<2, 2, 5, false, false>", ("Talker QKV GEMM", "Predictor QKV GEMM")),
-                       ("k_bgemm<1, 2, 8, false, false>", ("Talker O projection", "Talker down projection")),
-                       ("k_bgemm<2, 3, 4, false, false>", ("Predictor gate/up GEMM",)),
-                       ("k_bgemm<4, 3, 2, true, false>", ("Talker gate/up GEMM",)),
-                       ("k_attend_small<2>", ("Predictor attention",)),
-                       ("k_attend_gqa2", ("Talker attention",))]
+            # The symbol of a GEMM kind is what the launcher's cost model picks for its shape (q3tts_k_bgemm_pick: asked, not assumed — a change of
+            # the model, of the batch size or of Q3TTS_BG_LDS_CAP moves the names with it); kinds that share an instance are one symbol.
+            import ctypes as _C
+            EPI = {"gate/up GEMM": 2, "QKV GEMM": 0, "O projection": 1, "down projection": 1}
+            sym_kinds = {}
+            for p in legs:
+                name = "%s %s" % (p["model"], p["kind"])
+                if p["kind"] == "attention":
+                    sym = "k_attend_gqa2" if p["model"] == "Talker" else "k_attend_small<2>"
+                else:
+                    o5 = (_C.c_int32 * 5)()
+                    rc = eng.lib.q3tts_k_bgemm_pick(p["rows"], p["K"], p["N"], EPI[p["kind"]], 1 if p["model"] == "Talker" else 0, 0, o5)
+                    assert rc == 0
+                    sym = "k_bgemm_big" if o5[4] else "k_bgemm<%d, %d, %d, %s, false>" % (o5[0], o5[1], o5[2], "true" if o5[3] else "false")
+                sym_kinds.setdefault(sym, []).append(name)
+            symbols = [(sym, tuple(kinds)) for sym, kinds in sym_kinds.items()]
             traffic_src = step_traffic = None
             tj = {}
-            tpath = os.path.join(REPO, "profiles", ROUND, "pmc_traffic.json")
+            tround = ROUND if os.path.exists(os.path.join(REPO, "profiles", ROUND, "pmc_traffic.json")) else "r03"   # (until this round's PMC passes are collected)
+            tpath = os.path.join(REPO, "profiles", tround, "pmc_traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
                     tj = json.load(f)
                 step_traffic = tj.get("frame_step")
-                traffic_src = f"profiled offline (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --probe-only`, profiles/{ROUND}/pmc_traffic.json), not measured in this run"
+                traffic_src = f"profiled offline (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --probe-only`, profiles/{tround}/pmc_traffic.json), not measured in this run"
             by_symbol = []
             for sym, kinds in symbols:
                 ks = [k for k in by_kernel if k["kernel"] in kinds]
@@ -564,7 +586,7 @@ def main():
                     "shapes": ["M=%d K=%d N=%d" % (k["M"], k["K"], k["N"]) for k in ks]})
             by_symbol.sort(key=lambda k: -k["share"])
             top = by_symbol[0]
-            gbs, gbs_lb = top["bytes"] / (top["us"] * 1e-6) / 1e9, top["bytes"] / (top["us_bracket"] * 1e-6) / 1e9
+            gbs, gbs_lb = top["bytes"] / (top["us"] * 1e-6) / 1e9, top["bytes"] / (top["us_bracket"] * 1e-6) / 1e9   # (bracket - empty: upper end; whole bracket: lower end)
             line["roofline_dominant_symbol"] = {
                 "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                 "achieved_lower_bound": round(gbs_lb, 1), "frac_lower_bound": round(gbs_lb / HBM_PEAK_GBS, 4),
@@ -577,9 +599,25 @@ def main():
                 "launches_timed": top["launches_timed"], "algorithmic_bytes_per_launch": int(top["bytes"]),
                 "how": "achieved = algorithmic bytes / (launch_us - empty_bracket_us); HIP events on the decode stream around this launch in block 0 of every frame step, eager frame steps, "
                        f"64 live utterances, codes only (q3tts_k_probe); rocprofv3 of the same leg: profiles/{ROUND}/probe_kernel_stats.csv"}
-            line["roofline_by_symbol"] = [{"symbol": g["symbol"], "kinds": g["kinds"], "launches_per_frame_step": g["launches_per_frame_step"], "us_per_launch": round(g["us"], 2),
-                                           "algorithmic_bytes_per_launch": int(g["bytes"]), "frac": round(g["bytes"] / (g["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                           "share_of_step": round(g["share"], 4), "traffic": g["traffic"]} for g in by_symbol]
+            # rocprofv3's own average duration per symbol over the same probe leg (profiles/<round>/probe_kernel_stats.csv, collected offline with
+            # `rocprofv3 --kernel-trace --stats -- python3 bench.py --probe-only`): the figure quoted as us_per_launch when the file is there; the
+            # live event brackets bound it from both sides (us_lower_bound = bracket - empty bracket, us_upper_bound = the whole bracket)
+            prof_us = {}
+            spath = os.path.join(REPO, "profiles", tround, "probe_kernel_stats.csv")
+            if os.path.exists(spath):
+                import csv
+                with open(spath) as f:
+                    for row in csv.DictReader(f):
+                        nm = row["Name"].replace("void ", "").split("(")[0].strip()
+                        prof_us[nm] = float(row["AverageNs"]) * 1e-3
+            def sym_us(g):
+                return prof_us.get(g["symbol"], g["us_bracket"])
+            line["roofline_by_symbol"] = [{"symbol": g["symbol"], "kinds": g["kinds"], "launches_per_frame_step": g["launches_per_frame_step"],
+                                           "us_per_launch": round(sym_us(g), 2), "us_per_launch_source": (f"rocprofv3 average, profiles/{tround}/probe_kernel_stats.csv (offline)" if g["symbol"] in prof_us else "whole event bracket of this run (upper bound)"),
+                                           "us_lower_bound": round(g["us"], 2), "us_upper_bound": round(g["us_bracket"], 2),
+                                           "algorithmic_bytes_per_launch": int(g["bytes"]), "frac": round(g["bytes"] / (sym_us(g) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                           "frac_upper_bound": round(g["bytes"] / (g["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                           "share_of_step": round(g["launches_per_frame_step"] * sym_us(g) / step_us, 4), "traffic": g["traffic"]} for g in by_symbol]
             line["roofline_by_kernel"] = by_kernel
             line["roofline_by_kernel_what"] = ("every kernel kind of a decoder block, sorted by share of the frame step (launches_per_frame_step x us_per_launch / the probe legs' frame step of "
                                                "%.0f us); us_per_launch = event bracket - empty bracket (the lower end of a launch's period: the in-kernel timestamps of "
@@ -692,6 +730,17 @@ def main():
         picks = sorted({0, len(timed_outs) // 2, len(timed_outs) - 1})
         line["parity_batch_leg"] = batch_parity(cfg, spk, make_workload.meta, timed_outs, picks)
     if rank == 0:
+        # the scalars a reader needs, LAST in the object (a log tail keeps them): repeated from the entries above
+        su = line.get("single_utterance", {})
+        line["headline"] = {
+            "frame_step_64_rows_codes_only_ms": line.get("frame_step_64_rows_codes_only_ms"),
+            "roofline_frac": line.get("roofline", {}).get("frac"),
+            "roofline_vocoder_frac": line.get("roofline_vocoder", {}).get("frac"), "vocoder_ms_per_call": line.get("roofline_vocoder", {}).get("ms_per_call"),
+            "single_rtf_p50": su.get("rtf_p50"), "first_chunk_ms_p50": su.get("first_chunk_ms_p50"),
+            "clone_first_chunk_ms_p50": su.get("clone_variant", {}).get("first_chunk_ms_p50"),
+            "utterance_latency_rtf_mean": line["utterance_latency_rtf"]["mean"],
+            "ms_per_step": line["ms_per_step"], "frame_step_ms": line["frame_step_ms"], "rtf_per_utterance": line["rtf_per_utterance"],
+            "audio_sec_per_s": line["value"]}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -106,6 +106,10 @@ typedef struct q3tts_engine_config {
                                * src/tts/engine.rs:91-95). Q8_0 tensors of weights_path are kept as stored; other tensor types and the
                                * synthetic weights are quantised with ggml's reference rule. 0 (default): bf16 weights. The Predictor
                                * keeps bf16 weights either way (157 MB, Infinity-Cache resident: its launches are latency-bound). */
+    int32_t vocoder_flush_tail; /* Only matters with vocoder.lookahead_frames > 0 (V4). 0 (default): as the reference — its vocoder thread sends
+                               * is_last only with a non-empty final buffer (src/tts/engine.rs:510-536), so an utterance of n_frames % 4 == 0
+                               * never flushes the withheld look-ahead tail and its audio ends lookahead_frames short (restated by the oracle's
+                               * q3o_chunk_plan). 1: always flush at the end of an utterance (every generated frame becomes audio). */
 } q3tts_engine_config;
 
 typedef struct q3tts_engine q3tts_engine;
@@ -197,7 +201,10 @@ int q3tts_stream_end(q3tts_stream* s, q3tts_result* out_codes_optional);
  * over xGMI — one ncclAllGather of the per-utterance sample counts, one group of ncclSend / ncclRecv — then copied to the
  * host once: pcm_i16[i] = malloc'd [outs[i].n_samples] samples of request i (release with q3tts_free; outs[i].pcm stays
  * NULL). With pcm_i16 == NULL requests behave as in q3tts_generate_batch (want_pcm = 1: f32 PCM in host memory) and RCCL
- * is never loaded. RCCL is resolved at run time (librccl.so.1); a node handle is not re-entrant. */
+ * is never loaded. RCCL is resolved at run time (librccl.so.1); a node handle is not re-entrant.
+ * Errors: a request that fails by itself (e.g. prompt + max_steps > n_ctx) carries its own outs[i].status and the call still returns
+ * Q3TTS_OK with every other result intact. When a device or the gather fails the call returns the error, every outs[i] — including
+ * the results of the devices that succeeded — is still valid to pass to q3tts_result_free, and no pcm_i16[i] is left allocated. */
 typedef struct q3tts_node q3tts_node;
 typedef struct q3tts_node_timings {
     float generate_ms;      /* slowest device: its q3tts_generate_batch wall time */
@@ -344,6 +351,13 @@ int q3tts_k_bgemm(int32_t device, const uint16_t* xb, int32_t B, int32_t K, cons
 /* Which kernel serves launches of >= 256 rows: 1 = the many-row kernel (k_bgemm_big) whenever eligible, -1 = never, 0 = when it fills the
  * chip (default; the environment variable Q3TTS_BG_BIG sets the initial value once per process). The results are the same bits. */
 int q3tts_k_bgemm_policy(int32_t big);
+/* Which kernel variant serves the Talker's decode attention (0 = k_attend_gqa2, default; 1 = k_attend<2, true>) and the prefill of whole
+ * prompts (0 = k_attend_prefill when the launch has >= 128 (run, KV head) workgroups, default; 1 = never: k_attend<2, false>; 2 = whenever
+ * eligible). Same bits either way (tests compare them in one process); Q3TTS_ATT_OLD / Q3TTS_ATT_PREFILL_OLD set the initial values. */
+int q3tts_k_attend_policy(int32_t decode, int32_t prefill);
+/* The k_bgemm instance the launcher takes for a shape, without launching: out5 = {row tiles, column tiles, ring depth, non-temporal weight
+ * loads, 1 if k_bgemm_big}. bench.py names the kernel symbol of a probed launch from it. */
+int q3tts_k_bgemm_pick(int32_t B, int32_t K, int32_t N, int32_t epilogue, int32_t w_once, int32_t q8, int32_t* out5);
 /* The same launch with ggml Q8_0 weights kept in block form on the device: q int8 [N][K] row-major (epilogue 2: the
  * N/2 gate rows, then the N/2 up rows), d_f16 the blocks' f16 scales as bit patterns [N][K/32]; K % 512 == 0. Equals oracle q3o_bgemm_q8
  * bit for bit. */

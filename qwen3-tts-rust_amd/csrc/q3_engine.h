@@ -80,7 +80,7 @@ struct q3tts_engine {
     float* xp = nullptr;                  // [n_ctx][d]
     uint16_t* xbp = nullptr; float* sspp = nullptr;  // norm inputs of the prefill rows
     int *pf_pos = nullptr, *pf_slot = nullptr;
-    int* pf_seg = nullptr; int pf_nseg = 0, pf_seg_max = 0;  // the prefill launch's rows as per-slot runs {first row, n, slot} (device, 3 ints each): admit_group -> run_layers
+    int* pf_seg = nullptr;              // the prefill launch's rows as per-slot runs {first row, n, slot} (device, 3 ints each): admit_group hands it to run_layers
     Q3PromptRow* prow_dev = nullptr; int prow_cap = 0;
     float* spk_dev = nullptr; int* refcodes_dev = nullptr;
     // sampler defaults (SamplerConfig::default: src/tts/engine.rs:25-34)
@@ -100,6 +100,7 @@ struct q3tts_engine {
     double probe_ms = 0, probe_empty_ms = 0; long long probe_cnt = 0, probe_empty_cnt = 0, row_steps = 0;
     // q3tts_set_device_pcm: packed device copy of the last batch's PCM, one row of dev_pcm_stride samples per request
     int dev_pcm_on = 0; float* dev_pcm = nullptr; int dev_pcm_n = 0; size_t dev_pcm_stride = 0;
+    double hp_launch = 0, hp_sync = 0;  // Q3TTS_HOST_PROF: host wall of run_chunk's launch part / of its wait (per engine: the node drives several from threads)
     float* first_chunk_host = nullptr;  // pinned landing buffer of the first 4-frame PCM chunk (first-chunk latency)
 };
 

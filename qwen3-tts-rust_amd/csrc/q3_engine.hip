@@ -44,7 +44,7 @@ extern "C" void q3tts_default_config(q3tts_engine_config* c) {
     v.dec_rates[0] = 8; v.dec_rates[1] = 5; v.dec_rates[2] = 4; v.dec_rates[3] = 3;
     v.lookahead_frames = 0; v.sample_rate = 24000;
     c->device = 0; c->max_batch = 1; c->n_ctx = 4096; c->max_steps_cap = 512; c->with_vocoder = 1;
-    c->synth_seed = 0; c->weights_path = nullptr; c->talker_q8_0 = 0;
+    c->synth_seed = 0; c->weights_path = nullptr; c->talker_q8_0 = 0; c->vocoder_flush_tail = 0;
 }
 
 static int validate(const q3tts_engine_config& c, std::string& why) {
@@ -295,7 +295,8 @@ static int alloc_scratch(q3tts_engine* e, Q3Scratch& sc, int rows, int nqkv, int
 // inputs for attn_norm[0] on entry, for out_norm on exit. Restated by oracle/q3_oracle.c tfm_layers.
 // Returns the number of launches the GEMM launcher refused (a shape it cannot run: stale activations would follow silently).
 static int run_layers(q3tts_engine* e, Q3Tfm& t, float* x, uint16_t* xb, float* ssp, int rows, const int* row_pos, const int* row_slot, Q3Scratch& sc,
-                       hipStream_t s, bool one_row_per_slot = false, hipEvent_t* probe = nullptr, int slot_mod = 0, int pos_const = 0) {
+                       hipStream_t s, bool one_row_per_slot = false, hipEvent_t* probe = nullptr, int slot_mod = 0, int pos_const = 0,
+                       const int* seg = nullptr, int n_seg = 0, int seg_max_n = 0) {
     const float eps = e->cfg.model.rms_eps;
     int bad = 0;
     const int nt = t.d / 16;
@@ -320,7 +321,7 @@ static int run_layers(q3tts_engine* e, Q3Tfm& t, float* x, uint16_t* xb, float* 
         Q3Attend at{}; at.qkv = sc.qkv; at.ld = t.nqkv; at.rows = rows; at.out = (float*)sc.att; at.ldo = t.nq; at.Hq = t.Hq; at.Hkv = t.Hkv; at.hd = t.hd;
         at.kc = qp.kc; at.vc = qp.vc; at.n_ctx = t.n_ctx; at.row_pos = row_pos; at.row_slot = row_slot;
         at.fused = pair ? 2 : (fused ? 1 : 0); at.prep = qp; at.out_bf16 = 1; at.slot_mod = slot_mod; at.pos_const = pos_const;
-        if (!fused && !pair && e->pf_nseg > 0 && &t == &e->T) { at.seg = e->pf_seg; at.n_seg = e->pf_nseg; at.seg_max_n = e->pf_seg_max; }  // prefill of whole prompts (admit_group)
+        if (!fused && !pair && n_seg > 0) { at.seg = seg; at.n_seg = n_seg; at.seg_max_n = seg_max_n; }  // prefill of whole prompts (admit_group): the launch's rows as per-slot runs
         if (pk == 2) hipEventRecord(probe[0], s);
         q3_launch_attend(at, s);
         if (pk == 2) hipEventRecord(probe[1], s);
@@ -816,7 +817,6 @@ static int plan_rows(q3tts_engine* e, const std::vector<int>& live_in) {
 
 // CH frame steps over the current row bucket; afterwards the slot mirror is on the host. Returns the device time (ms).
 static double now_ms();
-static double g_hp_launch = 0, g_hp_sync = 0;  // Q3TTS_HOST_PROF: host wall of run_chunk's launch part / of its wait
 static int run_chunk(q3tts_engine* e, int CH, float* dev_ms) {
     hipStream_t s = e->stream;
     Q3Lane& L = e->lanes[0];
@@ -840,7 +840,7 @@ static int run_chunk(q3tts_engine* e, int CH, float* dev_ms) {
     Q3_HIP(e, hipMemcpyAsync(e->slots_host, e->slots, sizeof(Q3Slot) * e->B, hipMemcpyDeviceToHost, s));
     const double hp1 = now_ms();
     Q3_HIP(e, hipStreamSynchronize(s));
-    g_hp_launch += hp1 - hp0; g_hp_sync += now_ms() - hp1;
+    e->hp_launch += hp1 - hp0; e->hp_sync += now_ms() - hp1;  // Q3TTS_HOST_PROF: host wall of the launch part / of the wait
     if (dev_ms) { *dev_ms = 0.0f; hipEventElapsedTime(dev_ms, L.ev_begin, L.ev_end); }
     for (int i = 0; i + 1 < e->probe_i; i += 2) {
         float ms = 0.0f;
@@ -873,11 +873,9 @@ static int admit_group(q3tts_engine* e, std::vector<Adm>& grp, int total) {
     std::vector<int> seg; int seg_max = 0;  // the same rows as runs: every request's rows are consecutive, positions 0 .. n - 1
     for (const Adm& a : grp) { seg.push_back(a.row0); seg.push_back(a.n); seg.push_back(a.b); seg_max = std::max(seg_max, a.n); }
     Q3_HIP(e, hipMemcpyAsync(e->pf_seg, seg.data(), seg.size() * 4, hipMemcpyHostToDevice, s));
-    e->pf_nseg = (int)grp.size(); e->pf_seg_max = seg_max;
     Q3_HIP(e, hipStreamSynchronize(s));  // pos/slot are locals
     q3_launch_norm_inputs(e->xp, m.t_d_model, total, m.t_d_model, e->T.attn_norm[0], e->xbp, 0, e->sspp, m.t_d_model / 16, s);
-    const int rl = run_layers(e, e->T, e->xp, e->xbp, e->sspp, total, e->pf_pos, e->pf_slot, e->sc_pre, s);
-    e->pf_nseg = 0;
+    const int rl = run_layers(e, e->T, e->xp, e->xbp, e->sspp, total, e->pf_pos, e->pf_slot, e->sc_pre, s, false, nullptr, 0, 0, e->pf_seg, (int)grp.size(), seg_max);
     if (rl) return q3_set_err(e, Q3TTS_ERR_INVALID, "prefill: a kernel launch was refused for this model shape");
     Q3_HIP(e, hipGetLastError());
     for (const Adm& a : grp) {
@@ -1152,7 +1150,9 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
             if (pending[j] >= 0 && hipEventQuery(e->fin_ev[j]) == hipSuccess) TRY(drain(j));
         for (int b = 0; b < B; ++b) {
             if (run[b].req < 0 || e->slots_host[b].active) continue;
-            if (e->voc) q3_voc_mark_last(e, b);
+            // V4 flush: the reference sends is_last only when its final buffer is not empty, i.e. n_frames % 4 != 0 (src/tts/engine.rs:510-536,
+            // restated by q3o_chunk_plan); with lookahead_frames > 0 an utterance of n_frames % 4 == 0 keeps its withheld tail (vocoder_flush_tail = 1: always flush)
+            if (e->voc && (e->cfg.vocoder_flush_tail || e->slots_host[b].n_frames % 4 != 0)) q3_voc_mark_last(e, b);
             // hand the slot's results over without waiting for the vocoder (completed at slot reuse / at the end)
             for (int j = 0; j < B; ++j)
                 if (pending[j] >= 0 && hipEventQuery(e->fin_ev[j]) == hipSuccess) TRY(drain(j));
@@ -1166,8 +1166,8 @@ extern "C" int q3tts_generate_batch(q3tts_engine* e, const q3tts_request* reqs, 
     hp_lap(hp_tail);
     if (host_prof) {
         fprintf(stderr, "q3tts_generate_batch host wall (ms): admit + plan %.1f | chunks (launch + wait) %.1f = launch %.1f + wait %.1f, device events %.1f over %lld steps | vocoder issue %.1f | finalize %.1f | tail (last results) %.1f | total %.1f\n",
-                hp_admit, hp_chunk, g_hp_launch, g_hp_sync, dec_ms, steps, hp_voc, hp_fin, hp_tail, now_ms() - t0);
-        g_hp_launch = g_hp_sync = 0;
+                hp_admit, hp_chunk, e->hp_launch, e->hp_sync, dec_ms, steps, hp_voc, hp_fin, hp_tail, now_ms() - t0);
+        e->hp_launch = e->hp_sync = 0;
     }
     e->tm.prefill_ms = (float)pre_ms; e->tm.decode_ms = (float)dec_ms; e->tm.vocoder_ms = (float)voc_ms;
     e->tm.total_ms = (float)(now_ms() - t0); e->tm.frame_steps = steps; e->tm.frame_step_ms = steps ? (float)(dec_ms / steps) : 0.0f;
@@ -1247,6 +1247,9 @@ extern "C" int q3tts_stream_poll(q3tts_stream* st, const float** chunk, int32_t*
         int nf = 0, last = 0;
         if (sl.n_frames - st->voc_frames >= 4) nf = 4;
         else if (st->finished && sl.n_frames > st->voc_frames) { nf = sl.n_frames - st->voc_frames; last = 1; }
+        // (a last chunk of exactly 4 frames goes without is_last, as the reference's vocoder thread sends it: src/tts/engine.rs:510-536;
+        // vocoder_flush_tail = 1 flushes the look-ahead tail with it)
+        if (nf == 4 && st->finished && st->voc_frames + 4 >= sl.n_frames && e->cfg.vocoder_flush_tail) last = 1;
         if (nf > 0) {
             const int before = q3_voc_samples(e, 0);
             TRY(q3_voc_decode(e, 0, st->voc_frames, nf, last, s));
@@ -1262,7 +1265,20 @@ extern "C" int q3tts_stream_poll(q3tts_stream* st, const float** chunk, int32_t*
             (void)spf;
             return Q3TTS_OK;
         }
-        if (st->finished) { *is_final = 1; st->final_sent = true; return Q3TTS_OK; }
+        if (st->finished) {
+            if (e->cfg.vocoder_flush_tail) {  // EOS arrived with no frames left over: the withheld look-ahead tail goes out as a last chunk of its own
+                const int before = q3_voc_samples(e, 0);
+                q3_voc_mark_last(e, 0);
+                const int after = q3_voc_samples(e, 0);
+                if (after > before) {
+                    st->chunk.resize((size_t)(after - before));
+                    Q3_HIP(e, hipMemcpyAsync(st->chunk.data(), q3_voc_pcm(e, 0) + before, sizeof(float) * (size_t)(after - before), hipMemcpyDeviceToHost, s));
+                    Q3_HIP(e, hipStreamSynchronize(s));
+                    *chunk = st->chunk.data(); *n_samples = after - before;
+                }
+            }
+            *is_final = 1; st->final_sent = true; return Q3TTS_OK;
+        }
     }
 }
 
@@ -1710,6 +1726,24 @@ extern "C" int q3tts_k_alloc_upload(q3tts_engine* e, int64_t bytes, int64_t* mis
 extern "C" int q3tts_k_bgemm_policy(int32_t big) {
     if (big < -1 || big > 1) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm policy: -1, 0 or 1");
     q3_bgemm_big_policy(big);
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_k_attend_policy(int32_t decode, int32_t prefill) {
+    if (decode < 0 || decode > 1 || prefill < 0 || prefill > 2) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "attend policy: decode 0..1, prefill 0..2");
+    q3_attend_policy(decode, prefill);
+    return Q3TTS_OK;
+}
+
+extern "C" int q3tts_k_bgemm_pick(int32_t B, int32_t K, int32_t N, int32_t epilogue, int32_t w_once, int32_t q8, int32_t* out5) {
+    if (!out5 || B < 1 || K < 256 || K % 256 || N % 16) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm pick: bad shape");
+    Q3BGemm g{}; g.B = B; g.K = K; g.N = N; g.epi = epilogue; g.w_once = w_once;
+    g.a = (const uint16_t*)16; g.w = (const uint4*)16; g.wscale = q8 ? (const uint16_t*)16 : nullptr;  // (never dereferenced: nothing is launched)
+    if (epilogue == Q3_EPI_SWIGLU || epilogue == Q3_EPI_GELU) g.yb = (uint16_t*)16;
+    if (epilogue == Q3_EPI_RESID) { g.yb = (uint16_t*)16; g.nw_next = (const float*)16; }
+    int rt, nt, d, ntw, big;
+    q3_bgemm_pick(g, &rt, &nt, &d, &ntw, &big);
+    out5[0] = rt; out5[1] = nt; out5[2] = d; out5[3] = ntw; out5[4] = big;
     return Q3TTS_OK;
 }
 

@@ -81,6 +81,7 @@ struct Q3BGemm {
     Q3_STAMP_FIELD
 };
 int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s);
+void q3_bgemm_pick(const Q3BGemm& g, int* rt, int* nt, int* d, int* ntw, int* big);  // the instance q3_launch_bgemm takes for g (no launch)
 void q3_bgemm_force(int rt, int nt);  // tuning only: force a tile instance (0, 0: back to the cost model)
 void q3_bgemm_prepare();  // kernel attributes + the Q3TTS_BG_BIG policy (read once); call once outside stream capture
 void q3_bgemm_big_policy(int policy);  // 1 / -1 / 0: k_bgemm_big always / never / when it fills the chip (tests, A/B runs)
@@ -163,6 +164,7 @@ struct Q3Attend {
     Q3_STAMP_FIELD
 };
 void q3_launch_attend(const Q3Attend& a, hipStream_t s);
+void q3_attend_policy(int decode, int prefill);  // test hook (q3tts_k_attend_policy): which kernel variant serves decode / prefill attention (same bits)
 
 // Talker sampler + frame bookkeeping (H4/H5). One workgroup per slot.
 struct Q3Sample {

@@ -925,7 +925,23 @@ __global__ __launch_bounds__(512) void k_attend_prefill(Q3Attend a) {
     }
 }
 
+// Which kernel serves the Talker's decode attention / the prefill of whole prompts. The variants produce the same bits
+// (tests/test_parity_gpu.py compares them in one process through q3tts_k_attend_policy); the environment variables Q3TTS_ATT_OLD /
+// Q3TTS_ATT_PREFILL_OLD give the initial values once per process (A/B runs).
+//   decode:  0 = k_attend_gqa2 (default), 1 = k_attend<2, true>
+//   prefill: 0 = k_attend_prefill when the launch has >= 128 (run, KV head) workgroups (default), 1 = never (k_attend<2, false>), 2 = whenever eligible
+static int g_att_decode = 0, g_att_prefill = 0;
+static std::once_flag g_att_once;
+static void att_policy_init() {
+    std::call_once(g_att_once, []() {
+        const char* ev = getenv("Q3TTS_ATT_OLD"); g_att_decode = (ev && atoi(ev)) ? 1 : 0;
+        ev = getenv("Q3TTS_ATT_PREFILL_OLD"); g_att_prefill = (ev && atoi(ev)) ? 1 : 0;
+    });
+}
+void q3_attend_policy(int decode, int prefill) { att_policy_init(); g_att_decode = decode; g_att_prefill = prefill; }
+
 void q3_launch_attend(const Q3Attend& a, hipStream_t s) {
+    att_policy_init();
     const int R = a.Hq / a.Hkv;
     const size_t lds = ((size_t)R * a.n_ctx + R * a.hd + R * 4 * a.hd + R * 8 + 2 * a.hd) * sizeof(float);
     dim3 grid(a.Hkv, a.rows);
@@ -948,8 +964,7 @@ void q3_launch_attend(const Q3Attend& a, hipStream_t s) {
         return;
     }
     if (a.fused && R == 2 && a.hd == 128) {  // the Talker's decode step: one workgroup of four waves per (slot, KV head), both query heads
-        static const bool old_kernel = getenv("Q3TTS_ATT_OLD") && atoi(getenv("Q3TTS_ATT_OLD"));  // A/B runs and the test that compares the two (same bits)
-        if (!old_kernel) {
+        if (g_att_decode == 0) {  // (1: k_attend<2, true> below — same bits: test_attention_kernel_variants_agree)
             const size_t lds2 = ((size_t)2 * a.n_ctx + 2 * a.hd + 8 * a.hd + 16 + 128) * sizeof(float);
             static Q3PerDevice pd2;
             if (lds2 > 65536) pd2.ensure(lds2, [&]() { hipFuncSetAttribute((const void*)k_attend_gqa2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); });
@@ -964,9 +979,8 @@ void q3_launch_attend(const Q3Attend& a, hipStream_t s) {
     }
     // whole prompt runs (admit_group): keys and values once per run — when there are enough runs to occupy the chip (one workgroup per run and
     // KV head walks its rows 8 at a time: a single prompt of 31 rows took 45 us per layer on 8 workgroups against 9 us on k_attend's 248)
-    if (R == 2 && a.hd == 128 && a.seg && a.n_seg * a.Hkv >= 128 && a.seg_max_n <= 128) {
-        static const bool off = getenv("Q3TTS_ATT_PREFILL_OLD") && atoi(getenv("Q3TTS_ATT_PREFILL_OLD"));  // A/B runs, the test that compares the two
-        if (!off) {
+    if (R == 2 && a.hd == 128 && a.seg && a.seg_max_n <= 128 && g_att_prefill != 1 && (a.n_seg * a.Hkv >= 128 || g_att_prefill == 2)) {
+        {
             const int nblk = (a.seg_max_n + 63) / 64;
             const size_t lds3 = (size_t)nblk * 16384 + (size_t)a.seg_max_n * 256 + 8 * 256 * sizeof(float);
             static Q3PerDevice pd3;

@@ -157,41 +157,18 @@ static double node_now_ms() { return std::chrono::duration<double, std::milli>(s
 #define NHIP(n, call) do { hipError_t er__ = (call); if (er__ != hipSuccess) return node_err((n), Q3TTS_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(er__)); } while (0)
 #define NNCCL(n, call) do { nccl_result_t rc__ = (call); if (rc__ != 0) return node_err((n), Q3TTS_ERR_DEVICE, std::string(#call) + ": " + g_rccl.GetErrorString(rc__)); } while (0)
 
-extern "C" int q3tts_node_generate_batch(q3tts_node* n, const q3tts_request* reqs, int32_t n_reqs, q3tts_result* outs, int16_t** pcm_i16) {
-    if (!n || !reqs || !outs || n_reqs <= 0) return node_err(n, Q3TTS_ERR_INVALID, "node: null/empty argument");
+// An open RCCL group is closed on every way out: an early return between ncclGroupStart and ncclGroupEnd would leave the group open and
+// the next collective of the process queued behind it for good.
+struct NcclGroup {
+    bool open = false;
+    nccl_result_t start() { const nccl_result_t rc = g_rccl.GroupStart(); open = rc == 0; return rc; }
+    nccl_result_t end() { open = false; return g_rccl.GroupEnd(); }
+    ~NcclGroup() { if (open) g_rccl.GroupEnd(); }
+};
+
+// the one collective: i16 PCM of every utterance to device 0, then one buffer per utterance (q3tts_free) at its global index
+static int node_gather(q3tts_node* n, q3tts_result* outs, int16_t** pcm_i16) {
     const int G = (int)n->dev.size();
-    const bool gather = pcm_i16 != nullptr;
-    if (gather) { const int rc = node_comms(n); if (rc != Q3TTS_OK) return rc; }
-    for (int i = 0; i < n_reqs; ++i) { memset(&outs[i], 0, sizeof(outs[i])); outs[i].status = Q3TTS_ERR_STATE; if (gather) pcm_i16[i] = nullptr; }
-    const double t0 = node_now_ms();
-    // ---- generation: device r runs requests {i : i mod G == r} through its own continuous-batching engine, no exchange
-    std::vector<std::thread> th;
-    for (int r = 0; r < G; ++r) {
-        NodeDev& d = n->dev[r];
-        d.idx.clear(); d.reqs.clear();
-        for (int i = r; i < n_reqs; i += G) { d.idx.push_back(i); d.reqs.push_back(reqs[i]); if (gather && reqs[i].want_pcm) d.reqs.back().want_pcm = 2; }
-        d.outs.assign(d.reqs.size(), q3tts_result{});
-        d.rc = Q3TTS_OK; d.err.clear(); d.gen_ms = 0;
-        if (d.reqs.empty()) continue;
-        th.emplace_back([&d]() {
-            const double a = node_now_ms();
-            d.rc = q3tts_generate_batch(d.eng, d.reqs.data(), (int)d.reqs.size(), d.outs.data());
-            if (d.rc != Q3TTS_OK) d.err = q3tts_last_error(d.eng);
-            d.gen_ms = node_now_ms() - a;
-        });
-    }
-    for (auto& t : th) t.join();
-    double gen_ms = 0;
-    for (int r = 0; r < G; ++r) {
-        NodeDev& d = n->dev[r];
-        if (d.rc != Q3TTS_OK) return node_err(n, d.rc, "device " + std::to_string(d.device) + ": " + d.err);
-        for (size_t j = 0; j < d.idx.size(); ++j) outs[d.idx[j]] = d.outs[j];
-        gen_ms = std::max(gen_ms, d.gen_ms);
-    }
-    n->tm.generate_ms = (float)gen_ms; n->tm.gather_ms = 0; n->tm.gathered_bytes = 0; n->tm.n_devices = G;
-    if (!gather) { n->tm.total_ms = (float)(node_now_ms() - t0); return Q3TTS_OK; }
-    // ---- the one collective: i16 PCM of every utterance to device 0
-    const double tg = node_now_ms();
     int maxn = 1;
     for (int r = 0; r < G; ++r) maxn = std::max(maxn, (int)n->dev[r].idx.size());
     std::vector<size_t> pack_samples(G, 0);
@@ -201,7 +178,7 @@ extern "C" int q3tts_node_generate_batch(q3tts_node* n, const q3tts_request* req
         const int cnt = (int)d.idx.size();
         std::vector<int> lens(maxn, 0); std::vector<long long> off(maxn, 0);
         size_t tot = 0;
-        for (int j = 0; j < cnt; ++j) { lens[j] = d.reqs[j].want_pcm ? d.outs[j].n_samples : 0; off[j] = (long long)tot; tot += (size_t)lens[j]; }
+        for (int j = 0; j < cnt; ++j) { lens[j] = (d.reqs[j].want_pcm && d.outs[j].status == Q3TTS_OK) ? d.outs[j].n_samples : 0; off[j] = (long long)tot; tot += (size_t)lens[j]; }
         pack_samples[r] = tot;
         if (d.lens_cap < maxn) {
             hipFree(d.lens_dev); hipFree(d.off_dev); hipFree(d.all_lens_dev); d.lens_dev = nullptr; d.off_dev = nullptr; d.all_lens_dev = nullptr; d.lens_cap = 0;
@@ -220,14 +197,15 @@ extern "C" int q3tts_node_generate_batch(q3tts_node* n, const q3tts_request* req
             NHIP(n, hipGetLastError());
         }
     }
+    NcclGroup grp;
     // sample counts of every utterance of every device, on every device: one all-gather of maxn int32 per rank
-    NNCCL(n, g_rccl.GroupStart());
+    NNCCL(n, grp.start());
     for (int r = 0; r < G; ++r) {
         NodeDev& d = n->dev[r];
         NHIP(n, hipSetDevice(d.device));
         NNCCL(n, g_rccl.AllGather(d.lens_dev, d.all_lens_dev, (size_t)maxn, Q3_NCCL_INT32, d.comm, d.stream));
     }
-    NNCCL(n, g_rccl.GroupEnd());
+    NNCCL(n, grp.end());
     NodeDev& d0 = n->dev[0];
     NHIP(n, hipSetDevice(d0.device));
     std::vector<int> all_lens((size_t)maxn * G);
@@ -241,7 +219,7 @@ extern "C" int q3tts_node_generate_batch(q3tts_node* n, const q3tts_request* req
     if (n->root_cap < total + 1) { hipFree(n->root); n->root = nullptr; n->root_cap = 0; NHIP(n, hipMalloc((void**)&n->root, sizeof(int16_t) * (total + 1))); n->root_cap = total + 1; }
     if (n->host_cap < total + 1) { if (n->host) hipHostFree(n->host); n->host = nullptr; n->host_cap = 0; NHIP(n, hipHostMalloc((void**)&n->host, sizeof(int16_t) * (total + 1), hipHostMallocDefault)); n->host_cap = total + 1; }
     // PCM: one group of point-to-point transfers over xGMI, every peer straight into its place in device 0's buffer
-    NNCCL(n, g_rccl.GroupStart());
+    NNCCL(n, grp.start());
     for (int r = 1; r < G; ++r) {
         const size_t bytes = (rank_off[r + 1] - rank_off[r]) * sizeof(int16_t);
         if (!bytes) continue;
@@ -250,7 +228,7 @@ extern "C" int q3tts_node_generate_batch(q3tts_node* n, const q3tts_request* req
         NHIP(n, hipSetDevice(d0.device));
         NNCCL(n, g_rccl.Recv(n->root + rank_off[r], bytes, Q3_NCCL_INT8, r, d0.comm, d0.stream));
     }
-    NNCCL(n, g_rccl.GroupEnd());
+    NNCCL(n, grp.end());
     NHIP(n, hipSetDevice(d0.device));
     if (rank_off[1] > 0) NHIP(n, hipMemcpyAsync(n->root, d0.pack, rank_off[1] * sizeof(int16_t), hipMemcpyDeviceToDevice, d0.stream));
     if (total > 0) NHIP(n, hipMemcpyAsync(n->host, n->root, total * sizeof(int16_t), hipMemcpyDeviceToHost, d0.stream));
@@ -271,8 +249,56 @@ extern "C" int q3tts_node_generate_batch(q3tts_node* n, const q3tts_request* req
             o += (size_t)len;
         }
     }
-    n->tm.gather_ms = (float)(node_now_ms() - tg);
     n->tm.gathered_bytes = (int64_t)(total * sizeof(int16_t));
+    return Q3TTS_OK;
+}
+
+// Error contract: whatever the return code, every outs[i] is valid to pass to q3tts_result_free (the results of the devices that
+// succeeded are handed over even when another device failed; a request that failed by itself carries its own status and the call
+// still returns OK), and on a non-OK return no pcm_i16[i] is left allocated (all NULL).
+extern "C" int q3tts_node_generate_batch(q3tts_node* n, const q3tts_request* reqs, int32_t n_reqs, q3tts_result* outs, int16_t** pcm_i16) {
+    if (!n || !reqs || !outs || n_reqs <= 0) return node_err(n, Q3TTS_ERR_INVALID, "node: null/empty argument");
+    const int G = (int)n->dev.size();
+    const bool gather = pcm_i16 != nullptr;
+    for (int i = 0; i < n_reqs; ++i) { memset(&outs[i], 0, sizeof(outs[i])); outs[i].status = Q3TTS_ERR_STATE; if (gather) pcm_i16[i] = nullptr; }
+    if (gather) { const int rc = node_comms(n); if (rc != Q3TTS_OK) return rc; }
+    const double t0 = node_now_ms();
+    // ---- generation: device r runs requests {i : i mod G == r} through its own continuous-batching engine, no exchange
+    std::vector<std::thread> th;
+    for (int r = 0; r < G; ++r) {
+        NodeDev& d = n->dev[r];
+        d.idx.clear(); d.reqs.clear();
+        for (int i = r; i < n_reqs; i += G) { d.idx.push_back(i); d.reqs.push_back(reqs[i]); if (gather && reqs[i].want_pcm) d.reqs.back().want_pcm = 2; }
+        d.outs.assign(d.reqs.size(), q3tts_result{});
+        for (auto& o : d.outs) o.status = Q3TTS_ERR_STATE;
+        d.rc = Q3TTS_OK; d.err.clear(); d.gen_ms = 0;
+        if (d.reqs.empty()) continue;
+        th.emplace_back([&d]() {
+            const double a = node_now_ms();
+            d.rc = q3tts_generate_batch(d.eng, d.reqs.data(), (int)d.reqs.size(), d.outs.data());
+            if (d.rc != Q3TTS_OK) d.err = q3tts_last_error(d.eng);
+            d.gen_ms = node_now_ms() - a;
+        });
+    }
+    for (auto& t : th) t.join();
+    double gen_ms = 0;
+    int first_bad = -1;
+    for (int r = 0; r < G; ++r) {  // every device's results go to the caller first — also those of the devices beside a failing one
+        NodeDev& d = n->dev[r];
+        for (size_t j = 0; j < d.idx.size(); ++j) outs[d.idx[j]] = d.outs[j];
+        if (d.rc != Q3TTS_OK && first_bad < 0) first_bad = r;
+        gen_ms = std::max(gen_ms, d.gen_ms);
+    }
+    n->tm.generate_ms = (float)gen_ms; n->tm.gather_ms = 0; n->tm.gathered_bytes = 0; n->tm.n_devices = G;
+    if (first_bad >= 0) return node_err(n, n->dev[first_bad].rc, "device " + std::to_string(n->dev[first_bad].device) + ": " + n->dev[first_bad].err);
+    if (!gather) { n->tm.total_ms = (float)(node_now_ms() - t0); return Q3TTS_OK; }
+    const double tg = node_now_ms();
+    const int grc = node_gather(n, outs, pcm_i16);
+    if (grc != Q3TTS_OK) {  // no half-delivered gather: what was handed out so far is taken back
+        for (int i = 0; i < n_reqs; ++i) { free(pcm_i16[i]); pcm_i16[i] = nullptr; }
+        return grc;
+    }
+    n->tm.gather_ms = (float)(node_now_ms() - tg);
     n->tm.total_ms = (float)(node_now_ms() - t0);
     return Q3TTS_OK;
 }

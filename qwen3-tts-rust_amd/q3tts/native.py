@@ -287,6 +287,10 @@ class NativeNode:
         i16 = (C.POINTER(C.c_int16) * n)() if gather_i16 else None
         rc = self.lib.q3tts_node_generate_batch(self.h, arr, n, res, i16)
         if rc != 0:
+            self.last_failed_statuses = [int(res[i].status) for i in range(n)]
+            for i in range(n):   # (the contract: every result is valid to free, whatever the return code; no i16 buffer is left allocated)
+                self.lib.q3tts_result_free(C.byref(res[i]))
+            assert not gather_i16 or not any(bool(i16[i]) for i in range(n))
             raise _abi.Q3Error(f"q3tts_node_generate_batch failed ({rc}): {self.lib.q3tts_node_last_error(self.h).decode()}")
         ncb = self.cfg.model.n_codebooks
         outs = []

@@ -28,6 +28,7 @@ pub struct q3tts_engine_config {
     pub device: i32, pub max_batch: i32, pub n_ctx: i32, pub max_steps_cap: i32, pub with_vocoder: i32,
     pub synth_seed: u64, pub weights_path: *const c_char,
     pub talker_q8_0: i32,   // 1: the Talker's Q8_0 blocks stay quantised on the device (the crate's default "q8_0" directory)
+    pub vocoder_flush_tail: i32,   // 0: the look-ahead tail is flushed as the reference does (only when n_frames % 4 != 0); 1: always
 }
 #[repr(C)]
 pub struct q3tts_prompt_desc {

@@ -103,6 +103,56 @@ def test_node_api_one_device_gathers_the_reference_i16_pcm():
     print(f"node API, 1 device: 7 utterances, {tm.gathered_bytes} bytes gathered in {tm.gather_ms:.2f} ms (generate {tm.generate_ms:.1f} ms)")
 
 
+def test_node_error_paths_leave_every_result_intact_and_freeable():
+    """q3tts_node_generate_batch's error contract (include/q3tts.h). A request that fails by itself — prompt + max_steps beyond n_ctx —
+    carries its own status while every other utterance of the batch comes back complete (ids equal a plain engine's, gathered i16 PCM
+    present) and the failed one gathers nothing; a device-level failure (want_pcm on a node without a vocoder) returns the error with
+    every result still valid to free and no i16 buffer allocated (NativeNode frees them all before raising)."""
+    sys.path.insert(0, os.path.join(REPO, "qwen3-tts-rust_amd")); sys.path.insert(0, os.path.join(REPO, "tests"))
+    import _oracle as O
+    from q3tts import _abi, native
+    cfg = _abi.tiny_config(max_batch=2, n_ctx=128, with_vocoder=1)
+    spk = ((np.arange(cfg.model.d_embed) % 13 - 6) * 0.03125).astype(np.float32)
+    rng = np.random.default_rng(5)
+    keep, reqs = [], []
+    for i in range(5):
+        n_text = 110 if i == 2 else int(rng.integers(3, 9))    # request 2: 121 prompt rows + 12 steps > n_ctx = 128
+        desc, k = O.make_prompt_desc(rng.integers(0, 151643, size=n_text), spk_emb=spk)
+        keep.append((desc, k))
+        reqs.append(dict(desc=desc, temperature=0.7, top_k=40, top_p=0.9, seed=900 + i, max_steps=12, min_frames=5 + i, force_eos_at=5 + i, want_pcm=1))
+    eng = native.NativeEngine(cfg)
+    try:
+        plain = eng.generate_batch([r for i, r in enumerate(reqs) if i != 2])
+    finally:
+        eng.close()
+    node = native.NativeNode(cfg, [0])
+    try:
+        for gather in (True, False):
+            got = node.generate_batch(reqs, gather_i16=gather)
+            assert got[2].status != 0 and got[2].codes.shape[0] == 0 and got[2].pcm is None and got[2].pcm_i16 is None
+            for a, b in zip(plain, [g for i, g in enumerate(got) if i != 2]):
+                assert b.status == 0 and np.array_equal(a.codes, b.codes)
+                if gather:
+                    want = np.trunc(np.clip(a.pcm.astype(np.float32) * np.float32(32767.0), -32768.0, 32767.0)).astype(np.int16)
+                    assert np.array_equal(b.pcm_i16, want)
+                else:
+                    assert np.array_equal(b.pcm, a.pcm)
+        again = node.generate_batch([r for i, r in enumerate(reqs) if i != 2], gather_i16=True)   # the node is usable after a failed request
+        assert all(o.status == 0 for o in again) and all(np.array_equal(a.codes, b.codes) for a, b in zip(plain, again))
+    finally:
+        node.close()
+    cfg0 = _abi.tiny_config(max_batch=2, n_ctx=128, with_vocoder=0)
+    node0 = native.NativeNode(cfg0, [0])
+    try:
+        with pytest.raises(_abi.Q3Error):
+            node0.generate_batch(reqs[:2], gather_i16=False)    # want_pcm without a vocoder: the device's whole call fails
+        assert node0.last_failed_statuses == [-5, -5]   # Q3TTS_ERR_STATE: untouched results, valid to free
+        ok = node0.generate_batch([dict(r, want_pcm=0) for r in reqs[:2]], gather_i16=False)    # ... and the node goes on working
+        assert all(o.status == 0 and o.codes.shape[0] > 0 for o in ok)
+    finally:
+        node0.close()
+
+
 def test_bench_node_mode_one_gpu():
     """bench.py --node (the q3tts_node_* leg) on the one GPU of this box."""
     env = dict(os.environ)

@@ -92,6 +92,45 @@ def test_sharding_is_a_partition_and_seeds_ignore_world_size():
     assert dist.global_seed(1000, 5) == 1005
 
 
+def test_weak_scaling_workload_is_the_same_on_every_rank():
+    """bench.py's workload: an utterance's prompt and forced length come from its length class
+    c(i) = (i + i // 64) mod 64, its sampler seed from its global index. For G in {1, 2, 4, 8} and 64 utterances per rank every rank's
+    indices {r + G j} hit every class exactly once — each rank (and N = 1, whose classes are its indices) runs the same 64 lengths, so
+    value(G) / (G value(1)) measures the hardware and not the draw; seeds stay distinct across the whole job."""
+    import bench
+    from q3tts import dist as qd
+    spk = np.zeros(2048, dtype=np.float32)
+    base = None
+    for G in (1, 2, 4, 8):
+        seeds = []
+        for r in range(G):
+            idx = qd.shard_indices(64 * G, r, G)
+            assert sorted(qd.workload_class(i, 64) for i in idx) == list(range(64)), (G, r)
+            keep = []
+            reqs, frames = bench.make_workload(64, r, G, spk, keep, 0)
+            by_class = {qd.workload_class(gi, 64): (len(ids), int(t), tuple(int(x) for x in ids[:4])) for (gi, ids, t, sd) in bench.make_workload.meta}
+            per_rank = [by_class[c] for c in range(64)]
+            if base is None:
+                base = per_rank
+                assert sum(frames) == 9865 and [m[0] for m in bench.make_workload.meta] == list(range(64))   # N = 1: the round-3 workload, unchanged
+            assert per_rank == base, (G, r)
+            assert sorted(frames) == sorted(t for _, t, _ in base) and max(frames) == max(t for _, t, _ in base)
+            seeds += [sd for (_, _, _, sd) in bench.make_workload.meta]
+        assert sorted(seeds) == [1000 + i for i in range(64 * G)]
+    # the node leg (one process, all utterances): same classes through n_classes
+    keep = []
+    reqs, frames = bench.make_workload(64 * 2, 0, 1, spk, keep, 0)
+    assert sum(frames) == 2 * 9865
+    # an utterance is a function of its global index alone (never of the rank count or of --batch): 2 ranks x 3 == 1 rank x 6
+    keep = []
+    bench.make_workload(6, 0, 1, spk, keep, 0)
+    one = {m[0]: (tuple(m[1]), m[2], m[3]) for m in bench.make_workload.meta}
+    for r in range(2):
+        bench.make_workload(3, r, 2, spk, keep, 0)
+        for m in bench.make_workload.meta:
+            assert one[m[0]] == (tuple(m[1]), m[2], m[3])
+
+
 def test_pcm_gather_over_gloo_world2(tmp_path):
     """The N > 1 path on CPU: 2 ranks, gloo, variable-length PCM gathered to rank 0 and re-assembled in global order."""
     out = tmp_path / "ok"

@@ -453,6 +453,87 @@ def test_streaming_api_chunks(oracle, tiny_voc):
     assert np.array_equal(eng.last_stream_result.codes, whole.codes)
 
 
+def _oracle_pcm_by_chunk_plan(oracle, v, codes, lookahead, spf=1920):
+    """What the reference's vocoder thread delivers for an utterance (src/tts/engine.rs:507-541): the calls of q3o_chunk_plan — 4-frame
+    chunks, a final call with is_last only when frames are left over — fed to q3o_vocoder_decode one by one; returns the per-call PCM."""
+    L = oracle.lib()
+    n = codes.shape[0]
+    cf, cl = np.zeros(n + 2, dtype=np.int32), np.zeros(n + 2, dtype=np.int32)
+    k = L.q3o_chunk_plan(n, oracle.ptr(cf, oracle.i32p), oracle.ptr(cl, oracle.i32p), cf.size)
+    L.q3o_vocoder_reset(v)
+    parts, f = [], 0
+    for i in range(k):
+        buf = np.zeros((int(cf[i]) + lookahead) * spf + 64, dtype=np.float32)
+        m = L.q3o_vocoder_decode(v, oracle.ptr(codes[f:f + cf[i]].copy(), oracle.i32p), int(cf[i]), int(cl[i]), oracle.ptr(buf, oracle.f32p), buf.size)
+        parts.append(buf[:m].copy())
+        f += int(cf[i])
+    assert f == n
+    return parts
+
+
+def test_vocoder_lookahead_on_the_device(oracle):
+    """V4 with lookahead_frames = 2 (src/models/onnx.rs:364-366: the vocoder withholds a tail until is_last; src/tts/engine.rs:510-536:
+    is_last is only ever sent with a non-empty final buffer, so an utterance of n_frames % 4 == 0 keeps its tail for good). One-shot,
+    4-frame streaming and whole utterances through generate_batch against q3o_vocoder_decode driven by q3o_chunk_plan: the same number
+    of samples per call as the reference's thread would see, PCM within tolerance; vocoder_flush_tail = 1 delivers every frame."""
+    from q3tts import _abi, native
+    LA = 2
+    cfg = _abi.tiny_config(max_batch=2, n_ctx=256, with_vocoder=1)
+    cfg.vocoder.lookahead_frames = LA
+    L = oracle.lib()
+    v = L.q3o_vocoder_create(C.byref(cfg.vocoder), 0, 4)
+    eng = native.NativeEngine(cfg)
+    cfg_f = _abi.tiny_config(max_batch=2, n_ctx=256, with_vocoder=1)
+    cfg_f.vocoder.lookahead_frames = LA
+    cfg_f.vocoder_flush_tail = 1
+    eng_f = native.NativeEngine(cfg_f)
+    om = oracle.OracleModel(cfg.model, seed=0, n_ctx=256, n_threads=4)
+    try:
+        # the hook with an explicit is_last at the end: every frame, in any chunking (the withheld tail is only a delay)
+        codes = np.random.default_rng(8).integers(0, cfg.vocoder.codebook_size, size=(9, 16)).astype(np.int32)
+        ref_all = _oracle_pcm(oracle, v, codes)
+        one = eng.vocoder(codes)
+        assert one.shape == ref_all.shape == (9 * 1920,) and float(np.sqrt(np.mean((one - ref_all) ** 2))) <= PCM_RMS_TOL
+        assert np.array_equal(eng.vocoder(codes, chunk_frames=4), one)
+        desc, keep = oracle.make_prompt_desc(np.arange(60, 70), spk_emb=_spk(cfg.model.d_embed))
+        pe = om.build_prompt(desc)
+        reqs, want = [], []
+        for n in (8, 6, 3, 4, 12, 13):   # n % 4 == 0: the reference never flushes -> n - 2 frames of audio
+            kw = dict(temperature=0.7, top_k=40, top_p=0.9, seed=40 + n, max_steps=16, min_frames=n, force_eos_at=n)
+            ref_codes = om.generate(pe, **kw)[0]
+            assert ref_codes.shape[0] == n
+            parts = _oracle_pcm_by_chunk_plan(oracle, v, np.clip(ref_codes, 0, cfg.vocoder.codebook_size - 1).astype(np.int32), LA)
+            want.append((n, ref_codes, parts))
+            reqs.append(dict(embd=pe, want_pcm=1, **kw))
+        outs = eng.generate_batch(reqs)      # 6 utterances over 2 slots: batched 4-frame vocoder calls, slot reuse
+        outs_f = eng_f.generate_batch(reqs)
+        for o, of, (n, ref_codes, parts) in zip(outs, outs_f, want):
+            ref = np.concatenate(parts)
+            kept = n - LA if n % 4 == 0 else n
+            assert o.status == 0 and np.array_equal(o.codes, ref_codes), n
+            assert ref.size == kept * 1920 and o.pcm.size == ref.size, (n, o.pcm.size, ref.size)
+            assert float(np.sqrt(np.mean((o.pcm - ref) ** 2))) <= PCM_RMS_TOL, n
+            assert of.status == 0 and np.array_equal(of.codes, ref_codes) and of.pcm.size == n * 1920, n
+            assert np.array_equal(of.pcm[:o.pcm.size], o.pcm), n   # the flush only adds the tail
+            full = _oracle_pcm(oracle, v, np.clip(ref_codes, 0, cfg.vocoder.codebook_size - 1).astype(np.int32))
+            assert float(np.sqrt(np.mean((of.pcm - full) ** 2))) <= PCM_RMS_TOL, n
+        # streaming: per-call sample counts equal the reference thread's
+        for (n, ref_codes, parts), r in zip(want, reqs):
+            chunks = list(native.stream_chunks(eng, **r))
+            sizes = [p.size for p in parts if p.size]
+            assert [c.size for c, _ in chunks] == sizes, (n, [c.size for c, _ in chunks], sizes)
+            got = np.concatenate([c for c, _ in chunks])
+            assert float(np.sqrt(np.mean((got - np.concatenate(parts)) ** 2))) <= PCM_RMS_TOL, n
+            assert np.array_equal(eng.last_stream_result.codes, ref_codes)
+            chunks_f = list(native.stream_chunks(eng_f, **r))
+            assert sum(c.size for c, _ in chunks_f) == n * 1920 and chunks_f[-1][1], n
+    finally:
+        eng.close()
+        eng_f.close()
+        om.close()
+        L.q3o_vocoder_destroy(v)
+
+
 def test_api_mirror_generate_with_voice(tiny_voc, tmp_path):
     """TtsEngine / VoiceFile / SamplerConfig / AudioSample mirror over the same engine handle (token ids in, WAV out)."""
     from q3tts import api
@@ -1061,6 +1142,101 @@ def test_full_shape_64_slots_sampled_mixed_lengths_ids_and_pcm(oracle):
         eng.close()
         om.close()
         L.q3o_vocoder_destroy(v)
+
+
+def _attend_policy(decode, prefill):
+    from q3tts import _abi
+    rc = _abi.load_library().q3tts_k_attend_policy(decode, prefill)
+    assert rc == 0
+
+
+@pytest.mark.parametrize("n_rows", [1, 2, 63, 64, 65, 100, 127, 128])
+def test_attention_kernel_variants_agree_on_prompt_runs(oracle, tiny, n_rows):
+    """k_attend_prefill (a whole prompt run served from LDS: one key block for runs of <= 64 rows, two for 65..128, the value loop in
+    trips of 64) against k_attend<2, false> (a workgroup per row and KV head) IN ONE PROCESS through q3tts_k_attend_policy, and both
+    against the oracle: hidden row and logits of the last prompt row, bit for bit (the comparison the kernels' comments cite)."""
+    cfg, eng, om = tiny
+    desc, keep = oracle.make_prompt_desc(np.random.default_rng(n_rows).integers(0, 151643, size=130), spk_emb=_spk(cfg.model.d_embed))
+    pe = np.ascontiguousarray(om.build_prompt(desc)[:n_rows])
+    h_ref, l_ref = om.talker_prefill(pe)
+    try:
+        for prefill in (2, 1):   # 2: k_attend_prefill even for one run; 1: never
+            _attend_policy(0, prefill)
+            h, l = eng.talker_prefill(pe)
+            assert np.array_equal(_bits(h), _bits(h_ref)) and np.array_equal(_bits(l), _bits(l_ref)), prefill
+    finally:
+        _attend_policy(0, 0)
+
+
+def test_decode_attention_kernel_variants_agree(oracle, tiny):
+    """k_attend_gqa2 (four waves per (slot, KV head)) against k_attend<2, true> in one process: greedy ids of two utterances with
+    contexts that cross a key block (60 + frames, 130 + frames) equal each other and the oracle's."""
+    cfg, eng, om = tiny
+    reqs, refs = [], []
+    for nt in (52, 122):
+        desc, keep = oracle.make_prompt_desc(np.random.default_rng(nt).integers(0, 151643, size=nt), spk_emb=_spk(cfg.model.d_embed))
+        pe = om.build_prompt(desc)
+        refs.append(om.generate(pe, temperature=0.0, max_steps=7, min_frames=7)[0])
+        reqs.append(dict(embd=pe, temperature=0.0, max_steps=7, min_frames=7))
+    try:
+        for decode in (1, 0):
+            _attend_policy(decode, 0)
+            for o, r in zip(eng.generate_batch(reqs), refs):
+                assert o.status == 0 and np.array_equal(o.codes, r), decode
+    finally:
+        _attend_policy(0, 0)
+
+
+def test_full_shape_long_prompts_batched_prefill_and_long_decode_context(oracle):
+    """The full 1.7B shape (16 query / 8 KV heads) where round 3's value checks stopped at 70-row contexts:
+    seventeen prompts admitted by one q3tts_generate_batch call — sixteen runs of 1, 63, 64, 65, 127, 128 and ten times 128 rows
+    (1 728 rows: 16 x 8 = 128 (run, KV head) workgroups, so the launcher takes k_attend_prefill by itself, at its longest LDS-resident runs
+    and both key-block counts; the GEMMs run k_bgemm_big at 1 728 rows), then — the group is full — a run of 330 rows alone (the
+    k_attend<2, false> fallback, k_bgemm's 64-row chunks at 330 rows), two greedy frames each: decode attention (k_attend_gqa2) over
+    contexts of 2 .. 332 keys. The oracle replays the 330-row, one 128-row, the 65-row and the 1-row utterance: ids equal. The same batch
+    under the old kernels (k_attend<2, false> everywhere, k_attend<2, true> for decode) gives the same ids for all seventeen; the last
+    prompt row's hidden state and logits of the 65- and 128-row prompts equal the oracle's bit for bit under both prefill kernels."""
+    import time
+    from q3tts import _abi, native
+    cfg = _abi.full_config_py()
+    cfg.max_batch, cfg.n_ctx, cfg.max_steps_cap, cfg.with_vocoder = 18, 2048, 8, 0
+    threads = min(64, os.cpu_count() or 4)
+    eng = native.NativeEngine(cfg)
+    om = oracle.OracleModel(cfg.model, seed=0, n_ctx=512, n_threads=threads)
+    try:
+        lens = [1, 63, 64, 65, 127, 128] + [128] * 10 + [330]
+        assert sum(lens[:16]) == 1728 and sum(lens) > cfg.n_ctx   # the 330-row run does not fit behind the sixteen: a group of its own
+        reqs, pes = [], []
+        for i, n in enumerate(lens):
+            desc, keep = oracle.make_prompt_desc(np.random.default_rng(4000 + i).integers(0, 151643, size=max(n, 11) - 11 + 8), spk_emb=_spk(cfg.model.d_embed))
+            pe = np.ascontiguousarray(om.build_prompt(desc)[-n:] if n >= 11 else om.build_prompt(desc)[:n])
+            assert pe.shape == (n, cfg.model.d_embed)
+            pes.append(pe)
+            reqs.append(dict(embd=pe, temperature=0.0, max_steps=2, min_frames=2))
+        outs = eng.generate_batch(reqs)
+        assert all(o.status == 0 and o.codes.shape == (2, 16) for o in outs)
+        t0 = time.time()
+        for i in (16, 15, 3, 0):
+            ref, _ = om.generate(pes[i], temperature=0.0, max_steps=2, min_frames=2)
+            assert np.array_equal(outs[i].codes, ref), (i, lens[i])
+        t_or = time.time() - t0
+        try:
+            _attend_policy(1, 1)
+            old = eng.generate_batch(reqs)
+            for i, (a, b) in enumerate(zip(outs, old)):
+                assert b.status == 0 and np.array_equal(a.codes, b.codes), (i, lens[i])
+            for i in (3, 15):
+                h_ref, l_ref = om.talker_prefill(pes[i])
+                for prefill in (2, 1):
+                    _attend_policy(0, prefill)
+                    h, l = eng.talker_prefill(pes[i])
+                    assert np.array_equal(_bits(h), _bits(h_ref)) and np.array_equal(_bits(l), _bits(l_ref)), (i, prefill)
+        finally:
+            _attend_policy(0, 0)
+        print(f"full shape, 17 prompts of {lens[0]}..{lens[-1]} rows: ids of 4 replayed utterances equal, old and new attention kernels agree on all 17; oracle {t_or:.0f} s on {threads} threads")
+    finally:
+        eng.close()
+        om.close()
 
 
 def test_allocator_hands_out_memory_with_the_zero_fill_completed():
