@@ -364,6 +364,14 @@ int q3tts_k_bgemm_pick(int32_t B, int32_t K, int32_t N, int32_t epilogue, int32_
 int q3tts_k_bgemm_q8(int32_t device, const uint16_t* xb, int32_t B, int32_t K, const int8_t* q, const uint16_t* d_f16, int32_t N, const float* ssp,
                      int32_t ntiles, int32_t d_norm, float eps, int32_t epilogue, const float* nw_next, float* y, uint16_t* yb, float* ssp_out,
                      uint64_t* keys, int32_t iters, float* mean_kernel_ms);
+/* The same launch in ggml's Q8_0 x Q8_0 arithmetic (W8A8: csrc/q3_bgemm8.hip; q3tts_engine_config.talker_q8_0 = 2): the
+ * ACTIVATIONS are Q8_0 blocks too — aq int8 [B][K], ad their f16 scales as bit patterns [B][K/32] — a block's product is its exact int32
+ * sum times f32(d_w) * f32(d_x). epilogue 0: y = s_r * RAW; 1: y += RAW, then the consumer's operand v = y * nw_next quantised per 32
+ * columns by ggml's rule -> yq int8 [B][N], yd f16 [B][N/32], and ssp_out; 2: h = swiglu(s_r * RAW_gate, s_r * RAW_up) quantised ->
+ * yq [B][N/2], yd [B][N/64]. K % 512 == 0; N % 32 == 0 (1: % 64, 2: % 128). Equals oracle q3o_bgemm_q8a8 bit for bit. */
+int q3tts_k_bgemm_q8a8(int32_t device, const int8_t* aq, const uint16_t* ad, int32_t B, int32_t K, const int8_t* q, const uint16_t* d_f16, int32_t N,
+                       const float* ssp, int32_t ntiles, int32_t d_norm, float eps, int32_t epilogue, const float* nw_next, float* y, int8_t* yq,
+                       uint16_t* yd, float* ssp_out, int32_t iters, float* mean_kernel_ms);
 /* The same GEMM with the epilogue extras only the vocoder uses (nothing in the reference: its vocoder is an ONNX graph, src/models/onnx.rs:342-459):
  * bias[col % bias_n] added to RAW first; epilogue 0: y = RAW + bias; 1: y += col_scale[col] * (RAW + bias), optionally yb = bf16(y);
  * 4: yb = bf16(gelu_erf(RAW + bias)). seg_rows > 0: the f32 rows live in B / seg_rows segments separated by gap_rows rows the kernel

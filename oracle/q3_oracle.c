@@ -489,6 +489,8 @@ void q3o_bgemm_raw_p(const uint16_t* xp, int32_t rows, int32_t K, const uint16_t
 void q3o_bgemm_q8_raw_p(const uint16_t* xp, int32_t rows, int32_t K, const uint16_t* qp, const float* dsc, int32_t N, float* out, int32_t ldo, int32_t threads);
 void q3o_quantize_q8_0(const float* x, int64_t n, int8_t* q, uint16_t* d_f16);
 void q3o_permute_rows_q8(const int8_t* src, int32_t rows, int32_t K, uint16_t* dst);
+void q3o_bgemm_q8a8_raw(const int8_t* qa, const float* da, int32_t rows, int32_t K, const uint16_t* qp, const float* dsc, int32_t N, float* out,
+                        int32_t ldo, int32_t threads);
 float q3o_f16_to_f32(uint16_t h);
 
 typedef struct {
@@ -500,6 +502,7 @@ typedef struct {
     /* Q8_0 mode (q3o_set_talker_q8): the matrices above then hold the block quants as (exact) bf16 in operand order and these the
      * block scales f32(f16 d) [N][K/32]; NULL = bf16 weights */
     float** s_qkv; float** s_o; float** s_g; float** s_u; float** s_d; float* s_head;
+    int a8;  /* 1: the ACTIVATIONS of every GEMM are Q8_0 blocks too (W8A8, ggml's vec_dot_q8_0_q8_0: q3o_bgemm_q8a8_raw); needs s_* */
     float *kc, *vc; int n_ctx; /* [L][Hkv][n_ctx][hd] */
     float *cs, *sn;
 } tfm;
@@ -615,6 +618,17 @@ static void bgemm_rows(const uint16_t* ab, int n, int K, const uint16_t* wp, con
     free(ap);
 }
 
+/* W8A8: f32 activation rows v [n][K] -> ggml Q8_0 blocks -> RAW against a Q8_0 matrix (q3_oracle_bf16.c) */
+static void bgemm_rows_a8(const float* v, int n, int K, const uint16_t* wp, const float* dsc, int N, float* out, int ldo) {
+    int8_t* qa = (int8_t*)malloc((size_t)n * K);
+    uint16_t* d16 = (uint16_t*)malloc((size_t)n * (K / 32) * 2);
+    float* da = (float*)malloc((size_t)n * (K / 32) * 4);
+    for (int r = 0; r < n; ++r) q3o_quantize_q8_0(v + (size_t)r * K, K, qa + (size_t)r * K, d16 + (size_t)r * (K / 32));
+    for (size_t i = 0; i < (size_t)n * (K / 32); ++i) da[i] = q3o_f16_to_f32(d16[i]);
+    q3o_bgemm_q8a8_raw(qa, da, n, K, wp, dsc, N, out, ldo, g_threads > 0 ? g_threads : 1);
+    free(qa); free(d16); free(da);
+}
+
 /* One transformer over n rows (positions pos0.. of one sequence), canonical arithmetic. x [n][d] is the f32 residual stream,
  * updated in place. On entry xb / ssp are the norm inputs of x for attn_norm[0] (q3o_norm_inputs); on exit for out_norm.
  * Device: run_layers in q3_engine.hip — bgemm(QKV) -> k_attend -> bgemm(O, residual + norm outputs) -> bgemm(gate/up, SwiGLU)
@@ -628,28 +642,49 @@ static void tfm_layers(tfm* t, float* x, uint16_t* xb, float* ssp, int n, int po
     float* u = malloc((size_t)n * F * 4);
     float* y = malloc((size_t)n * d * 4);
     float* sc = malloc((size_t)n * 4);
+    float* vf = t->a8 ? malloc((size_t)n * d * 4) : NULL;
     for (int l = 0; l < t->L; ++l) {
         for (int r = 0; r < n; ++r) sc[r] = q3o_row_scale(ssp + (size_t)r * nt, nt, d, eps);
+        if (t->a8) {  /* the quantiser sees v = x * nw in f32 (what the producer multiplies before it rounds to bf16 in the other modes) */
+            const float* nw = t->attn_norm[l];
+            for (int r = 0; r < n; ++r) for (int k = 0; k < d; ++k) vf[(size_t)r * d + k] = x[(size_t)r * d + k] * nw[k];
+            bgemm_rows_a8(vf, n, d, t->wqkv[l], t->s_qkv[l], nqkv, qkv, nqkv);
+        } else
         bgemm_rows(xb, n, d, t->wqkv[l], t->s_qkv ? t->s_qkv[l] : NULL, nqkv, qkv, nqkv);
         scale_rows(qkv, n, nqkv, nqkv, sc);
         size_t co = (size_t)l * t->Hkv * t->n_ctx * t->hd;
         attn_rows(qkv, n, pos0, t->Hq, t->Hkv, t->hd, t->qn[l], t->kn[l], eps, t->cs, t->sn, t->kc + co, t->vc + co, t->n_ctx, att);
+        if (t->a8) bgemm_rows_a8(att, n, nq, t->wo[l], t->s_o[l], d, y, d);
+        else {
         for (size_t i = 0; i < (size_t)n * nq; ++i) ab[i] = q3o_bf16(att[i]);
         bgemm_rows(ab, n, nq, t->wo[l], t->s_o ? t->s_o[l] : NULL, d, y, d);
+        }
         for (size_t i = 0; i < (size_t)n * d; ++i) x[i] = x[i] + y[i];
         for (int r = 0; r < n; ++r) q3o_norm_inputs(x + (size_t)r * d, d, t->ffn_norm[l], xb + (size_t)r * d, ssp + (size_t)r * nt);
         for (int r = 0; r < n; ++r) sc[r] = q3o_row_scale(ssp + (size_t)r * nt, nt, d, eps);
+        if (t->a8) {
+            const float* nw = t->ffn_norm[l];
+            for (int r = 0; r < n; ++r) for (int k = 0; k < d; ++k) vf[(size_t)r * d + k] = x[(size_t)r * d + k] * nw[k];
+            bgemm_rows_a8(vf, n, d, t->wg[l], t->s_g[l], F, g, F);
+            bgemm_rows_a8(vf, n, d, t->wu[l], t->s_u[l], F, u, F);
+        } else {
         bgemm_rows(xb, n, d, t->wg[l], t->s_g ? t->s_g[l] : NULL, F, g, F);
         bgemm_rows(xb, n, d, t->wu[l], t->s_u ? t->s_u[l] : NULL, F, u, F);
+        }
         scale_rows(g, n, F, F, sc);
         scale_rows(u, n, F, F, sc);
+        if (t->a8) {
+            for (size_t i = 0; i < (size_t)n * F; ++i) g[i] = swiglu(g[i], u[i]);   /* h stays f32: the quantiser's input */
+            bgemm_rows_a8(g, n, F, t->wd[l], t->s_d[l], d, y, d);
+        } else {
         for (size_t i = 0; i < (size_t)n * F; ++i) ab[i] = q3o_bf16(swiglu(g[i], u[i]));
         bgemm_rows(ab, n, F, t->wd[l], t->s_d ? t->s_d[l] : NULL, d, y, d);
+        }
         for (size_t i = 0; i < (size_t)n * d; ++i) x[i] = x[i] + y[i];
         const float* nxt = l + 1 < t->L ? t->attn_norm[l + 1] : t->out_norm;
         for (int r = 0; r < n; ++r) q3o_norm_inputs(x + (size_t)r * d, d, nxt, xb + (size_t)r * d, ssp + (size_t)r * nt);
     }
-    free(qkv); free(att); free(ab); free(g); free(u); free(y); free(sc);
+    free(qkv); free(att); free(ab); free(g); free(u); free(y); free(sc); free(vf);
 }
 
 /* ---- plain f32 arithmetic of the same structure (arith == 1): what the family code computes up to summation order; used by
@@ -758,6 +793,8 @@ void q3o_set_arith(q3o_model* m, int32_t arith) { m->arith = arith; }
 /* The Talker's matrices (and lm_head) as ggml Q8_0 blocks, multiplied in the canonical Q8 order of q3_oracle_bf16.c — what the device
  * computes with q3tts_engine_config.talker_q8_0 = 1. One-way (the bf16 weights are replaced). */
 void q3o_set_talker_q8(q3o_model* m) { tfm_to_q8(&m->T); }
+/* ... and every GEMM's activations as Q8_0 blocks as well: W8A8, what llama.cpp computes on a gguf_q8_0 model (talker_q8_0 = 2) */
+void q3o_set_talker_q8a8(q3o_model* m) { tfm_to_q8(&m->T); m->T.a8 = 1; }
 void q3o_set_threads(int32_t n) { g_threads = n > 0 ? n : 1; }  /* OpenMP threads of the GEMMs (bench.py: the 4-thread and all-cores legs) */
 /* natural-order f32 copies of the synthetic tensors, for loading the same model into the family code (tests) */
 const float* q3o_norm_weight(const q3o_model* m, int32_t talker, int32_t layer, int32_t which) {
@@ -891,6 +928,12 @@ static void head_row(const q3o_model* m, tfm* t, const float* xrow, const uint16
     }
     if (hidden_out) q3o_rmsnorm(xrow, t->d, t->out_norm, eps, hidden_out); /* standalone canonical RMSNorm (§4.2): the projection's input */
     const float sc = q3o_row_scale(ssp, t->d / 16, t->d, eps);
+    if (t->a8) {
+        float* v = malloc((size_t)t->d * 4);
+        for (int k = 0; k < t->d; ++k) v[k] = xrow[k] * t->out_norm[k];
+        bgemm_rows_a8(v, 1, t->d, t->head + (size_t)col0 * t->d, t->s_head + (size_t)col0 * (t->d / 32), ncols, logits, ncols);
+        free(v);
+    } else
     bgemm_rows(xb, 1, t->d, t->head + (size_t)col0 * t->d, t->s_head ? t->s_head + (size_t)col0 * (t->d / 32) : NULL, ncols, logits, ncols);
     scale_rows(logits, 1, ncols, ncols, &sc);
 }

@@ -105,6 +105,10 @@ void q3o_bgemm(const uint16_t* xb, int32_t B, int32_t K, const uint16_t* w, int3
 void q3o_project_rows(const float* w, const float* bias, int32_t n_in, int32_t n_out, const float* x, int32_t rows, float* y);
 /* 0: canonical bf16-MFMA order (default, what the device computes); 1: plain f32 of the same structure (family pinning) */
 void q3o_set_arith(q3o_model* m, int32_t arith);
+void q3o_set_talker_q8a8(q3o_model* m);  /* ... and the activations as Q8_0 blocks too: ggml's W8A8 (q3tts_engine_config.talker_q8_0 = 2; q3_oracle_bf16.c) */
+void q3o_quantize_rows_q8(const float* v, int32_t rows, int32_t K, int8_t* q, uint16_t* d_f16);
+void q3o_bgemm_q8a8(const int8_t* aq, const uint16_t* ad, int32_t B, int32_t K, const int8_t* q, const uint16_t* d_f16, int32_t N, const float* ssp,
+                    int32_t ntiles, int32_t d_norm, float eps, int32_t epi, const float* nw_next, float* y, int8_t* yq, uint16_t* yd, float* ssp_out);
 void q3o_set_talker_q8(q3o_model* m);  /* the Talker's matrices + lm_head as ggml Q8_0 blocks, canonical Q8 order (q3tts_engine_config.talker_q8_0) */
 void q3o_quantize_q8_0(const float* x, int64_t n, int8_t* q, uint16_t* d_f16);  /* ggml's reference quantiser */
 float q3o_f16_to_f32(uint16_t h);

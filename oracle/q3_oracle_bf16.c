@@ -284,6 +284,56 @@ void q3o_bgemm_q8_raw_p(const uint16_t* xp, int32_t rows, int32_t K, const uint1
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* W8A8 (q3tts_engine_config.talker_q8_0 = 2): Q8_0 weights against Q8_0 ACTIVATIONS, the arithmetic of ggml's             */
+/* vec_dot_q8_0_q8_0 — what llama.cpp computes for the reference's default gguf_q8_0 directory (src/tts/engine.rs:91-95): the f32          */
+/* activation row is quantised per block of 32 by ggml's rule (q3o_quantize_q8_0: d = amax / 127, q = roundf(x / d), d kept as f16), a      */
+/* block's product is the EXACT int32 sum of its 32 int8 products times (f32(d_w) * f32(d_x)) — one f32 product of the scales, one of the   */
+/* (exactly converted) integer, one f32 add, no fused multiply-add: `sumf += sumi * (dx * dy)` as ggml's scalar code spells it — blocks     */
+/* ascending inside a K slice from t = +0, the 8 slices added in order as everywhere: RAW = ((t_0 + t_1) + ...) + t_7.                      */
+/* Stated difference to ggml: the split RMSNorm stays — the quantiser sees v = x * nw and the row scale s_r multiplies RAW afterwards        */
+/* (ggml quantises s_r * x * nw; s_r > 0 commutes through amax / 127 and the rounding up to f32 rounding).                                  */
+/* ------------------------------------------------------------------------------------------ */
+/* qa int8 [rows][K] and da = f32(f16 d) [rows][K/32] in natural order; qp = the weight quants as permuted bf16-coded rows (q3o_permute_rows_q8) */
+void q3o_bgemm_q8a8_raw(const int8_t* qa, const float* da, int32_t rows, int32_t K, const uint16_t* qp, const float* dsc, int32_t N, float* out,
+                        int32_t ldo, int32_t threads) {
+    const int per = K / 256, kb = K / 32;
+    /* the weights back in natural order as int8 (the integer sum does not depend on the order, the loop below is then a plain dot product) */
+    int8_t* wn = (int8_t*)malloc((size_t)N * K);
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+    for (int n = 0; n < N; ++n)
+        for (int k0 = 0; k0 < K; k0 += 32)
+            for (int p = 0; p < 32; ++p) wn[(size_t)n * K + k0 + kperm(p)] = (int8_t)u2f((uint32_t)qp[(size_t)n * K + k0 + p] << 16);
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+    for (int n = 0; n < N; ++n) {
+        const int8_t* w = wn + (size_t)n * K;
+        const float* dn = dsc + (size_t)n * kb;
+        for (int r = 0; r < rows; ++r) {
+            const int8_t* x = qa + (size_t)r * K;
+            const float* dx = da + (size_t)r * kb;
+            float tot = 0.0f;
+            for (int sl = 0; sl < 8; ++sl) {
+                float acc = 0.0f;
+                for (int st = 0; st < per; ++st) {
+                    const int b = sl * per + st;
+                    int32_t sumi = 0;
+                    for (int k = 0; k < 32; ++k) sumi += (int32_t)w[b * 32 + k] * (int32_t)x[b * 32 + k];
+                    const float sc = dn[b] * dx[b];
+                    const float pr = (float)sumi * sc;
+                    acc = acc + pr;
+                }
+                tot = sl == 0 ? acc : tot + acc;
+            }
+            out[(size_t)r * ldo + n] = tot;
+        }
+    }
+    free(wn);
+}
+/* f32 rows -> their Q8_0 blocks: q int8 [rows][K], d as f16 bit patterns [rows][K/32] (natural order) */
+void q3o_quantize_rows_q8(const float* v, int32_t rows, int32_t K, int8_t* q, uint16_t* d_f16) {
+    for (int r = 0; r < rows; ++r) q3o_quantize_q8_0(v + (size_t)r * K, K, q + (size_t)r * K, d_f16 + (size_t)r * (K / 32));
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* RMSNorm split between producer and consumer                                */
 /* ------------------------------------------------------------------------------------------ */
 /* sum of squares of 16 consecutive columns: squares, then the 16-lane butterfly v += v[lane ^ m], m = 1, 2, 4, 8 */
@@ -360,6 +410,41 @@ void q3o_bgemm_q8(const uint16_t* xb, int32_t B, int32_t K, const int8_t* q, con
     q3o_bgemm_q8_raw_p(xp, B, K, qp, dsc, N, raw, N, 8);
     bgemm_epilogues(raw, B, N, ssp, ntiles, d_norm, eps, epi, nw_next, y, yb, ssp_out, keys);
     free(raw); free(dsc); free(qp); free(xp);
+}
+/* The W8A8 launch (q3tts_k_bgemm_q8a8): activations already as Q8_0 blocks (aq int8 [B][K], ad f16 bits [B][K/32]), weights q / d as in
+ * q3o_bgemm_q8. Epilogues: 0: y = s * RAW; 1: y += RAW, then the consumer's operand: v = y * nw_next quantised per 32 columns -> yq int8 [B][N],
+ * yd f16 [B][N/32], and ssp_out; 2: h = swiglu(s * RAW_gate, s * RAW_up) (f32) quantised per 32 columns -> yq [B][N/2], yd [B][N/64]. */
+void q3o_bgemm_q8a8(const int8_t* aq, const uint16_t* ad, int32_t B, int32_t K, const int8_t* q, const uint16_t* d_f16, int32_t N, const float* ssp,
+                    int32_t ntiles, int32_t d_norm, float eps, int32_t epi, const float* nw_next, float* y, int8_t* yq, uint16_t* yd, float* ssp_out) {
+    uint16_t* qp = (uint16_t*)malloc((size_t)N * K * 2);
+    float* dsc = (float*)malloc((size_t)N * (K / 32) * 4);
+    float* da = (float*)malloc((size_t)B * (K / 32) * 4);
+    float* raw = (float*)malloc((size_t)B * N * 4);
+    q3o_permute_rows_q8(q, N, K, qp);
+    for (size_t i = 0; i < (size_t)N * (K / 32); ++i) dsc[i] = q3o_f16_to_f32(d_f16[i]);
+    for (size_t i = 0; i < (size_t)B * (K / 32); ++i) da[i] = q3o_f16_to_f32(ad[i]);
+    q3o_bgemm_q8a8_raw(aq, da, B, K, qp, dsc, N, raw, N, 8);
+    for (int b = 0; b < B; ++b) {
+        const float s = ssp ? q3o_row_scale(ssp + (size_t)b * ntiles, ntiles, d_norm, eps) : 1.0f;
+        float* r = raw + (size_t)b * N;
+        if (epi == 0) {
+            for (int n = 0; n < N; ++n) y[(size_t)b * N + n] = ssp ? s * r[n] : r[n];
+        } else if (epi == 1) {
+            float* xr = y + (size_t)b * N;
+            float* v = (float*)malloc((size_t)N * 4);
+            for (int n = 0; n < N; ++n) { xr[n] = xr[n] + r[n]; v[n] = xr[n] * nw_next[n]; }
+            q3o_quantize_q8_0(v, N, yq + (size_t)b * N, yd + (size_t)b * (N / 32));
+            for (int t = 0; t < N / 16; ++t) ssp_out[(size_t)b * (N / 16) + t] = q3o_tss16(xr + 16 * t);
+            free(v);
+        } else {
+            const int F = N / 2;
+            float* h = (float*)malloc((size_t)F * 4);
+            for (int j = 0; j < F; ++j) h[j] = swiglu(s * r[j], s * r[F + j]);
+            q3o_quantize_q8_0(h, F, yq + (size_t)b * F, yd + (size_t)b * (F / 32));
+            free(h);
+        }
+    }
+    free(raw); free(da); free(dsc); free(qp);
 }
 static void bgemm_epilogues(float* raw, int32_t B, int32_t N, const float* ssp, int32_t ntiles, int32_t d_norm, float eps, int32_t epi,
                             const float* nw_next, float* y, uint16_t* yb, float* ssp_out, uint64_t* keys) {

@@ -625,6 +625,20 @@ __global__ __launch_bounds__(256) void k_norm_inputs(const float* x, int ldx, in
     for (int i = threadIdx.x; i < d; i += 256)
         q3_norm_out(x[(size_t)row * ldx + i], nw[i], xb + q3_atile_off(xb_row0 + row, i, d >> 5), ssp + (size_t)row * ld_ssp + (i >> 4), (i & 15) == 0);
 }
+// the W8A8 consumer's form: v = x * nw quantised per 32 columns by ggml's rule (q3_q8_out32: a half wave = one block), ssp as above
+__global__ __launch_bounds__(256) void k_norm_inputs_q8(const float* x, int ldx, int d, const float* nw, int8_t* xq, uint16_t* xscale, int rt16, float* ssp, int ld_ssp) {
+    const int row = blockIdx.x;
+    for (int i = threadIdx.x; i < d; i += 256) {
+        const float v = x[(size_t)row * ldx + i];
+        q3_q8_out32(v * nw[i], row, i, d >> 6, rt16, xq, xscale);
+        float sq = v * v;
+        sq = sq + __shfl_xor(sq, 1); sq = sq + __shfl_xor(sq, 2); sq = sq + __shfl_xor(sq, 4); sq = sq + __shfl_xor(sq, 8);
+        if ((i & 15) == 0) ssp[(size_t)row * ld_ssp + (i >> 4)] = sq;
+    }
+}
+void q3_launch_norm_inputs_q8(const float* x, int ldx, int rows, int d, const float* nw, int8_t* xq, uint16_t* xscale, int rt16, float* ssp, int ld_ssp, hipStream_t s) {
+    hipLaunchKernelGGL(k_norm_inputs_q8, dim3(rows), dim3(256), 0, s, x, ldx, d, nw, xq, xscale, rt16, ssp, ld_ssp);
+}
 // rows [0, rows) of x -> A-tiled rows [xb_row0, xb_row0 + rows) of xb, ssp rows [0, rows)
 void q3_launch_norm_inputs(const float* x, int ldx, int rows, int d, const float* nw, uint16_t* xb, int xb_row0, float* ssp, int ld_ssp, hipStream_t s) {
     hipLaunchKernelGGL(k_norm_inputs, dim3(rows), dim3(256), 0, s, x, ldx, d, nw, xb, xb_row0, ssp, ld_ssp);

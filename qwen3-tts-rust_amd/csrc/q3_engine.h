@@ -20,6 +20,7 @@ struct Q3Tfm {
     // Q8_0 mode (cfg.talker_q8_0, the Talker only): the matrices above hold ggml block quants in the tiled Q8 layout (q3_kernels.h) and
     // these the f16 block scales [N][K/32]; empty / null = bf16 weights
     std::vector<uint16_t*> sqkv, so, sgu, sd; uint16_t* shead = nullptr; bool q8 = false;
+    bool a8 = false;  // cfg.talker_q8_0 = 2: the GEMMs' ACTIVATIONS are Q8_0 blocks as well (W8A8, q3_bgemm8.hip): every operand buffer then holds int8 quants + f16 block scales
     uint16_t *kc = nullptr, *vc = nullptr;  // [L][slots][Hkv][n_ctx*hd]
     size_t layer_stride = 0;
     int n_ctx = 0, n_slots = 0;
@@ -30,6 +31,7 @@ struct Q3Tfm {
 struct Q3Scratch {
     float* qkv = nullptr;                   // [rows][nqkv] f32 (the attention kernel's input)
     uint16_t *att = nullptr, *h = nullptr;  // bf16 rows: attention output [rows][nq], SwiGLU output [rows][F] (GEMM operands)
+    uint16_t *asc_att = nullptr, *asc_h = nullptr; int rt16 = 0;  // W8A8: the f16 block scales of att / h (q3_q8_scale_idx), row tiles of the buffers
     int rows = 0;
 };
 
@@ -41,6 +43,7 @@ struct Q3Lane {
     // norm inputs of the residual rows: bf16(x * nw) and the per-tile sums of squares, Talker [nb] / Predictor [2 nb]
     uint16_t *xbT = nullptr, *xbP = nullptr;
     float *sspT = nullptr, *sspP = nullptr;
+    uint16_t* ascT = nullptr; int rt16T = 0;   // W8A8: block scales of xbT
     unsigned long long* keys = nullptr;
     int *row_pos_t = nullptr, *slot_id = nullptr, *posA = nullptr, *slotA = nullptr, *pos_q = nullptr, *perm = nullptr;
     Q3Scratch sc;
@@ -79,6 +82,7 @@ struct q3tts_engine {
     // prefill
     float* xp = nullptr;                  // [n_ctx][d]
     uint16_t* xbp = nullptr; float* sspp = nullptr;  // norm inputs of the prefill rows
+    uint16_t* ascp = nullptr; int rt16p = 0;         // W8A8: block scales of xbp
     int *pf_pos = nullptr, *pf_slot = nullptr;
     int* pf_seg = nullptr;              // the prefill launch's rows as per-slot runs {first row, n, slot} (device, 3 ints each): admit_group hands it to run_layers
     Q3PromptRow* prow_dev = nullptr; int prow_cap = 0;

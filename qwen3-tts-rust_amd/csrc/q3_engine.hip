@@ -68,7 +68,9 @@ static int validate(const q3tts_engine_config& c, std::string& why) {
     REQ(c.n_ctx >= 64 && c.n_ctx % 64 == 0 && c.n_ctx <= 8192);
     REQ(c.max_steps_cap >= 1 && c.max_steps_cap < c.n_ctx);
     REQ(m.n_codebooks + 1 <= 64);
+    REQ(c.talker_q8_0 >= 0 && c.talker_q8_0 <= 2);
     if (c.talker_q8_0) REQ(m.t_d_model % 512 == 0 && m.t_d_ffn % 512 == 0 && (m.t_n_head * m.t_head_dim) % 512 == 0);  // Q8_0: an even number of 32-blocks per K slice
+    if (c.talker_q8_0 == 2) REQ(m.t_vocab % 32 == 0 && ((m.t_n_head + 2 * m.t_n_kv_head) * m.t_head_dim) % 32 == 0 && m.t_d_ffn % 64 == 0);  // W8A8: whole 32-column blocks per workgroup
 #undef REQ
     return Q3TTS_OK;
 }
@@ -178,9 +180,10 @@ struct GgSrc {
 };
 
 static int init_tfm(q3tts_engine* e, Q3Tfm& t, int grp, int L, int d, int Hq, int Hkv, int hd, int F, int head_n, float theta,
-                    const int* sections, int n_ctx, int n_slots, GgSrc* gg = nullptr, bool q8 = false) {
+                    const int* sections, int n_ctx, int n_slots, GgSrc* gg = nullptr, int q8mode = 0) {
+    const bool q8 = q8mode != 0;
     t.L = L; t.d = d; t.Hq = Hq; t.Hkv = Hkv; t.hd = hd; t.F = F; t.nq = Hq * hd; t.nkv = Hkv * hd; t.nqkv = t.nq + 2 * t.nkv;
-    t.head_n = head_n; t.n_ctx = n_ctx; t.n_slots = n_slots; t.q8 = q8;
+    t.head_n = head_n; t.n_ctx = n_ctx; t.n_slots = n_slots; t.q8 = q8; t.a8 = q8mode == 2;
     const uint64_t seed = e->cfg.synth_seed;
     const float ms = 0.02f / Q3_IH4_STD, ns = 0.05f / Q3_IH4_STD;
     hipStream_t s = e->stream;
@@ -286,6 +289,8 @@ static int alloc_scratch(q3tts_engine* e, Q3Scratch& sc, int rows, int nqkv, int
     sc.rows = rows;
     const size_t r16 = ((size_t)rows + 15) & ~(size_t)15;  // A-tiled buffers hold whole 16-row tiles
     TRY(dalloc(e, &sc.qkv, (size_t)rows * nqkv)); TRY(dalloc(e, &sc.att, r16 * nq)); TRY(dalloc(e, &sc.h, r16 * F));
+    sc.rt16 = (int)(r16 / 16);
+    if (e->T.a8) { TRY(dalloc(e, &sc.asc_att, r16 * (nq / 32))); TRY(dalloc(e, &sc.asc_h, r16 * (F / 32))); }  // W8A8: block scales of both operands
     return Q3TTS_OK;
 }
 
@@ -296,7 +301,10 @@ static int alloc_scratch(q3tts_engine* e, Q3Scratch& sc, int rows, int nqkv, int
 // Returns the number of launches the GEMM launcher refused (a shape it cannot run: stale activations would follow silently).
 static int run_layers(q3tts_engine* e, Q3Tfm& t, float* x, uint16_t* xb, float* ssp, int rows, const int* row_pos, const int* row_slot, Q3Scratch& sc,
                        hipStream_t s, bool one_row_per_slot = false, hipEvent_t* probe = nullptr, int slot_mod = 0, int pos_const = 0,
-                       const int* seg = nullptr, int n_seg = 0, int seg_max_n = 0) {
+                       const int* seg = nullptr, int n_seg = 0, int seg_max_n = 0, uint16_t* xscale = nullptr, int x_rt16 = 0) {
+    // W8A8 (t.a8: the Talker with talker_q8_0 = 2): xb / sc.att / sc.h hold Q8_0 blocks (int8 quants + the f16 scales xscale / sc.asc_att /
+    // sc.asc_h) and every GEMM runs q3_launch_bgemm8: ggml's Q8_0 x Q8_0 arithmetic
+    auto gemm = [&](Q3BGemm& g) { return t.a8 ? q3_launch_bgemm8(g, s) : q3_launch_bgemm(g, s); };
     const float eps = e->cfg.model.rms_eps;
     int bad = 0;
     const int nt = t.d / 16;
@@ -306,9 +314,10 @@ static int run_layers(q3tts_engine* e, Q3Tfm& t, float* x, uint16_t* xb, float* 
         g.w_once = once;
         g.a = xb; g.B = rows; g.w = t.wqkv[l]; g.wscale = t.q8 ? t.sqkv[l] : nullptr; g.K = t.d; g.N = t.nqkv; g.ssp = ssp; g.ld_ssp = nt; g.ntiles = nt; g.d_norm = t.d; g.eps = eps;
         g.epi = Q3_EPI_STORE; g.y = sc.qkv; g.ldy = t.nqkv;
+        if (t.a8) { g.ascale = xscale; g.a_rt16 = x_rt16; }
         const int pk = (probe && l == 0) ? e->probe_kind : -1;  // which launch of block 0 the probe events bracket (q3tts_k_probe)
         if (pk == 1) hipEventRecord(probe[0], s);
-        bad += q3_launch_bgemm(g, s) != 0;
+        bad += gemm(g) != 0;
         if (pk == 1) hipEventRecord(probe[1], s);
         Q3QkPrep qp{}; qp.qkv = sc.qkv; qp.ld = t.nqkv; qp.rows = rows; qp.Hq = t.Hq; qp.Hkv = t.Hkv; qp.hd = t.hd;
         qp.qnw = t.qn[l]; qp.knw = t.kn[l]; qp.eps = eps; qp.cs = t.cs; qp.sn = t.sn;
@@ -321,24 +330,28 @@ static int run_layers(q3tts_engine* e, Q3Tfm& t, float* x, uint16_t* xb, float* 
         Q3Attend at{}; at.qkv = sc.qkv; at.ld = t.nqkv; at.rows = rows; at.out = (float*)sc.att; at.ldo = t.nq; at.Hq = t.Hq; at.Hkv = t.Hkv; at.hd = t.hd;
         at.kc = qp.kc; at.vc = qp.vc; at.n_ctx = t.n_ctx; at.row_pos = row_pos; at.row_slot = row_slot;
         at.fused = pair ? 2 : (fused ? 1 : 0); at.prep = qp; at.out_bf16 = 1; at.slot_mod = slot_mod; at.pos_const = pos_const;
+        if (t.a8) { at.out_bf16 = 2; at.out_scale = sc.asc_att; at.out_rt16 = sc.rt16; }
         if (!fused && !pair && n_seg > 0) { at.seg = seg; at.n_seg = n_seg; at.seg_max_n = seg_max_n; }  // prefill of whole prompts (admit_group): the launch's rows as per-slot runs
         if (pk == 2) hipEventRecord(probe[0], s);
         q3_launch_attend(at, s);
         if (pk == 2) hipEventRecord(probe[1], s);
         g = Q3BGemm{}; g.w_once = once; g.a = sc.att; g.B = rows; g.w = t.wo[l]; g.wscale = t.q8 ? t.so[l] : nullptr; g.K = t.nq; g.N = t.d; g.epi = Q3_EPI_RESID; g.y = x; g.ldy = t.d;
         g.yb = xb; g.nw_next = t.ffn_norm[l]; g.ssp_out = ssp; g.ld_ssp_out = nt;
+        if (t.a8) { g.ascale = sc.asc_att; g.a_rt16 = sc.rt16; g.yscale = xscale; g.y_rt16 = x_rt16; }
         if (pk == 3) hipEventRecord(probe[0], s);
-        bad += q3_launch_bgemm(g, s) != 0;
+        bad += gemm(g) != 0;
         if (pk == 3) hipEventRecord(probe[1], s);
         g = Q3BGemm{}; g.w_once = once; g.a = xb; g.B = rows; g.w = t.wgu[l]; g.wscale = t.q8 ? t.sgu[l] : nullptr; g.K = t.d; g.N = 2 * t.F; g.ssp = ssp; g.ld_ssp = nt; g.ntiles = nt; g.d_norm = t.d;
         g.eps = eps; g.epi = Q3_EPI_SWIGLU; g.yb = sc.h;
+        if (t.a8) { g.ascale = xscale; g.a_rt16 = x_rt16; g.yscale = sc.asc_h; g.y_rt16 = sc.rt16; }
         if (pk == 0) hipEventRecord(probe[0], s);
-        bad += q3_launch_bgemm(g, s) != 0;
+        bad += gemm(g) != 0;
         if (pk == 0) hipEventRecord(probe[1], s);
         g = Q3BGemm{}; g.w_once = once; g.a = sc.h; g.B = rows; g.w = t.wd[l]; g.wscale = t.q8 ? t.sd[l] : nullptr; g.K = t.F; g.N = t.d; g.epi = Q3_EPI_RESID; g.y = x; g.ldy = t.d;
         g.yb = xb; g.nw_next = l + 1 < t.L ? t.attn_norm[l + 1] : t.out_norm; g.ssp_out = ssp; g.ld_ssp_out = nt;
+        if (t.a8) { g.ascale = sc.asc_h; g.a_rt16 = sc.rt16; g.yscale = xscale; g.y_rt16 = x_rt16; }
         if (pk == 4) hipEventRecord(probe[0], s);
-        bad += q3_launch_bgemm(g, s) != 0;
+        bad += gemm(g) != 0;
         if (pk == 4) hipEventRecord(probe[1], s);
     }
     return bad;
@@ -372,6 +385,7 @@ static int record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
         pn.tts_pad = e->tts_pad; pn.xT = L.xT; pn.row_pos_t = L.row_pos_t; pn.pproj_q = e->pproj[q]; pn.proj_b = e->proj_b; pn.dp = dp; pn.px = L.px;
         const bool last = q == ncb - 1;
         pn.nw = last ? e->T.attn_norm[0] : e->P.attn_norm[0]; pn.xb = last ? L.xbT : L.xbP; pn.ssp = last ? L.sspT : L.sspP;
+        if (last && e->T.a8) { pn.xscale = L.ascT; pn.x_rt16 = L.rt16T; }  // W8A8 Talker: its first operand as Q8_0 blocks
         q3_launch_pred_next(pn, s);
     };
     for (int q = 0; q < ncb - 1; ++q) {  // pass q produces code_{q+1}
@@ -391,11 +405,12 @@ static int record_frame(q3tts_engine* e, Q3Lane& L, hipStream_t s, int B) {
     pred_next(ncb - 1);
     hipEvent_t* pt = nullptr;  // probe mode 2: the Talker's layer-0 gate/up GEMM (the largest GEMM of the frame step)
     if (e->probe == 2 && B == L.nb && e->probe_i + 2 <= 8) { pt = &e->probe_ev[e->probe_i]; e->probe_i += 2; }
-    bad += run_layers(e, e->T, L.xT, L.xbT, L.sspT, B, L.row_pos_t, L.slot_id, L.sc, s, true, pt);
+    bad += run_layers(e, e->T, L.xT, L.xbT, L.sspT, B, L.row_pos_t, L.slot_id, L.sc, s, true, pt, 0, 0, nullptr, 0, 0, L.ascT, L.rt16T);
     Q3BGemm g{}; g.w_once = 1; g.a = L.xbT; g.B = B; g.w = e->T.head; g.wscale = e->T.q8 ? e->T.shead : nullptr; g.K = m.t_d_model; g.N = m.t_vocab;
     g.ssp = L.sspT; g.ld_ssp = m.t_d_model / 16; g.ntiles = m.t_d_model / 16; g.d_norm = m.t_d_model; g.eps = eps;
     g.epi = Q3_EPI_STORE; g.y = L.logits; g.ldy = m.t_vocab;
-    bad += q3_launch_bgemm(g, s) != 0;
+    if (e->T.a8) { g.ascale = L.ascT; g.a_rt16 = L.rt16T; bad += q3_launch_bgemm8(g, s) != 0; }
+    else bad += q3_launch_bgemm(g, s) != 0;
     return bad;
 }
 
@@ -518,7 +533,7 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
         if (gt.open(wdir + "/qwen3_tts_talker.gguf", er) || gp.open(wdir + "/qwen3_tts_predictor.gguf", er)) { q3_set_err(e, Q3TTS_ERR_INVALID, er); return fail(Q3TTS_ERR_INVALID); }
     }
     TRYC(init_tfm(e, e->T, Q3G_TALKER, m.t_n_layer, m.t_d_model, m.t_n_head, m.t_n_kv_head, m.t_head_dim, m.t_d_ffn, m.t_vocab,
-                  m.t_rope_theta, m.t_mrope_sections, cfg->n_ctx, B, wdir.empty() ? nullptr : &st, cfg->talker_q8_0 != 0));
+                  m.t_rope_theta, m.t_mrope_sections, cfg->n_ctx, B, wdir.empty() ? nullptr : &st, cfg->talker_q8_0));
     TRYC(init_tfm(e, e->P, Q3G_PRED, m.p_n_layer, m.p_d_model, m.p_n_head, m.p_n_kv_head, m.p_head_dim, m.p_d_ffn,
                   (m.n_codebooks - 1) * m.codebook_size, m.p_rope_theta, nullptr, 64, B, wdir.empty() ? nullptr : &sp));
     // assets (F32 tables like qwen3_assets.gguf: src/assets_manager.rs:212-241; values bf16-representable)
@@ -575,6 +590,8 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
         TRYC(dalloc(e, &L.px, (size_t)2 * nb * m.p_d_model)); TRYC(dalloc(e, &L.keys, (size_t)nb * (m.codebook_size / 16)));
         const size_t nb16 = ((size_t)nb + 15) & ~(size_t)15, nb2_16 = ((size_t)2 * nb + 15) & ~(size_t)15;  // A-tiled buffers hold whole 16-row tiles
         TRYC(dalloc(e, &L.xbT, nb16 * m.t_d_model)); TRYC(dalloc(e, &L.sspT, (size_t)nb * (m.t_d_model / 16)));
+        L.rt16T = (int)(nb16 / 16);
+        if (e->T.a8) TRYC(dalloc(e, &L.ascT, nb16 * (m.t_d_model / 32)));
         TRYC(dalloc(e, &L.xbP, nb2_16 * m.p_d_model)); TRYC(dalloc(e, &L.sspP, (size_t)2 * nb * (m.p_d_model / 16)));
         TRYC(dalloc(e, &L.row_pos_t, (size_t)nb)); TRYC(dalloc(e, &L.slot_id, (size_t)nb)); TRYC(dalloc(e, &L.perm, (size_t)nb));
         TRYC(dalloc(e, &L.posA, (size_t)2 * nb)); TRYC(dalloc(e, &L.slotA, (size_t)2 * nb)); TRYC(dalloc(e, &L.pos_q, (size_t)m.n_codebooks * nb));
@@ -600,6 +617,8 @@ extern "C" int q3tts_engine_create(const q3tts_engine_config* cfg, q3tts_engine*
     TRYC(alloc_scratch(e, e->sc_pre, cfg->n_ctx, e->T.nqkv, e->T.nq, e->T.F, m.t_d_model));
     TRYC(dalloc(e, &e->xp, (size_t)cfg->n_ctx * m.t_d_model));
     TRYC(dalloc(e, &e->xbp, (((size_t)cfg->n_ctx + 15) & ~(size_t)15) * m.t_d_model)); TRYC(dalloc(e, &e->sspp, (size_t)cfg->n_ctx * (m.t_d_model / 16)));
+    e->rt16p = (cfg->n_ctx + 15) / 16;
+    if (e->T.a8) TRYC(dalloc(e, &e->ascp, (size_t)e->rt16p * 16 * (m.t_d_model / 32)));
     TRYC(dalloc(e, &e->pf_pos, (size_t)cfg->n_ctx)); TRYC(dalloc(e, &e->pf_slot, (size_t)cfg->n_ctx)); TRYC(dalloc(e, &e->pf_seg, (size_t)3 * cfg->max_batch));
     { std::vector<int> pp(cfg->n_ctx); for (int i = 0; i < cfg->n_ctx; ++i) pp[i] = i;
       HIPC(hipMemcpyAsync(e->pf_pos, pp.data(), pp.size() * 4, hipMemcpyHostToDevice, s)); HIPC(hipStreamSynchronize(s)); }
@@ -657,9 +676,9 @@ extern "C" void q3tts_engine_destroy(q3tts_engine* e) {
         for (auto gr : L.graphs) if (gr) hipGraphDestroy(gr);
         hipFree(L.logits_tmp); hipFree(L.perm);
         hipFree(L.xT); hipFree(L.logits); hipFree(L.fb); hipFree(L.px); hipFree(L.keys);
-        hipFree(L.xbT); hipFree(L.sspT); hipFree(L.xbP); hipFree(L.sspP);
+        hipFree(L.xbT); hipFree(L.sspT); hipFree(L.xbP); hipFree(L.sspP); hipFree(L.ascT);
         hipFree(L.row_pos_t); hipFree(L.slot_id); hipFree(L.posA); hipFree(L.slotA); hipFree(L.pos_q);
-        hipFree(L.sc.qkv); hipFree(L.sc.att); hipFree(L.sc.h);
+        hipFree(L.sc.qkv); hipFree(L.sc.att); hipFree(L.sc.h); hipFree(L.sc.asc_att); hipFree(L.sc.asc_h);
         if (L.ev_begin) hipEventDestroy(L.ev_begin); if (L.ev_end) hipEventDestroy(L.ev_end);
         if (L.stream) hipStreamDestroy(L.stream);
     }
@@ -668,7 +687,7 @@ extern "C" void q3tts_engine_destroy(q3tts_engine* e) {
     hipFree(e->tts_pad_own); hipFree(e->marker_row); hipFree(e->dev_pcm);
     hipFree(e->slots); if (e->slots_host) hipHostFree(e->slots_host);
     hipFree(e->codes); hipFree(e->rng);
-    hipFree(e->sc_pre.qkv); hipFree(e->sc_pre.att); hipFree(e->sc_pre.h);
+    hipFree(e->sc_pre.qkv); hipFree(e->sc_pre.att); hipFree(e->sc_pre.h); hipFree(e->sc_pre.asc_att); hipFree(e->sc_pre.asc_h); hipFree(e->ascp);
     hipFree(e->xp); hipFree(e->xbp); hipFree(e->sspp); hipFree(e->pf_pos); hipFree(e->pf_slot); hipFree(e->pf_seg); hipFree(e->prow_dev); hipFree(e->spk_dev); hipFree(e->refcodes_dev);
     for (auto ev : e->fin_ev) if (ev) hipEventDestroy(ev);
     for (auto ev : e->probe_ev) if (ev) hipEventDestroy(ev);
@@ -874,8 +893,9 @@ static int admit_group(q3tts_engine* e, std::vector<Adm>& grp, int total) {
     for (const Adm& a : grp) { seg.push_back(a.row0); seg.push_back(a.n); seg.push_back(a.b); seg_max = std::max(seg_max, a.n); }
     Q3_HIP(e, hipMemcpyAsync(e->pf_seg, seg.data(), seg.size() * 4, hipMemcpyHostToDevice, s));
     Q3_HIP(e, hipStreamSynchronize(s));  // pos/slot are locals
-    q3_launch_norm_inputs(e->xp, m.t_d_model, total, m.t_d_model, e->T.attn_norm[0], e->xbp, 0, e->sspp, m.t_d_model / 16, s);
-    const int rl = run_layers(e, e->T, e->xp, e->xbp, e->sspp, total, e->pf_pos, e->pf_slot, e->sc_pre, s, false, nullptr, 0, 0, e->pf_seg, (int)grp.size(), seg_max);
+    if (e->T.a8) q3_launch_norm_inputs_q8(e->xp, m.t_d_model, total, m.t_d_model, e->T.attn_norm[0], (int8_t*)e->xbp, e->ascp, e->rt16p, e->sspp, m.t_d_model / 16, s);
+    else q3_launch_norm_inputs(e->xp, m.t_d_model, total, m.t_d_model, e->T.attn_norm[0], e->xbp, 0, e->sspp, m.t_d_model / 16, s);
+    const int rl = run_layers(e, e->T, e->xp, e->xbp, e->sspp, total, e->pf_pos, e->pf_slot, e->sc_pre, s, false, nullptr, 0, 0, e->pf_seg, (int)grp.size(), seg_max, e->ascp, e->rt16p);
     if (rl) return q3_set_err(e, Q3TTS_ERR_INVALID, "prefill: a kernel launch was refused for this model shape");
     Q3_HIP(e, hipGetLastError());
     for (const Adm& a : grp) {
@@ -888,7 +908,8 @@ static int admit_group(q3tts_engine* e, std::vector<Adm>& grp, int total) {
         Q3BGemm g{}; g.a = e->xbp; g.a_row0 = (int)lastr; g.B = 1; g.w = e->T.head; g.wscale = e->T.q8 ? e->T.shead : nullptr; g.K = m.t_d_model; g.N = m.t_vocab;
         g.ssp = e->sspp + lastr * (m.t_d_model / 16); g.ld_ssp = m.t_d_model / 16; g.ntiles = m.t_d_model / 16; g.d_norm = m.t_d_model; g.eps = m.rms_eps;
         g.epi = Q3_EPI_STORE; g.y = L.logits + (size_t)row * m.t_vocab; g.ldy = m.t_vocab;
-        if (q3_launch_bgemm(g, s)) return q3_set_err(e, Q3TTS_ERR_INVALID, "prefill head: launch refused for this model shape");
+        if (e->T.a8) { g.ascale = e->ascp; g.a_rt16 = e->rt16p; }
+        if (e->T.a8 ? q3_launch_bgemm8(g, s) : q3_launch_bgemm(g, s)) return q3_set_err(e, Q3TTS_ERR_INVALID, "prefill head: launch refused for this model shape");
         // sampler stream (src/tts/engine.rs:473-485)
         float temperature = e->temperature, top_p = e->top_p; int top_k = e->top_k, has_seed = e->has_seed; uint64_t seed = e->seed;
         if (!r->use_engine_sampler) { temperature = r->temperature; top_k = r->top_k; top_p = r->top_p; has_seed = r->has_seed; seed = r->seed; }
@@ -1549,6 +1570,74 @@ extern "C" int q3tts_k_bgemm_q8(int32_t device, const uint16_t* xb, int32_t B, i
 // The vocoder's extras of the decoder GEMM (bias, GELU -> bf16, LayerScale column scale, per-slot row segments, a bf16 copy of the
 // residual result) through one hook: epi 0 (store) / 1 (residual) / 4 (GELU). y0 / y are dense [B][N]; with seg_rows > 0 the kernel
 // works on a buffer of B / seg_rows segments, each preceded by gap_rows sentinel rows that must come back untouched.
+// W8A8 (q3_bgemm8.hip): activations and weights as ggml Q8_0 blocks in natural order in / out; the hook tiles them for the device
+extern "C" int q3tts_k_bgemm_q8a8(int32_t device, const int8_t* aq, const uint16_t* ad, int32_t B, int32_t K, const int8_t* q, const uint16_t* d_f16, int32_t N,
+                                  const float* ssp, int32_t ntiles, int32_t d_norm, float eps, int32_t epi, const float* nw_next, float* y, int8_t* yq, uint16_t* yd,
+                                  float* ssp_out, int32_t iters, float* mean_ms) {
+    if (!aq || !ad || !q || !d_f16 || B <= 0 || K % 512 || K < 512 || N % 32 || epi < 0 || epi > 2) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm_q8a8 hook: K % 512 == 0, N % 32 == 0, epilogue 0..2");
+    if (epi == Q3_EPI_SWIGLU && (N % 128 || !yq || !yd)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm_q8a8 hook: swiglu needs N % 128 == 0, yq, yd");
+    if (epi == Q3_EPI_RESID && (N % 64 || !nw_next || !yq || !yd || !ssp_out || !y)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm_q8a8 hook: residual needs N % 64 == 0, nw_next, y, yq, yd, ssp_out");
+    if (epi == Q3_EPI_STORE && !y) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm_q8a8 hook: y missing");
+    HK(hipSetDevice(device));
+    const int F = N / 2, kb = K / 32, Nout = epi == Q3_EPI_SWIGLU ? F : N;
+    const size_t B16 = ((size_t)B + 15) & ~(size_t)15; const int rt16 = (int)(B16 / 16);
+    std::vector<uint8_t> blocks((size_t)N * kb * 34);
+    for (size_t n = 0; n < (size_t)N; ++n)
+        for (int b = 0; b < kb; ++b) {
+            uint8_t* blk = &blocks[(n * kb + b) * 34];
+            const uint16_t dd = d_f16[n * kb + b];
+            blk[0] = (uint8_t)(dd & 0xff); blk[1] = (uint8_t)(dd >> 8);
+            memcpy(blk + 2, q + n * K + (size_t)b * 32, 32);
+        }
+    std::vector<int8_t> at(B16 * K, 0); std::vector<uint16_t> ast((size_t)kb * B16, 0);
+    for (int r = 0; r < B; ++r) {
+        for (int k = 0; k < K; ++k) at[q3_q8_off(r, k, K >> 6)] = aq[(size_t)r * K + k];
+        for (int b = 0; b < kb; ++b) ast[q3_q8_scale_idx(r, b, rt16)] = ad[(size_t)r * kb + b];
+    }
+    DevBuf dx, dxs, dw, dwt, dsc, ds, dn, dy, dyq, dys, dso;
+    if (dx.alloc(at.size()) || dxs.alloc(ast.size() * 2) || dw.alloc(blocks.size()) || dwt.alloc((size_t)N * K) || dsc.alloc((size_t)N * kb * 2) ||
+        ds.alloc((size_t)B * (ntiles > 0 ? ntiles : 1) * 4) || dn.alloc((size_t)N * 4) || dy.alloc((size_t)B * N * 4) || dyq.alloc(B16 * Nout) ||
+        dys.alloc((size_t)(Nout / 32 + 2) * B16 * 2) || dso.alloc((size_t)B * (N / 16) * 4))
+        return q3_set_err(nullptr, Q3TTS_ERR_OOM, "hipMalloc");
+    HK(hipMemcpy(dx.p, at.data(), at.size(), hipMemcpyHostToDevice)); HK(hipMemcpy(dxs.p, ast.data(), ast.size() * 2, hipMemcpyHostToDevice));
+    HK(hipMemcpy(dw.p, blocks.data(), blocks.size(), hipMemcpyHostToDevice));
+    if (ssp) HK(hipMemcpy(ds.p, ssp, (size_t)B * ntiles * 4, hipMemcpyHostToDevice));
+    if (nw_next) HK(hipMemcpy(dn.p, nw_next, (size_t)N * 4, hipMemcpyHostToDevice));
+    if (epi == Q3_EPI_RESID) HK(hipMemcpy(dy.p, y, (size_t)B * N * 4, hipMemcpyHostToDevice));
+    Q3Fill f{}; f.dst = (uint4*)dwt.p; f.dst_scale = (uint16_t*)dsc.p; f.N = N; f.K = K;
+    if (epi == Q3_EPI_SWIGLU) { f.mode = 1; f.src8_a = (const uint8_t*)dw.p; f.src8_b = (const uint8_t*)dw.p + (size_t)F * kb * 34; }
+    else { f.mode = 0; f.row0 = 0; f.rows = N; f.src8_a = (const uint8_t*)dw.p; }
+    q3_launch_fill_tiled_q8(f, nullptr);
+    Q3BGemm g{}; g.a = (const uint16_t*)dx.p; g.ascale = (const uint16_t*)dxs.p; g.a_rt16 = rt16; g.a_row0 = 0; g.B = B;
+    g.w = (const uint4*)dwt.p; g.wscale = (const uint16_t*)dsc.p; g.K = K; g.N = N;
+    g.ssp = ssp ? (const float*)ds.p : nullptr; g.ld_ssp = ntiles; g.ntiles = ntiles; g.d_norm = d_norm; g.eps = eps; g.epi = epi;
+    g.y = (float*)dy.p; g.ldy = N; g.yb = (uint16_t*)dyq.p; g.yscale = (uint16_t*)dys.p; g.y_rt16 = rt16;
+    g.nw_next = nw_next ? (const float*)dn.p : nullptr; g.ssp_out = (float*)dso.p; g.ld_ssp_out = N / 16;
+    if (q3_launch_bgemm8(g, nullptr)) return q3_set_err(nullptr, Q3TTS_ERR_INVALID, "bgemm_q8a8: shape");
+    HK(hipDeviceSynchronize());
+    if (epi == Q3_EPI_STORE || epi == Q3_EPI_RESID) HK(hipMemcpy(y, dy.p, (size_t)B * N * 4, hipMemcpyDeviceToHost));
+    if (epi != Q3_EPI_STORE) {
+        std::vector<int8_t> qt(B16 * Nout); std::vector<uint16_t> st((size_t)(Nout / 32) * B16);
+        HK(hipMemcpy(qt.data(), dyq.p, qt.size(), hipMemcpyDeviceToHost)); HK(hipMemcpy(st.data(), dys.p, st.size() * 2, hipMemcpyDeviceToHost));
+        for (int r = 0; r < B; ++r) {
+            for (int k = 0; k < Nout; ++k) yq[(size_t)r * Nout + k] = qt[q3_q8_off(r, k, Nout >> 6)];
+            for (int b = 0; b < Nout / 32; ++b) yd[(size_t)r * (Nout / 32) + b] = st[q3_q8_scale_idx(r, b, rt16)];
+        }
+        if (epi == Q3_EPI_RESID) HK(hipMemcpy(ssp_out, dso.p, (size_t)B * (N / 16) * 4, hipMemcpyDeviceToHost));
+    }
+    if (iters > 0 && mean_ms) {
+        if (epi == Q3_EPI_RESID) g.epi = Q3_EPI_STORE;
+        hipEvent_t a, b; HK(hipEventCreate(&a)); HK(hipEventCreate(&b));
+        q3_launch_bgemm8(g, nullptr);
+        HK(hipEventRecord(a, nullptr));
+        for (int i = 0; i < iters; ++i) q3_launch_bgemm8(g, nullptr);
+        HK(hipEventRecord(b, nullptr)); HK(hipEventSynchronize(b));
+        float ms = 0; hipEventElapsedTime(&ms, a, b); *mean_ms = ms / iters;
+        hipEventDestroy(a); hipEventDestroy(b);
+    }
+    return Q3TTS_OK;
+}
+
 extern "C" int q3tts_k_bgemm_voc(int32_t device, const uint16_t* xb, int32_t B, int32_t K, const uint16_t* w, int32_t N, int32_t epi, const float* bias,
                                  int32_t bias_n, const float* col_scale, int32_t seg_rows, int32_t gap_rows, float* y, uint16_t* yb, int32_t want_yb) {
     if (!xb || !w || B <= 0 || K % 256 || K < 256 || N % 32 || (epi != Q3_EPI_STORE && epi != Q3_EPI_RESID && epi != Q3_EPI_GELU))

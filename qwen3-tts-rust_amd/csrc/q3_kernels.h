@@ -58,6 +58,19 @@ Q3_HD size_t q3_atile_off(int row, int k, int kblocks) {
     const int c = k & 31;
     return ((((size_t)(row >> 4) * kblocks + (k >> 5)) * 64 + ((c & 15) >> 2) * 16 + (row & 15)) << 3) + (c & 3) + ((c & 16) >> 2);
 }
+// Q8_0 ACTIVATIONS (W8A8: q3_bgemm8.hip). The int8 quants of a row operand live in the weights' tiled Q8 form with rows in
+// place of columns: tile PAIR (rt = row/16, kp = k/64) is 1 KiB, lane (kq, r) owns 16 bytes — the 8 int8 of k-block 2 kp that its MFMA
+// fragment holds (k = 4kq..4kq+3, 16+4kq..16+4kq+3), then the 8 of block 2 kp + 1. q3_q8_off = BYTE offset of element (row, k); kpairs = K/64.
+Q3_HD size_t q3_q8_off(int row, int k, int kpairs) {
+    const int c = k & 31;
+    return ((((size_t)(row >> 4) * kpairs + (k >> 6)) * 64 + ((c & 15) >> 2) * 16 + (row & 15)) << 4) + ((k >> 5) & 1) * 8 + (c & 3) + ((c & 16) >> 2);
+}
+// ... and their f16 block scales as [K/64][row tiles][4 row quads][2 blocks][4 rows]: the 8 scales an MFMA lane needs for one (row tile, block
+// pair) — rows 4 kq .. 4 kq + 3 of the tile, both blocks — are one 16-byte load. Index (in f16 elements) of the scale of (row, k-block kb);
+// rt16 = row tiles of the buffer (rows padded to 16).
+Q3_HD size_t q3_q8_scale_idx(int row, int kb, int rt16) {
+    return ((((size_t)(kb >> 1) * rt16 + (row >> 4)) * 4 + ((row & 15) >> 2)) << 3) + (kb & 1) * 4 + (row & 3);
+}
 struct Q3BGemm {
     const uint16_t* a; int a_row0; int B;       // A-tiled bf16 rows [a_row0, a_row0 + B) of a buffer with K columns
     const uint4* w; int K, N;                   // tiled bf16
@@ -78,15 +91,22 @@ struct Q3BGemm {
     // fragment would hold (k = 4kq..4kq+3, 16+4kq..16+4kq+3), then the 8 of k-block 2 kp + 1 — and wscale the f16 block scales
     // [N][K/32] (physical column order). RAW = the canonical Q8 order: per block P = MFMA from zero, t = fmaf(f32(d), P, t). K % 512 == 0.
     const uint16_t* wscale;
+    // W8A8 (q3_launch_bgemm8; the Talker with talker_q8_0 = 2): `a` then holds the rows' int8 quants (q3_q8_off) and ascale their block scales
+    // (q3_q8_scale_idx, a_rt16 row tiles); RESID / SWIGLU write the consumer's operand the same way: yb = int8 quants, yscale / y_rt16.
+    const uint16_t* ascale; int a_rt16; uint16_t* yscale; int y_rt16;
     Q3_STAMP_FIELD
 };
 int q3_launch_bgemm(const Q3BGemm& g, hipStream_t s);
+int q3_launch_bgemm8(const Q3BGemm& g, hipStream_t s);   // the same launch in ggml's Q8_0 x Q8_0 arithmetic (STORE / RESID / SWIGLU)
+void q3_bgemm8_pick(const Q3BGemm& g, int* rt, int* nt);
 void q3_bgemm_pick(const Q3BGemm& g, int* rt, int* nt, int* d, int* ntw, int* big);  // the instance q3_launch_bgemm takes for g (no launch)
 void q3_bgemm_force(int rt, int nt);  // tuning only: force a tile instance (0, 0: back to the cost model)
 void q3_bgemm_prepare();  // kernel attributes + the Q3TTS_BG_BIG policy (read once); call once outside stream capture
 void q3_bgemm_big_policy(int policy);  // 1 / -1 / 0: k_bgemm_big always / never / when it fills the chip (tests, A/B runs)
 // producer side of the split RMSNorm for plain f32 rows: xb = bf16(x * nw), ssp[row][t] = sum of squares of columns 16t..16t+15
 void q3_launch_norm_inputs(const float* x, int ldx, int rows, int d, const float* nw, uint16_t* xb, int xb_row0, float* ssp, int ld_ssp, hipStream_t s);
+// the same for a W8A8 consumer: v = x * nw as Q8_0 blocks (int8 quants at xq, f16 scales at xscale, rt16 row tiles) + ssp
+void q3_launch_norm_inputs_q8(const float* x, int ldx, int rows, int d, const float* nw, int8_t* xq, uint16_t* xscale, int rt16, float* ssp, int ld_ssp, hipStream_t s);
 // H6 (src/assets_manager.rs:383-399) in the reference's own f32 sequence: y[row][o] = bias[o]; for i: y += x[row][i] * w[o][i].
 // nw != nullptr: also the norm inputs of y (xb, ssp) for the Predictor's first layer.
 struct Q3Project {
@@ -114,6 +134,42 @@ __device__ __forceinline__ void q3_norm_out(float v, float nwv, uint16_t* xb_ele
     float sq = v * v;
     sq = sq + __shfl_xor(sq, 1); sq = sq + __shfl_xor(sq, 2); sq = sq + __shfl_xor(sq, 4); sq = sq + __shfl_xor(sq, 8);
     if (tile_leader) *ssp_tile = sq;
+}
+#endif
+
+#ifdef __HIPCC__
+// Q8_0 activation producers (W8A8): ggml's quantiser on a block of 32 consecutive columns of one row, from the f32 values.
+// q3_q8_out32: lane <-> column — the 32 lanes of a half wave hold v for columns k .. k + 31 (k % 32 == lane % 32), all active.
+__device__ __forceinline__ void q3_q8_out32(float v, int row, int k, int kpairs, int rt16, int8_t* q, uint16_t* sc) {
+    float amax = fabsf(v);
+#pragma unroll
+    for (int m = 1; m <= 16; m <<= 1) amax = fmaxf(amax, __shfl_xor(amax, m));
+    const float d = amax / 127.0f, id = d != 0.0f ? 1.0f / d : 0.0f;
+    q[q3_q8_off(row, k, kpairs)] = (int8_t)(int)roundf(v * id);
+    if ((k & 31) == 0) sc[q3_q8_scale_idx(row, k >> 5, rt16)] = __builtin_bit_cast(unsigned short, (_Float16)d);
+}
+// q3_q8_out2x16: a lane holds columns k0, k0 + 1 (k0 even), 16 consecutive lanes the block
+__device__ __forceinline__ void q3_q8_out2x16(float v0, float v1, int row, int k0, int kpairs, int rt16, int8_t* q, uint16_t* sc) {
+    float amax = fmaxf(fabsf(v0), fabsf(v1));
+#pragma unroll
+    for (int m = 1; m <= 8; m <<= 1) amax = fmaxf(amax, __shfl_xor(amax, m));
+    const float d = amax / 127.0f, id = d != 0.0f ? 1.0f / d : 0.0f;
+    q[q3_q8_off(row, k0, kpairs)] = (int8_t)(int)roundf(v0 * id);
+    q[q3_q8_off(row, k0 + 1, kpairs)] = (int8_t)(int)roundf(v1 * id);
+    if ((k0 & 31) == 0) sc[q3_q8_scale_idx(row, k0 >> 5, rt16)] = __builtin_bit_cast(unsigned short, (_Float16)d);
+}
+// q3_q8_out8x4: a lane holds 8 consecutive columns k0 .. k0 + 7 (k0 % 8 == 0), four neighbouring lanes (lane ^ 1, lane ^ 2) the block
+__device__ __forceinline__ void q3_q8_out8x4(const float* v, int row, int k0, int kpairs, int rt16, int8_t* q, uint16_t* sc, bool store) {
+    float amax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1)); amax = fmaxf(amax, __shfl_xor(amax, 2));
+    const float d = amax / 127.0f, id = d != 0.0f ? 1.0f / d : 0.0f;
+    if (store) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[q3_q8_off(row, k0 + i, kpairs)] = (int8_t)(int)roundf(v[i] * id);
+        if ((k0 & 31) == 0) sc[q3_q8_scale_idx(row, k0 >> 5, rt16)] = __builtin_bit_cast(unsigned short, (_Float16)d);
+    }
 }
 #endif
 
@@ -151,6 +207,8 @@ struct Q3Attend {
     const float* qkv; int ld; int rows;
     float* out; int ldo;
     int out_bf16;     // 1: out is an A-tiled bf16 buffer with Hq*hd columns (the O projection's operand); 0: f32 rows [row][ldo] (test hook)
+                      // 2: W8A8 — out holds the rows as Q8_0 blocks (int8 quants, q3_q8_off) and out_scale / out_rt16 their f16 scales
+    uint16_t* out_scale; int out_rt16;
     int Hq, Hkv, hd;
     const uint16_t* kc; const uint16_t* vc; int n_ctx;
     const int* row_pos; const int* row_slot;
@@ -204,6 +262,7 @@ struct Q3PredNext {
     float* fb; const float* tts_pad; float* xT; int* row_pos_t;
     const float* pproj_q; const float* proj_b; int dp; float* px;  // q < ncb-1: px[b] = proj(codec_q[code]) from the table
     const float* nw; uint16_t* xb; float* ssp;  // norm inputs of the row just written: px[b] (Predictor layer 0) or, last, xT[b] (Talker layer 0)
+    uint16_t* xscale; int x_rt16;               // last pass with a W8A8 Talker: xb then takes the row as Q8_0 blocks (int8 quants + these f16 scales)
     Q3_STAMP_FIELD
 };
 void q3_launch_pred_next(const Q3PredNext& a, hipStream_t s);

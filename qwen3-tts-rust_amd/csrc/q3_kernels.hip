@@ -349,7 +349,8 @@ __global__ __launch_bounds__(R * 256) void k_attend(Q3Attend a) {
         const float ov = ((r0 + r1) + r2) + r3;
         const float l = ((lw[h2 * 4] + lw[h2 * 4 + 1]) + lw[h2 * 4 + 2]) + lw[h2 * 4 + 3];
         const size_t oi = (size_t)row * a.ldo + (size_t)(g * R + h2) * hd + d;
-        if (a.out_bf16) ((uint16_t*)a.out)[q3_atile_off(row, (g * R + h2) * hd + d, (a.Hq * hd) >> 5)] = q3_bf16(ov / l);  // the O projection's A-tiled operand
+        if (a.out_bf16 == 2) q3_q8_out32(ov / l, row, (g * R + h2) * hd + d, (a.Hq * hd) >> 6, a.out_rt16, (int8_t*)a.out, a.out_scale);  // W8A8: Q8_0 blocks (hd % 32 == 0: a half wave = one block)
+        else if (a.out_bf16) ((uint16_t*)a.out)[q3_atile_off(row, (g * R + h2) * hd + d, (a.Hq * hd) >> 5)] = q3_bf16(ov / l);  // the O projection's A-tiled operand
         else a.out[oi] = ov / l;
     }
 #ifdef Q3_STAMPS
@@ -564,7 +565,8 @@ __global__ __launch_bounds__(256, 2) void k_attend_gqa2(Q3Attend a) {  // (<= 25
             ov[q] = (((r0 + r1) + r2) + r3) / l;
         }
         const int hq = g * 2 + h2;
-        if (a.out_bf16) *(uint32_t*)((uint16_t*)a.out + q3_atile_off(row, hq * hd + d0, (a.Hq * hd) >> 5)) = (uint32_t)q3_bf16(ov[0]) | ((uint32_t)q3_bf16(ov[1]) << 16);
+        if (a.out_bf16 == 2) q3_q8_out2x16(ov[0], ov[1], row, hq * hd + d0, (a.Hq * hd) >> 6, a.out_rt16, (int8_t*)a.out, a.out_scale);  // W8A8: Q8_0 blocks (16 lanes x 2 dims)
+        else if (a.out_bf16) *(uint32_t*)((uint16_t*)a.out + q3_atile_off(row, hq * hd + d0, (a.Hq * hd) >> 5)) = (uint32_t)q3_bf16(ov[0]) | ((uint32_t)q3_bf16(ov[1]) << 16);
         else *(float2*)(a.out + (size_t)row * a.ldo + (size_t)hq * hd + d0) = make_float2(ov[0], ov[1]);
     }
 #ifdef Q3_STAMPS
@@ -912,7 +914,12 @@ __global__ __launch_bounds__(512) void k_attend_prefill(Q3Attend a) {
             }
         }
         const float l = ((lw[0] + lw[1]) + lw[2]) + lw[3];
-        if (kg == 0) {
+        if (a.out_bf16 == 2) {  // W8A8: the head's output as Q8_0 blocks — a lane owns 8 consecutive dims, lanes dl ^ 1, dl ^ 2 the rest of its block
+            float ov8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov8[e] = (((rsw[0][e] + rsw[1][e]) + rsw[2][e]) + rsw[3][e]) / l;
+            q3_q8_out8x4(ov8, row, (g * 2 + hh) * hd + dl * 8, (a.Hq * hd) >> 6, a.out_rt16, (int8_t*)a.out, a.out_scale, kg == 0);
+        } else if (kg == 0) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float ov = ((rsw[0][e] + rsw[1][e]) + rsw[2][e]) + rsw[3][e];
@@ -1383,6 +1390,12 @@ __global__ __launch_bounds__(256) void k_pred_next(Q3PredNext a) {
             if (!last) a.fb[(size_t)b * d + i] = f;
             else {  // the Talker's next input row and its norm inputs for layer 0
                 f = f + tp[u]; a.xT[(size_t)b * d + i] = f;
+                if (a.xscale) {  // W8A8 Talker: the row as Q8_0 blocks (a half wave = 32 consecutive columns = one block)
+                    q3_q8_out32(f * nv[u], b, i, d >> 6, a.x_rt16, (int8_t*)a.xb, a.xscale);
+                    float sq = f * f;
+                    sq = sq + __shfl_xor(sq, 1); sq = sq + __shfl_xor(sq, 2); sq = sq + __shfl_xor(sq, 4); sq = sq + __shfl_xor(sq, 8);
+                    if ((i & 15) == 0) a.ssp[(size_t)b * (d >> 4) + (i >> 4)] = sq;
+                } else
                 q3_norm_out(f, nv[u], a.xb + q3_atile_off(b, i, d >> 5), a.ssp + (size_t)b * (d >> 4) + (i >> 4), (i & 15) == 0);
             }
         }

@@ -125,7 +125,7 @@ SYMBOLS = [
     "q3tts_k_vocoder", "q3tts_k_vocoder_bench", "q3tts_set_device_pcm", "q3tts_get_device_pcm", "q3tts_k_rng_f32", "q3tts_k_probe", "q3tts_k_gguf_read", "q3tts_mel_frames", "q3tts_mel",
     "q3tts_clone_default_config", "q3tts_clone_init", "q3tts_clone_audio_frames", "q3tts_clone_audio_encode",
     "q3tts_clone_speaker_encode", "q3tts_k_speaker_from_mel", "q3tts_k_audio_latent",
-    "q3tts_node_create", "q3tts_node_destroy", "q3tts_node_generate_batch", "q3tts_node_get_timings", "q3tts_node_last_error", "q3tts_node_size", "q3tts_node_engine", "q3tts_node_shard", "q3tts_k_bgemm_q8", "q3tts_k_alloc_upload", "q3tts_k_bgemm_policy", "q3tts_k_attend_policy", "q3tts_k_bgemm_pick", "q3tts_k_mfma_bf16", "q3tts_k_bgemm", "q3tts_k_bgemm_voc", "q3tts_k_project", "q3tts_k_norm_inputs", "q3tts_tokenizer_load", "q3tts_tokenizer_free", "q3tts_tokenizer_vocab_size", "q3tts_tokenizer_encode", "q3tts_tokenizer_decode",
+    "q3tts_node_create", "q3tts_node_destroy", "q3tts_node_generate_batch", "q3tts_node_get_timings", "q3tts_node_last_error", "q3tts_node_size", "q3tts_node_engine", "q3tts_node_shard", "q3tts_k_bgemm_q8", "q3tts_k_bgemm_q8a8", "q3tts_k_alloc_upload", "q3tts_k_bgemm_policy", "q3tts_k_attend_policy", "q3tts_k_bgemm_pick", "q3tts_k_mfma_bf16", "q3tts_k_bgemm", "q3tts_k_bgemm_voc", "q3tts_k_project", "q3tts_k_norm_inputs", "q3tts_tokenizer_load", "q3tts_tokenizer_free", "q3tts_tokenizer_vocab_size", "q3tts_tokenizer_encode", "q3tts_tokenizer_decode",
 ]
 
 
@@ -217,6 +217,8 @@ def load_library(path=None):
     lib.q3tts_node_shard.restype = C.c_int32
     lib.q3tts_k_bgemm_q8.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, f32p]
+    lib.q3tts_k_bgemm_q8a8.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
+                                       C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, f32p]
     lib.q3tts_k_bgemm_policy.argtypes = [C.c_int32]
     lib.q3tts_k_attend_policy.argtypes = [C.c_int32, C.c_int32]
     lib.q3tts_k_bgemm_pick.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, i32p]

@@ -387,6 +387,28 @@ def k_bgemm_q8(xb, q, d16, ssp, d_norm, eps, epi, nw_next=None, y0=None, device=
     return dict(y=y, yb=yb, ssp_out=sso, keys=keys, ms=ms.value)
 
 
+def k_bgemm_q8a8(aq, ad, q, d16, ssp, d_norm, eps, epi, nw_next=None, y0=None, device=0, iters=0):
+    """The decoder's GEMM in ggml's Q8_0 x Q8_0 arithmetic (q3tts_k_bgemm_q8a8): activations aq int8 [B][K] + ad f16 bits [B][K/32], weights q / d16."""
+    lib = _abi.load_library()
+    aq = np.ascontiguousarray(aq, dtype=np.int8); ad = np.ascontiguousarray(ad, dtype=np.uint16)
+    q = np.ascontiguousarray(q, dtype=np.int8); d16 = np.ascontiguousarray(d16, dtype=np.uint16)
+    B, K = aq.shape
+    N = q.shape[0]
+    nout = N // 2 if epi == 2 else N
+    y = np.zeros((B, N), dtype=np.float32) if y0 is None else np.ascontiguousarray(y0, dtype=np.float32).copy()
+    yq = np.zeros((B, nout), dtype=np.int8); yd = np.zeros((B, nout // 32), dtype=np.uint16)
+    sso = np.zeros((B, N // 16), dtype=np.float32)
+    sp = None if ssp is None else np.ascontiguousarray(ssp, dtype=np.float32)
+    nw = None if nw_next is None else np.ascontiguousarray(nw_next, dtype=np.float32)
+    ms = C.c_float(0)
+    rc = lib.q3tts_k_bgemm_q8a8(device, aq.ctypes.data, ad.ctypes.data, B, K, q.ctypes.data, d16.ctypes.data, N, None if sp is None else sp.ctypes.data,
+                                0 if sp is None else sp.shape[1], d_norm, eps, epi, None if nw is None else nw.ctypes.data, y.ctypes.data, yq.ctypes.data,
+                                yd.ctypes.data, sso.ctypes.data, iters, C.byref(ms))
+    if rc != 0:
+        raise _abi.Q3Error(f"q3tts_k_bgemm_q8a8 failed ({rc}): {lib.q3tts_last_error(None).decode()}")
+    return dict(y=y, yq=yq, yd=yd, ssp_out=sso, ms=ms.value)
+
+
 def k_bgemm_voc(xb, wb, epi, bias=None, col_scale=None, seg_rows=0, gap_rows=0, y0=None, want_yb=False, device=0):
     """The decoder's GEMM with the vocoder's epilogue extras (q3tts_k_bgemm_voc): returns dict(y=[B][N] f32 or None, yb=[B][N] bf16 bits or None)."""
     lib = _abi.load_library()

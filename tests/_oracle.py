@@ -98,6 +98,11 @@ def lib():
     L.q3o_bgemm_q8.restype = None
     L.q3o_quantize_q8_0.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.q3o_quantize_q8_0.restype = None
+    L.q3o_bgemm_q8a8.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.q3o_bgemm_q8a8.restype = None
+    L.q3o_set_talker_q8a8.argtypes = [vp]
+    L.q3o_set_talker_q8a8.restype = None
     L.q3o_set_talker_q8.argtypes = [vp]
     L.q3o_set_talker_q8.restype = None
     L.q3o_project_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
@@ -155,6 +160,10 @@ class OracleModel:
     def set_talker_q8(self):
         """The Talker's matrices + lm_head as ggml Q8_0 blocks in the canonical Q8 order (device: q3tts_engine_config.talker_q8_0 = 1). One-way."""
         self.L.q3o_set_talker_q8(self.h)
+
+    def set_talker_q8a8(self):
+        """... and every Talker GEMM's activations as Q8_0 blocks as well: ggml's W8A8 (device: talker_q8_0 = 2). One-way."""
+        self.L.q3o_set_talker_q8a8(self.h)
 
     def set_arith(self, mode):
         """0: the canonical bf16-MFMA order (default); 1: plain f32 of the same structure (family pinning)."""
@@ -218,6 +227,24 @@ def quantize_q8_0(x):
     q = np.zeros(x.shape, dtype=np.int8); d = np.zeros(x.shape[:-1] + (x.shape[-1] // 32,), dtype=np.uint16)
     lib().q3o_quantize_q8_0(x.ctypes.data, x.size, q.ctypes.data, d.ctypes.data)
     return q, d
+
+
+def bgemm_q8a8(aq, ad, q, d16, ssp, d_norm, eps, epi, nw_next=None, y0=None):
+    """oracle/q3_oracle_bf16.c q3o_bgemm_q8a8: ggml's Q8_0 x Q8_0 arithmetic (exact int32 block sums x f32(d_w) * f32(d_x)), the quantising epilogues."""
+    aq = np.ascontiguousarray(aq, dtype=np.int8); ad = np.ascontiguousarray(ad, dtype=np.uint16)
+    q = np.ascontiguousarray(q, dtype=np.int8); d16 = np.ascontiguousarray(d16, dtype=np.uint16)
+    B, K = aq.shape
+    N = q.shape[0]
+    nout = N // 2 if epi == 2 else N
+    y = np.zeros((B, N), dtype=np.float32) if y0 is None else np.ascontiguousarray(y0, dtype=np.float32).copy()
+    yq = np.zeros((B, nout), dtype=np.int8); yd = np.zeros((B, nout // 32), dtype=np.uint16)
+    sso = np.zeros((B, N // 16), dtype=np.float32)
+    sp = None if ssp is None else np.ascontiguousarray(ssp, dtype=np.float32)
+    nw = None if nw_next is None else np.ascontiguousarray(nw_next, dtype=np.float32)
+    lib().q3o_bgemm_q8a8(aq.ctypes.data, ad.ctypes.data, B, K, q.ctypes.data, d16.ctypes.data, N, None if sp is None else sp.ctypes.data,
+                         0 if sp is None else sp.shape[1], d_norm, eps, epi, None if nw is None else nw.ctypes.data, y.ctypes.data, yq.ctypes.data,
+                         yd.ctypes.data, sso.ctypes.data)
+    return dict(y=y, yq=yq, yd=yd, ssp_out=sso)
 
 
 def bgemm_q8(xb, q, d16, ssp, d_norm, eps, epi, nw_next=None, y0=None):

@@ -872,22 +872,65 @@ def test_bgemm_q8_matches_oracle(oracle, native, B, K, N, epi):
         assert np.abs(got["y"] - want).max() <= 3e-5 * np.abs(want).max()
 
 
-def _q8_engine_and_oracle(oracle, cfg, n_ctx):
+@pytest.mark.parametrize("B,K,N,epi", [(64, 2048, 12288, 2), (64, 2048, 4096, 0), (64, 6144, 2048, 1), (64, 2048, 2048, 1), (1, 2048, 3072, 0), (1, 6144, 2048, 1),
+                                       (37, 512, 1024, 2), (48, 2048, 4096, 0), (17, 1024, 256, 2), (130, 512, 512, 1), (300, 2048, 4096, 0), (5, 1536, 32, 0), (200, 1024, 512, 2)])
+def test_bgemm_q8a8_matches_oracle(oracle, native, B, K, N, epi):
+    """W8A8 on v_mfma_i32_16x16x32_i8 (csrc/q3_bgemm8.hip): activations AND weights as ggml Q8_0 blocks — what llama.cpp multiplies for the
+    reference's gguf_q8_0 directory (src/tts/engine.rs:91-95). A block's product = its exact int32 sum x (f32(d_w) * f32(d_x)), blocks added in
+    order inside a K slice, the 8 slices in order: bit for bit q3o_bgemm_q8a8 — RAW with the row scale, the residual epilogue whose NEXT operand is
+    quantised in the kernel (int8 quants + f16 scales + tile sums of squares), SwiGLU quantised in the kernel; the Talker's shapes at 64 rows,
+    ragged row tiles, many rows, blocks of zeros, q = -128 on both sides."""
+    rng = np.random.default_rng(7 * B + K + N + epi)
+    a = _rand(rng, (B, K), 1.5); a[:, :7] *= 300.0; a[:, 100:140] *= 1e-3; a[B // 2, 64:96] = 0.0
+    w = _rand(rng, (N, K), 0.02); w[3, 64:96] = 0.0; w[5 % N, :32] *= 40.0
+    aq, ad = oracle.quantize_q8_0(a)
+    q, d16 = oracle.quantize_q8_0(w)
+    q[1, 0] = -128; aq[0, 1] = -128
+    scaled = epi in (0, 2)
+    ssp = (np.abs(_rand(rng, (B, K // 16), 4.0)) + 0.5).astype(np.float32) if scaled else None
+    nw_next = (1.0 + _rand(rng, (N,), 0.05)).astype(np.float32) if epi == 1 else None
+    y0 = _rand(rng, (B, N), 2.0) if epi == 1 else None
+    ref = oracle.bgemm_q8a8(aq, ad, q, d16, ssp, K, 1e-6, epi, nw_next, y0)
+    got = native.k_bgemm_q8a8(aq, ad, q, d16, ssp, K, 1e-6, epi, nw_next, y0)
+    if epi in (0, 1):
+        assert np.array_equal(_bits(got["y"]), _bits(ref["y"]))
+    if epi == 1:
+        assert np.array_equal(_bits(got["ssp_out"]), _bits(ref["ssp_out"]))
+    if epi in (1, 2):
+        assert np.array_equal(got["yd"], ref["yd"]) and np.array_equal(got["yq"], ref["yq"])
+        assert np.count_nonzero(got["yq"]) > got["yq"].size // 2
+    if epi == 0 and B == 64:   # and it IS the product of the de-quantised operands, to f32 rounding
+        ad_f = ad.view(np.float16).astype(np.float64); wd_f = d16.view(np.float16).astype(np.float64)
+        af = (aq.astype(np.float64).reshape(B, K // 32, 32) * ad_f[:, :, None]).reshape(B, K)
+        wf = (q.astype(np.float64).reshape(N, K // 32, 32) * wd_f[:, :, None]).reshape(N, K)
+        s = np.array([oracle.row_scale(ssp[r], K, 1e-6) for r in range(B)], dtype=np.float64)
+        want = (af @ wf.T) * s[:, None]
+        assert np.abs(got["y"] - want).max() <= 3e-5 * np.abs(want).max()
+
+
+def _q8_engine_and_oracle(oracle, cfg, n_ctx, mode=1):
+    """mode 1: W8A16 (Q8_0 weights, bf16 activations); mode 2: W8A8 — the activations are Q8_0 blocks too (ggml's vec_dot_q8_0_q8_0)."""
     from q3tts import native
-    cfg.talker_q8_0 = 1
+    cfg.talker_q8_0 = mode
     eng = native.NativeEngine(cfg)
     om = oracle.OracleModel(cfg.model, seed=0, n_ctx=n_ctx, n_threads=min(16, os.cpu_count() or 4))
-    om.set_talker_q8()
+    if mode == 2:
+        om.set_talker_q8a8()
+    else:
+        om.set_talker_q8()
     return eng, om
 
 
-def test_talker_q8_0_on_the_device_ids_match_the_oracle(oracle):
-    """q3tts_engine_config.talker_q8_0 = 1 with the synthetic model: device and oracle quantise the same bf16 weights with ggml's reference
-    rule and multiply the blocks in the canonical Q8 order — prompt rows, prefill logits / hidden, greedy and sampled ids are equal, on one
-    slot and on several of different length; and the ids DIFFER from the bf16 engine's (the quantisation is really in the path)."""
+@pytest.mark.parametrize("mode", [1, 2])
+def test_talker_q8_0_on_the_device_ids_match_the_oracle(oracle, mode):
+    """q3tts_engine_config.talker_q8_0 = 1 / 2 with the synthetic model: device and oracle quantise the same bf16 weights with ggml's reference
+    rule and multiply the blocks in the canonical Q8 order (mode 2: against activations quantised where they are produced — the GEMM epilogues,
+    the attention kernels, the feedback row, the prompt rows — in ggml's Q8_0 x Q8_0 arithmetic) — prompt rows, prefill logits / hidden, greedy
+    and sampled ids are equal, on one slot and on several of different length, with every attention kernel variant; and the ids DIFFER from
+    the bf16 engine's and from the other mode's (the quantisation is really in the path)."""
     from q3tts import _abi, native
     cfg = _abi.tiny_config(max_batch=4, n_ctx=256, with_vocoder=0)
-    eng, om = _q8_engine_and_oracle(oracle, cfg, 256)
+    eng, om = _q8_engine_and_oracle(oracle, cfg, 256, mode)
     try:
         desc, keep = oracle.make_prompt_desc(np.arange(100, 120), spk_emb=_spk(cfg.model.d_embed))
         pe = om.build_prompt(desc)
@@ -907,7 +950,15 @@ def test_talker_q8_0_on_the_device_ids_match_the_oracle(oracle):
             refs.append(om.generate(p2, **kw)[0]); reqs.append(dict(embd=p2, **kw))
         for o, r in zip(eng.generate_batch(reqs), refs):
             assert o.status == 0 and np.array_equal(o.codes, r)
+        try:   # the other attention kernels (k_attend<2, true> for decode, k_attend<2, false> / k_attend_prefill for whole prompts) write the same operand
+            for pol in ((1, 1), (0, 2)):
+                _attend_policy(*pol)
+                for o, r in zip(eng.generate_batch(reqs), refs):
+                    assert o.status == 0 and np.array_equal(o.codes, r), pol
+        finally:
+            _attend_policy(0, 0)
         cfg16 = _abi.tiny_config(max_batch=4, n_ctx=256, with_vocoder=0)
+        cfg16.talker_q8_0 = 0 if mode == 1 else 1
         e16 = native.NativeEngine(cfg16)
         try:
             assert not np.array_equal(e16.generate(embd=pe, temperature=0.0, max_steps=12, min_frames=12).codes, ref)
@@ -918,8 +969,8 @@ def test_talker_q8_0_on_the_device_ids_match_the_oracle(oracle):
         om.close()
 
 
-@pytest.mark.parametrize("talker_type", [8, 30])
-def test_talker_q8_0_from_model_files(oracle, tmp_path, talker_type):
+@pytest.mark.parametrize("talker_type,mode", [(8, 1), (30, 1), (8, 2)])
+def test_talker_q8_0_from_model_files(oracle, tmp_path, talker_type, mode):
     """weights_path + talker_q8_0 = 1. A Q8_0 Talker container (type 8: the reference's gguf_q8_0 directory, src/tts/engine.rs:91-95) goes
     to the device AS STORED — the file's own f16 scales and int8 quants, never widened to bf16 — and a BF16 container (type 30) is quantised
     on the device with ggml's rule; either way the ids equal the oracle's Q8 mode (tests/_gguf.py's writer and the oracle's quantiser are
@@ -929,10 +980,13 @@ def test_talker_q8_0_from_model_files(oracle, tmp_path, talker_type):
     cfg = _abi.tiny_config(max_batch=2, n_ctx=128, with_vocoder=0)
     oracle.write_model_dir(str(tmp_path), cfg.model, 0, matrix_type=talker_type, predictor_type=G.BF16)
     cfg.weights_path = str(tmp_path).encode()
-    cfg.talker_q8_0 = 1
+    cfg.talker_q8_0 = mode   # (2: W8A8 — the file's blocks against activations quantised on the device, as llama.cpp multiplies them)
     eng = native.NativeEngine(cfg)
     om = oracle.OracleModel(_abi.tiny_config(max_batch=2, n_ctx=128, with_vocoder=0).model, seed=0, n_ctx=128, n_threads=4)
-    om.set_talker_q8()
+    if mode == 2:
+        om.set_talker_q8a8()
+    else:
+        om.set_talker_q8()
     try:
         desc, keep = oracle.make_prompt_desc(np.arange(900, 912), spk_emb=_spk(cfg.model.d_embed))
         pe = om.build_prompt(desc)
@@ -945,14 +999,15 @@ def test_talker_q8_0_from_model_files(oracle, tmp_path, talker_type):
         om.close()
 
 
-def test_talker_q8_0_full_shape_prefill_and_frames(oracle):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_talker_q8_0_full_shape_prefill_and_frames(oracle, mode):
     """The same at the benchmarked shape (28 x 2048 Talker in Q8_0 blocks, 1.5 GB instead of 2.8 GB of weights): prefill logits / hidden
-    and 4 greedy frames equal the oracle's."""
+    and 4 greedy frames equal the oracle's (mode 2: W8A8 on the int8 MFMA)."""
     import time
     from q3tts import _abi
     cfg = _abi.full_config_py()
     cfg.max_batch, cfg.n_ctx, cfg.max_steps_cap, cfg.with_vocoder = 2, 128, 16, 0
-    eng, om = _q8_engine_and_oracle(oracle, cfg, 128)
+    eng, om = _q8_engine_and_oracle(oracle, cfg, 128, mode)
     try:
         t0 = time.time()
         desc, keep = oracle.make_prompt_desc(np.random.default_rng(1234).integers(0, 151643, size=12), spk_emb=_spk(cfg.model.d_embed))
@@ -963,7 +1018,7 @@ def test_talker_q8_0_full_shape_prefill_and_frames(oracle):
         ref, _ = om.generate(pe, temperature=0.0, max_steps=4, min_frames=4)
         res = eng.generate(desc=desc, temperature=0.0, max_steps=4, min_frames=4)
         assert ref.shape == (4, 16) and np.array_equal(res.codes, ref)
-        print(f"full shape, Talker in Q8_0 blocks: prefill + 4 frames equal; oracle {time.time() - t0:.0f} s")
+        print(f"full shape, Talker in Q8_0 blocks (mode {mode}): prefill + 4 frames equal; oracle {time.time() - t0:.0f} s")
     finally:
         eng.close()
         om.close()
