@@ -371,6 +371,7 @@ def main():
         ptm = pe.timings()
         pe.probe(0)
         wb = 1.0625 if q8 else 2.0   # bytes per weight: ggml Q8_0 = 34 bytes per 32 weights
+        ab = 1.0625 if q8 else 2.0   # bytes per activation element of a GEMM operand (W8A8: the rows are Q8_0 blocks as well)
         assert all(o.status == 0 and o.n_frames == 24 for o in pouts)
         m = cfg.model
         M = len(preqs)
@@ -381,13 +382,13 @@ def main():
             T_ctx = 3.0 * M  # pass 1: 3 keys per utterance in the per-frame cache
         nqkv = nq + 2 * nkv
         if kind == 0:
-            K, N = d, 2 * F; nbytes = wb * N * K + 2.0 * M * K + 4.0 * M * (K // 16) + 2.0 * M * (N // 2)   # weights + bf16 rows + tile partials + bf16 SwiGLU rows
+            K, N = d, 2 * F; nbytes = wb * N * K + ab * M * K + 4.0 * M * (K // 16) + ab * M * (N // 2)   # weights + bf16 rows + tile partials + bf16 SwiGLU rows
         elif kind == 1:
-            K, N = d, nqkv; nbytes = wb * N * K + 2.0 * M * K + 4.0 * M * (K // 16) + 4.0 * M * N            # ... + f32 q/k/v rows
+            K, N = d, nqkv; nbytes = wb * N * K + ab * M * K + 4.0 * M * (K // 16) + 4.0 * M * N            # ... + f32 q/k/v rows
         elif kind == 3:
-            K, N = nq, d; nbytes = wb * N * K + 2.0 * M * K + 8.0 * M * N + 2.0 * M * N + 4.0 * M * (N // 16)  # weights + bf16 rows + residual read/write + next norm inputs
+            K, N = nq, d; nbytes = wb * N * K + ab * M * K + 8.0 * M * N + ab * M * N + 4.0 * M * (N // 16)  # weights + bf16 rows + residual read/write + next norm inputs
         elif kind == 4:
-            K, N = F, d; nbytes = wb * N * K + 2.0 * M * K + 8.0 * M * N + 2.0 * M * N + 4.0 * M * (N // 16)
+            K, N = F, d; nbytes = wb * N * K + ab * M * K + 8.0 * M * N + ab * M * N + 4.0 * M * (N // 16)
         else:
             K, N = hd, nq; nbytes = 2.0 * 2.0 * nkv * T_ctx + 4.0 * M * nqkv + 2.0 * 2.0 * M * nkv + 2.0 * M * nq   # K + V of the context, f32 q/k/v rows, bf16 K/V append, bf16 out rows
         flops = 2.0 * M * K * N if kind != 2 else 2.0 * 2.0 * nq * T_ctx
@@ -641,12 +642,12 @@ def main():
             if cfg.with_vocoder:
                 line["roofline_vocoder"] = vocoder_leg()
             if not args.no_q8:
-                # The Talker on ggml Q8_0 blocks kept in block form on the device (q3tts_engine_config.talker_q8_0 = 1; the reference's default
+                # The Talker in ggml Q8_0 x Q8_0 arithmetic on the device (q3tts_engine_config.talker_q8_0 = 2: W8A8; the reference's default
                 # quantisation, src/tts/engine.rs:91-95): NOT the headline configuration (BASELINE configs name bf16) — a second engine, same
                 # probe legs, so the halved weight stream is measured next to the bf16 one. ids bit-exact vs the oracle: tests/test_parity_gpu.py.
                 eng.close()
                 cfg8 = _abi.full_config_py()
-                cfg8.device, cfg8.max_batch, cfg8.n_ctx, cfg8.max_steps_cap, cfg8.with_vocoder, cfg8.talker_q8_0 = local_rank, cfg.max_batch, args.n_ctx, 512, 0, 1
+                cfg8.device, cfg8.max_batch, cfg8.n_ctx, cfg8.max_steps_cap, cfg8.with_vocoder, cfg8.talker_q8_0 = local_rank, cfg.max_batch, args.n_ctx, 512, 0, 2
                 e8 = native.NativeEngine(cfg8)
                 l8 = [probe_leg(2, kind, engine=e8, q8=True) for kind in (0, 1, 3, 4)]
                 preqs = [dict(r, min_frames=24, force_eos_at=24, max_steps=32, want_pcm=0) for r in reqs]
@@ -660,8 +661,9 @@ def main():
                     bf = [k for k in by_kernel if k["kernel"] == "%s %s" % (p["model"], p["kind"])][0]
                     ent.append({"kernel": "Talker %s" % p["kind"], "us_per_launch": round(us, 2), "bf16_us_per_launch": bf["us_per_launch"], "algorithmic_bytes_per_launch": int(p["bytes"]),
                                 "bytes_per_us": round(p["bytes"] / us, 0), "achieved_GBs": round(p["bytes"] / (us * 1e-6) / 1e9, 1), "frac": round(p["bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)})
-                line["talker_q8_0"] = {"what": "the same 64-row frame step with the Talker's matrices as ggml Q8_0 blocks on the device (1.0625 bytes per weight; W8A16: bf16 activations, "
-                                               "per-block f16 scales applied to each block's MFMA product); second engine, codes only; not the headline configuration",
+                line["talker_q8_0"] = {"what": "the same 64-row frame step with the Talker in ggml's Q8_0 x Q8_0 arithmetic (talker_q8_0 = 2, W8A8: weights AND activations as Q8_0 blocks, "
+                                               "1.0625 bytes per element, a block's product = its exact int32 sum on v_mfma_i32_16x16x32_i8 x f32(d_w) * f32(d_x): what llama.cpp computes for the "
+                                               "reference's gguf_q8_0 directory); second engine, codes only; not the headline configuration",
                                        "frame_step_64_rows_codes_only_ms": round(g8, 4), "bf16_frame_step_64_rows_codes_only_ms": round(step_us * 1e-3, 4), "by_kernel": ent}
         else:
             line["roofline"] = {"bound": "hbm", "achieved": round(hbm_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_gbs / HBM_PEAK_GBS, 4), "traffic": None,
