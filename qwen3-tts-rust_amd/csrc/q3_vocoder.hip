@@ -1101,6 +1101,77 @@ __global__ __launch_bounds__(64 * VOC_FCAP) void k_voc_attn(const VCall* __restr
     }
 }
 
+// The same attention with the (slot, head)'s key / value window staged in LDS ONCE for the call's tokens: the rows arrive by coalesced
+// 16-byte loads (k_voc_attn's score pass has every lane walk its own key row: 64 cache lines per load instruction, and the four tokens of a
+// slot read the same window four times), keys in rows of hd + 1 floats (lane j reads row j: conflict-free). Same chains in the same order as
+// k_voc_attn — bit-identical (the tests compare chunkings and launch modes bit for bit); hd <= 64.
+__global__ __launch_bounds__(64 * VOC_FCAP) void k_voc_attn_lds(const VCall* __restrict__ clp, const float* qkv, float* kring, float* vring, const float* rope,
+                                                                int H, int hd, int RW, int W, float* att, int tiled) {
+    extern __shared__ float al[];   // K rows [NR][hd + 1] | V rows [NR][hd], NR = W + T - 1
+    __shared__ float sc_s[VOC_FCAP][512];
+    __shared__ float qs_s[VOC_FCAP][128];
+    const VCall& cl = *clp;
+    const int s = blockIdx.y, h = blockIdx.x, t = threadIdx.x >> 6, lane = threadIdx.x & 63, HH = H * hd, half = hd >> 1, tid = threadIdx.x;
+    const int slot = cl.slot[s], T = cl.nf;  // blockDim.x = 64 * T
+    float* kr = kring + (size_t)slot * RW * HH + h * hd;
+    float* vr = vring + (size_t)slot * RW * HH + h * hd;
+    float* sc = sc_s[t]; float* qs = qs_s[t];
+    const float scale = 1.0f / sqrtf((float)hd);
+    const int pos0 = cl.pos[s], pos = pos0 + t, m = s * T + t;
+    const int jmin = pos0 - W + 1 > 0 ? pos0 - W + 1 : 0, NR = W + T - 1, KS = hd + 1;
+    float* kl = al; float* vl = al + (size_t)NR * KS;
+    {   // the rows cached by earlier calls: [jmin, pos0) — 16 bytes per thread per trip
+        const int nold = pos0 - jmin, q4 = hd >> 2;
+        for (int i = tid; i < nold * q4; i += 64 * T) {
+            const int r = i / q4, c = (i - r * q4) * 4;
+            const size_t ro = (size_t)((jmin + r) % RW) * HH + c;
+            const float4 kk = *(const float4*)(kr + ro), vv = *(const float4*)(vr + ro);
+            float* kd = kl + (size_t)r * KS + c; kd[0] = kk.x; kd[1] = kk.y; kd[2] = kk.z; kd[3] = kk.w;
+            *(float4*)(vl + (size_t)r * hd + c) = vv;
+        }
+        // this wave's token: RoPE, append to the ring (later calls) and to the staged window
+        const float* qp = qkv + (size_t)m * 3 * HH + h * hd;
+        const float* kp0 = qp + HH; const float* vp = qp + 2 * HH;
+        const int lr = pos - jmin;
+        if (lane < half) {
+            const float2 csn = ((const float2*)rope)[(size_t)pos * half + lane];
+            const float cs = csn.x, sn = csn.y;
+            float a = qp[lane], b = qp[lane + half];
+            qs[lane] = a * cs - b * sn; qs[lane + half] = b * cs + a * sn;
+            a = kp0[lane]; b = kp0[lane + half];
+            const float k0 = a * cs - b * sn, k1 = b * cs + a * sn;
+            float* kd = kr + (size_t)(pos % RW) * HH;
+            kd[lane] = k0; kd[lane + half] = k1;
+            kl[(size_t)lr * KS + lane] = k0; kl[(size_t)lr * KS + lane + half] = k1;
+        }
+        for (int i = lane; i < hd; i += 64) { const float vv = vp[i]; vr[(size_t)(pos % RW) * HH + i] = vv; vl[(size_t)lr * hd + i] = vv; }
+    }
+    __syncthreads();
+    const int j0 = pos - W + 1 > 0 ? pos - W + 1 : 0, nk = pos - j0 + 1, r0 = j0 - jmin;
+    for (int j = lane; j < nk; j += 64) {
+        const float* kp = kl + (size_t)(r0 + j) * KS;
+        float a = 0.0f;
+        for (int i = 0; i < hd; i += 4) { a += qs[i] * kp[i]; a += qs[i + 1] * kp[i + 1]; a += qs[i + 2] * kp[i + 2]; a += qs[i + 3] * kp[i + 3]; }
+        sc[j] = a * scale;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int j = lane; j < nk; j += 64) mx = fmaxf(mx, sc[j]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float l = 0.0f;
+    for (int j = lane; j < nk; j += 64) { const float pj = expf(sc[j] - mx); sc[j] = pj; l += pj; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) l += __shfl_xor(l, o);
+    __syncthreads();
+    for (int i = lane; i < hd; i += 64) {
+        float o = 0.0f;
+        for (int j = 0; j < nk; ++j) o += sc[j] * vl[(size_t)(r0 + j) * hd + i];
+        const size_t off = tiled ? q3_atile_off(m, h * hd + i, HH >> 5) : (size_t)m * HH + h * hd + i;
+        ((__bf16*)att)[off] = (__bf16)(o / l);
+    }
+}
+
 // ConvNeXt front: depthwise causal conv k7 + LayerNorm(eps 1e-6) per position; one wave per (slot, t)
 __global__ __launch_bounds__(64) void k_voc_dw_ln(const float* x, size_t x_stride, int H, int T, int C, const float* dw_w, const float* dw_b,
                                                   const float* ln_w, const float* ln_b, float* y, int tiled) {
@@ -1581,6 +1652,18 @@ static void hist_all(hipStream_t s, const VCall& cl, const VCall* cld, Q3Voc* v,
     if (tab.n) hipLaunchKernelGGL(k_voc_hist_all, dim3(16, cl.ns, tab.n), dim3(256), 0, s, cld, tab, save);
 }
 // one batched streaming call: ns slots x nf new frames each (uniform nf <= VOC_FCAP)
+// sliding-window attention of a call: the LDS-staged kernel for heads of <= 64 dims (Q3TTS_VOC_ATTN_OLD=1: the row-walking kernel; same bits)
+static void voc_launch_attn(hipStream_t s, const VCall* cld, Q3Voc* v, float* kr, float* vr, int ns, int nf, int tiled) {
+    const q3tts_vocoder_config& c = v->c;
+    const char* ev = getenv("Q3TTS_VOC_ATTN_OLD");   // (read per launch: a test compares the two kernels in one process)
+    const bool old = ev && atoi(ev);
+    const size_t lds = (size_t)(c.sliding_window + nf - 1) * (2 * c.head_dim + 1) * sizeof(float);
+    if (!old && c.head_dim <= 64 && c.head_dim % 4 == 0 && lds <= 48 * 1024) {
+        hipLaunchKernelGGL(k_voc_attn_lds, dim3(c.n_head, ns), dim3(64 * nf), lds, s, cld, v->qkv, kr, vr, v->rope, c.n_head, c.head_dim, v->RW, c.sliding_window, v->att, tiled);
+        return;
+    }
+    hipLaunchKernelGGL(k_voc_attn, dim3(c.n_head, ns), dim3(64 * nf), 0, s, cld, v->qkv, kr, vr, v->rope, c.n_head, c.head_dim, v->RW, c.sliding_window, v->att, tiled);
+}
 static int voc_call_body(q3tts_engine* e, const VCall& cl, hipStream_t s) {
     Q3Voc* v = e->voc;
     const VCall* cld = v->call_dev;
@@ -1601,7 +1684,7 @@ static int voc_call_body(q3tts_engine* e, const VCall& cl, hipStream_t s) {
             hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, L.in_norm, c.rms_eps, d, v->xnb, 2);
             g.a = (const uint16_t*)v->xnb; g.w = L.qkv_t; g.K = d; g.N = 3 * HH; g.epi = Q3_EPI_STORE; g.y = v->qkv; g.ldy = 3 * HH;
             if (q3_launch_bgemm(g, s)) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder: qkv GEMM shape");
-            hipLaunchKernelGGL(k_voc_attn, dim3(c.n_head, ns), dim3(64 * nf), 0, s, cld, v->qkv, kr, vr, v->rope, c.n_head, c.head_dim, v->RW, c.sliding_window, v->att, 1);
+            voc_launch_attn(s, cld, v, kr, vr, ns, nf, 1);
             g.a = (const uint16_t*)v->att; g.w = L.o_t; g.K = HH; g.N = d; g.epi = Q3_EPI_RESID; g.y = v->x; g.ldy = d; g.col_scale = L.ls_attn;
             if (q3_launch_bgemm(g, s)) return q3_set_err(e, Q3TTS_ERR_INVALID, "vocoder: o GEMM shape");
             hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, L.post_norm, c.rms_eps, d, v->xnb, 2);
@@ -1613,7 +1696,7 @@ static int voc_call_body(q3tts_engine* e, const VCall& cl, hipStream_t s) {
         }
         hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, L.in_norm, c.rms_eps, d, v->xnb, 1);
         vgemm(s, L.qkv, v->xnb, 0, 0, 1, M, v->qkv, 0, 0, 0, nullptr, 1, nullptr, 1, 1);
-        hipLaunchKernelGGL(k_voc_attn, dim3(c.n_head, ns), dim3(64 * nf), 0, s, cld, v->qkv, kr, vr, v->rope, c.n_head, c.head_dim, v->RW, c.sliding_window, v->att, 0);
+        voc_launch_attn(s, cld, v, kr, vr, ns, nf, 0);
         vgemm(s, L.o, v->att, 0, 0, 1, M, v->x, 0, 0, 1, L.ls_attn, d, nullptr, 1, 1);
         hipLaunchKernelGGL(k_voc_rmsnorm, dim3(M), dim3(64), 0, s, v->x, L.post_norm, c.rms_eps, d, v->xnb, 1);
         vgemm(s, L.gu, v->xnb, 0, 0, 1, M, v->g, 0, 0, 4, nullptr, 1, nullptr, 1, 1, 1);  // gate | up in one launch, SwiGLU in the epilogue
@@ -1655,6 +1738,11 @@ static int voc_call_body(q3tts_engine* e, const VCall& cl, hipStream_t s) {
             vgemm(s, p.pw2, v->t2, (size_t)T * 4 * d, 0, ns, T, p.dw_in.p, p.dw_in.stride(), p.dw_in.H * d, 1, p.gamma, d);  // residual in place
             cur = p.dw_in.p; cur_stride = p.dw_in.stride(); cur_off = p.dw_in.H * d;
         }
+    }
+    {   // timing experiment only (results are then garbage): Q3TTS_EXP_VOC_SKIP=2 ends the call here — the launch-bound front end (embedding,
+        // transformer, up-sampling) alone beside the decoder, to split the interference between the two halves of a call (profiles/README.md)
+        static const int exp_skip = getenv("Q3TTS_EXP_VOC_SKIP") ? atoi(getenv("Q3TTS_EXP_VOC_SKIP")) : 0;
+        if (exp_skip == 2) { Q3_HIP(e, hipGetLastError()); return Q3TTS_OK; }
     }
     // V5b decoder
     hipLaunchKernelGGL(k_voc_rows_bf16, dim3((unsigned)(((size_t)T * d / 4 + 255) / 256), ns), dim3(256), 0, s, cur + cur_off, cur_stride,
@@ -1718,7 +1806,7 @@ static int voc_call_body(q3tts_engine* e, const VCall& cl, hipStream_t s) {
 static unsigned long long voc_call_key(const VCall& cl) {
     unsigned long long k = (unsigned long long)cl.ns | ((unsigned long long)cl.nf << 8) | ((unsigned long long)(voc_polite() ? 1 : 0) << 12);
     unsigned long long h = 1469598103934665603ull;  // the launch-time switches (tests flip them inside one process)
-    for (const char* name : {"Q3TTS_VOC_NORING", "Q3TTS_VOC_NOFUSE", "Q3TTS_VOC_NOTAP", "Q3TTS_VOC_TAP_MIN", "Q3TTS_VOC_OUT_OLD"}) {
+    for (const char* name : {"Q3TTS_VOC_NORING", "Q3TTS_VOC_NOFUSE", "Q3TTS_VOC_NOTAP", "Q3TTS_VOC_TAP_MIN", "Q3TTS_VOC_OUT_OLD", "Q3TTS_VOC_ATTN_OLD"}) {
         const char* ev = getenv(name);
         for (const char* c = ev ? ev : "-"; *c; ++c) h = (h ^ (unsigned char)*c) * 1099511628211ull;
         h = (h ^ 0xFFu) * 1099511628211ull;

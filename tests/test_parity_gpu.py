@@ -316,6 +316,23 @@ def test_vocoder_streaming_equals_one_shot(tiny_voc):
         assert np.array_equal(eng.vocoder(codes, chunk_frames=ch), one), ch
 
 
+def test_vocoder_attention_kernels_agree(tiny_voc):
+    """The sliding-window attention with the (slot, head) window staged in LDS (k_voc_attn_lds) against the row-walking kernel it replaces
+    (Q3TTS_VOC_ATTN_OLD=1): same chains in the same order, so the PCM is the same bits — one-shot and chunked (1, 3 and 4 tokens per call,
+    call positions before and after the sliding window has filled)."""
+    import os
+    cfg, eng, v = tiny_voc
+    codes = np.random.default_rng(12).integers(0, cfg.vocoder.codebook_size, size=(min(80, cfg.max_steps_cap), 16)).astype(np.int32)
+    new = [eng.vocoder(codes, chunk_frames=ch) for ch in (0, 1, 3, 4)]
+    os.environ["Q3TTS_VOC_ATTN_OLD"] = "1"
+    try:
+        old = [eng.vocoder(codes, chunk_frames=ch) for ch in (0, 1, 3, 4)]
+    finally:
+        del os.environ["Q3TTS_VOC_ATTN_OLD"]
+    for a, b in zip(new, old):
+        assert np.array_equal(a, b) and np.array_equal(a, new[0])
+
+
 def test_vocoder_clamps_out_of_range_codes(oracle, tiny_voc):
     """Codes outside [0, codebook_size) are clamped like the reference's vocoder thread (src/tts/engine.rs:515-519)."""
     cfg, eng, v = tiny_voc
