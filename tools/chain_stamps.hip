@@ -4,7 +4,7 @@
 // the previous kernel's last store and this kernel's first instruction (= the real launch-to-launch cost, which a tracer cannot see).
 //   Predictor chain: 3 passes x 5 blocks x [QKV, attention (<= 17 keys), O, gate/up, down] + head, 64 rows, weights hot (157 MB re-read)
 //   Talker chain   : 4 blocks x [QKV, attention (T = 150), O, gate/up, down], 64 rows, weights cold (rotating through 2 GiB)
-// Build: see tools/r3_chain_stamps.sh
+// Build: bash tools/build_stamps.sh chain (here or on the GPU box)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
