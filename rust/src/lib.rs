@@ -27,7 +27,7 @@ pub struct q3tts_engine_config {
     pub model: q3tts_model_config, pub vocoder: q3tts_vocoder_config,
     pub device: i32, pub max_batch: i32, pub n_ctx: i32, pub max_steps_cap: i32, pub with_vocoder: i32,
     pub synth_seed: u64, pub weights_path: *const c_char,
-    pub talker_q8_0: i32,   // 1: the Talker's Q8_0 blocks stay quantised on the device (the crate's default "q8_0" directory)
+    pub talker_q8_0: i32,   // 2: the Talker's Q8_0 blocks stay quantised on the device and meet Q8_0 activations (W8A8, the crate's default "q8_0" directory); 1: W8A16; 0: bf16
     pub vocoder_flush_tail: i32,   // 0: the look-ahead tail is flushed as the reference does (only when n_frames % 4 != 0); 1: always
 }
 #[repr(C)]
@@ -118,7 +118,7 @@ impl TtsEngine {
             let mut cfg: q3tts_engine_config = std::mem::zeroed();
             q3tts_default_config(&mut cfg);
             cfg.weights_path = dir.as_ptr();   // borrowed for the call only
-            cfg.talker_q8_0 = (quant == "q8_0") as i32;   // gguf_q8_0: keep the Talker's blocks as stored (halves its weight stream)
+            cfg.talker_q8_0 = if quant == "q8_0" { 2 } else { 0 };   // gguf_q8_0: the Talker's blocks stay as stored and are multiplied as llama.cpp does (Q8_0 x Q8_0, W8A8)
             let mut raw = std::ptr::null_mut();
             let rc = q3tts_engine_create(&cfg, &mut raw);
             if rc != 0 { return Err(format!("q3tts_engine_create failed: {}", rc)); }
