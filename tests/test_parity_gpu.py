@@ -986,6 +986,33 @@ def test_talker_q8_0_on_the_device_ids_match_the_oracle(oracle, mode):
         om.close()
 
 
+def test_talker_q8a8_64_slots_row_buckets(oracle):
+    """W8A8 with max_batch = 64 on the small shape: 80 sampled requests of mixed prompt and target length — the decode rows run every row-tile
+    instance of k_bgemm8 (64 -> 48 -> 32 -> 16 -> 8 ... 1 rows as the batch drains, (2,2) / (4,2) / (2,4) / (1,x) tiles, prefill at > 64 rows in
+    64-row chunks), slots are re-used — every request's ids equal the oracle's W8A8 replay."""
+    from q3tts import _abi
+    cfg = _abi.tiny_config(max_batch=64, n_ctx=256, with_vocoder=0)
+    eng, om = _q8_engine_and_oracle(oracle, cfg, 256, 2)
+    try:
+        rng = np.random.default_rng(88)
+        reqs, refs = [], []
+        for i in range(80):
+            n_text = int(rng.integers(3, 30)); target = int(rng.integers(2, 33))
+            desc, keep = oracle.make_prompt_desc(rng.integers(0, 151643, size=n_text), spk_emb=_spk(cfg.model.d_embed))
+            pe = om.build_prompt(desc)
+            kw = dict(temperature=0.7, top_k=40, top_p=0.9, seed=3000 + i, max_steps=40, min_frames=target, force_eos_at=target)
+            refs.append(om.generate(pe, **kw)[0])
+            reqs.append(dict(embd=pe, **kw))
+        outs = eng.generate_batch(reqs)
+        tm = eng.timings()
+        for i, (o, r) in enumerate(zip(outs, refs)):
+            assert o.status == 0 and o.codes.shape == r.shape and np.array_equal(o.codes, r), i
+        assert tm.mean_rows < 60.0   # the batch did drain through smaller row buckets
+    finally:
+        eng.close()
+        om.close()
+
+
 @pytest.mark.parametrize("talker_type,mode", [(8, 1), (30, 1), (8, 2)])
 def test_talker_q8_0_from_model_files(oracle, tmp_path, talker_type, mode):
     """weights_path + talker_q8_0 = 1. A Q8_0 Talker container (type 8: the reference's gguf_q8_0 directory, src/tts/engine.rs:91-95) goes
