@@ -47,7 +47,7 @@ __global__ __launch_bounds__(512) void k_bgemm8(Q3BGemm g) {
     for (int i = 0; i < RT; ++i) {
         const int R = g.a_row0 + min(row0 + 16 * i + r, B - 1);
         ap[i] = (const u32x4*)g.a + ((size_t)(R >> 4) * kpairs + kp0) * 64 + kq * 16 + (R & 15);
-        const int Rb = g.a_row0 + row0 + 16 * i;   // (aligned: a multiple of 16; rows past B - 1 read the buffer's padding rows, their results are dropped)
+        const int Rb = min(g.a_row0 + row0 + 16 * i, g.a_row0 + B - 1);   // (aligned: a_row0 is a multiple of 16; a row tile past the last row's re-reads that tile: its results are dropped)
         asp[i] = (const u32x4*)g.ascale + ((size_t)kp0 * g.a_rt16 + (Rb >> 4)) * 4 + kq;
     }
     const u32x4* wq[NT]; const uint32_t* sq[NT];
