@@ -137,6 +137,8 @@ class TtsEngine:
         """TtsEngine::new(model_dir, quant) (src/tts/engine.rs:84-169). There is no network here: with no weight
         container under model_dir the engine uses seeded synthetic weights of the configured shape."""
         cfg = config or _abi.default_config()
+        if quant == "q8_0" and not cfg.talker_q8_0:
+            cfg.talker_q8_0 = 2   # the gguf_q8_0 directory is multiplied as llama.cpp multiplies it: Q8_0 x Q8_0 (W8A8, DESIGN.md §4.1d)
         if model_dir:
             quant_dir = {"q5_k_m": "gguf_q5_k_m", "q8_0": "gguf_q8_0"}.get(quant, "gguf")  # src/tts/engine.rs:91-95
             wdir = os.path.join(model_dir, quant_dir)
